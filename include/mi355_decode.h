@@ -1,0 +1,305 @@
+/*
+ * mi355_decode.h — C-ABI of libmi355_decode.so
+ *
+ * MI355X (gfx950 / CDNA4) native implementation of the quantized transformer
+ * decode hot path of alibaba/rtp-llm: weight-only INT4/INT8 dequant-GEMM,
+ * paged flash-decoding attention with fp16 / INT8 KV-cache, fused
+ * RMSNorm / RoPE+KV-write / SiLU-gate epilogues, greedy sampling, and a
+ * C++ decode-step driver that replays the whole step as one hipGraph.
+ *
+ * Conventions (mirrors the one C-ABI precedent in the reference,
+ * rtp_llm/models_py/bindings/rocm/kernels/pa_decode_dot_kernel.h:9 —
+ * raw device pointers, explicit stream, integer status):
+ *   - every pointer marked "dev" is a HIP device pointer; all 16-bit float
+ *     tensors are IEEE fp16; tensors are dense row-major unless stated;
+ *   - `stream` is a hipStream_t passed as void*; kernels are only enqueued,
+ *     nothing synchronises, nothing allocates (graph-capturable, the
+ *     constraint the reference puts on ops under its HIP-graph runner,
+ *     rtp_llm/cpp/cuda_graph/cuda_graph_runner.cc:1139-1203);
+ *   - return value: 0 = ok, <0 = error (see MI355_ERR_*); no C++ exception
+ *     crosses this boundary; mi355_last_error() gives a thread-local message.
+ *
+ * Each entry point cites the reference interface it replaces.
+ */
+#ifndef MI355_DECODE_H
+#define MI355_DECODE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_ABI_VERSION 1
+
+typedef void* mi355_stream_t; /* hipStream_t */
+
+enum {
+    MI355_OK              = 0,
+    MI355_ERR_ARG         = -1, /* bad argument / unsupported shape */
+    MI355_ERR_HIP         = -2, /* HIP runtime error at launch */
+    MI355_ERR_UNSUPPORTED = -3,
+    MI355_ERR_WORKSPACE   = -4  /* workspace too small */
+};
+
+/* weight element kinds */
+enum { MI355_W4 = 4, MI355_W8 = 8, MI355_W16 = 16 };
+/* KV-cache element kinds (reference: KvCacheDataType, cpp/model_utils/AttentionConfig.h:9-12;
+ * value 1 is the INT8 slot the reference removed, kept here) */
+enum { MI355_KV_FP16 = 0, MI355_KV_INT8 = 1 };
+
+int         mi355_abi_version(void);
+const char* mi355_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Packed weight descriptor.
+ *
+ * Replaces the reference's DenseWeights{kernel,bias,scales,zeros}
+ * (rtp_llm/cpp/models/models_weight/Weights.h:23-29) for one linear layer.
+ * `qweight` is the MI355-native tile image produced at load time by
+ * rtp_llm_amd.quant (the counterpart of RocmImpl.preprocess_groupwise_weight_params,
+ * rtp_llm/device/device_impl.py:797-868, and apply_int8, :211-222):
+ *
+ *   tile (nt, c) covers output columns [16nt, 16nt+16) x input rows
+ *   [128c, 128c+128) and is stored at byte offset
+ *       ((nt * (K_pad/128) + c) * LPC) * 1024,   LPC = wbits/4 (1, 2, 4)
+ *   as LPC wave-loads of 64 lanes x 16 bytes.  Lane l = (i = l & 15, q = l >> 4)
+ *   owns column 16nt+i; MFMA k-step s (0..3) of the chunk uses rows
+ *       k = 128c + 32s + 8q + e,  e = 0..7.
+ *   W4 : dword s of the lane's 16 bytes holds the 8 unsigned nibbles of step s,
+ *        nibble e at bit 4*(e/2) + 16*(e&1)   (pairs land in fp16x2 lanes);
+ *   W8 : wave-load p (0..1) holds steps 2p and 2p+1, 8 offset-binary bytes each
+ *        (stored byte = q + 128);
+ *   W16: wave-load s holds the 8 fp16 values of step s.
+ *
+ * `meta` (W4/W8) is fp16x2 {zneg, scale} per (group, column):
+ *       meta[g * N_pad + n],  zneg = -(1024 + z_eff), W = scale * (u - z_eff)
+ *   with u the stored unsigned code.  GPTQ: z_eff = z + 1 (GPTQ_FLAG,
+ *   device_impl.py:252); AWQ: z_eff = z; symmetric autoquant: z_eff = 8 / 128.
+ *   group_size 0 means one group spanning all of K (per-channel scale,
+ *   reference a1: device_impl.py:183-192).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    const void* qweight; /* dev */
+    const void* meta;    /* dev, NULL for W16 */
+    int32_t     wbits;   /* MI355_W4 / W8 / W16 */
+    int32_t     K;       /* logical input features */
+    int32_t     N;       /* logical output features */
+    int32_t     K_pad;   /* multiple of 128 */
+    int32_t     N_pad;   /* multiple of 16 */
+    int32_t     group_size; /* 32, 64, 128, or 0 = per-channel */
+} mi355_weight_t;
+
+/* epilogue flags for mi355_linear_forward */
+enum {
+    MI355_EPI_NONE     = 0,
+    MI355_EPI_SILU_MUL = 1, /* columns are interleaved (gate,up) pairs; y is [M, N/2] */
+    MI355_EPI_OUT_F32  = 2  /* y is fp32 [M, N] (lm_head logits) */
+};
+
+/* Workspace needed by mi355_linear_forward for a given (M, weight). */
+size_t mi355_linear_workspace_bytes(int32_t M, const mi355_weight_t* w);
+
+/*
+ * y[M,N] = x[M,K] @ W[K,N] (+ bias[N]) — the op behind LinearBase.forward
+ * (rtp_llm/models_py/modules/factory/linear/linear_base.py:75-85; only ROCm
+ * 16-bit impl: impl/rocm/f16_linear.py:100-112).  fp32 accumulation on MFMA
+ * (v_mfma_f32_16x16x32_f16), output rounded once to fp16 (or fp32 with
+ * MI355_EPI_OUT_F32, the lm_head contract of PyWrappedModel.cc:1039-1047).
+ * M may be any positive value (processed in slabs of 64 rows).
+ */
+int mi355_linear_forward(const void* x, int32_t M, const mi355_weight_t* w, const void* bias,
+                         void* y, int32_t epilogue, void* workspace, size_t workspace_bytes,
+                         mi355_stream_t stream);
+
+/*
+ * Split-K half of the same GEMM: writes fp32 partial slabs
+ * partials[split][M][N_pad] and returns the slab count (>0) — consumed by
+ * mi355_rope_kv_write / mi355_add_rmsnorm, which fold the reduction into the
+ * next op.  `max_splits` bounds the slab count the caller has room for.
+ */
+int mi355_linear_partial(const void* x, int32_t M, const mi355_weight_t* w, float* partials,
+                         int32_t max_splits, mi355_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * RMSNorm family — replaces RMSNorm / RMSResNorm
+ * (rtp_llm/models_py/modules/base/rocm/norm.py:51-77; torch spec
+ * modules/base/common/norm.py:83-92: fp32 x*rsqrt(mean(x^2)+eps), cast to
+ * fp16, then multiply by weight).
+ *
+ * x_sum = (x_f16 or sum of nsplit fp32 slabs [nsplit][M][ld]) (+ bias) (+ residual)
+ * if residual_out: residual_out = fp16(x_sum)
+ * y = weight * fp16(normalise(x_sum))
+ * ---------------------------------------------------------------------- */
+int mi355_rmsnorm(const void* x, const void* weight, float eps, int32_t M, int32_t H, void* y,
+                  mi355_stream_t stream);
+
+int mi355_add_rmsnorm(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld,
+                      const void* bias, const void* residual_in, void* residual_out,
+                      const void* weight, float eps, int32_t M, int32_t H, void* y,
+                      mi355_stream_t stream);
+
+/* out[M,I] = silu(gate_up[:, :I]) * gate_up[:, I:] — FusedSiluAndMul
+ * (modules/base/rocm/activation.py:9-24). */
+int mi355_silu_mul(const void* gate_up, int32_t M, int32_t I, void* out, mi355_stream_t stream);
+
+/* out[T,H] = table[ids[T]] — Embedding (modules/base/common/embedding.py:35-49,
+ * kernel bindings/common/kernels/embedding_kernels.cu:90). */
+int mi355_embedding(const int32_t* ids, int32_t T, const void* table, int32_t H, int32_t vocab,
+                    void* out, mi355_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Paged KV cache, one layer.  Same allocator contract as the reference
+ * (per-layer tensor [blocks, 2, nkv, page, hd], K block = pool index 2b,
+ * V block = 2b+1: bindings/OpDefs.h:24-28,201-202, kv_cache_kernels.cu:58-61;
+ * 8-bit scale plane fp32 [blocks][2][nkv][page]: kv_cache_utils.h:265-271,
+ * MHAKVCacheSpec.h:52-54,82-92).  Intra-block layout is native:
+ *   K block: [nkv][page][hd]       (token-major, hd contiguous)
+ *   V block: [nkv][hd][page]       (channel-major: the MFMA k-dim of P.V is
+ *                                   tokens, so tokens are contiguous per channel —
+ *                                   same as the reference's NonAsm V layout,
+ *                                   kv_cache_utils.h:236-241)
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    void*   kv_base;    /* dev: fp16 or int8 elements */
+    float*  scale_base; /* dev: INT8 only, else NULL */
+    int32_t kv_dtype;   /* MI355_KV_FP16 / MI355_KV_INT8 */
+    int32_t page;       /* tokens per block: 16, 32 or 64 */
+    int32_t nkv;        /* local kv heads */
+    int32_t hd;         /* head dim: 64 or 128 */
+    int32_t num_blocks;
+} mi355_kv_layer_t;
+
+/*
+ * Bias + RoPE + Q-extract + paged KV write for decode — replaces
+ * FusedRopeKVCacheDecodeOp::forward (bindings/rocm/FusedRopeKVCacheOp.cc:519-646,
+ * kernel fused_rope_kvcache_kernel.cu:1297-1466).  NeoX pairing (i, i+rope_dim/2),
+ * fp32 rotation with the fp32 {cos,sin} table cos_sin[pos][rope_dim/2][2]
+ * (RopeCache.cc:16-41, interleave=true form), one rounding to fp16.
+ * Input is either fp16 qkv[T][(nh+2nkv)*hd] or nsplit fp32 slabs of the QKV GEMM.
+ * Token t is written at position positions[t] of sequence t (decode: one token
+ * per sequence) through block_table[t][pos / page].
+ * INT8 cache: scale = max|x| / 127 per (token, kv head) fp32, q = rne_sat(x / scale)
+ * (rounding of rocm_utils/_cast_to_int8.h:5-24).
+ */
+int mi355_rope_kv_write(const void* qkv_f16, const float* partials, int32_t nsplit, int32_t ld,
+                        const void* qkv_bias, const float* cos_sin, int32_t rope_dim,
+                        const int32_t* positions, const int32_t* block_table,
+                        int32_t max_blocks_per_seq, int32_t T, int32_t nh,
+                        const mi355_kv_layer_t* kv, void* q_out, mi355_stream_t stream);
+
+/*
+ * Paged decode attention (flash-decoding, split over the sequence) — replaces
+ * AiterDecodeAttnOp*.forward / paged_attention_atrex
+ * (factory/attention/rocm_impl/aiter.py:1340-1561, bindings/rocm/atrexPA.cc:444-496).
+ * out[B][nh*hd] = softmax(scale * q.K^T) . V over seq_lens[b] tokens gathered
+ * through block_table[b][*]; fp32 logits/softmax; GQA group nh/nkv <= 16.
+ */
+size_t mi355_paged_attn_workspace_bytes(int32_t B, int32_t nh, int32_t hd, int32_t max_seq_len);
+
+int mi355_paged_decode_attn(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_table,
+                            int32_t max_blocks_per_seq, const int32_t* seq_lens, int32_t B,
+                            int32_t nh, float scale, int32_t max_seq_len, void* out,
+                            void* workspace, size_t workspace_bytes, mi355_stream_t stream);
+
+/* Greedy fast path: ids[b] = argmax(logits[b, :]) on fp32 logits, lowest index on ties
+ * (bindings/core/CudaSampleOp.cc:687-700).  workspace >= B * 64 * 8 bytes. */
+int mi355_argmax(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t* ids,
+                 void* workspace, size_t workspace_bytes, mi355_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Decode-step driver (C++): owns no tensors, only pointers.  It enqueues the
+ * whole decode step of a Qwen2/Llama-style decoder (the body of
+ * Qwen3Model.forward, rtp_llm/models_py/model_desc/qwen3.py:57-79,124-138,
+ * plus lm_head + greedy of PyWrappedModel.cc:938-1080) and can capture it into
+ * a hipGraph per batch size (the job of rtp_llm/cpp/cuda_graph/cuda_graph_runner.cc).
+ * With tp_size > 1 the step is cut at the two all-reduce points of each layer
+ * (causal_attention.py:91-92, dense_mlp.py:104-105); the caller reduces
+ * `ar_buf` between segments.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    int32_t num_layers, hidden, nh, nkv, hd, inter, vocab; /* per-rank values */
+    int32_t rope_dim, max_pos;
+    float   rms_eps;
+    int32_t kv_dtype, page, num_blocks;
+    int32_t max_batch, max_blocks_per_seq, max_seq_len;
+    int32_t tp_size;
+} mi355_model_config_t;
+
+typedef struct {
+    mi355_weight_t qkv, o, gate_up, down; /* gate_up: interleaved (gate,up) columns */
+    const void*    qkv_bias;              /* fp16 [(nh+2nkv)*hd] or NULL */
+    const void*    input_norm;            /* fp16 [hidden] */
+    const void*    post_norm;             /* fp16 [hidden] */
+    void*          kv_base;               /* this layer's cache */
+    float*         kv_scale_base;
+} mi355_layer_weights_t;
+
+typedef struct {
+    const void*    embedding;  /* fp16 [vocab_full, hidden] */
+    int32_t        vocab_full;
+    const void*    final_norm; /* fp16 [hidden] */
+    mi355_weight_t lm_head;    /* W16/W8/W4, N = vocab (per rank) */
+    const float*   cos_sin;    /* fp32 [max_pos][rope_dim/2][2] */
+} mi355_model_weights_t;
+
+/* Step I/O buffers (device, caller-owned, address-stable for graph replay) */
+typedef struct {
+    int32_t* token_ids;   /* [max_batch]   in: current token; out (greedy): next token */
+    int32_t* positions;   /* [max_batch]   tokens already in cache (= sequence_lengths) */
+    int32_t* block_table; /* [max_batch][max_blocks_per_seq] */
+    float*   logits;      /* [max_batch][vocab] fp32 */
+    void*    hidden;      /* fp16 [max_batch][hidden]: last hidden state (post final norm) */
+    void*    ar_buf;      /* fp16 [max_batch][hidden]: tensor to all-reduce (tp_size > 1) */
+    void*    workspace;
+    size_t   workspace_bytes;
+} mi355_step_buffers_t;
+
+typedef struct mi355_decoder mi355_decoder_t;
+
+size_t           mi355_decoder_workspace_bytes(const mi355_model_config_t* cfg);
+mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg,
+                                      const mi355_layer_weights_t* layers,
+                                      const mi355_model_weights_t* model,
+                                      const mi355_step_buffers_t* bufs);
+void             mi355_decoder_destroy(mi355_decoder_t* d);
+
+/* Segments, in order, for batch B (all enqueue on `stream`):
+ *   begin            : embedding -> residual stream
+ *   layer_attn(l)    : norm, QKV, RoPE+KV write, attention, O-proj
+ *                      (tp>1: reduced fp16 result left in ar_buf)
+ *   layer_mlp(l)     : (+residual) norm, gate_up+SiLU, down (tp>1: ar_buf)
+ *   finish           : final norm, lm_head -> logits, greedy argmax -> token_ids,
+ *                      positions += 1
+ * mi355_decoder_step = all of them (tp_size == 1 only). */
+int mi355_decoder_begin(mi355_decoder_t* d, int32_t B, mi355_stream_t stream);
+int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t layer, mi355_stream_t stream);
+int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t layer, mi355_stream_t stream);
+int mi355_decoder_finish(mi355_decoder_t* d, int32_t sample, mi355_stream_t stream);
+int mi355_decoder_step(mi355_decoder_t* d, int32_t B, mi355_stream_t stream);
+
+/* hipGraph: capture one full step for batch B on an internal stream, then replay
+ * `nsteps` times back-to-back on `stream` (greedy feedback stays on device). */
+int mi355_decoder_capture(mi355_decoder_t* d, int32_t B);
+int mi355_decoder_replay(mi355_decoder_t* d, int32_t B, int32_t nsteps, mi355_stream_t stream);
+
+/* Per-kernel-class timing of `nsteps` eager steps with hipEvents on `stream`
+ * (bench.py's roofline.achieved).  out_ms[class] = summed milliseconds,
+ * out_launches[class] = launches; classes: MI355_KC_*. Synchronises the stream. */
+enum {
+    MI355_KC_GEMM_QUANT = 0, /* W4/W8 linears (qkv, o, gate_up, down) */
+    MI355_KC_GEMM_LMHEAD = 1,
+    MI355_KC_ATTN       = 2, /* paged decode attention (+partition reduce) */
+    MI355_KC_ROPE_KV    = 3,
+    MI355_KC_NORM       = 4,
+    MI355_KC_OTHER      = 5,
+    MI355_KC_COUNT      = 6
+};
+int mi355_decoder_profile(mi355_decoder_t* d, int32_t B, int32_t nsteps, float* out_ms,
+                          int32_t* out_launches, mi355_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_DECODE_H */

@@ -1,0 +1,201 @@
+"""CPU oracle for the quantized decode hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under rtp_llm_amd/ may import this module; only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as
+the checker / the timed CPU baseline — never as the product path.
+
+It is a plain-torch (CPU, fp32 math) restatement of the reference's algorithm for
+this path, each function citing the reference lines it follows.  Pinning status
+(see DESIGN.md "Oracle"):
+  * GPTQ/AWQ canonicalisation + INT8 autoquant: PINNED against golden vectors generated
+    by importing the reference's own rtp_llm/device/device_impl.py (tests/golden/quant_*.npz,
+    generator oracle/gen_golden.py).
+  * RMSNorm / RoPE / SiLU-mul / paged attention (fp16 KV) / greedy: restated from the
+    reference's own torch test references (cited per function); those references are
+    what the reference's ROCm unit tests compare against at atol=rtol=1e-2.
+  * W4A16 / W8A16 GEMM results and INT8 KV-cache numerics: PARITY UNPINNED — the reference
+    snapshot contains no kernel, test or golden vector for them; the oracle
+    defines them from the loader formulas (W = scale*(q - z - gptq_flag), W = q*scale_col)
+    and the FasterTransformer-lineage KV convention (scale = amax/127 per token*kv_head).
+"""
+import math
+from typing import List, Optional
+
+import torch
+
+# --------------------------------------------------------------------------- weights
+def dequant_groupwise(q: torch.Tensor, z_eff: torch.Tensor, scales: torch.Tensor, group_size: int) -> torch.Tensor:
+    """W[k,n] = scale[k//g, n] * (q[k,n] - z_eff[k//g, n]) in fp32 (exact: fp16 scale x small int).
+    Reference formula: device_impl.py:283-289 (W = q_s*scale + (8 - z - GPTQ_FLAG)*scale with
+    q_s = q - 8), i.e. W = scale*(q - z - GPTQ_FLAG)."""
+    K, N = q.shape
+    s = scales.float().repeat_interleave(group_size, dim=0)[:K]
+    z = z_eff.float().repeat_interleave(group_size, dim=0)[:K]
+    return s * (q.float() - z)
+
+
+def dequant_reference_folded(q: torch.Tensor, z_eff: torch.Tensor, scales: torch.Tensor, group_size: int) -> torch.Tensor:
+    """The representation the reference hands its kernel: signed nibble * scale + fp16(zeros_x_scales)."""
+    K, N = q.shape
+    zs = ((8 - z_eff.to(torch.int16)).to(scales.dtype) * scales).half()  # device_impl.py:286-289
+    s = scales.float().repeat_interleave(group_size, dim=0)[:K]
+    zsr = zs.float().repeat_interleave(group_size, dim=0)[:K]
+    return (q.float() - 8.0) * s + zsr
+
+
+def dequant_int8(q: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """W = q * scale_col (a1, device_impl.py:183-192)."""
+    return q.float() * scale.float().reshape(1, -1)
+
+
+def linear(x: torch.Tensor, w_f32: torch.Tensor, bias: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
+    """y = x @ W (+bias): fp32 accumulate, one rounding to the activation dtype
+    (LinearBase contract, linear_base.py:75-85; SURVEY 8c' "GEMM")."""
+    y = x.float() @ w_f32
+    if bias is not None:
+        y = y + bias.float()
+    return y if out_f32 else y.to(x.dtype)
+
+
+# --------------------------------------------------------------------------- layer math
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """modules/base/common/norm.py:83-92: fp32 normalise, cast to input dtype, then * weight."""
+    xf = x.float()
+    var = xf.pow(2).mean(-1, keepdim=True)
+    xn = (xf * torch.rsqrt(var + eps)).to(x.dtype)
+    return weight * xn
+
+
+def silu_mul(gate_up: torch.Tensor) -> torch.Tensor:
+    """FusedSiluAndMul (modules/base/rocm/activation.py:9-24; ref hybrid/test/dense_mlp_ref.py:28-34):
+    silu(gate) * up, gate = first half; fp32 internally, one rounding."""
+    I = gate_up.shape[-1] // 2
+    g, u = gate_up[..., :I].float(), gate_up[..., I:].float()
+    return (torch.nn.functional.silu(g) * u).to(gate_up.dtype)
+
+
+def rope_cos_sin(rope_dim: int, theta: float, max_pos: int, rope_scale: float = 1.0) -> torch.Tensor:
+    """genBaseCache (cpp/model_utils/RopeCache.cc:16-41), interleaved {cos,sin} form:
+    table[pos, i] = (cos, sin)(pos/scale * theta^(-2i/dim)), fp32."""
+    inv_freq = 1.0 / torch.pow(torch.tensor(float(theta)), torch.arange(0, rope_dim, 2).float() / rope_dim)
+    t = torch.arange(int(max_pos * rope_scale)).float() / rope_scale
+    freqs = torch.outer(t, inv_freq)
+    return torch.stack((freqs.cos(), freqs.sin()), dim=-1).contiguous()  # [max_pos, dim/2, 2]
+
+
+def apply_rope(x: torch.Tensor, positions: torch.Tensor, cos_sin: torch.Tensor) -> torch.Tensor:
+    """NeoX split-halves RoPE (rotary_position_embedding.h:444-449,481-505; torch restatement
+    test_fused_qkv_transpose_v3.py:246-307): x' = cos*x - sin*y, y' = cos*y + sin*x in fp32,
+    one rounding.  x: [T, H, D]; positions: [T]."""
+    T, H, D = x.shape
+    half = D // 2
+    cs = cos_sin[positions.long()]           # [T, half, 2]
+    cos, sin = cs[..., 0].unsqueeze(1), cs[..., 1].unsqueeze(1)
+    xf = x.float()
+    lo, hi = xf[..., :half], xf[..., half:]
+    out = torch.cat((lo * cos - hi * sin, hi * cos + lo * sin), dim=-1)
+    return out.to(x.dtype)
+
+
+def quant_kv_int8(x: torch.Tensor):
+    """INT8 KV convention (inferred): per (token, kv head) scale = amax/127 (fp32),
+    q = clamp(rint(x/scale), -128, 127) — rounding of rocm_utils/_cast_to_int8.h:8-14.
+    x: [..., hd] fp16.  Returns (int8, fp32 scale[...])."""
+    xf = x.float()
+    amax = xf.abs().amax(dim=-1)
+    scale = torch.where(amax > 0, amax / 127.0, torch.ones_like(amax))
+    q = torch.clamp(torch.round(xf / scale.unsqueeze(-1)), -128, 127).to(torch.int8)
+    return q, scale
+
+
+def attention_decode(q: torch.Tensor, keys: torch.Tensor, values: torch.Tensor, scale: float,
+                     k_scale: Optional[torch.Tensor] = None, v_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One sequence, q_len = 1 — ref_masked_attention (modules/base/rocm/test/rocm_fmha_test.py:262-298):
+    fp32 logits scale*q.k (* k_scale), fp32 softmax, (* v_scale), P.V, cast.
+    q [nh, hd]; keys/values [ctx, nkv, hd] (fp16 or int8); k_scale/v_scale [ctx, nkv] fp32."""
+    nh, hd = q.shape
+    ctx, nkv, _ = keys.shape
+    g = nh // nkv
+    kf = keys.float().repeat_interleave(g, dim=1)      # head h -> kv head h // g
+    vf = values.float().repeat_interleave(g, dim=1)
+    logits = scale * torch.einsum("hd,khd->hk", q.float(), kf)
+    if k_scale is not None:
+        logits = logits * k_scale.float().repeat_interleave(g, dim=1).t()
+    p = torch.softmax(logits, dim=-1)
+    if v_scale is not None:
+        p = p * v_scale.float().repeat_interleave(g, dim=1).t()
+    out = torch.einsum("hk,khd->hd", p, vf)
+    return out.to(q.dtype)
+
+
+def greedy(logits_f32: torch.Tensor) -> torch.Tensor:
+    """top_k == 1 fast path: argmax on fp32 logits, no softmax (bindings/core/CudaSampleOp.cc:687-700)."""
+    return torch.argmax(logits_f32, dim=-1).to(torch.int32)
+
+
+# --------------------------------------------------------------------------- whole decoder
+class OracleKV:
+    """Natural-layout KV store per layer: lists of [nkv, hd] rows per sequence (fp16 or int8+scale)."""
+
+    def __init__(self, num_layers: int, batch: int, int8: bool):
+        self.int8 = int8
+        self.k = [[[] for _ in range(batch)] for _ in range(num_layers)]
+        self.v = [[[] for _ in range(batch)] for _ in range(num_layers)]
+        self.ks = [[[] for _ in range(batch)] for _ in range(num_layers)]
+        self.vs = [[[] for _ in range(batch)] for _ in range(num_layers)]
+
+    def append(self, layer: int, b: int, k: torch.Tensor, v: torch.Tensor):
+        if self.int8:
+            kq, ksc = quant_kv_int8(k); vq, vsc = quant_kv_int8(v)
+            self.k[layer][b].append(kq); self.v[layer][b].append(vq)
+            self.ks[layer][b].append(ksc); self.vs[layer][b].append(vsc)
+        else:
+            self.k[layer][b].append(k); self.v[layer][b].append(v)
+
+    def get(self, layer: int, b: int):
+        K, V = torch.stack(self.k[layer][b]), torch.stack(self.v[layer][b])
+        if self.int8:
+            return K, V, torch.stack(self.ks[layer][b]), torch.stack(self.vs[layer][b])
+        return K, V, None, None
+
+
+class OracleDecoder:
+    """Qwen2/Llama decoder in fp32-accumulate torch: embedding -> N x [RMSNorm, QKV(+bias), RoPE,
+    KV append, attention, O, +res, RMSNorm, gate_up, SiLU*mul, down, +res] -> RMSNorm -> lm_head
+    -> argmax (Qwen3DecoderLayer.forward, models_py/model_desc/qwen3.py:57-79,124-138;
+    CausalAttention causal_attention.py:75-93; DenseMLP dense_mlp.py:95-106; post-layers
+    PyWrappedModel.cc:984-1047).  Weights are given dequantised ([K,N] fp32)."""
+
+    def __init__(self, cfg: dict, weights: dict):
+        self.cfg, self.w = cfg, weights
+        self.cos_sin = rope_cos_sin(cfg["hd"], cfg["rope_theta"], cfg["max_pos"])
+
+    def forward_tokens(self, token_ids: torch.Tensor, positions: torch.Tensor, kv: OracleKV, seq_idx: List[int]):
+        """Process T tokens (token t belongs to sequence seq_idx[t] at position positions[t]); the
+        tokens of one sequence must be given in order.  Returns (hidden fp16 [T,H], logits fp32 [T,V])."""
+        c, w = self.cfg, self.w
+        nh, nkv, hd, eps = c["nh"], c["nkv"], c["hd"], c["rms_eps"]
+        h = w["embedding"][token_ids.long()]
+        T = h.shape[0]
+        for l in range(c["num_layers"]):
+            L = w["layers"][l]
+            x = rmsnorm(h, L["input_norm"], eps)
+            qkv = linear(x, L["qkv"], L.get("qkv_bias"))
+            qh = qkv[:, : nh * hd].reshape(T, nh, hd)
+            kh = qkv[:, nh * hd: (nh + nkv) * hd].reshape(T, nkv, hd)
+            vh = qkv[:, (nh + nkv) * hd:].reshape(T, nkv, hd)
+            qh, kh = apply_rope(qh, positions, self.cos_sin), apply_rope(kh, positions, self.cos_sin)
+            attn = torch.empty(T, nh * hd, dtype=h.dtype)
+            for t in range(T):
+                b = seq_idx[t]
+                kv.append(l, b, kh[t], vh[t])
+                K, V, ks, vs = kv.get(l, b)
+                attn[t] = attention_decode(qh[t], K, V, 1.0 / math.sqrt(hd), ks, vs).reshape(-1)
+            o = linear(attn, L["o"])
+            h = h + o
+            x = rmsnorm(h, L["post_norm"], eps)
+            act = silu_mul(linear(x, L["gate_up"]))
+            h = h + linear(act, L["down"])
+        hn = rmsnorm(h, w["final_norm"], eps)
+        logits = linear(hn, w["lm_head"], out_f32=True)
+        return hn, logits

@@ -1,0 +1,109 @@
+"""ctypes binding of libmi355_decode.so (the C-ABI of include/mi355_decode.h).
+
+The library is the product: if it is missing, importing ``lib()`` raises — there is
+no CPU or PyTorch fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmi355_decode.so")
+
+OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_WORKSPACE = 0, -1, -2, -3, -4
+W4, W8, W16 = 4, 8, 16
+KV_FP16, KV_INT8 = 0, 1
+EPI_NONE, EPI_SILU_MUL, EPI_OUT_F32 = 0, 1, 2
+KC_NAMES = ["gemm_quant", "gemm_lmhead", "attn", "rope_kv", "norm", "other"]
+
+vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+
+
+class Weight(C.Structure):  # mi355_weight_t
+    _fields_ = [("qweight", vp), ("meta", vp), ("wbits", i32), ("K", i32), ("N", i32),
+                ("K_pad", i32), ("N_pad", i32), ("group_size", i32)]
+
+
+class KVLayer(C.Structure):  # mi355_kv_layer_t
+    _fields_ = [("kv_base", vp), ("scale_base", vp), ("kv_dtype", i32), ("page", i32),
+                ("nkv", i32), ("hd", i32), ("num_blocks", i32)]
+
+
+class ModelConfig(C.Structure):  # mi355_model_config_t
+    _fields_ = [(n, i32) for n in ("num_layers", "hidden", "nh", "nkv", "hd", "inter", "vocab", "rope_dim", "max_pos")] + \
+               [("rms_eps", f32)] + \
+               [(n, i32) for n in ("kv_dtype", "page", "num_blocks", "max_batch", "max_blocks_per_seq", "max_seq_len", "tp_size")]
+
+
+class LayerWeights(C.Structure):  # mi355_layer_weights_t
+    _fields_ = [("qkv", Weight), ("o", Weight), ("gate_up", Weight), ("down", Weight),
+                ("qkv_bias", vp), ("input_norm", vp), ("post_norm", vp), ("kv_base", vp), ("kv_scale_base", vp)]
+
+
+class ModelWeights(C.Structure):  # mi355_model_weights_t
+    _fields_ = [("embedding", vp), ("vocab_full", i32), ("final_norm", vp), ("lm_head", Weight), ("cos_sin", vp)]
+
+
+class StepBuffers(C.Structure):  # mi355_step_buffers_t
+    _fields_ = [("token_ids", vp), ("positions", vp), ("block_table", vp), ("logits", vp), ("hidden", vp),
+                ("ar_buf", vp), ("workspace", vp), ("workspace_bytes", sz)]
+
+
+# symbol -> (restype, argtypes); every symbol include/mi355_decode.h declares
+SIGNATURES = {
+    "mi355_abi_version": (i32, []),
+    "mi355_last_error": (C.c_char_p, []),
+    "mi355_linear_workspace_bytes": (sz, [i32, C.POINTER(Weight)]),
+    "mi355_linear_forward": (i32, [vp, i32, C.POINTER(Weight), vp, vp, i32, vp, sz, vp]),
+    "mi355_linear_partial": (i32, [vp, i32, C.POINTER(Weight), vp, i32, vp]),
+    "mi355_rmsnorm": (i32, [vp, vp, f32, i32, i32, vp, vp]),
+    "mi355_add_rmsnorm": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, vp]),
+    "mi355_silu_mul": (i32, [vp, i32, i32, vp, vp]),
+    "mi355_embedding": (i32, [vp, i32, vp, i32, i32, vp, vp]),
+    "mi355_rope_kv_write": (i32, [vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, C.POINTER(KVLayer), vp, vp]),
+    "mi355_paged_attn_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "mi355_paged_decode_attn": (i32, [vp, C.POINTER(KVLayer), vp, i32, vp, i32, i32, f32, i32, vp, vp, sz, vp]),
+    "mi355_argmax": (i32, [vp, i32, i32, i32, vp, vp, sz, vp]),
+    "mi355_decoder_workspace_bytes": (sz, [C.POINTER(ModelConfig)]),
+    "mi355_decoder_create": (vp, [C.POINTER(ModelConfig), C.POINTER(LayerWeights), C.POINTER(ModelWeights), C.POINTER(StepBuffers)]),
+    "mi355_decoder_destroy": (None, [vp]),
+    "mi355_decoder_begin": (i32, [vp, i32, vp]),
+    "mi355_decoder_layer_attn": (i32, [vp, i32, vp]),
+    "mi355_decoder_layer_mlp": (i32, [vp, i32, vp]),
+    "mi355_decoder_finish": (i32, [vp, i32, vp]),
+    "mi355_decoder_step": (i32, [vp, i32, vp]),
+    "mi355_decoder_capture": (i32, [vp, i32]),
+    "mi355_decoder_replay": (i32, [vp, i32, i32, vp]),
+    "mi355_decoder_profile": (i32, [vp, i32, i32, C.POINTER(f32), C.POINTER(i32), vp]),
+}
+
+_lib = None
+
+
+class Mi355Error(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it has not been built: no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Mi355Error(f"{LIB_PATH} not found - build it with `python -m rtp_llm_amd.build` "
+                             "(the HIP extension is required; there is no CPU fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the ABI lost a symbol
+            fn.restype, fn.argtypes = res, args
+        if l.mi355_abi_version() != 1:
+            raise Mi355Error("libmi355_decode.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> int:
+    """Status -> RuntimeError, the error behaviour of the reference's ops
+    (TORCH_CHECK -> RuntimeError, bindings/common/Torch_ext.h:48-66)."""
+    if rc < 0:
+        msg = lib().mi355_last_error().decode(errors="replace")
+        raise Mi355Error(f"{what}: mi355 error {rc}: {msg}")
+    return rc

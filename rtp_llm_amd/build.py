@@ -1,0 +1,67 @@
+"""Build libmi355_decode.so (gfx950) in-tree with hipcc.
+
+    python -m rtp_llm_amd.build [--force]
+
+Objects go to rtp_llm_amd/csrc/build/, the library to rtp_llm_amd/lib/.  Only
+stale translation units are recompiled (mtime of source + headers).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libmi355_decode.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+SOURCES = ["gemm.hip", "attention.hip", "rope_kv.hip", "elementwise.hip", "engine.cpp", "error.cpp"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "internal.h"), os.path.join(INCLUDE, "mi355_decode.h")]
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+CFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wno-unused-result", "-x", "hip"]
+
+
+def _stale(src, obj):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(p) > t for p in [src] + HEADERS)
+
+
+def _compile(name, force):
+    src = os.path.join(CSRC, name)
+    obj = os.path.join(OBJ, os.path.splitext(name)[0] + ".o")
+    if not force and not _stale(src, obj):
+        return obj, False
+    cmd = [HIPCC] + CFLAGS + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {name}:\n{r.stdout}\n{r.stderr}")
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        res = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    objs = [o for o, _ in res]
+    rebuilt = any(ch for _, ch in res)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[rtp_llm_amd.build] built {LIB}")
+    elif verbose:
+        print(f"[rtp_llm_amd.build] up to date: {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

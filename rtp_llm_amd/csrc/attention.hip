@@ -1,0 +1,325 @@
+// Paged flash-decoding attention (q_len = 1, GQA) with fp16 or INT8 KV-cache, gfx950.
+//
+// Replaces AiterDecodeAttnOp*.forward / paged_attention_atrex
+// (rtp_llm/models_py/modules/factory/attention/rocm_impl/aiter.py:1340-1561,
+// rtp_llm/models_py/bindings/rocm/atrexPA.cc:444-496); numerics follow the
+// reference's torch oracle run_native/ref_masked_attention
+// (modules/base/rocm/test/rocm_fmha_test.py:262-372): fp32 logits
+// scale*q.k (* k_scale), fp32 softmax, (* v_scale), P.V.
+//
+// Work split: grid (partition, kv_head, sequence); a block of 4 waves owns one
+// partition of the sequence, each wave streams 32-token groups and keeps its own
+// online-softmax state (wavefront split-K); waves merge through LDS, partitions
+// through a small reduce kernel.  All G = nh/nkv query heads of a kv head ride
+// in the 16-wide N dimension of v_mfma_f32_16x16x32_f16, so K/V are read once
+// per kv head:
+//   S^T[tok][j] : A = K tile (16 tokens x 32 d),   B = q^T (32 d x 16 heads)
+//   O^T[d][j]   : A = V^T tile (16 d x 32 tokens), B = P   (32 tokens x 16 heads)
+// The two 16-token K tiles of a group take tokens {8w+r} and {8w+4+r} (w = lane>>4)
+// so that the S accumulators of a lane *are* its P.V B-fragment (8 consecutive
+// tokens) — no cross-lane traffic between the two MFMA chains.  V is stored
+// channel-major per block so the V^T fragment is one 16-byte load.
+// INT8: K/V bytes are widened in-register (v_perm + exact fp16 add), the per-token
+// scales are applied to S (K) and to P (V) in fp32.
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+struct AttnParams {
+    const f16*     q;
+    const void*    kv_base;
+    const float*   scale_base;
+    const int32_t* block_table;
+    const int32_t* seq_lens;
+    f16*           out;
+    float*         tmp_out; // [B][nh][P][hd]
+    float*         tmp_ml;  // [B][nh][P][2]
+    int B, nh, nkv, G, page, max_blocks, P, PS, seq_add;
+    float scale_log2; // softmax scale * log2(e)
+};
+
+constexpr float NEG_BIG = -1e30f;
+
+template <int HD, bool INT8>
+__global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
+    constexpr int NSTEP = HD / 32; // QK k-steps
+    constexpr int NDB   = HD / 16; // PV d-blocks
+    const int part = blockIdx.x, kh = blockIdx.y, b = blockIdx.z;
+    const int seq_len = p.seq_lens[b] + p.seq_add;
+    const int pstart = part * p.PS;
+    if (pstart >= seq_len) return;
+    const int pend = min(seq_len, pstart + p.PS);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, w = lane >> 4;
+
+    // q fragments (B operand): head kh*G + j, zero for j >= G
+    f16x8 qf[NSTEP];
+    {
+        const f16* qrow = p.q + ((size_t)b * p.nh + kh * p.G + (j < p.G ? j : 0)) * HD;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const int d = INT8 ? (s >> 1) * 64 + w * 16 + (s & 1) * 8 : s * 32 + w * 8;
+            f16x8 v = *reinterpret_cast<const f16x8*>(qrow + d);
+            if (j >= p.G) v = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            qf[s] = v;
+        }
+    }
+
+    const int32_t* bt = p.block_table + (size_t)b * p.max_blocks;
+    const size_t head_elems = (size_t)p.page * HD;
+    const char* kvb = (const char*)p.kv_base;
+    constexpr int ES = INT8 ? 1 : 2;
+
+    f32x4 o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    for (int tb = pstart + wave * 32; tb < pend; tb += 128) {
+        // ---- addresses. K rows: lane row i=j -> token window (j>>2), V: window w.
+        const int kwin = tb + (j >> 2) * 8;             // first token of the 8-window of this K row
+        const int vwin = tb + w * 8;                    // first token of this lane's V / P window
+        const int last = seq_len - 1;
+        const int kw_c = min(kwin, last & ~7), vw_c = min(vwin, last & ~7); // clamp whole windows in range
+        const int kblk = bt[kw_c / p.page], vblk = bt[vw_c / p.page];
+        const size_t khead = ((size_t)kblk * 2 + 0) * p.nkv + kh;
+        const size_t vhead = ((size_t)vblk * 2 + 1) * p.nkv + kh;
+
+        // ---- K loads: tile tau row j -> token kw_c + (j&3) + 4*tau
+        u32x4 kf[2][INT8 ? NSTEP / 2 : NSTEP];
+#pragma unroll
+        for (int tau = 0; tau < 2; ++tau) {
+            const int tok_in = (kw_c % p.page) + (j & 3) + 4 * tau;
+            const char* krow = kvb + (khead * head_elems + (size_t)tok_in * HD) * ES;
+            if (INT8) {
+#pragma unroll
+                for (int sp = 0; sp < NSTEP / 2; ++sp) kf[tau][sp] = *reinterpret_cast<const u32x4*>(krow + sp * 64 + w * 16);
+            } else {
+#pragma unroll
+                for (int s = 0; s < NSTEP; ++s) kf[tau][s] = *reinterpret_cast<const u32x4*>(krow + (s * 32 + w * 8) * 2);
+            }
+        }
+        // ---- V loads: d-block db row j (channel db*16+j), tokens vw_c .. vw_c+7
+        u32x4 vf16[INT8 ? 1 : NDB];
+        u32x2 vf8[INT8 ? NDB : 1];
+        {
+            const int tok_in = vw_c % p.page;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const char* vrow = kvb + (vhead * head_elems + (size_t)(db * 16 + j) * p.page + tok_in) * ES;
+                if (INT8) vf8[db] = *reinterpret_cast<const u32x2*>(vrow);
+                else      vf16[db] = *reinterpret_cast<const u32x4*>(vrow);
+            }
+        }
+        // ---- INT8 scales: S rows of this lane are tokens vwin + {r, 4+r}; P slots the same 8 tokens
+        f32x4 ksc[2], vsc[2];
+        if (INT8) {
+            // scale plane: [blk][K|V][nkv][page]; this lane's S/P tokens sit in window w -> block vblk
+            const float* ks = p.scale_base + (((size_t)vblk * 2 + 0) * p.nkv + kh) * p.page + (vw_c % p.page);
+            const float* vs = p.scale_base + (((size_t)vblk * 2 + 1) * p.nkv + kh) * p.page + (vw_c % p.page);
+            ksc[0] = *reinterpret_cast<const f32x4*>(ks); ksc[1] = *reinterpret_cast<const f32x4*>(ks + 4);
+            vsc[0] = *reinterpret_cast<const f32x4*>(vs); vsc[1] = *reinterpret_cast<const f32x4*>(vs + 4);
+        }
+
+        // ---- S^T = K q^T
+        f32x4 sacc[2];
+#pragma unroll
+        for (int tau = 0; tau < 2; ++tau) {
+            sacc[tau] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                f16x8 a;
+                if (INT8) {
+                    const u32x4 kk = kf[tau][s >> 1];
+                    const uint32_t lo = kk[(s & 1) * 2] ^ 0x80808080u, hi = kk[(s & 1) * 2 + 1] ^ 0x80808080u;
+                    const f16x2 zneg2 = {(f16)-1152.f, (f16)-1152.f};
+                    a = dequant_w8<false>(lo, hi, zneg2, zneg2);
+                } else {
+                    a = __builtin_bit_cast(f16x8, kf[tau][s]);
+                }
+                sacc[tau] = mfma16x16x32(a, qf[s], sacc[tau]);
+            }
+        }
+        // ---- scale, mask, online softmax (log2 domain)
+        float sv[8];
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int tau = 0; tau < 2; ++tau)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = sacc[tau][r] * p.scale_log2;
+                if (INT8) v *= ksc[tau][r];
+                const int tok = vwin + tau * 4 + r;
+                v = tok < seq_len ? v : NEG_BIG;
+                sv[tau * 4 + r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        f16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool valid = vwin + e < seq_len;
+            float pe = valid ? __builtin_amdgcn_exp2f(sv[e] - m_new) : 0.f;
+            psum += pe;
+            if (INT8) pe = valid ? pe * vsc[e >> 2][e & 3] : 0.f; // scale bytes past seq_len may be garbage
+            pf[e] = (f16)pe;
+        }
+        l_run = l_run * alpha + psum;
+        // ---- O^T = alpha * O^T + V^T P
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            f16x8 a;
+            if (INT8) {
+                const f16x2 zneg2 = {(f16)-1152.f, (f16)-1152.f};
+                a = dequant_w8<false>(vf8[db][0] ^ 0x80808080u, vf8[db][1] ^ 0x80808080u, zneg2, zneg2);
+            } else {
+                a = __builtin_bit_cast(f16x8, vf16[db]);
+            }
+            // tokens past seq_len carry p = 0 but V bytes there may be garbage (NaN/Inf): zero them
+            if (vwin + 7 >= seq_len) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (vwin + e >= seq_len) a[e] = (f16)0.f;
+            }
+            o[db] = mfma16x16x32(a, pf, o[db] * alpha);
+        }
+    }
+
+    // ---- merge the 4 waves through LDS.  o[db][r] is O^T[d = db*16 + w*4 + r][j].
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+    __shared__ float s_o[4][16][HD + 4];
+    __shared__ float s_m[4][16], s_l[4][16];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+        *reinterpret_cast<f32x4*>(&s_o[wave][j][db * 16 + w * 4]) = o[db];
+    if (w == 0) { s_m[wave][j] = m_run; s_l[wave][j] = l_run; }
+    __syncthreads();
+    // thread -> (head jj, 4 channels); 16 heads * HD/4 vectors
+    for (int idx = tid; idx < p.G * (HD / 4); idx += 256) {
+        const int jj = idx / (HD / 4), d0 = (idx - jj * (HD / 4)) * 4;
+        float mstar = fmaxf(fmaxf(s_m[0][jj], s_m[1][jj]), fmaxf(s_m[2][jj], s_m[3][jj]));
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float l = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const float f = __builtin_amdgcn_exp2f(s_m[ww][jj] - mstar);
+            acc += *reinterpret_cast<const f32x4*>(&s_o[ww][jj][d0]) * f;
+            l += s_l[ww][jj] * f;
+        }
+        const int h = kh * p.G + jj;
+        if (p.P == 1) {
+            const float inv = 1.f / l;
+            f16x4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = (f16)(acc[r] * inv);
+            *reinterpret_cast<f16x4*>(p.out + ((size_t)b * p.nh + h) * HD + d0) = ov;
+        } else {
+            const size_t slot = ((size_t)b * p.nh + h) * p.P + part;
+            *reinterpret_cast<f32x4*>(p.tmp_out + slot * HD + d0) = acc;
+            if (d0 == 0) { p.tmp_ml[slot * 2] = mstar; p.tmp_ml[slot * 2 + 1] = l; }
+        }
+    }
+}
+
+// Merge partitions: one wave per (sequence, head); lane owns HD/64 channels.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_reduce_kernel(const AttnParams p) {
+    const int lane = threadIdx.x & 63;
+    const int gid = blockIdx.x * 4 + (threadIdx.x >> 6); // (b, h)
+    if (gid >= p.B * p.nh) return;
+    const int b = gid / p.nh;
+    const int np = (p.seq_lens[b] + p.seq_add + p.PS - 1) / p.PS;
+    const float* ml = p.tmp_ml + (size_t)gid * p.P * 2;
+    float mstar = NEG_BIG;
+    for (int i = 0; i < np; ++i) mstar = fmaxf(mstar, ml[i * 2]);
+    constexpr int CPL = HD / 64;
+    float acc[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+    float l = 0.f;
+    for (int i = 0; i < np; ++i) {
+        const float f = __builtin_amdgcn_exp2f(ml[i * 2] - mstar);
+        l += ml[i * 2 + 1] * f;
+        const float* src = p.tmp_out + ((size_t)gid * p.P + i) * HD + lane * CPL;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[c] += src[c] * f;
+    }
+    const float inv = 1.f / l;
+    f16* dst = p.out + (size_t)gid * HD + lane * CPL;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) dst[c] = (f16)(acc[c] * inv);
+}
+
+int plan_partitions(int B, int nkv, int max_seq_len, int* ps_out) {
+    // enough blocks to fill 256 CUs (~4 blocks per CU), partitions of 128..1024 tokens
+    int PS = 1024;
+    while (PS > 128 && (long)B * nkv * cdiv(max_seq_len, PS) < 1024) PS >>= 1;
+    *ps_out = PS;
+    return cdiv(max_seq_len, PS);
+}
+
+} // namespace
+
+extern "C" size_t mi355_paged_attn_workspace_bytes(int32_t B, int32_t nh, int32_t hd, int32_t max_seq_len) {
+    if (B <= 0 || nh <= 0 || hd <= 0 || max_seq_len <= 0) return 0;
+    const int P = cdiv(max_seq_len, 128); // upper bound over every plan
+    return (size_t)B * nh * P * (hd + 2) * sizeof(float);
+}
+
+extern "C" int mi355_paged_decode_attn(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_table,
+                                       int32_t max_blocks_per_seq, const int32_t* seq_lens, int32_t B, int32_t nh,
+                                       float scale, int32_t max_seq_len, void* out, void* workspace,
+                                       size_t workspace_bytes, mi355_stream_t stream) {
+    return mi355_paged_decode_attn_ex(q, kv, block_table, max_blocks_per_seq, seq_lens, 0, B, nh, scale, max_seq_len, out,
+                                      workspace, workspace_bytes, stream);
+}
+
+extern "C" int mi355_paged_decode_attn_ex(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_table,
+                                          int32_t max_blocks_per_seq, const int32_t* seq_lens, int32_t seq_lens_minus_one,
+                                          int32_t B, int32_t nh, float scale, int32_t max_seq_len, void* out,
+                                          void* workspace, size_t workspace_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(q && kv && kv->kv_base && block_table && seq_lens && out, "paged_decode_attn: null pointer");
+    MI355_CHECK_ARG(kv->hd == 64 || kv->hd == 128, "paged_decode_attn: hd=%d (64 or 128)", kv->hd);
+    MI355_CHECK_ARG(kv->page >= 16 && kv->page % 8 == 0, "paged_decode_attn: page=%d (>= 16, multiple of 8)", kv->page);
+    MI355_CHECK_ARG(B > 0 && nh > 0 && kv->nkv > 0 && nh % kv->nkv == 0 && nh / kv->nkv <= 16,
+                    "paged_decode_attn: nh=%d nkv=%d (group <= 16)", nh, kv->nkv);
+    MI355_CHECK_ARG(max_seq_len > 0 && (long)max_blocks_per_seq * kv->page >= max_seq_len,
+                    "paged_decode_attn: max_seq_len=%d exceeds block table", max_seq_len);
+    const bool int8 = kv->kv_dtype == MI355_KV_INT8;
+    MI355_CHECK_ARG(!int8 || kv->scale_base, "paged_decode_attn: int8 cache needs scale_base");
+    AttnParams p;
+    p.q = (const f16*)q; p.kv_base = kv->kv_base; p.scale_base = kv->scale_base; p.block_table = block_table;
+    p.seq_lens = seq_lens; p.out = (f16*)out; p.B = B; p.nh = nh; p.nkv = kv->nkv; p.G = nh / kv->nkv;
+    p.page = kv->page; p.max_blocks = max_blocks_per_seq; p.seq_add = seq_lens_minus_one ? 1 : 0;
+    p.P = plan_partitions(B, kv->nkv, max_seq_len, &p.PS);
+    p.scale_log2 = scale * 1.4426950408889634f;
+    const size_t need = p.P > 1 ? (size_t)B * nh * p.P * (kv->hd + 2) * sizeof(float) : 0;
+    if (need > workspace_bytes || (need && !workspace)) {
+        mi355_set_error("paged_decode_attn: workspace %zu < %zu", workspace_bytes, need);
+        return MI355_ERR_WORKSPACE;
+    }
+    p.tmp_out = (float*)workspace;
+    p.tmp_ml  = p.tmp_out + (size_t)B * nh * p.P * kv->hd;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(p.P, kv->nkv, B);
+#define L_(HD_, I8_) hipLaunchKernelGGL((paged_attn_kernel<HD_, I8_>), grid, dim3(256), 0, st, p)
+    if (kv->hd == 128) { if (int8) L_(128, true); else L_(128, false); }
+    else               { if (int8) L_(64, true);  else L_(64, false); }
+#undef L_
+    MI355_CHECK_LAUNCH("paged_attn_kernel");
+    if (p.P > 1) {
+        const int nblk = cdiv(B * nh, 4);
+        if (kv->hd == 128) hipLaunchKernelGGL(attn_reduce_kernel<128>, dim3(nblk), dim3(256), 0, st, p);
+        else               hipLaunchKernelGGL(attn_reduce_kernel<64>, dim3(nblk), dim3(256), 0, st, p);
+        MI355_CHECK_LAUNCH("attn_reduce_kernel");
+    }
+    return MI355_OK;
+}

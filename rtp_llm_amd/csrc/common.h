@@ -1,0 +1,94 @@
+// Shared device/host helpers for libmi355_decode.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/mi355_decode.h"
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float    f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define MI355_WAVE 64
+
+// host-side error plumbing -------------------------------------------------
+void mi355_set_error(const char* fmt, ...);
+
+#define MI355_CHECK_ARG(cond, ...)            \
+    do {                                      \
+        if (!(cond)) {                        \
+            mi355_set_error(__VA_ARGS__);     \
+            return MI355_ERR_ARG;             \
+        }                                     \
+    } while (0)
+
+#define MI355_CHECK_LAUNCH(name)                                                  \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            mi355_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return MI355_ERR_HIP;                                                 \
+        }                                                                         \
+    } while (0)
+
+// device helpers -------------------------------------------------------------
+__device__ __forceinline__ uint32_t as_u32(f16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ f16x2 as_h2(uint32_t v) { return __builtin_bit_cast(f16x2, v); }
+
+__device__ __forceinline__ f32x4 mfma16x16x32(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// 8 unsigned nibbles (native W4 order: nibble e at bit 4*(e/2)+16*(e&1)) -> 8 fp16
+// holding scale * (u - z) with zneg2 = {-(1024+z)} x2, s2 = {scale} x2.
+// (u | 0x6400) is the fp16 1024+u exactly; the add is exact; one rounding in the mul.
+__device__ __forceinline__ f16x8 dequant_w4(uint32_t w, f16x2 zneg2, f16x2 s2) {
+    const uint32_t M = 0x000F000Fu, E = 0x64006400u;
+    f16x2 h0 = as_h2((w & M) | E);
+    f16x2 h1 = as_h2(((w >> 4) & M) | E);
+    f16x2 h2 = as_h2(((w >> 8) & M) | E);
+    f16x2 h3 = as_h2(((w >> 12) & M) | E);
+    h0 = (h0 + zneg2) * s2;
+    h1 = (h1 + zneg2) * s2;
+    h2 = (h2 + zneg2) * s2;
+    h3 = (h3 + zneg2) * s2;
+    f16x8 r;
+    r[0] = h0[0]; r[1] = h0[1]; r[2] = h1[0]; r[3] = h1[1];
+    r[4] = h2[0]; r[5] = h2[1]; r[6] = h3[0]; r[7] = h3[1];
+    return r;
+}
+
+// 8 offset-binary bytes (lo dword = e0..e3, hi dword = e4..e7) -> 8 fp16 (u - z) [* scale]
+template <bool SCALE>
+__device__ __forceinline__ f16x8 dequant_w8(uint32_t lo, uint32_t hi, f16x2 zneg2, f16x2 s2) {
+    // v_perm_b32: bytes of {S0,S1}: selectors 0-3 pick S1 bytes, 4-7 pick S0 bytes.
+    const uint32_t C = 0x64646464u;
+    f16x2 h0 = as_h2(__builtin_amdgcn_perm(C, lo, 0x04010400u)); // [b0,0x64,b1,0x64]
+    f16x2 h1 = as_h2(__builtin_amdgcn_perm(C, lo, 0x04030402u)); // [b2,0x64,b3,0x64]
+    f16x2 h2 = as_h2(__builtin_amdgcn_perm(C, hi, 0x04010400u));
+    f16x2 h3 = as_h2(__builtin_amdgcn_perm(C, hi, 0x04030402u));
+    h0 = h0 + zneg2; h1 = h1 + zneg2; h2 = h2 + zneg2; h3 = h3 + zneg2;
+    if (SCALE) { h0 = h0 * s2; h1 = h1 * s2; h2 = h2 * s2; h3 = h3 * s2; }
+    f16x8 r;
+    r[0] = h0[0]; r[1] = h0[1]; r[2] = h1[0]; r[3] = h1[1];
+    r[4] = h2[0]; r[5] = h2[1]; r[6] = h3[0]; r[7] = h3[1];
+    return r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

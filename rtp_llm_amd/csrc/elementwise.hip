@@ -1,0 +1,234 @@
+// Row-wise fused epilogue kernels of the decode layer: (split-K reduce +) bias +
+// residual add + RMSNorm, SiLU-gate, embedding gather, greedy argmax.  gfx950.
+//
+// These are launch/latency-bound (M <= 64 rows of a few KB); the design goal is
+// to need as few launches per layer as possible, so the split-K reduction of the
+// preceding GEMM and the residual add are folded into the norm kernel.
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+// ---------------------------------------------------------------- RMSNorm
+// Reference numerics (rtp_llm/models_py/modules/base/common/norm.py:83-92):
+//   var = mean(x_f32^2); xn = (x_f32 * rsqrt(var + eps)).to(fp16); y = weight * xn
+// One block (256 threads) per row; each thread owns 8-element vectors.
+template <int VPT> // vectors (of 8 halfs) per thread
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(const f16* __restrict__ x, const float* __restrict__ partials,
+                                                          int nsplit, int ld, int M, const f16* __restrict__ bias,
+                                                          const f16* __restrict__ res_in, f16* __restrict__ res_out,
+                                                          const f16* __restrict__ weight, float eps, int H,
+                                                          f16* __restrict__ y) {
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int nvec = H >> 3;
+    float v[VPT][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int t = 0; t < VPT; ++t) {
+        const int vi = tid + t * 256;
+        if (vi < nvec) {
+            const int c0 = vi * 8;
+            if (partials) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[t][e] = 0.f;
+                for (int s = 0; s < nsplit; ++s) {
+                    const float* src = partials + ((size_t)s * M + row) * ld + c0;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[t][e] += a[e]; v[t][4 + e] += b[e]; }
+                }
+            } else {
+                const f16x8 a = *reinterpret_cast<const f16x8*>(x + (size_t)row * H + c0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[t][e] = (float)a[e];
+            }
+            if (bias) {
+                const f16x8 b = *reinterpret_cast<const f16x8*>(bias + c0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[t][e] += (float)b[e];
+            }
+            if (partials) { // the GEMM output is an fp16 tensor in the reference: round once
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[t][e] = (float)(f16)v[t][e];
+            }
+            if (res_in) {
+                const f16x8 r = *reinterpret_cast<const f16x8*>(res_in + (size_t)row * H + c0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[t][e] = (float)(f16)(v[t][e] + (float)r[e]);
+            }
+            if (res_out) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)v[t][e];
+                *reinterpret_cast<f16x8*>(res_out + (size_t)row * H + c0) = o;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += v[t][e] * v[t][e];
+        }
+    }
+    __shared__ float red[4];
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float rs = rsqrtf(tot / (float)H + eps);
+    if (!y) return;
+#pragma unroll
+    for (int t = 0; t < VPT; ++t) {
+        const int vi = tid + t * 256;
+        if (vi < nvec) {
+            const int c0 = vi * 8;
+            const f16x8 w = *reinterpret_cast<const f16x8*>(weight + c0);
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = w[e] * (f16)(v[t][e] * rs);
+            *reinterpret_cast<f16x8*>(y + (size_t)row * H + c0) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void silu_mul_kernel(const f16* __restrict__ gu, int M, int I, f16* __restrict__ out) {
+    const int nvec = I >> 3;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * nvec) return;
+    const int m = idx / nvec, c0 = (idx - m * nvec) * 8;
+    const f16x8 g = *reinterpret_cast<const f16x8*>(gu + (size_t)m * 2 * I + c0);
+    const f16x8 u = *reinterpret_cast<const f16x8*>(gu + (size_t)m * 2 * I + I + c0);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float gf = (float)g[e];
+        o[e] = (f16)((gf / (1.f + __expf(-gf))) * (float)u[e]);
+    }
+    *reinterpret_cast<f16x8*>(out + (size_t)m * I + c0) = o;
+}
+
+__global__ __launch_bounds__(256) void embedding_kernel(const int32_t* __restrict__ ids, int T, const f16* __restrict__ table,
+                                                        int H, int vocab, f16* __restrict__ out) {
+    const int nvec = H >> 3;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * nvec) return;
+    const int t = idx / nvec, c0 = (idx - t * nvec) * 8;
+    int id = ids[t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    *reinterpret_cast<f16x8*>(out + (size_t)t * H + c0) = *reinterpret_cast<const f16x8*>(table + (size_t)id * H + c0);
+}
+
+// ---------------------------------------------------------------- argmax
+// Stage 1: grid (B, 64): each block scans a contiguous 1/64 of the row.
+// Stage 2: one wave per row picks the best of the 64 candidates.
+// Ties resolve to the lowest index (torch.argmax on this platform returns the first max).
+__device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+__global__ __launch_bounds__(256) void argmax_stage1(const float* __restrict__ logits, int V, int ld, float* __restrict__ cand_v,
+                                                     int* __restrict__ cand_i) {
+    const int b = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
+    const int per = ((V + nparts - 1) / nparts + 3) & ~3;
+    const int lo = part * per, hi = min(V, lo + per);
+    const float* row = logits + (size_t)b * ld;
+    float bv = -INFINITY; int bi = 0x7FFFFFFF;
+    for (int i = lo + threadIdx.x * 4; i < hi; i += 256 * 4) {
+        if (i + 3 < hi) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (v[e] > bv) { bv = v[e]; bi = i + e; }
+        } else {
+            for (int e = 0; e < 4 && i + e < hi; ++e) if (row[i + e] > bv) { bv = row[i + e]; bi = i + e; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+        argmax_combine(bv, bi, ov, oi);
+    }
+    __shared__ float sv[4]; __shared__ int si[4];
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) argmax_combine(bv, bi, sv[w], si[w]);
+        cand_v[b * nparts + part] = bv; cand_i[b * nparts + part] = bi;
+    }
+}
+
+__global__ __launch_bounds__(64) void argmax_stage2(const float* __restrict__ cand_v, const int* __restrict__ cand_i, int nparts,
+                                                    int32_t* __restrict__ ids, int32_t* __restrict__ positions) {
+    const int b = blockIdx.x, l = threadIdx.x;
+    float bv = l < nparts ? cand_v[b * nparts + l] : -INFINITY;
+    int bi = l < nparts ? cand_i[b * nparts + l] : 0x7FFFFFFF;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+        argmax_combine(bv, bi, ov, oi);
+    }
+    if (l == 0) {
+        ids[b] = bi;
+        if (positions) positions[b] += 1;
+    }
+}
+
+} // namespace
+
+extern "C" int mi355_add_rmsnorm(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
+                                 const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M,
+                                 int32_t H, void* y, mi355_stream_t stream) {
+    MI355_CHECK_ARG((x_f16 != nullptr) != (partials != nullptr), "add_rmsnorm: exactly one of x_f16 / partials");
+    MI355_CHECK_ARG(M > 0 && H > 0 && H % 8 == 0 && H <= 8 * 256 * 4, "add_rmsnorm: M=%d H=%d (H %% 8 == 0, H <= 8192)", M, H);
+    MI355_CHECK_ARG(!partials || (nsplit >= 1 && ld >= H && ld % 4 == 0), "add_rmsnorm: nsplit=%d ld=%d", nsplit, ld);
+    MI355_CHECK_ARG(!y || weight, "add_rmsnorm: weight required");
+    hipStream_t st = (hipStream_t)stream;
+    const int vpt = cdiv(H / 8, 256);
+#define L_(V)                                                                                                        \
+    hipLaunchKernelGGL(add_rmsnorm_kernel<V>, dim3(M), dim3(256), 0, st, (const f16*)x_f16, partials, nsplit, ld, M, \
+                       (const f16*)bias, (const f16*)residual_in, (f16*)residual_out, (const f16*)weight, eps, H, (f16*)y)
+    switch (vpt) { case 1: L_(1); break; case 2: L_(2); break; case 3: L_(3); break; default: L_(4); break; }
+#undef L_
+    MI355_CHECK_LAUNCH("add_rmsnorm_kernel");
+    return MI355_OK;
+}
+
+extern "C" int mi355_rmsnorm(const void* x, const void* weight, float eps, int32_t M, int32_t H, void* y,
+                             mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && weight && y, "rmsnorm: null pointer");
+    return mi355_add_rmsnorm(x, nullptr, 0, 0, nullptr, nullptr, nullptr, weight, eps, M, H, y, stream);
+}
+
+extern "C" int mi355_silu_mul(const void* gate_up, int32_t M, int32_t I, void* out, mi355_stream_t stream) {
+    MI355_CHECK_ARG(gate_up && out && M > 0 && I > 0 && I % 8 == 0, "silu_mul: M=%d I=%d", M, I);
+    const int total = M * (I / 8);
+    hipLaunchKernelGGL(silu_mul_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)gate_up, M, I,
+                       (f16*)out);
+    MI355_CHECK_LAUNCH("silu_mul_kernel");
+    return MI355_OK;
+}
+
+extern "C" int mi355_embedding(const int32_t* ids, int32_t T, const void* table, int32_t H, int32_t vocab, void* out,
+                               mi355_stream_t stream) {
+    MI355_CHECK_ARG(ids && table && out && T > 0 && H > 0 && H % 8 == 0 && vocab > 0, "embedding: T=%d H=%d", T, H);
+    const int total = T * (H / 8);
+    hipLaunchKernelGGL(embedding_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, ids, T, (const f16*)table,
+                       H, vocab, (f16*)out);
+    MI355_CHECK_LAUNCH("embedding_kernel");
+    return MI355_OK;
+}
+
+extern "C" int mi355_argmax_ex(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t* ids, int32_t* positions,
+                               void* workspace, size_t workspace_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(logits && ids && workspace && B > 0 && V > 0 && ld >= V && ld % 4 == 0, "argmax: B=%d V=%d ld=%d", B, V, ld);
+    const int nparts = 64;
+    if (workspace_bytes < (size_t)B * nparts * 8) { mi355_set_error("argmax: workspace too small"); return MI355_ERR_WORKSPACE; }
+    float* cv = (float*)workspace; int* ci = (int*)(cv + (size_t)B * nparts);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(argmax_stage1, dim3(B, nparts), dim3(256), 0, st, logits, V, ld, cv, ci);
+    hipLaunchKernelGGL(argmax_stage2, dim3(B), dim3(64), 0, st, (const float*)cv, (const int*)ci, nparts, ids, positions);
+    MI355_CHECK_LAUNCH("argmax");
+    return MI355_OK;
+}
+
+extern "C" int mi355_argmax(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t* ids, void* workspace,
+                            size_t workspace_bytes, mi355_stream_t stream) {
+    return mi355_argmax_ex(logits, B, V, ld, ids, nullptr, workspace, workspace_bytes, stream);
+}

@@ -1,0 +1,298 @@
+// Decode-step driver: enqueues one whole decode step of a Qwen2/Llama-style decoder
+// from C++ and replays it as a hipGraph.
+//
+// Scope: the body of Qwen3Model.forward / Qwen3DecoderLayer.forward
+// (rtp_llm/models_py/model_desc/qwen3.py:57-79,124-138), CausalAttention.forward
+// (modules/hybrid/causal_attention.py:75-93), DenseMLP.forward
+// (modules/hybrid/dense_mlp.py:95-106), lm_head + greedy
+// (rtp_llm/cpp/models/PyWrappedModel.cc:938-1080, bindings/core/CudaSampleOp.cc:687-700)
+// and the per-batch-size graph capture of rtp_llm/cpp/cuda_graph/cuda_graph_runner.cc.
+//
+// Launches per layer (tp = 1): QKV GEMM (split-K slabs) -> reduce+bias+RoPE+KV-write ->
+// paged attention (+ partition reduce) -> O GEMM (slabs) -> reduce+residual+RMSNorm ->
+// gate_up GEMM with fused SiLU-gate -> down GEMM (slabs) -> reduce+residual+RMSNorm
+// (already the next layer's input norm).  No standalone reduce / add / activation kernels.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include <map>
+#include <new>
+#include <vector>
+#include "internal.h"
+
+void mi355_set_error(const char* fmt, ...);
+
+namespace {
+constexpr int kMaxSplits = 16;
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+inline int    imax(int a, int b) { return a > b ? a : b; }
+} // namespace
+
+struct mi355_decoder {
+    mi355_model_config_t               cfg;
+    std::vector<mi355_layer_weights_t> layers;
+    mi355_model_weights_t              model;
+    mi355_step_buffers_t               bufs;
+    // carved workspace
+    void *resid, *xn, *q_buf, *attn_out, *act, *attn_ws, *argmax_ws;
+    float* partials;
+    size_t attn_ws_bytes, argmax_ws_bytes;
+    int    B;
+    // graphs
+    hipStream_t                    cap_stream;
+    std::map<int, hipGraphExec_t>  graphs;
+    // profiling
+    bool                     prof_on;
+    std::vector<hipEvent_t>  ev;
+    std::vector<int>         ev_class;
+    size_t                   ev_used;
+};
+
+namespace {
+
+struct Carve {
+    char*  base;
+    size_t off;
+    void*  take(size_t bytes) {
+        void* p = base ? base + off : nullptr;
+        off += align256(bytes);
+        return p;
+    }
+};
+
+size_t carve_all(mi355_decoder* d, const mi355_model_config_t& c, void* base) {
+    Carve cv{(char*)base, 0};
+    const size_t MB_ = (size_t)c.max_batch;
+    const int qdim = c.nh * c.hd, qkvdim = (c.nh + 2 * c.nkv) * c.hd;
+    const int npad = (imax(qkvdim, c.hidden) + 15) & ~15;
+    void* resid    = cv.take(MB_ * c.hidden * 2);
+    void* xn       = cv.take(MB_ * c.hidden * 2);
+    void* q_buf    = cv.take(MB_ * qdim * 2);
+    void* attn_out = cv.take(MB_ * qdim * 2);
+    void* act      = cv.take(MB_ * c.inter * 2);
+    void* partials = cv.take((size_t)kMaxSplits * MB_ * npad * 4);
+    const size_t aw = mi355_paged_attn_workspace_bytes(c.max_batch, c.nh, c.hd, c.max_seq_len);
+    void* attn_ws  = cv.take(aw);
+    const size_t gw = MB_ * 64 * 8;
+    void* argmax_ws = cv.take(gw);
+    if (d) {
+        d->resid = resid; d->xn = xn; d->q_buf = q_buf; d->attn_out = attn_out; d->act = act;
+        d->partials = (float*)partials; d->attn_ws = attn_ws; d->attn_ws_bytes = aw;
+        d->argmax_ws = argmax_ws; d->argmax_ws_bytes = gw;
+    }
+    return cv.off;
+}
+
+// run one op, optionally bracketed by events for the per-class profile
+template <class F>
+int run_op(mi355_decoder* d, int kclass, hipStream_t st, F&& f) {
+    if (!d->prof_on) return f();
+    if (d->ev_used + 2 > d->ev.size()) {
+        for (int i = 0; i < 2; ++i) { hipEvent_t e; hipEventCreate(&e); d->ev.push_back(e); }
+    }
+    hipEventRecord(d->ev[d->ev_used], st);
+    const int rc = f();
+    hipEventRecord(d->ev[d->ev_used + 1], st);
+    d->ev_class.push_back(kclass);
+    d->ev_used += 2;
+    return rc;
+}
+
+#define RUN(kclass, expr)                                                  \
+    do {                                                                   \
+        int rc__ = run_op(d, kclass, st, [&]() -> int { return (expr); }); \
+        if (rc__ < 0) return rc__;                                         \
+    } while (0)
+
+mi355_kv_layer_t kv_of(const mi355_decoder* d, int l) {
+    mi355_kv_layer_t kv;
+    kv.kv_base = d->layers[l].kv_base; kv.scale_base = d->layers[l].kv_scale_base;
+    kv.kv_dtype = d->cfg.kv_dtype; kv.page = d->cfg.page; kv.nkv = d->cfg.nkv; kv.hd = d->cfg.hd;
+    kv.num_blocks = d->cfg.num_blocks;
+    return kv;
+}
+
+} // namespace
+
+extern "C" size_t mi355_decoder_workspace_bytes(const mi355_model_config_t* cfg) {
+    if (!cfg) return 0;
+    return carve_all(nullptr, *cfg, nullptr);
+}
+
+extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg, const mi355_layer_weights_t* layers,
+                                                 const mi355_model_weights_t* model, const mi355_step_buffers_t* bufs) {
+    if (!cfg || !layers || !model || !bufs) { mi355_set_error("decoder_create: null argument"); return nullptr; }
+    if (cfg->num_layers <= 0 || cfg->max_batch <= 0 || cfg->max_batch > 64) {
+        mi355_set_error("decoder_create: num_layers=%d max_batch=%d (1..64)", cfg->num_layers, cfg->max_batch);
+        return nullptr;
+    }
+    if (cfg->nh % cfg->nkv != 0 || cfg->nh / cfg->nkv > 16 || (cfg->hd != 64 && cfg->hd != 128)) {
+        mi355_set_error("decoder_create: nh=%d nkv=%d hd=%d unsupported", cfg->nh, cfg->nkv, cfg->hd);
+        return nullptr;
+    }
+    const size_t need = carve_all(nullptr, *cfg, nullptr);
+    if (!bufs->workspace || bufs->workspace_bytes < need) {
+        mi355_set_error("decoder_create: workspace %zu < %zu", bufs->workspace_bytes, need);
+        return nullptr;
+    }
+    if (!bufs->token_ids || !bufs->positions || !bufs->block_table || !bufs->logits || !bufs->hidden ||
+        (cfg->tp_size > 1 && !bufs->ar_buf)) {
+        mi355_set_error("decoder_create: missing step buffer");
+        return nullptr;
+    }
+    mi355_decoder* d = new (std::nothrow) mi355_decoder();
+    if (!d) return nullptr;
+    d->cfg = *cfg; d->layers.assign(layers, layers + cfg->num_layers); d->model = *model; d->bufs = *bufs;
+    carve_all(d, *cfg, bufs->workspace);
+    d->xn = bufs->hidden; // the normed hidden state lives in the caller-visible buffer
+    d->B = 0; d->cap_stream = nullptr; d->prof_on = false; d->ev_used = 0;
+    return d;
+}
+
+extern "C" void mi355_decoder_destroy(mi355_decoder_t* d) {
+    if (!d) return;
+    for (auto& kv : d->graphs) hipGraphExecDestroy(kv.second);
+    if (d->cap_stream) hipStreamDestroy(d->cap_stream);
+    for (auto e : d->ev) hipEventDestroy(e);
+    delete d;
+}
+
+extern "C" int mi355_decoder_begin(mi355_decoder_t* d, int32_t B, mi355_stream_t stream) {
+    if (!d || B <= 0 || B > d->cfg.max_batch) { mi355_set_error("decoder_begin: B=%d", B); return MI355_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    d->B = B;
+    const auto& c = d->cfg;
+    RUN(MI355_KC_OTHER, mi355_embedding(d->bufs.token_ids, B, d->model.embedding, c.hidden, d->model.vocab_full, d->resid, st));
+    if (c.tp_size == 1) {
+        RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, d->layers[0].input_norm, c.rms_eps, B, c.hidden, d->xn, st));
+    }
+    return MI355_OK;
+}
+
+extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_stream_t stream) {
+    if (!d || l < 0 || l >= d->cfg.num_layers || d->B <= 0) { mi355_set_error("decoder_layer_attn: layer=%d", l); return MI355_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const auto& c = d->cfg; const auto& L = d->layers[l]; const int B = d->B;
+    if (c.tp_size > 1) {
+        if (l == 0) RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, L.input_norm, c.rms_eps, B, c.hidden, d->xn, st));
+        else RUN(MI355_KC_NORM, mi355_add_rmsnorm(d->bufs.ar_buf, nullptr, 0, 0, nullptr, d->resid, d->resid, L.input_norm,
+                                                   c.rms_eps, B, c.hidden, d->xn, st));
+    }
+    int ns = 0;
+    RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->xn, B, &L.qkv, d->partials, kMaxSplits, st));
+    mi355_kv_layer_t kv = kv_of(d, l);
+    RUN(MI355_KC_ROPE_KV, mi355_rope_kv_write(nullptr, d->partials, ns, L.qkv.N_pad, L.qkv_bias, d->model.cos_sin, c.rope_dim,
+                                              d->bufs.positions, d->bufs.block_table, c.max_blocks_per_seq, B, c.nh, &kv,
+                                              d->q_buf, st));
+    RUN(MI355_KC_ATTN, mi355_paged_decode_attn_ex(d->q_buf, &kv, d->bufs.block_table, c.max_blocks_per_seq, d->bufs.positions,
+                                                  1, B, c.nh, 1.0f / sqrtf((float)c.hd), c.max_seq_len, d->attn_out,
+                                                  d->attn_ws, d->attn_ws_bytes, st));
+    RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->attn_out, B, &L.o, d->partials, kMaxSplits, st));
+    if (c.tp_size == 1) {
+        RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid, L.post_norm,
+                                             c.rms_eps, B, c.hidden, d->xn, st));
+    } else { // local split-K reduce -> fp16 tensor for the TP all-reduce
+        RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.o.N_pad, nullptr, nullptr, d->bufs.ar_buf, nullptr,
+                                             c.rms_eps, B, c.hidden, nullptr, st));
+    }
+    return MI355_OK;
+}
+
+extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stream_t stream) {
+    if (!d || l < 0 || l >= d->cfg.num_layers || d->B <= 0) { mi355_set_error("decoder_layer_mlp: layer=%d", l); return MI355_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const auto& c = d->cfg; const auto& L = d->layers[l]; const int B = d->B;
+    if (c.tp_size > 1) {
+        RUN(MI355_KC_NORM, mi355_add_rmsnorm(d->bufs.ar_buf, nullptr, 0, 0, nullptr, d->resid, d->resid, L.post_norm, c.rms_eps,
+                                             B, c.hidden, d->xn, st));
+    }
+    RUN(MI355_KC_GEMM_QUANT, mi355_linear_direct(d->xn, B, &L.gate_up, nullptr, d->act, MI355_EPI_SILU_MUL, st));
+    int ns = 0;
+    RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->act, B, &L.down, d->partials, kMaxSplits, st));
+    if (c.tp_size == 1) {
+        const void* next_norm = (l + 1 < c.num_layers) ? d->layers[l + 1].input_norm : d->model.final_norm;
+        RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
+                                             c.rms_eps, B, c.hidden, d->xn, st));
+    } else {
+        RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.down.N_pad, nullptr, nullptr, d->bufs.ar_buf, nullptr,
+                                             c.rms_eps, B, c.hidden, nullptr, st));
+    }
+    return MI355_OK;
+}
+
+extern "C" int mi355_decoder_finish(mi355_decoder_t* d, int32_t sample, mi355_stream_t stream) {
+    if (!d || d->B <= 0) { mi355_set_error("decoder_finish: no step in flight"); return MI355_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const auto& c = d->cfg; const int B = d->B;
+    if (c.tp_size > 1) {
+        RUN(MI355_KC_NORM, mi355_add_rmsnorm(d->bufs.ar_buf, nullptr, 0, 0, nullptr, d->resid, d->resid, d->model.final_norm,
+                                             c.rms_eps, B, c.hidden, d->xn, st));
+    }
+    RUN(MI355_KC_GEMM_LMHEAD, mi355_linear_direct(d->xn, B, &d->model.lm_head, nullptr, d->bufs.logits, MI355_EPI_OUT_F32, st));
+    if (sample) {
+        RUN(MI355_KC_OTHER, mi355_argmax_ex(d->bufs.logits, B, c.vocab, c.vocab, d->bufs.token_ids, d->bufs.positions,
+                                            d->argmax_ws, d->argmax_ws_bytes, st));
+    }
+    return MI355_OK;
+}
+
+extern "C" int mi355_decoder_step(mi355_decoder_t* d, int32_t B, mi355_stream_t stream) {
+    if (!d || d->cfg.tp_size != 1) { mi355_set_error("decoder_step: tp_size must be 1 (use the segment calls)"); return MI355_ERR_ARG; }
+    int rc = mi355_decoder_begin(d, B, stream);
+    for (int l = 0; rc >= 0 && l < d->cfg.num_layers; ++l) {
+        rc = mi355_decoder_layer_attn(d, l, stream);
+        if (rc >= 0) rc = mi355_decoder_layer_mlp(d, l, stream);
+    }
+    if (rc >= 0) rc = mi355_decoder_finish(d, 1, stream);
+    return rc < 0 ? rc : MI355_OK;
+}
+
+extern "C" int mi355_decoder_capture(mi355_decoder_t* d, int32_t B) {
+    if (!d || B <= 0 || B > d->cfg.max_batch) { mi355_set_error("decoder_capture: B=%d", B); return MI355_ERR_ARG; }
+    if (d->graphs.count(B)) return MI355_OK;
+    if (!d->cap_stream && hipStreamCreateWithFlags(&d->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+        mi355_set_error("decoder_capture: stream create failed"); return MI355_ERR_HIP;
+    }
+    hipError_t e = hipStreamBeginCapture(d->cap_stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { mi355_set_error("decoder_capture: begin: %s", hipGetErrorString(e)); return MI355_ERR_HIP; }
+    const int rc = mi355_decoder_step(d, B, d->cap_stream);
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(d->cap_stream, &g);
+    if (rc < 0) { if (g) hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess || !g) { mi355_set_error("decoder_capture: end: %s", hipGetErrorString(e)); return MI355_ERR_HIP; }
+    hipGraphExec_t ge = nullptr;
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) { mi355_set_error("decoder_capture: instantiate: %s", hipGetErrorString(e)); return MI355_ERR_HIP; }
+    d->graphs[B] = ge;
+    return MI355_OK;
+}
+
+extern "C" int mi355_decoder_replay(mi355_decoder_t* d, int32_t B, int32_t nsteps, mi355_stream_t stream) {
+    if (!d || !d->graphs.count(B)) { mi355_set_error("decoder_replay: no graph for B=%d", B); return MI355_ERR_ARG; }
+    hipGraphExec_t ge = d->graphs[B];
+    for (int i = 0; i < nsteps; ++i) {
+        hipError_t e = hipGraphLaunch(ge, (hipStream_t)stream);
+        if (e != hipSuccess) { mi355_set_error("decoder_replay: %s", hipGetErrorString(e)); return MI355_ERR_HIP; }
+    }
+    return MI355_OK;
+}
+
+extern "C" int mi355_decoder_profile(mi355_decoder_t* d, int32_t B, int32_t nsteps, float* out_ms, int32_t* out_launches,
+                                     mi355_stream_t stream) {
+    if (!d || !out_ms || !out_launches || nsteps <= 0) { mi355_set_error("decoder_profile: bad args"); return MI355_ERR_ARG; }
+    for (int k = 0; k < MI355_KC_COUNT; ++k) { out_ms[k] = 0.f; out_launches[k] = 0; }
+    d->prof_on = true; d->ev_used = 0; d->ev_class.clear();
+    int rc = MI355_OK;
+    for (int i = 0; i < nsteps && rc >= 0; ++i) rc = mi355_decoder_step(d, B, stream);
+    d->prof_on = false;
+    hipStreamSynchronize((hipStream_t)stream);
+    if (rc < 0) return rc;
+    for (size_t i = 0; i < d->ev_class.size(); ++i) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, d->ev[2 * i], d->ev[2 * i + 1]);
+        out_ms[d->ev_class[i]] += ms;
+        out_launches[d->ev_class[i]] += 1;
+    }
+    return MI355_OK;
+}

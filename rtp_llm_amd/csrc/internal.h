@@ -1,0 +1,20 @@
+// Entry points shared between translation units of libmi355_decode.so but not part
+// of the public C-ABI (include/mi355_decode.h).
+#pragma once
+#include "../../include/mi355_decode.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+int mi355_gemm_plan(int M, const mi355_weight_t* w, int max_splits, int* nbw_out, int* cps_out);
+int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_t* w, const void* bias, void* y, int32_t epilogue,
+                        mi355_stream_t stream);
+int mi355_argmax_ex(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t* ids, int32_t* positions, void* workspace,
+                    size_t workspace_bytes, mi355_stream_t stream);
+/* seq_lens_minus_one != 0: seq_lens[] holds tokens already cached (decode "positions"), context = value + 1 */
+int mi355_paged_decode_attn_ex(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_table,
+                               int32_t max_blocks_per_seq, const int32_t* seq_lens, int32_t seq_lens_minus_one, int32_t B,
+                               int32_t nh, float scale, int32_t max_seq_len, void* out, void* workspace,
+                               size_t workspace_bytes, mi355_stream_t stream);
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,123 @@
+// (split-K reduce +) bias + RoPE + Q-extract + paged KV-cache write for decode, gfx950.
+//
+// Replaces FusedRopeKVCacheDecodeOp::forward (rtp_llm/models_py/bindings/rocm/
+// FusedRopeKVCacheOp.cc:519-646 -> add_fusedQKV_bias_transpose_decode_kernel,
+// rocm/kernels/fused_rope_kvcache_kernel.cu:1297-1466) and re-instates the INT8
+// KV branch the reference removed: per-(token, kv-head) fp32 scale
+// = max|x|/127, round-to-nearest-even + saturate (rocm_utils/_cast_to_int8.h:5-24),
+// scale plane [block][K|V][nkv][page] (kv_cache_utils.h:265-271).
+//
+// One wave per (token, head): lane i owns the NeoX pair (i, i + hd/2)
+// (rotary_position_embedding.h:278-321,444-449: x' = cos*x - sin*y, y' = cos*y + sin*x
+// in fp32, one rounding to fp16).  Launch-bound by nature (T*(nh+2nkv) waves).
+#include "common.h"
+
+namespace {
+
+struct RopeParams {
+    const f16*     qkv;
+    const float*   partials;
+    int            nsplit, ld;
+    const f16*     bias;
+    const float*   cos_sin;
+    const int32_t* positions;
+    const int32_t* block_table;
+    int            max_blocks, T, nh, nkv, hd, page;
+    void*          kv_base;
+    float*         scale_base;
+    int            kv_int8;
+    f16*           q_out;
+};
+
+__global__ __launch_bounds__(256) void rope_kv_write_kernel(const RopeParams p) {
+    const int t    = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int h    = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int nheads = p.nh + 2 * p.nkv;
+    if (h >= nheads) return;
+    const int half = p.hd >> 1;
+    const bool act = lane < half;
+    const int col0 = h * p.hd + lane, col1 = col0 + half;
+
+    float x0 = 0.f, x1 = 0.f;
+    if (act) {
+        if (p.partials) {
+            for (int s = 0; s < p.nsplit; ++s) {
+                const float* src = p.partials + ((size_t)s * p.T + t) * p.ld;
+                x0 += src[col0]; x1 += src[col1];
+            }
+        } else {
+            x0 = (float)p.qkv[(size_t)t * p.ld + col0];
+            x1 = (float)p.qkv[(size_t)t * p.ld + col1];
+        }
+        if (p.bias) { x0 += (float)p.bias[col0]; x1 += (float)p.bias[col1]; }
+        // the QKV linear's output is an fp16 tensor in the reference
+        x0 = (float)(f16)x0; x1 = (float)(f16)x1;
+    }
+    const int pos = p.positions[t];
+    const bool is_v = h >= p.nh + p.nkv;
+    if (!is_v && act) {
+        const float2 cs = *reinterpret_cast<const float2*>(p.cos_sin + ((size_t)pos * half + lane) * 2);
+        const float r0 = cs.x * x0 - cs.y * x1;
+        const float r1 = cs.x * x1 + cs.y * x0;
+        x0 = (float)(f16)r0; x1 = (float)(f16)r1;
+    }
+    if (h < p.nh) {
+        if (act) {
+            f16* dst = p.q_out + ((size_t)t * p.nh + h) * p.hd;
+            dst[lane] = (f16)x0; dst[lane + half] = (f16)x1;
+        }
+        return;
+    }
+    // ---- K / V into the paged cache
+    const int kh  = is_v ? h - p.nh - p.nkv : h - p.nh;
+    const int blk = p.block_table[(size_t)t * p.max_blocks + pos / p.page];
+    const int tok = pos % p.page;
+    const size_t head_elems = (size_t)p.page * p.hd;
+    const size_t blk_base   = ((size_t)blk * 2 + (is_v ? 1 : 0)) * p.nkv + kh; // in units of heads
+    int s0, s1; // element offsets inside this head's [page*hd] region
+    if (!is_v) { s0 = tok * p.hd + lane; s1 = s0 + half; }
+    else       { s0 = lane * p.page + tok; s1 = (lane + half) * p.page + tok; }
+    if (!p.kv_int8) {
+        if (act) {
+            f16* dst = (f16*)p.kv_base + blk_base * head_elems;
+            dst[s0] = (f16)x0; dst[s1] = (f16)x1;
+        }
+    } else {
+        float amax = act ? fmaxf(fabsf(x0), fabsf(x1)) : 0.f;
+        amax = wave_max(amax);
+        const float scale = amax > 0.f ? amax / 127.f : 1.f;
+        if (act) {
+            int8_t* dst = (int8_t*)p.kv_base + blk_base * head_elems;
+            const float q0 = fminf(fmaxf(rintf(x0 / scale), -128.f), 127.f);
+            const float q1 = fminf(fmaxf(rintf(x1 / scale), -128.f), 127.f);
+            dst[s0] = (int8_t)q0; dst[s1] = (int8_t)q1;
+        }
+        if (lane == 0) p.scale_base[blk_base * p.page + tok] = scale;
+    }
+}
+
+} // namespace
+
+extern "C" int mi355_rope_kv_write(const void* qkv_f16, const float* partials, int32_t nsplit, int32_t ld,
+                                   const void* qkv_bias, const float* cos_sin, int32_t rope_dim, const int32_t* positions,
+                                   const int32_t* block_table, int32_t max_blocks_per_seq, int32_t T, int32_t nh,
+                                   const mi355_kv_layer_t* kv, void* q_out, mi355_stream_t stream) {
+    MI355_CHECK_ARG((qkv_f16 != nullptr) != (partials != nullptr), "rope_kv_write: exactly one of qkv_f16 / partials");
+    MI355_CHECK_ARG(kv && kv->kv_base && cos_sin && positions && block_table && q_out, "rope_kv_write: null pointer");
+    MI355_CHECK_ARG(kv->hd == 64 || kv->hd == 128, "rope_kv_write: hd=%d (64 or 128)", kv->hd);
+    MI355_CHECK_ARG(rope_dim == kv->hd, "rope_kv_write: rope_dim=%d must equal hd=%d", rope_dim, kv->hd);
+    MI355_CHECK_ARG(kv->page > 0 && T > 0 && nh > 0 && kv->nkv > 0, "rope_kv_write: bad dims");
+    MI355_CHECK_ARG(kv->kv_dtype == MI355_KV_FP16 || (kv->kv_dtype == MI355_KV_INT8 && kv->scale_base),
+                    "rope_kv_write: int8 cache needs scale_base");
+    const int nheads = nh + 2 * kv->nkv;
+    MI355_CHECK_ARG(ld >= nheads * kv->hd, "rope_kv_write: ld=%d", ld);
+    RopeParams p;
+    p.qkv = (const f16*)qkv_f16; p.partials = partials; p.nsplit = nsplit; p.ld = ld; p.bias = (const f16*)qkv_bias;
+    p.cos_sin = cos_sin; p.positions = positions; p.block_table = block_table; p.max_blocks = max_blocks_per_seq;
+    p.T = T; p.nh = nh; p.nkv = kv->nkv; p.hd = kv->hd; p.page = kv->page; p.kv_base = kv->kv_base;
+    p.scale_base = kv->scale_base; p.kv_int8 = kv->kv_dtype == MI355_KV_INT8; p.q_out = (f16*)q_out;
+    hipLaunchKernelGGL(rope_kv_write_kernel, dim3(T, cdiv(nheads, 4)), dim3(256), 0, (hipStream_t)stream, p);
+    MI355_CHECK_LAUNCH("rope_kv_write_kernel");
+    return MI355_OK;
+}

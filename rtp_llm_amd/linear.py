@@ -1,0 +1,142 @@
+"""Linear strategies — same plug-in surface as the reference's LinearFactory
+(rtp_llm/models_py/modules/factory/linear/{linear_base.py:16-102, factory.py:33-145}):
+
+    LinearFactory.register(cls); cls.can_handle(...) must be unique among strategies;
+    cls(weight, weight_scales, input_scales, bias, quant_config, weight_scale_2); forward(x[M,K]) -> [M,N]
+
+The reference has no W4A16/W8A16 strategy in this snapshot (an int8/GPTQ/AWQ weight
+dict matches no strategy and raises); these classes fill that slot on MI355X, plus an fp16
+strategy for unquantised layers (lm_head).  One extension over the reference factory: the
+group-wise zeros (``W.*_z``) must reach the strategy — ``create_linear_from_weights`` forwards
+``zeros_key`` (the reference drops it, factory.py:86-93; SURVEY 8b "Gap").
+"""
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Type
+
+import torch
+from torch import nn
+
+from . import _C, ops, quant
+from .quant import PackedWeight
+
+
+@dataclass
+class QuantConfig:
+    """Subset of rtp_llm/config/quant_config.py:281-300,641-685 that the decode path reads."""
+    method: str = "none"        # "none" | "int8" (load-time autoquant) | "gptq" | "awq"
+    bits: int = 16
+    group_size: int = 0
+
+    def is_quanted(self) -> bool:
+        return self.method != "none"
+
+
+class LinearBase(nn.Module, ABC):
+    @classmethod
+    @abstractmethod
+    def can_handle(cls, quant_config, weight, weight_scales, hw_kernel_config=None, weight_scale_2=None,
+                   input_scale=None) -> bool:
+        ...
+
+    @abstractmethod
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        ...
+
+    def maybe_cache_quant_scale(self, max_len: int) -> None:  # linear_base.py:66-73 (no-op for weight-only)
+        pass
+
+    def __repr__(self) -> str:
+        return self.__class__.__name__
+
+
+class _PackedLinear(LinearBase):
+    """Common forward: one C-ABI call on the packed weight (bias fused in the GEMM epilogue,
+    as the reference applies Qwen2's QKV bias inside the linear, causal_attention.py:42-51)."""
+    packed: PackedWeight
+
+    def _finish_init(self, packed: PackedWeight, bias: Optional[torch.Tensor]):
+        self.packed = packed
+        self.bias = None if bias is None else bias.to(torch.float16).contiguous()
+        self.in_features, self.out_features = packed.K, packed.N
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return ops.linear(input.contiguous(), self.packed, self.bias)
+
+    def forward_silu_mul(self, input: torch.Tensor) -> torch.Tensor:
+        """gate_up projection + SiLU-gate in one kernel; requires interleaved (gate, up) columns."""
+        assert getattr(self, "gate_up_interleaved", False), "weight was not packed with interleaved gate/up columns"
+        return ops.linear(input.contiguous(), self.packed, self.bias, epilogue=_C.EPI_SILU_MUL)
+
+
+class Mi355F16Linear(_PackedLinear):
+    """fp16 weights [K, N] (the reference stores [K, N] and calls hipb_mm, f16_linear.py:100-112)."""
+
+    @classmethod
+    def can_handle(cls, quant_config, weight, weight_scales, hw_kernel_config=None, weight_scale_2=None, input_scale=None):
+        return weight_scales is None and weight.dtype == torch.float16
+
+    def __init__(self, weight, weight_scales=None, input_scales=None, bias=None, quant_config=None, weight_scale_2=None):
+        super().__init__()
+        self._finish_init(quant.pack_fp16(weight.contiguous()), bias)
+
+
+class Mi355W8A16Linear(_PackedLinear):
+    """INT8 weight-only, per-output-channel scale (load-time autoquant, device_impl.py:183-222).
+    weight int8 [K, N], weight_scales [N]."""
+
+    @classmethod
+    def can_handle(cls, quant_config, weight, weight_scales, hw_kernel_config=None, weight_scale_2=None, input_scale=None):
+        return weight_scales is not None and weight.dtype == torch.int8 and weight_scales.dim() == 1
+
+    def __init__(self, weight, weight_scales=None, input_scales=None, bias=None, quant_config=None, weight_scale_2=None):
+        super().__init__()
+        self._finish_init(quant.pack_int8_per_channel(weight.contiguous(), weight_scales), bias)
+
+
+class Mi355W4A16Linear(_PackedLinear):
+    """INT4 group-wise (GPTQ / AWQ after canonicalisation).  weight: uint8 codes [K, N] in 0..15,
+    weight_scales fp16 [K/g, N], weight_zeros: effective zero codes [K/g, N] (z+1 for GPTQ)."""
+
+    @classmethod
+    def can_handle(cls, quant_config, weight, weight_scales, hw_kernel_config=None, weight_scale_2=None, input_scale=None):
+        return weight_scales is not None and weight.dtype == torch.uint8 and weight_scales.dim() == 2
+
+    def __init__(self, weight, weight_scales=None, input_scales=None, bias=None, quant_config=None, weight_scale_2=None,
+                 weight_zeros=None):
+        super().__init__()
+        K = weight.shape[0]
+        gs = K // weight_scales.shape[0]
+        if weight_zeros is None:  # symmetric: stored code = q_s + 8
+            weight_zeros = torch.full_like(weight_scales, 8, dtype=torch.int16)
+        self._finish_init(quant.pack_groupwise_w4(weight, weight_zeros, weight_scales, gs), bias)
+
+
+class LinearFactory:
+    """factory.py:33-145 — registry + unique-match dispatch."""
+    _strategies: List[Type[LinearBase]] = []
+
+    @classmethod
+    def register(cls, strategy: Type[LinearBase]) -> None:
+        if strategy not in cls._strategies:
+            cls._strategies.append(strategy)
+
+    @classmethod
+    def create_linear(cls, weight, bias=None, weight_scales=None, quant_config=None, weight_zeros=None, **kw) -> LinearBase:
+        hits = [s for s in cls._strategies if s.can_handle(quant_config, weight, weight_scales)]
+        if len(hits) != 1:  # factory.py:106-127: zero or several matches is an error
+            raise ValueError(f"expected exactly one Linear strategy, got {[h.__name__ for h in hits]} for "
+                             f"weight dtype {weight.dtype}, scales {None if weight_scales is None else tuple(weight_scales.shape)}")
+        extra = {"weight_zeros": weight_zeros} if weight_zeros is not None else {}
+        return hits[0](weight, weight_scales, None, bias, quant_config, None, **extra)
+
+    @classmethod
+    def create_linear_from_weights(cls, weights: Dict[str, torch.Tensor], weight_key: str, scale_key: Optional[str] = None,
+                                   bias_key: Optional[str] = None, quant_config=None, zeros_key: Optional[str] = None) -> LinearBase:
+        return cls.create_linear(weights[weight_key], weights.get(bias_key) if bias_key else None,
+                                 weights.get(scale_key) if scale_key else None, quant_config,
+                                 weights.get(zeros_key) if zeros_key else None)
+
+
+for _s in (Mi355F16Linear, Mi355W8A16Linear, Mi355W4A16Linear):
+    LinearFactory.register(_s)

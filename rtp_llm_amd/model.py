@@ -1,0 +1,357 @@
+"""Model description, canonical weights, TP split and the two ways to run a decode step:
+
+  * ``Qwen2DecoderModel``  — the Python module graph, shaped like the reference's
+    Qwen3Model / Qwen3DecoderLayer / CausalAttention / DenseMLP
+    (rtp_llm/models_py/model_desc/qwen3.py:57-138, modules/hybrid/causal_attention.py:42-93,
+    modules/hybrid/dense_mlp.py:49-106) on top of the plug-in strategies of this package;
+  * ``DecoderEngine``      — the C++ step driver (csrc/engine.cpp) that enqueues the same
+    step with fused launches and replays it as a hipGraph.
+
+Canonical (pre-packing) weights follow the reference loader's conventions: linear weights are
+[K(in), N(out)] (device_impl.py:183-192), QKV merged as [q | k | v] columns (merge_qkv_hf),
+gate/up merged as ffn_w13 = [gate | up] (dense_mlp.py:49-70).
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field, replace
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import _C, ops, quant
+from .attention import AttentionConfigs, AttnImplFactory, LayerKVCache, PyAttentionInputs
+from .distributed import Group, all_gather, all_reduce
+from .kvcache import alloc_layer_cache
+from .linear import LinearFactory
+from .modules import Embedding, FusedSiluAndMul, RMSNorm
+from .quant import PackedWeight
+
+
+@dataclass
+class ModelConfig:
+    name: str
+    num_layers: int
+    hidden: int
+    nh: int
+    nkv: int
+    hd: int
+    inter: int
+    vocab: int
+    rope_theta: float = 1e6
+    rms_eps: float = 1e-6
+    qkv_bias: bool = True
+    max_pos: int = 8192
+
+    def per_rank(self, tp: int) -> "ModelConfig":
+        """Per-rank attention/FFN dims (model_config.getAttentionConfigs(tp), qwen3.py:33;
+        K/V heads split by tp when divisible, utils/model_weight.py:447-466)."""
+        if tp == 1:
+            return self
+        assert self.nh % tp == 0 and self.nkv % tp == 0 and self.inter % tp == 0 and self.vocab % tp == 0, \
+            f"{self.name}: nh={self.nh} nkv={self.nkv} inter={self.inter} vocab={self.vocab} not divisible by tp={tp}"
+        return replace(self, nh=self.nh // tp, nkv=self.nkv // tp, inter=self.inter // tp, vocab=self.vocab // tp)
+
+
+# dims from the HF config.json values quoted in SURVEY section 8 (models/qwen_v2.py:338-399 reads them)
+QWEN2_7B = ModelConfig("qwen2-7b", 28, 3584, 28, 4, 128, 18944, 152064)
+QWEN2_0_5B = ModelConfig("qwen2-0.5b", 24, 896, 14, 2, 64, 4864, 151936)
+LLAMA3_70B = ModelConfig("llama3-70b", 80, 8192, 64, 8, 128, 28672, 128256, rope_theta=5e5, qkv_bias=False)
+QWEN2_72B = ModelConfig("qwen2-72b", 80, 8192, 64, 8, 128, 29568, 152064)
+MODELS = {m.name: m for m in (QWEN2_7B, QWEN2_0_5B, LLAMA3_70B, QWEN2_72B)}
+
+
+# --------------------------------------------------------------------------- canonical weights
+@dataclass
+class CanonLinear:
+    """One linear layer before packing.  kind: 'fp16' | 'int8' | 'w4'."""
+    kind: str
+    K: int
+    N: int
+    w: Optional[torch.Tensor] = None        # fp16 [K,N]            (fp16)
+    q: Optional[torch.Tensor] = None        # int8 [K,N] / uint8 codes [K,N]
+    scales: Optional[torch.Tensor] = None   # [N] (int8) / fp16 [K/g, N] (w4)
+    z_eff: Optional[torch.Tensor] = None    # [K/g, N] effective zero codes (w4)
+    group_size: int = 0
+
+    def pack(self, gate_up: bool = False) -> PackedWeight:
+        il = (lambda t: quant.interleave_gate_up(t, -1)) if gate_up else (lambda t: t)
+        if self.kind == "fp16":
+            return quant.pack_fp16(il(self.w))
+        if self.kind == "int8":
+            return quant.pack_int8_per_channel(il(self.q), il(self.scales))
+        return quant.pack_groupwise_w4(il(self.q), il(self.z_eff), il(self.scales), self.group_size)
+
+    def cols(self, lo: int, hi: int) -> "CanonLinear":
+        """Column (output) slice — column-parallel split (sp_head / ffn_sp_neg1, utils/model_weight.py:265-277,472-509)."""
+        s = lambda t: None if t is None else t[..., lo:hi].contiguous()
+        return CanonLinear(self.kind, self.K, hi - lo, s(self.w), s(self.q), s(self.scales), s(self.z_eff), self.group_size)
+
+    def rows(self, lo: int, hi: int) -> "CanonLinear":
+        """Row (input) slice — row-parallel split (sp_0 / ffn_sp_0, :234-250); group aligned."""
+        s = lambda t: None if t is None else t[lo:hi].contiguous()
+        if self.kind == "w4":
+            g = self.group_size
+            assert lo % g == 0 and hi % g == 0, "row split must be aligned to the quantisation group (align_size = tp*g)"
+            return CanonLinear(self.kind, hi - lo, self.N, None, s(self.q), self.scales[lo // g: hi // g].contiguous(),
+                               self.z_eff[lo // g: hi // g].contiguous(), g)
+        return CanonLinear(self.kind, hi - lo, self.N, s(self.w), s(self.q), self.scales, None, 0)
+
+    @staticmethod
+    def cat_cols(parts: List["CanonLinear"]) -> "CanonLinear":
+        c = lambda name: None if getattr(parts[0], name) is None else torch.cat([getattr(p, name) for p in parts], dim=-1)
+        p0 = parts[0]
+        return CanonLinear(p0.kind, p0.K, sum(p.N for p in parts), c("w"), c("q"), c("scales"), c("z_eff"), p0.group_size)
+
+
+def synth_linear(K: int, N: int, kind: str, device, gen: torch.Generator, group_size: int = 128, method: str = "gptq") -> CanonLinear:
+    """Synthetic weights of SURVEY 8d: fp16 W ~ xavier_uniform; GPTQ/AWQ: q ~ U{0..15}, z ~ U{0..15},
+    scale ~ U(0.5,1.5) * (2*amax/15); INT8: autoquant of the fp16 weights via a1."""
+    a = math.sqrt(6.0 / (K + N))
+    if kind == "fp16" or kind == "int8":
+        w = ((torch.rand(K, N, device=device, generator=gen) * 2 - 1) * a).half()
+        if kind == "fp16":
+            return CanonLinear("fp16", K, N, w=w)
+        q, s = quant.symmetric_quantize_int8(w)
+        return CanonLinear("int8", K, N, q=q, scales=s)
+    G = K // group_size
+    q = torch.randint(0, 16, (K, N), device=device, generator=gen, dtype=torch.uint8)
+    z = torch.randint(0, 16, (G, N), device=device, generator=gen, dtype=torch.uint8)
+    z_eff = (z.to(torch.int16) + (1 if method == "gptq" else 0)).to(torch.uint8)
+    scales = ((torch.rand(G, N, device=device, generator=gen) + 0.5) * (2 * a / 15)).half()
+    return CanonLinear("w4", K, N, q=q, scales=scales, z_eff=z_eff, group_size=group_size)
+
+
+def synth_layer(cfg: ModelConfig, kind: str, device, gen, group_size=128, method="gptq") -> Dict:
+    H, qkv_n = cfg.hidden, (cfg.nh + 2 * cfg.nkv) * cfg.hd
+    lin = lambda K, N: synth_linear(K, N, kind, device, gen, group_size, method)
+    return {
+        "qkv": lin(H, qkv_n), "o": lin(cfg.nh * cfg.hd, H), "gate_up": lin(H, 2 * cfg.inter), "down": lin(cfg.inter, H),
+        "qkv_bias": ((torch.rand(qkv_n, device=device, generator=gen) - 0.5) * 0.2).half() if cfg.qkv_bias else None,
+        "input_norm": (1.0 + 0.1 * torch.randn(H, device=device, generator=gen)).half(),
+        "post_norm": (1.0 + 0.1 * torch.randn(H, device=device, generator=gen)).half(),
+    }
+
+
+def synth_model(cfg: ModelConfig, kind: str, device, seed: int = 0, group_size=128, method="gptq") -> Dict:
+    gen = torch.Generator(device=device).manual_seed(seed)
+    return {
+        "layers": [synth_layer(cfg, kind, device, gen, group_size, method) for _ in range(cfg.num_layers)],
+        "embedding": (torch.randn(cfg.vocab, cfg.hidden, device=device, generator=gen) * 0.5).half(),
+        "final_norm": (1.0 + 0.1 * torch.randn(cfg.hidden, device=device, generator=gen)).half(),
+        "lm_head": synth_linear(cfg.hidden, cfg.vocab, "fp16", device, gen),
+    }
+
+
+def weights_to(w: Dict, device) -> Dict:
+    """Move a canonical weight dict (synth_model layout) to `device`."""
+    def mv(v):
+        if torch.is_tensor(v):
+            return v.to(device)
+        if isinstance(v, CanonLinear):
+            return CanonLinear(v.kind, v.K, v.N, *(None if t is None else t.to(device) for t in (v.w, v.q, v.scales, v.z_eff)),
+                               v.group_size)
+        if isinstance(v, dict):
+            return {k: mv(x) for k, x in v.items()}
+        if isinstance(v, list):
+            return [mv(x) for x in v]
+        return v
+    return mv(w)
+
+
+def split_layer_tp(layer: Dict, cfg: ModelConfig, tp: int, rank: int) -> Dict:
+    """Megatron TP split of one layer (table utils/model_weight.py:1517-1563): column-parallel QKV
+    (q heads / tp, k and v heads / tp) and gate/up, row-parallel O and down; norms replicated;
+    QKV bias split like the QKV columns."""
+    if tp == 1:
+        return layer
+    hd, nh, nkv, I = cfg.hd, cfg.nh, cfg.nkv, cfg.inter
+    nh_r, nkv_r, I_r = nh // tp, nkv // tp, I // tp
+    qkv = layer["qkv"]
+    q_lo, k_lo, v_lo = rank * nh_r * hd, nh * hd + rank * nkv_r * hd, (nh + nkv) * hd + rank * nkv_r * hd
+    parts = [qkv.cols(q_lo, q_lo + nh_r * hd), qkv.cols(k_lo, k_lo + nkv_r * hd), qkv.cols(v_lo, v_lo + nkv_r * hd)]
+    gu = layer["gate_up"]
+    out = {
+        "qkv": CanonLinear.cat_cols(parts),
+        "o": layer["o"].rows(rank * nh_r * hd, (rank + 1) * nh_r * hd),
+        "gate_up": CanonLinear.cat_cols([gu.cols(rank * I_r, (rank + 1) * I_r), gu.cols(I + rank * I_r, I + (rank + 1) * I_r)]),
+        "down": layer["down"].rows(rank * I_r, (rank + 1) * I_r),
+        "input_norm": layer["input_norm"], "post_norm": layer["post_norm"], "qkv_bias": None,
+    }
+    if layer["qkv_bias"] is not None:
+        b = layer["qkv_bias"]
+        out["qkv_bias"] = torch.cat([b[q_lo:q_lo + nh_r * hd], b[k_lo:k_lo + nkv_r * hd], b[v_lo:v_lo + nkv_r * hd]]).contiguous()
+    return out
+
+
+def rope_table(cfg: ModelConfig, device) -> torch.Tensor:
+    """fp32 {cos,sin} table [max_pos][hd/2][2] (genBaseCache, cpp/model_utils/RopeCache.cc:16-41); built on the
+    host in fp32 so every rank holds identical bits."""
+    inv_freq = 1.0 / torch.pow(torch.tensor(float(cfg.rope_theta)), torch.arange(0, cfg.hd, 2).float() / cfg.hd)
+    freqs = torch.outer(torch.arange(cfg.max_pos).float(), inv_freq)
+    return torch.stack((freqs.cos(), freqs.sin()), dim=-1).contiguous().to(device)
+
+
+# --------------------------------------------------------------------------- Python module graph
+class CausalAttention(nn.Module):
+    """causal_attention.py:42-93: qkv_proj -> fmha_impl.forward -> o_proj -> all_reduce(TP)."""
+
+    def __init__(self, layer: Dict):
+        super().__init__()
+        mk = lambda c, bias=None: LinearFactory.create_linear(c.w if c.kind == "fp16" else c.q, bias, c.scales, None, c.z_eff)
+        self.qkv_proj, self.o_proj = mk(layer["qkv"], layer["qkv_bias"]), mk(layer["o"])
+
+    def forward(self, x, fmha_impl, kv_cache: LayerKVCache, layer_idx: int):
+        out = self.o_proj(fmha_impl.forward(self.qkv_proj(x), kv_cache, layer_idx))
+        return all_reduce(out, Group.TP)
+
+
+class DenseMLP(nn.Module):
+    """dense_mlp.py:95-106: up_proj (merged gate_up) -> FusedSiluAndMul -> down_proj -> all_reduce(TP)."""
+
+    def __init__(self, layer: Dict):
+        super().__init__()
+        mk = lambda c: LinearFactory.create_linear(c.w if c.kind == "fp16" else c.q, None, c.scales, None, c.z_eff)
+        self.gate_up_proj, self.down_proj, self.act = mk(layer["gate_up"]), mk(layer["down"]), FusedSiluAndMul()
+
+    def forward(self, x):
+        return all_reduce(self.down_proj(self.act(self.gate_up_proj(x))), Group.TP)
+
+
+class Qwen2DecoderModel(nn.Module):
+    """qwen3.py:82-138 for the Qwen2/Llama family; forward(input_ids, attn_inputs, kv_caches) -> hidden."""
+
+    def __init__(self, cfg: ModelConfig, weights: Dict, page: int, max_seq_len: int):
+        super().__init__()
+        self.cfg, self.page = cfg, page
+        dev = weights["embedding"].device
+        self.embed = Embedding(weights["embedding"])
+        self.layers = nn.ModuleList()
+        for L in weights["layers"]:
+            m = nn.Module()
+            m.input_layernorm, m.post_attention_layernorm = RMSNorm(L["input_norm"], cfg.rms_eps), RMSNorm(L["post_norm"], cfg.rms_eps)
+            m.self_attn, m.mlp = CausalAttention(L), DenseMLP(L)
+            self.layers.append(m)
+        self.norm = RMSNorm(weights["final_norm"], cfg.rms_eps)
+        self.lm_head = LinearFactory.create_linear(weights["lm_head"].w)
+        self.attn_cfg = AttentionConfigs(cfg.nh, cfg.nkv, cfg.hd, cfg.hd, cfg.rope_theta, max_seq_len, 1.0, page)
+        self.cos_sin = rope_table(cfg, dev)
+
+    def prepare_fmha_impl(self, attn_inputs: PyAttentionInputs):   # module_base.py:77-109
+        return AttnImplFactory.get_fmha_impl(self.attn_cfg, attn_inputs, None, cos_sin=self.cos_sin)
+
+    def forward(self, input_ids: torch.Tensor, fmha_impl, kv_caches: List[LayerKVCache]) -> torch.Tensor:
+        h = self.embed(input_ids)
+        for i, m in enumerate(self.layers):           # Qwen3DecoderLayer.forward, qwen3.py:57-79
+            r = h
+            h = m.self_attn(m.input_layernorm(h), fmha_impl, kv_caches[i], i)
+            h = r + h
+            r = h
+            h = m.mlp(m.post_attention_layernorm(h))
+            h = r + h
+        return self.norm(h)
+
+    def logits(self, hidden: torch.Tensor) -> torch.Tensor:   # PyWrappedModel.cc:1039-1047
+        return all_gather(ops.linear(hidden, self.lm_head.packed, None, epilogue=_C.EPI_OUT_F32), Group.TP)
+
+
+# --------------------------------------------------------------------------- C++ step driver
+class DecoderEngine:
+    """Owns the device buffers and drives csrc/engine.cpp.  Greedy decode only (top_k = 1)."""
+
+    def __init__(self, cfg: ModelConfig, weights: Dict, *, kv_int8: bool, page: int, num_blocks: int, max_batch: int,
+                 max_seq_len: int, device, tp_size: int = 1, vocab_full: Optional[int] = None):
+        self.cfg, self.device, self.tp_size = cfg, device, tp_size
+        self.page, self.num_blocks, self.max_batch, self.max_seq_len = page, num_blocks, max_batch, max_seq_len
+        self.max_blocks_per_seq = (max_seq_len + page - 1) // page
+        self.lib = _C.lib()
+        self._keep = []   # keep packed tensors alive
+        self.packed_bytes = 0
+        lw = (_C.LayerWeights * cfg.num_layers)()
+        self.kv, self.kv_scale = [], []
+        for i, L in enumerate(weights["layers"]):
+            p = {k: L[k].pack(gate_up=(k == "gate_up")) for k in ("qkv", "o", "gate_up", "down")}
+            self._keep.append((p, L))
+            self.packed_bytes += sum(v.nbytes for v in p.values())
+            kvb, kvs = alloc_layer_cache(num_blocks, cfg.nkv, page, cfg.hd, kv_int8, device)
+            self.kv.append(kvb); self.kv_scale.append(kvs)
+            lw[i].qkv, lw[i].o = ops.weight_struct(p["qkv"]), ops.weight_struct(p["o"])
+            lw[i].gate_up, lw[i].down = ops.weight_struct(p["gate_up"]), ops.weight_struct(p["down"])
+            lw[i].qkv_bias = 0 if L["qkv_bias"] is None else L["qkv_bias"].data_ptr()
+            lw[i].input_norm, lw[i].post_norm = L["input_norm"].data_ptr(), L["post_norm"].data_ptr()
+            lw[i].kv_base = kvb.data_ptr()
+            lw[i].kv_scale_base = 0 if kvs is None else kvs.data_ptr()
+        self.lm_head = weights["lm_head"].pack() if isinstance(weights["lm_head"], CanonLinear) else weights["lm_head"]
+        self.packed_bytes_lm_head = self.lm_head.nbytes
+        self.embedding, self.final_norm = weights["embedding"], weights["final_norm"]
+        self.cos_sin = rope_table(cfg, device)
+        mc = _C.ModelConfig(cfg.num_layers, cfg.hidden, cfg.nh, cfg.nkv, cfg.hd, cfg.inter, cfg.vocab, cfg.hd, cfg.max_pos,
+                            cfg.rms_eps, _C.KV_INT8 if kv_int8 else _C.KV_FP16, page, num_blocks, max_batch,
+                            self.max_blocks_per_seq, max_seq_len, tp_size)
+        mw = _C.ModelWeights(self.embedding.data_ptr(), vocab_full or self.embedding.shape[0], self.final_norm.data_ptr(),
+                             ops.weight_struct(self.lm_head), self.cos_sin.data_ptr())
+        i32 = dict(dtype=torch.int32, device=device)
+        self.token_ids = torch.zeros(max_batch, **i32)
+        self.positions = torch.zeros(max_batch, **i32)
+        self.block_table = torch.zeros(max_batch, self.max_blocks_per_seq, **i32)
+        self.logits = torch.zeros(max_batch, cfg.vocab, dtype=torch.float32, device=device)
+        self.hidden = torch.zeros(max_batch, cfg.hidden, dtype=torch.float16, device=device)
+        self.ar_buf = torch.zeros(max_batch, cfg.hidden, dtype=torch.float16, device=device)
+        ws_bytes = self.lib.mi355_decoder_workspace_bytes(C.byref(mc))
+        self.workspace = torch.zeros(ws_bytes, dtype=torch.uint8, device=device)
+        sb = _C.StepBuffers(self.token_ids.data_ptr(), self.positions.data_ptr(), self.block_table.data_ptr(),
+                            self.logits.data_ptr(), self.hidden.data_ptr(), self.ar_buf.data_ptr(), self.workspace.data_ptr(), ws_bytes)
+        self._structs = (mc, mw, sb, lw)
+        self.handle = self.lib.mi355_decoder_create(C.byref(mc), lw, C.byref(mw), C.byref(sb))
+        if not self.handle:
+            raise _C.Mi355Error("decoder_create failed: " + self.lib.mi355_last_error().decode())
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.mi355_decoder_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- inputs
+    def set_inputs(self, token_ids, positions, block_table):
+        B = len(token_ids)
+        self.token_ids[:B].copy_(torch.as_tensor(token_ids, dtype=torch.int32))
+        self.positions[:B].copy_(torch.as_tensor(positions, dtype=torch.int32))
+        bt = torch.as_tensor(block_table, dtype=torch.int32)
+        self.block_table[:B, : bt.shape[1]].copy_(bt)
+
+    def _st(self) -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    # ---- tp = 1
+    def step(self, B: int):
+        _C.check(self.lib.mi355_decoder_step(self.handle, B, self._st()), "decoder_step")
+
+    def capture(self, B: int):
+        _C.check(self.lib.mi355_decoder_capture(self.handle, B), "decoder_capture")
+
+    def replay(self, B: int, nsteps: int = 1):
+        _C.check(self.lib.mi355_decoder_replay(self.handle, B, nsteps, self._st()), "decoder_replay")
+
+    def profile(self, B: int, nsteps: int):
+        ms, n = (C.c_float * 6)(), (C.c_int32 * 6)()
+        _C.check(self.lib.mi355_decoder_profile(self.handle, B, nsteps, ms, n, self._st()), "decoder_profile")
+        return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(_C.KC_NAMES)}
+
+    # ---- tp > 1: the step cut at the all-reduce points (causal_attention.py:91-92, dense_mlp.py:104-105)
+    def step_tp(self, B: int, sample: bool = True):
+        st, h, lib = self._st(), self.handle, self.lib
+        ar = self.ar_buf[:B]
+        _C.check(lib.mi355_decoder_begin(h, B, st), "decoder_begin")
+        for l in range(self.cfg.num_layers):
+            _C.check(lib.mi355_decoder_layer_attn(h, l, st), "decoder_layer_attn")
+            all_reduce(ar, Group.TP)
+            _C.check(lib.mi355_decoder_layer_mlp(h, l, st), "decoder_layer_mlp")
+            all_reduce(ar, Group.TP)
+        _C.check(lib.mi355_decoder_finish(h, 0, st), "decoder_finish")
+        if sample:   # vocab-split lm_head: gather logits, greedy on the full row (PyWrappedModel.cc:915-936)
+            full = all_gather(self.logits[:B], Group.TP)
+            self.token_ids[:B].copy_(ops.argmax(full.contiguous()))
+            self.positions[:B] += 1

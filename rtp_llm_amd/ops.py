@@ -1,0 +1,154 @@
+"""Tensor-level wrappers over the C-ABI: the counterpart of the reference's pybind op
+module ``rtp_llm.ops.compute_ops.rtp_llm_ops`` (bindings/rocm/RegisterBaseBindings.hpp:14-129)
+for the decode hot path.  PyTorch is plumbing here (device memory + current stream);
+every function enqueues hand-written HIP kernels through ctypes and never falls back.
+"""
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import _C
+from .quant import PackedWeight
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise _C.Mi355Error(f"{name}: tensor must live on the GPU (no CPU path exists)")
+    if t.dtype != dtype:
+        raise _C.Mi355Error(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _C.Mi355Error(f"{name}: tensor must be contiguous")
+
+
+def weight_struct(w: PackedWeight) -> _C.Weight:
+    return _C.Weight(w.qweight.data_ptr(), 0 if w.meta is None else w.meta.data_ptr(), w.wbits, w.K, w.N,
+                     w.K_pad, w.N_pad, w.group_size)
+
+
+def kv_struct(kv_base: torch.Tensor, scale_base: Optional[torch.Tensor], page: int, nkv: int, hd: int) -> _C.KVLayer:
+    int8 = kv_base.dtype == torch.int8
+    if int8 and scale_base is None:
+        raise _C.Mi355Error("int8 KV cache requires the fp32 scale plane")
+    nblk = kv_base.numel() // (2 * nkv * page * hd)
+    return _C.KVLayer(kv_base.data_ptr(), 0 if scale_base is None else scale_base.data_ptr(),
+                      _C.KV_INT8 if int8 else _C.KV_FP16, page, nkv, hd, nblk)
+
+
+# ------------------------------------------------------------------ linear
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def linear(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None, epilogue: int = _C.EPI_NONE,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x @ W (+bias); epilogue EPI_SILU_MUL -> [M, N/2], EPI_OUT_F32 -> fp32."""
+    _chk(x, torch.float16, "linear.x")
+    M = x.numel() // w.K
+    if x.shape[-1] != w.K:
+        raise _C.Mi355Error(f"linear: x last dim {x.shape[-1]} != K {w.K}")
+    n_out = w.N // 2 if epilogue & _C.EPI_SILU_MUL else w.N
+    dt = torch.float32 if epilogue & _C.EPI_OUT_F32 else torch.float16
+    if out is None:
+        out = torch.empty(*x.shape[:-1], n_out, dtype=dt, device=x.device)
+    ws_struct = weight_struct(w)
+    need = _C.lib().mi355_linear_workspace_bytes(M, C.byref(ws_struct))
+    ws = _workspace(need, x.device)
+    _C.check(_C.lib().mi355_linear_forward(x.data_ptr(), M, C.byref(ws_struct), _p(bias), out.data_ptr(), epilogue,
+                                           ws.data_ptr(), ws.numel(), _stream()), "linear_forward")
+    return out
+
+
+# ------------------------------------------------------------------ norms / elementwise
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    _chk(x, torch.float16, "rmsnorm.x"); _chk(weight, torch.float16, "rmsnorm.weight")
+    H = x.shape[-1]
+    y = torch.empty_like(x)
+    _C.check(_C.lib().mi355_rmsnorm(x.data_ptr(), weight.data_ptr(), eps, x.numel() // H, H, y.data_ptr(), _stream()), "rmsnorm")
+    return y
+
+
+def add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float, bias: Optional[torch.Tensor] = None):
+    """(y, residual_out): residual_out = x (+bias) + residual;  y = rmsnorm(residual_out) * weight."""
+    _chk(x, torch.float16, "add_rmsnorm.x"); _chk(residual, torch.float16, "add_rmsnorm.residual")
+    H = x.shape[-1]
+    y, res_out = torch.empty_like(x), torch.empty_like(x)
+    _C.check(_C.lib().mi355_add_rmsnorm(x.data_ptr(), None, 0, 0, _p(bias), residual.data_ptr(), res_out.data_ptr(),
+                                        weight.data_ptr(), eps, x.numel() // H, H, y.data_ptr(), _stream()), "add_rmsnorm")
+    return y, res_out
+
+
+def silu_mul(gate_up: torch.Tensor) -> torch.Tensor:
+    _chk(gate_up, torch.float16, "silu_mul.gate_up")
+    I = gate_up.shape[-1] // 2
+    out = torch.empty(*gate_up.shape[:-1], I, dtype=torch.float16, device=gate_up.device)
+    _C.check(_C.lib().mi355_silu_mul(gate_up.data_ptr(), gate_up.numel() // (2 * I), I, out.data_ptr(), _stream()), "silu_mul")
+    return out
+
+
+def embedding(ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    _chk(ids, torch.int32, "embedding.ids"); _chk(table, torch.float16, "embedding.table")
+    T, (V, H) = ids.numel(), table.shape
+    out = torch.empty(T, H, dtype=torch.float16, device=table.device)
+    _C.check(_C.lib().mi355_embedding(ids.data_ptr(), T, table.data_ptr(), H, V, out.data_ptr(), _stream()), "embedding")
+    return out
+
+
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    _chk(logits, torch.float32, "argmax.logits")
+    B, V = logits.shape
+    ids = torch.empty(B, dtype=torch.int32, device=logits.device)
+    ws = _workspace(B * 64 * 8, logits.device)
+    _C.check(_C.lib().mi355_argmax(logits.data_ptr(), B, V, V, ids.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "argmax")
+    return ids
+
+
+# ------------------------------------------------------------------ attention
+def rope_kv_write(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], cos_sin: torch.Tensor, positions: torch.Tensor,
+                  block_table: torch.Tensor, kv_base: torch.Tensor, scale_base: Optional[torch.Tensor], nh: int, nkv: int,
+                  hd: int, page: int) -> torch.Tensor:
+    """RoPE + bias + Q-extract + paged KV write for decode tokens; returns q [T, nh, hd]."""
+    _chk(qkv, torch.float16, "rope_kv_write.qkv"); _chk(cos_sin, torch.float32, "rope_kv_write.cos_sin")
+    _chk(positions, torch.int32, "rope_kv_write.positions"); _chk(block_table, torch.int32, "rope_kv_write.block_table")
+    T = qkv.shape[0]
+    q_out = torch.empty(T, nh, hd, dtype=torch.float16, device=qkv.device)
+    kv = kv_struct(kv_base, scale_base, page, nkv, hd)
+    _C.check(_C.lib().mi355_rope_kv_write(qkv.data_ptr(), None, 0, qkv.shape[1], _p(qkv_bias), cos_sin.data_ptr(), hd,
+                                          positions.data_ptr(), block_table.data_ptr(), block_table.shape[1], T, nh,
+                                          C.byref(kv), q_out.data_ptr(), _stream()), "rope_kv_write")
+    return q_out
+
+
+def paged_decode_attention(q: torch.Tensor, kv_base: torch.Tensor, scale_base: Optional[torch.Tensor],
+                           block_table: torch.Tensor, seq_lens: torch.Tensor, nkv: int, page: int,
+                           max_seq_len: int, scale: Optional[float] = None) -> torch.Tensor:
+    """q [B, nh, hd] -> out [B, nh*hd]; seq_lens = context length including the new token."""
+    _chk(q, torch.float16, "paged_decode_attention.q"); _chk(block_table, torch.int32, "block_table")
+    _chk(seq_lens, torch.int32, "seq_lens")
+    B, nh, hd = q.shape
+    kv = kv_struct(kv_base, scale_base, page, nkv, hd)
+    out = torch.empty(B, nh * hd, dtype=torch.float16, device=q.device)
+    need = _C.lib().mi355_paged_attn_workspace_bytes(B, nh, hd, max_seq_len)
+    ws = _workspace(need, q.device)
+    _C.check(_C.lib().mi355_paged_decode_attn(q.data_ptr(), C.byref(kv), block_table.data_ptr(), block_table.shape[1],
+                                              seq_lens.data_ptr(), B, nh, scale if scale is not None else 1.0 / math.sqrt(hd),
+                                              max_seq_len, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+             "paged_decode_attn")
+    return out

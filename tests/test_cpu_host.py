@@ -1,0 +1,133 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol include/mi355_decode.h declares
+(no compute calls without a GPU), host logic (planning, TP split, module plumbing), oracle
+self-consistency.  Runs with -m "not gpu"."""
+import ctypes
+import math
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import oracle
+from rtp_llm_amd import _C, model, quant
+from rtp_llm_amd.linear import LinearFactory, Mi355W4A16Linear
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "mi355_decode.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi355_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from rtp_llm_amd.build import build
+    build(verbose=False)                      # hipcc cross-compiles gfx950 without a GPU
+    lib = ctypes.CDLL(_C.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mi355_decode.h but not exported"
+    assert set(declared) == set(_C.SIGNATURES), "ctypes SIGNATURES out of sync with the header"
+    assert _C.lib().mi355_abi_version() == 1
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    """Argument validation happens on the host before any launch: status + message, no exception across the ABI."""
+    l = _C.lib()
+    w = _C.Weight(None, None, 4, 256, 64, 256, 64, 128)
+    assert l.mi355_linear_forward(None, 1, ctypes.byref(w), None, None, 0, None, 0, None) == _C.ERR_ARG
+    assert b"null weight" in l.mi355_last_error()
+    kv = _C.KVLayer(1, None, _C.KV_INT8, 16, 4, 96, 8)
+    assert l.mi355_paged_decode_attn(1, ctypes.byref(kv), 1, 4, 1, 1, 28, 0.1, 64, 1, None, 0, None) == _C.ERR_ARG
+    with pytest.raises(_C.Mi355Error):
+        _C.check(_C.ERR_ARG, "x")
+    assert l.mi355_paged_attn_workspace_bytes(64, 28, 128, 4096) == 64 * 28 * 32 * 130 * 4
+
+
+def test_ops_refuse_cpu_tensors():
+    from rtp_llm_amd import ops
+    with pytest.raises(_C.Mi355Error):
+        ops.rmsnorm(torch.zeros(2, 64, dtype=torch.float16), torch.ones(64, dtype=torch.float16), 1e-6)
+
+
+def test_linear_factory_unique_dispatch():
+    q = torch.randint(0, 16, (256, 32), dtype=torch.uint8)
+    s = torch.rand(2, 32).half()
+    z = torch.randint(0, 16, (2, 32), dtype=torch.uint8)
+    lin = LinearFactory.create_linear(q, None, s, None, z)
+    assert isinstance(lin, Mi355W4A16Linear) and lin.packed.group_size == 128 and lin.packed.wbits == 4
+    with pytest.raises(ValueError):           # bf16 weights match no strategy, as in the reference factory
+        LinearFactory.create_linear(torch.zeros(8, 8, dtype=torch.bfloat16))
+
+
+def test_tp_split_is_exact_partition():
+    """Column-parallel + row-parallel split of the canonical tensors reproduces the unsplit layer:
+    sum over ranks of the oracle MLP / attention-projection outputs == unsplit output."""
+    cfg = model.ModelConfig("t", 1, 256, 8, 4, 64, 512, 64)   # o rows 512/4 and inter 512/4 stay group(128)-aligned
+    gen = torch.Generator().manual_seed(0)
+    L = model.synth_layer(cfg, "w4", "cpu", gen)
+    dense = lambda c: oracle.dequant_groupwise(c.q, c.z_eff, c.scales, c.group_size)
+    x = (torch.randn(3, 256, generator=gen) * 0.5)
+    full_mlp = (torch.nn.functional.silu((x @ dense(L["gate_up"]))[:, :512]) * (x @ dense(L["gate_up"]))[:, 512:]) @ dense(L["down"])
+    full_qkv = x @ dense(L["qkv"]) + L["qkv_bias"].float()
+    for tp in (2, 4):
+        acc = torch.zeros_like(full_mlp)
+        for r in range(tp):
+            Lr = model.split_layer_tp(L, cfg, tp, r)
+            gu = x @ dense(Lr["gate_up"])
+            Ir = 512 // tp
+            acc += (torch.nn.functional.silu(gu[:, :Ir]) * gu[:, Ir:]) @ dense(Lr["down"])
+            c = cfg.per_rank(tp)
+            qkv_r = x @ dense(Lr["qkv"]) + Lr["qkv_bias"].float()
+            nhr, nkr, hd = c.nh, c.nkv, c.hd
+            assert torch.equal(qkv_r[:, : nhr * hd], full_qkv[:, r * nhr * hd:(r + 1) * nhr * hd])
+            k0 = cfg.nh * hd + r * nkr * hd
+            assert torch.equal(qkv_r[:, nhr * hd:(nhr + nkr) * hd], full_qkv[:, k0:k0 + nkr * hd])
+        assert torch.allclose(acc, full_mlp, atol=1e-4, rtol=1e-4)
+
+
+def test_oracle_attention_matches_plain_softmax_and_int8_roundtrip():
+    g = torch.Generator().manual_seed(1)
+    q = torch.randn(8, 64, generator=g).half()
+    K, V = torch.randn(37, 2, 64, generator=g).half(), torch.randn(37, 2, 64, generator=g).half()
+    out = oracle.attention_decode(q, K, V, 0.125)
+    for h in range(8):
+        p = torch.softmax(0.125 * (K[:, h // 4].float() @ q[h].float()), 0)
+        assert torch.allclose(out[h].float(), p @ V[:, h // 4].float(), atol=2e-3)
+    Kq, ks = oracle.quant_kv_int8(K)
+    assert Kq.dtype == torch.int8 and int(Kq.abs().max()) == 127
+    assert torch.allclose(Kq.float() * ks.unsqueeze(-1), K.float(), atol=float(ks.max()) * 0.51)
+
+
+def test_oracle_rope_is_a_rotation_and_matches_reference_formula():
+    cs = oracle.rope_cos_sin(64, 1e6, 128)
+    x = torch.randn(5, 3, 64).half()
+    pos = torch.tensor([0, 1, 17, 100, 127])
+    y = oracle.apply_rope(x, pos, cs)
+    assert torch.equal(y[0], x[0])                                    # position 0: identity
+    assert torch.allclose(y.float().norm(dim=-1), x.float().norm(dim=-1), rtol=2e-3)
+    # test_fused_qkv_transpose_v3.py:279-284 formula
+    inv = 1e6 ** (-2.0 * torch.arange(32).float() / 64)
+    ang = pos.float().unsqueeze(1) * inv
+    lo, hi = x.float()[..., :32], x.float()[..., 32:]
+    ref = torch.cat((lo * ang.cos().unsqueeze(1) - hi * ang.sin().unsqueeze(1), hi * ang.cos().unsqueeze(1) + lo * ang.sin().unsqueeze(1)), -1)
+    assert torch.allclose(y.float(), ref, atol=4e-3)
+
+
+def test_kvcache_layout_roundtrip_cpu():
+    from rtp_llm_amd import kvcache
+    kv, sc = kvcache.alloc_layer_cache(8, 2, 16, 64, True, "cpu")
+    K = torch.randint(-128, 128, (40, 2, 64)).to(torch.int8)
+    V = torch.randint(-128, 128, (40, 2, 64)).to(torch.int8)
+    ks, vs = torch.rand(40, 2), torch.rand(40, 2)
+    bt = torch.tensor([5, 2, 7, 0], dtype=torch.int32)
+    kvcache.write_tokens(kv, sc, bt, 0, K, V, ks, vs)
+    K2, V2, ks2, vs2 = kvcache.read_tokens(kv, sc, bt, 40)
+    assert torch.equal(K2, K) and torch.equal(V2, V) and torch.equal(ks2, ks) and torch.equal(vs2, vs)
+    # native intra-block layout: K block [nkv][page][hd], V block [nkv][hd][page]
+    assert kv[5, 0].reshape(2, 16, 64)[1, 3, 10] == K[3, 1, 10]
+    assert kv[5, 1].reshape(2, 64, 16)[1, 10, 3] == V[3, 1, 10]
+    assert kv[2, 1].reshape(2, 64, 16)[0, 7, 4] == V[16 + 4, 0, 7]

@@ -1,0 +1,284 @@
+"""GPU parity tests: every HIP kernel, called through the C-ABI, against the CPU oracle on the
+same seeded inputs.  Tolerances are the reference's own (rocm_linear_test.py:140 and
+rocm_fmha_test.py:824-831: atol = rtol = 1e-2; rocm_norm_test.py:26-28: 5e-2); integer / index
+results (cache bytes, token ids) are bit-exact.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import oracle
+from rtp_llm_amd import _C, kvcache, model, ops, quant
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = dict(atol=1e-2, rtol=1e-2)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_native():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    _C.lib()  # raises loudly if libmi355_decode.so is missing: no fallback
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _x(M, K, seed):
+    return (torch.randn(M, K, generator=_gen(seed)) * 0.5).half()
+
+
+def _canon_cpu(K, N, kind, seed, group=128, method="gptq"):
+    return model.synth_linear(K, N, kind, "cpu", _gen(seed), group, method)
+
+
+def _dense(c: model.CanonLinear):
+    if c.kind == "fp16":
+        return c.w.float()
+    if c.kind == "int8":
+        return oracle.dequant_int8(c.q, c.scales)
+    return oracle.dequant_groupwise(c.q, c.z_eff, c.scales, c.group_size)
+
+
+# ------------------------------------------------------------------ linear
+@pytest.mark.parametrize("kind,group", [("w4", 128), ("w4", 64), ("w4", 32), ("int8", 0), ("fp16", 0)])
+@pytest.mark.parametrize("M", [1, 7, 16, 33, 64, 83])
+@pytest.mark.parametrize("K,N", [(256, 64), (1024, 4608), (3584, 512), (9472, 896)])
+def test_linear(kind, group, M, K, N):
+    if group and K % group:
+        pytest.skip("group does not divide K")
+    c = _canon_cpu(K, N, kind, 10 + K + N, group or 128)
+    x = _x(M, K, M)
+    bias = (torch.randn(N, generator=_gen(3)) * 0.1).half() if N % 3 == 0 else None
+    ref = oracle.linear(x, _dense(c), bias)
+    y = ops.linear(x.to(DEV), c.pack().to(DEV), None if bias is None else bias.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.allclose(y.cpu().float(), ref.float(), **TOL), (y.cpu().float() - ref.float()).abs().max()
+
+
+def test_linear_awq_and_gptq_from_checkpoint_tensors(golden_dir):
+    """Full load path on the reference-format tensors of the golden fixtures: int32 qweight/qzeros ->
+    canonicalise -> native repack -> HIP GEMM, vs the oracle on the reference-decoded codes."""
+    import numpy as np
+    import os
+    for kind in ("gptq", "awq"):
+        g = np.load(os.path.join(golden_dir, f"quant_{kind}.npz"))
+        qw, qz, sc = (torch.from_numpy(g[k]) for k in ("qweight", "qzeros", "scales"))
+        packed = (quant.pack_gptq if kind == "gptq" else quant.pack_awq)(qw, qz, sc, int(g["group_size"]))
+        z_eff = torch.from_numpy(g["ref_z_codes"]).to(torch.int16) + (1 if kind == "gptq" else 0)
+        W = oracle.dequant_groupwise(torch.from_numpy(g["ref_q_codes"]), z_eff, sc, int(g["group_size"]))
+        x = _x(5, W.shape[0], 2)
+        y = ops.linear(x.to(DEV), packed.to(DEV))
+        assert torch.allclose(y.cpu().float(), oracle.linear(x, W).float(), **TOL)
+
+
+@pytest.mark.parametrize("M", [1, 16, 64])
+def test_linear_silu_and_f32_epilogues(M):
+    K, I = 1024, 1152
+    c = _canon_cpu(K, 2 * I, "w4", 5)
+    x = _x(M, K, 1)
+    ref = oracle.silu_mul(oracle.linear(x, _dense(c)))
+    y = ops.linear(x.to(DEV), c.pack(gate_up=True).to(DEV), epilogue=_C.EPI_SILU_MUL)
+    assert torch.allclose(y.cpu().float(), ref.float(), **TOL)
+    c16 = _canon_cpu(K, 4096, "fp16", 6)
+    y32 = ops.linear(x.to(DEV), c16.pack().to(DEV), epilogue=_C.EPI_OUT_F32)
+    assert y32.dtype == torch.float32
+    assert torch.allclose(y32.cpu(), oracle.linear(x, _dense(c16), out_f32=True), **TOL)
+
+
+def test_linear_is_deterministic():
+    c = _canon_cpu(3584, 512, "w4", 9)
+    x, p = _x(16, 3584, 4).to(DEV), c.pack().to(DEV)
+    y0 = ops.linear(x, p).clone()
+    for _ in range(5):
+        assert torch.equal(ops.linear(x, p), y0)
+
+
+def test_linear_rejects_cpu_tensor_and_bad_shape():
+    c = _canon_cpu(256, 64, "w4", 1)
+    with pytest.raises(_C.Mi355Error):
+        ops.linear(_x(2, 256, 0), c.pack().to(DEV))          # CPU activations: no fallback path
+    with pytest.raises(_C.Mi355Error):
+        ops.linear(_x(2, 128, 0).to(DEV), c.pack().to(DEV))  # K mismatch
+
+
+# ------------------------------------------------------------------ norms / elementwise
+@pytest.mark.parametrize("M", [1, 7, 64, 83])
+@pytest.mark.parametrize("H", [768, 896, 3584, 8192])
+def test_rmsnorm_and_add(M, H):
+    x, r = _x(M, H, 1), _x(M, H, 2)
+    w = (1 + 0.1 * torch.randn(H, generator=_gen(3))).half()
+    y = ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-6)
+    assert torch.allclose(y.cpu().float(), oracle.rmsnorm(x, w, 1e-6).float(), atol=5e-2, rtol=5e-2)
+    y2, res = ops.add_rmsnorm(x.to(DEV), r.to(DEV), w.to(DEV), 1e-6)
+    assert torch.equal(res.cpu(), x + r)                     # fp16 add is exact-rounded: bit equal
+    assert torch.allclose(y2.cpu().float(), oracle.rmsnorm(x + r, w, 1e-6).float(), atol=5e-2, rtol=5e-2)
+
+
+def test_silu_mul_embedding_argmax():
+    gu = _x(33, 2 * 4864, 5)
+    assert torch.allclose(ops.silu_mul(gu.to(DEV)).cpu().float(), oracle.silu_mul(gu).float(), **TOL)
+    table = _x(1000, 896, 6)
+    ids = torch.randint(0, 1000, (17,), generator=_gen(7), dtype=torch.int32)
+    assert torch.equal(ops.embedding(ids.to(DEV), table.to(DEV)).cpu(), table[ids.long()])
+    logits = torch.randn(9, 151936, generator=_gen(8))
+    logits[3, 77] = logits[3, 5000] = 99.0                   # tie -> lowest index, like torch.argmax
+    assert torch.equal(ops.argmax(logits.to(DEV)).cpu(), oracle.greedy(logits))
+
+
+# ------------------------------------------------------------------ RoPE + KV write
+@pytest.mark.parametrize("int8", [False, True])
+@pytest.mark.parametrize("nh,nkv,hd,page", [(28, 4, 128, 16), (14, 2, 64, 64), (8, 1, 128, 16)])
+def test_rope_kv_write(int8, nh, nkv, hd, page):
+    T, max_blocks, nblk = 6, 8, 64
+    cfg = model.ModelConfig("t", 1, nh * hd, nh, nkv, hd, 64, 128, max_pos=max_blocks * page)
+    cs = oracle.rope_cos_sin(hd, cfg.rope_theta, cfg.max_pos)
+    assert torch.equal(cs, model.rope_table(cfg, "cpu"))      # host table == oracle table, bit for bit
+    qkv = _x(T, (nh + 2 * nkv) * hd, 11)
+    pos = torch.tensor([0, 1, 15, 16, 37, max_blocks * page - 1], dtype=torch.int32)
+    bt = torch.randperm(nblk, generator=_gen(2))[: T * max_blocks].reshape(T, max_blocks).to(torch.int32)
+    kv, sc = kvcache.alloc_layer_cache(nblk, nkv, page, hd, int8, DEV)
+    q = ops.rope_kv_write(qkv.to(DEV), None, cs.to(DEV), pos.to(DEV), bt.to(DEV), kv, sc, nh, nkv, hd, page)
+    torch.cuda.synchronize()
+    qh = qkv[:, : nh * hd].reshape(T, nh, hd)
+    kh = qkv[:, nh * hd: (nh + nkv) * hd].reshape(T, nkv, hd)
+    vh = qkv[:, (nh + nkv) * hd:].reshape(T, nkv, hd)
+    q_ref, k_ref = oracle.apply_rope(qh, pos, cs), oracle.apply_rope(kh, pos, cs)
+    assert torch.allclose(q.cpu().float(), q_ref.float(), **TOL)
+    for t in range(T):
+        K, V, ks, vs = kvcache.read_tokens(kv, sc, bt[t], int(pos[t]) + 1)
+        K, V = K[-1].cpu(), V[-1].cpu()
+        if not int8:
+            assert torch.allclose(K.float(), k_ref[t].float(), **TOL)
+            assert torch.equal(V, vh[t])                     # V is a pure copy: bit exact
+        else:
+            vq, vsc = oracle.quant_kv_int8(vh[t])
+            assert torch.equal(V, vq) and torch.equal(vs[-1].cpu(), vsc)       # integer path: bit exact
+            kq, ksc = oracle.quant_kv_int8(k_ref[t])                             # oracle on the oracle's rotated K
+            # rotated K may differ by 1 fp16 ulp between GPU and CPU sincos products; allow 1 code
+            assert (K.int() - kq.int()).abs().max() <= 1
+            assert torch.allclose(ks[-1].cpu(), ksc, rtol=2e-3, atol=0)
+
+
+# ------------------------------------------------------------------ paged decode attention
+def _fill_cache(B, ctx_lens, nkv, hd, page, int8, nblk, seed):
+    g = _gen(seed)
+    max_blocks = (max(ctx_lens) + page - 1) // page
+    bt = torch.randperm(nblk, generator=g)[: B * max_blocks].reshape(B, max_blocks).to(torch.int32)
+    kv, sc = kvcache.alloc_layer_cache(nblk, nkv, page, hd, int8, DEV)
+    nat = []
+    for b in range(B):
+        K = (torch.randn(ctx_lens[b], nkv, hd, generator=g)).half()
+        V = (torch.randn(ctx_lens[b], nkv, hd, generator=g)).half()
+        if int8:
+            Kq, ks = oracle.quant_kv_int8(K); Vq, vs = oracle.quant_kv_int8(V)
+            kvcache.write_tokens(kv, sc, bt[b], 0, Kq, Vq, ks, vs)
+            nat.append((Kq, Vq, ks, vs))
+        else:
+            kvcache.write_tokens(kv, sc, bt[b], 0, K, V)
+            nat.append((K, V, None, None))
+    return kv, sc, bt, nat
+
+
+@pytest.mark.parametrize("int8", [False, True])
+@pytest.mark.parametrize("nh,nkv,hd,page", [(28, 4, 128, 16), (32, 8, 128, 16), (14, 2, 64, 64), (8, 1, 128, 64), (16, 16, 128, 16)])
+def test_paged_attention(int8, nh, nkv, hd, page):
+    ctx = [1, 7, 8, 15, 16, 17, 31, 33, 127, 128, 129, 500, 1024, 1500]
+    B = len(ctx)
+    nblk = sum((c + page - 1) // page for c in ctx) + B * ((max(ctx) + page - 1) // page)
+    kv, sc, bt, nat = _fill_cache(B, ctx, nkv, hd, page, int8, nblk, 21)
+    q = (torch.randn(B, nh, hd, generator=_gen(4))).half()
+    out = ops.paged_decode_attention(q.to(DEV), kv, sc, bt.to(DEV), torch.tensor(ctx, dtype=torch.int32, device=DEV), nkv,
+                                     page, max(ctx))
+    torch.cuda.synchronize()
+    for b in range(B):
+        K, V, ks, vs = nat[b]
+        ref = oracle.attention_decode(q[b], K, V, 1 / math.sqrt(hd), ks, vs).reshape(-1)
+        assert torch.allclose(out[b].cpu().float(), ref.float(), **TOL), (b, ctx[b])
+
+
+def test_paged_attention_long_context_and_spike():
+    """ctx 4096 (cfg 3 length) + a key that dominates the softmax at a partition boundary: exercises the
+    online-softmax rescale branch (max jumps late) and the partition merge."""
+    nh, nkv, hd, page, ctx = 28, 4, 128, 16, 4096
+    kv, sc, bt, nat = _fill_cache(2, [ctx, ctx - 3], nkv, hd, page, False, 600, 5)
+    q = torch.randn(2, nh, hd, generator=_gen(6)).half()
+    K, V, _, _ = nat[0]
+    K[2049, 1] = (q[0, 9] * 0.9).half()                      # aligned with q head 9 (kv head 1): huge logit late
+    kvcache.write_tokens(kv, sc, bt[0], 0, K, V)
+    out = ops.paged_decode_attention(q.to(DEV), kv, sc, bt.to(DEV), torch.tensor([ctx, ctx - 3], dtype=torch.int32, device=DEV),
+                                     nkv, page, ctx)
+    for b in range(2):
+        Kb, Vb, _, _ = nat[b]
+        ref = oracle.attention_decode(q[b], Kb, Vb, 1 / math.sqrt(hd)).reshape(-1)
+        assert torch.allclose(out[b].cpu().float(), ref.float(), **TOL)
+
+
+# ------------------------------------------------------------------ whole decode step: engine vs module graph vs oracle
+def _tiny_cfg():
+    return model.ModelConfig("tiny-qwen2", 3, 512, 8, 2, 64, 1024, 2048, max_pos=512)
+
+
+def _oracle_weights(w):
+    return {"embedding": w["embedding"], "final_norm": w["final_norm"], "lm_head": _dense(w["lm_head"]),
+            "layers": [{"input_norm": L["input_norm"], "post_norm": L["post_norm"], "qkv_bias": L["qkv_bias"],
+                        **{k: _dense(L[k]) for k in ("qkv", "o", "gate_up", "down")}} for L in w["layers"]]}
+
+
+@pytest.mark.parametrize("kind,kv_int8", [("w4", False), ("w4", True), ("int8", False), ("fp16", False)])
+def test_engine_greedy_decode_matches_oracle(kind, kv_int8):
+    """Prompt fed token by token through the decode path, then greedy generation; compared with the oracle:
+    logits within 1e-2 (fp16), greedy token ids identical (north_star parity gate)."""
+    cfg = _tiny_cfg()
+    w = model.synth_model(cfg, kind, "cpu", seed=3)
+    B, page, prompt_len, gen_len = 3, 16, 5, 8
+    odec = oracle.OracleDecoder({**cfg.__dict__}, _oracle_weights(w))
+    okv = oracle.OracleKV(cfg.num_layers, B, kv_int8)
+    wd = model.weights_to(w, DEV)
+    eng = model.DecoderEngine(cfg, wd, kv_int8=kv_int8, page=page, num_blocks=64, max_batch=4, max_seq_len=64, device=DEV)
+    bt = torch.randperm(64, generator=_gen(1))[: B * 4].reshape(B, 4).to(torch.int32)
+    prompt = torch.randint(0, cfg.vocab, (B, prompt_len), generator=_gen(2), dtype=torch.int32)
+    tok = prompt[:, 0].clone()
+    eng.set_inputs(tok.tolist(), [0] * B, bt)
+    use_graph = True
+    eng.capture(B)
+    for step in range(prompt_len + gen_len - 1):
+        pos = torch.full((B,), step, dtype=torch.int32)
+        _, ref_logits = odec.forward_tokens(tok, pos, okv, list(range(B)))
+        eng.replay(B, 1) if use_graph else eng.step(B)
+        torch.cuda.synchronize()
+        got = eng.logits[:B].cpu()
+        assert torch.allclose(got, ref_logits, **TOL), (step, (got - ref_logits).abs().max())
+        ref_next = oracle.greedy(ref_logits)
+        # greedy ids must agree wherever the oracle's top-2 margin exceeds the logits tolerance
+        top2 = ref_logits.topk(2, dim=-1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 2e-2
+        got_next = eng.token_ids[:B].cpu()
+        assert torch.equal(got_next[safe], ref_next[safe])
+        assert torch.equal(eng.positions[:B].cpu(), pos + 1)
+        tok = prompt[:, step + 1].clone() if step + 1 < prompt_len else ref_next
+        eng.token_ids[:B].copy_(tok)                          # teacher-force the oracle's token (keeps streams aligned)
+
+
+def test_module_graph_matches_engine():
+    """The reference-shaped Python module graph (LinearFactory / FMHA impl / RMSNorm modules) and the C++ step
+    driver run the same kernels: hidden states agree to fp16 rounding of the fused epilogues."""
+    cfg = _tiny_cfg()
+    w = model.synth_model(cfg, "w4", DEV, seed=5)
+    B, page = 2, 16
+    eng = model.DecoderEngine(cfg, w, kv_int8=False, page=page, num_blocks=32, max_batch=2, max_seq_len=64, device=DEV)
+    pym = model.Qwen2DecoderModel(cfg, w, page, 64)
+    kvs = [model.LayerKVCache(*kvcache.alloc_layer_cache(32, cfg.nkv, page, cfg.hd, False, DEV), page, i) for i in range(cfg.num_layers)]
+    bt = torch.arange(B * 4, dtype=torch.int32).reshape(B, 4)
+    toks = torch.randint(0, cfg.vocab, (B, 6), generator=_gen(9), dtype=torch.int32)
+    eng.set_inputs(toks[:, 0].tolist(), [0] * B, bt)
+    for step in range(6):
+        eng.token_ids[:B].copy_(toks[:, step])
+        eng.step(B)
+        ai = model.PyAttentionInputs(False, torch.full((B,), step, dtype=torch.int32), None, bt.to(DEV))
+        hid = pym(toks[:, step].to(DEV), pym.prepare_fmha_impl(ai), kvs)
+        torch.cuda.synchronize()
+        assert torch.allclose(hid.float(), eng.hidden[:B].float(), atol=2e-2, rtol=2e-2)
+        assert torch.allclose(pym.logits(hid), eng.logits[:B], atol=3e-2, rtol=3e-2)
