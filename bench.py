@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""Decode benchmark — the reference's batch-decode protocol on MI355X.
+
+Mirrors rtp_llm/test/perf_test/batch_decode_test.py + BatchDecodeScheduler
+(docs/benchmark/benchmark.md:1-12): exactly `batch` sequences, KV cache allocated and filled
+without running prefill, every step decodes one token per sequence (greedy, fed back on
+device), W warm-up steps then K timed steps.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload NAME --batch B --ctx C]
+
+One JSON line on stdout (rank 0): BASELINE.json's metric (decode tokens/s + p50 latency,
+Qwen2-7B W4A16, seq 1024), plus `roofline` (dominant kernel = the weight-only dequant GEMM,
+algorithmic bytes / HIP-event time) and `cpu_baseline` (the CPU oracle timed on this host).
+Data: synthetic (random-init weights of the named architecture, random KV) — there is no
+network for checkpoints.  N > 1: tensor parallel over RCCL (one process per GPU, torchrun env).
+"""
+import argparse
+import json
+import math
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (model, weight kind, kv_int8, default batch, default ctx, page)
+    "qwen2-7b-w4a16": ("qwen2-7b", "w4", False, 64, 1024, 16),           # BASELINE.json metric (GPTQ g128, fp16 KV)
+    "qwen2-7b-w8a16": ("qwen2-7b", "int8", False, 16, 1024, 16),         # configs[1]
+    "qwen2-7b-w4a16-kv8": ("qwen2-7b", "w4", True, 64, 4096, 16),        # configs[2]
+    "qwen2-0.5b-fp16": ("qwen2-0.5b", "fp16", False, 1, 128, 16),        # configs[0] shape (GPU run of the plumbing config)
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def bytes_per_step(cfg, eng, B, ctx, kv_int8):
+    """Algorithmic HBM bytes of one decode step: packed linear weights (+scales/zeros) once,
+    lm_head once, KV of every cached token once."""
+    kv_tok = (2 * cfg.nkv * cfg.hd * (1 if kv_int8 else 2) + (2 * cfg.nkv * 4 if kv_int8 else 0)) * cfg.num_layers
+    return {"linears": eng.packed_bytes, "lm_head": eng.packed_bytes_lm_head, "kv": B * ctx * kv_tok}
+
+
+def fill_kv_random(eng, B, ctx, seed):
+    """Perf-mode cache: random K/V for the first ctx-1 tokens of every sequence ("allocate KV without prefill")."""
+    g = torch.Generator(device=eng.device).manual_seed(seed)
+    for l in range(eng.cfg.num_layers):
+        kv = eng.kv[l]
+        if kv.dtype == torch.int8:
+            kv.copy_(torch.randint(-127, 128, kv.shape, device=eng.device, generator=g, dtype=torch.int8))
+            eng.kv_scale[l].copy_(torch.rand(eng.kv_scale[l].shape, device=eng.device, generator=g) * 0.02 + 0.005)
+        else:
+            kv.copy_(torch.randn(kv.shape, device=eng.device, generator=g, dtype=torch.float16))
+
+
+def cpu_baseline(cfg, kind, kv_int8, B, ctx, budget_s=25.0):
+    """Time the CPU oracle (oracle/oracle.py) on this host: a reduced-layer proxy scaled linearly in L
+    (the reference's own perf knob hack_layer_num, docs/benchmark/benchmark.md)."""
+    from oracle import oracle
+    from rtp_llm_amd import model
+    torch.set_num_threads(os.cpu_count() or 1)
+    nl = 2
+    small = model.ModelConfig(cfg.name, nl, cfg.hidden, cfg.nh, cfg.nkv, cfg.hd, cfg.inter, cfg.vocab, cfg.rope_theta,
+                              cfg.rms_eps, cfg.qkv_bias, ctx + 8)
+    gen = torch.Generator().manual_seed(0)
+    dense = lambda c: (c.w.float() if c.kind == "fp16" else oracle.dequant_int8(c.q, c.scales) if c.kind == "int8"
+                       else oracle.dequant_groupwise(c.q, c.z_eff, c.scales, c.group_size))
+    layers = []
+    for _ in range(nl):
+        L = model.synth_layer(small, kind, "cpu", gen)
+        layers.append({"input_norm": L["input_norm"], "post_norm": L["post_norm"], "qkv_bias": L["qkv_bias"],
+                       **{k: dense(L[k]) for k in ("qkv", "o", "gate_up", "down")}})
+    w = {"layers": layers, "embedding": torch.randn(1024, cfg.hidden).half(), "final_norm": torch.ones(cfg.hidden).half(),
+         "lm_head": torch.zeros(cfg.hidden, 8)}  # lm_head timed separately below
+    dec = oracle.OracleDecoder({**small.__dict__}, w)
+    kv = oracle.OracleKV(nl, B, kv_int8)
+    # pre-populate ctx-1 cached tokens per sequence (stacked once, not via append)
+    for l in range(nl):
+        for b in range(B):
+            K = torch.randn(ctx - 1, cfg.nkv, cfg.hd).half(); V = torch.randn(ctx - 1, cfg.nkv, cfg.hd).half()
+            if kv_int8:
+                Kq, ks = oracle.quant_kv_int8(K); Vq, vs = oracle.quant_kv_int8(V)
+                kv.k[l][b], kv.v[l][b], kv.ks[l][b], kv.vs[l][b] = list(Kq), list(Vq), list(ks), list(vs)
+            else:
+                kv.k[l][b], kv.v[l][b] = list(K), list(V)
+    ids = torch.randint(0, 1024, (B,), dtype=torch.int32)
+    times = []
+    t_start = time.time()
+    for it in range(4):
+        pos = torch.full((B,), ctx - 1 + it, dtype=torch.int32)
+        t0 = time.time()
+        dec.forward_tokens(ids, pos, kv, list(range(B)))
+        times.append(time.time() - t0)
+        if time.time() - t_start > budget_s:
+            break
+    t_layers = statistics.median(times[1:] or times) / nl
+    lm = torch.randn(cfg.hidden, cfg.vocab)
+    x = torch.randn(B, cfg.hidden).half()
+    t0 = time.time(); oracle.greedy(oracle.linear(x, lm, out_f32=True)); t_lm = time.time() - t0
+    step = t_layers * cfg.num_layers + t_lm
+    return {"value": round(B / step, 2), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/oracle.py OracleDecoder: {nl} of {cfg.num_layers} layers x {len(times)} steps at batch {B} ctx {ctx} "
+                      f"(median, first step dropped) + one lm_head, scaled linearly to {cfg.num_layers} layers; weights dequantised once",
+            "ms_per_step": round(step * 1e3, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="qwen2-7b-w4a16", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--ctx", type=int, default=None)
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then labelled invalid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    from rtp_llm_amd import _C, distributed, model
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    _C.lib()  # fail loudly when the HIP extension is missing
+
+    mname, kind, kv_int8, dB, dctx, page = WORKLOADS[args.workload]
+    B, ctx = args.batch or dB, args.ctx or dctx
+    cfg_full = model.MODELS[mname]
+    if args.layers:
+        cfg_full = model.ModelConfig(**{**cfg_full.__dict__, "num_layers": args.layers})
+    # ---- parallel layout: TP over the largest divisor of the head counts, data-parallel replicas for the rest
+    tp = 1
+    if world > 1:
+        distributed.init_distributed("nccl")
+        tp = max(t for t in range(1, world + 1) if world % t == 0 and cfg_full.nh % t == 0 and cfg_full.nkv % t == 0
+                 and cfg_full.inter % (t * 128) == 0)
+        dp = world // tp
+        import torch.distributed as dist
+        for r0 in range(0, world, tp):   # every rank creates every group (torch.distributed contract)
+            grp = dist.new_group(list(range(r0, r0 + tp)))
+            if r0 <= rank < r0 + tp:
+                distributed.set_tp_group(grp)
+    dp = world // tp
+    tp_rank = rank % tp
+    cfg = cfg_full.per_rank(tp)
+    total_steps = args.steps + args.warmup + 8
+    max_seq_len = ctx + total_steps + 64
+    blocks_per_seq = (max_seq_len + page - 1) // page
+    num_blocks = B * blocks_per_seq
+
+    # ---- synthetic weights, generated per rank directly at per-rank shapes (random init: the TP split of
+    # random tensors is random tensors; norms/embedding use the same seed on every rank)
+    t0 = time.time()
+    wseed = 1000 + tp_rank
+    gen = torch.Generator(device=dev).manual_seed(wseed)
+    layers = [model.synth_layer(cfg, kind, dev, gen) for _ in range(cfg.num_layers)]
+    gshared = torch.Generator(device=dev).manual_seed(7)
+    for L in layers:  # replicated tensors must be identical on all TP ranks
+        L["input_norm"] = (1.0 + 0.1 * torch.randn(cfg.hidden, device=dev, generator=gshared)).half()
+        L["post_norm"] = (1.0 + 0.1 * torch.randn(cfg.hidden, device=dev, generator=gshared)).half()
+    weights = {
+        "layers": layers,
+        "embedding": (torch.randn(cfg_full.vocab, cfg.hidden, device=dev, generator=gshared) * 0.5).half(),
+        "final_norm": (1.0 + 0.1 * torch.randn(cfg.hidden, device=dev, generator=gshared)).half(),
+        "lm_head": model.synth_linear(cfg.hidden, cfg.vocab, "fp16", dev, gen),
+    }
+    eng = model.DecoderEngine(cfg, weights, kv_int8=kv_int8, page=page, num_blocks=num_blocks, max_batch=B,
+                              max_seq_len=max_seq_len, device=dev, tp_size=tp, vocab_full=cfg_full.vocab)
+    del weights, layers
+    torch.cuda.empty_cache()
+    fill_kv_random(eng, B, ctx, seed=2 + rank)
+    gi = torch.Generator().manual_seed(1 + rank // tp)
+    ids0 = torch.randint(0, cfg_full.vocab, (B,), generator=gi, dtype=torch.int32)
+    bt = torch.randperm(num_blocks, generator=torch.Generator().manual_seed(2)).reshape(B, blocks_per_seq).to(torch.int32)
+
+    def reset():
+        eng.set_inputs(ids0.tolist(), [ctx - 1] * B, bt)
+
+    reset()
+    torch.cuda.synchronize()
+    log(f"[rank {rank}] setup {time.time() - t0:.1f}s: {args.workload} B={B} ctx={ctx} tp={tp} dp={dp} "
+        f"weights {eng.packed_bytes / 1e9:.2f} GB + lm_head {eng.packed_bytes_lm_head / 1e9:.2f} GB")
+
+    # ---- step runner
+    graph = None
+    if tp == 1:
+        if not args.no_graph:
+            eng.capture(B)
+        run = (lambda n: eng.replay(B, n)) if not args.no_graph else (lambda n: [eng.step(B) for _ in range(n)])
+    else:
+        run_eager = lambda n: [eng.step_tp(B) for _ in range(n)]
+        run = run_eager
+        if not args.no_graph and os.environ.get("MI355_TP_GRAPH", "1") == "1":
+            try:  # capture the TP step (RCCL collectives included) into one graph; fall back to eager on any failure
+                run_eager(2)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    eng.step_tp(B)
+                graph = g
+                run = lambda n: [graph.replay() for _ in range(n)]
+                log(f"[rank {rank}] TP step captured in a hipGraph")
+            except Exception as e:  # noqa: BLE001
+                log(f"[rank {rank}] TP graph capture failed ({type(e).__name__}: {e}); running eager")
+                graph = None
+                run = run_eager
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    # ---- warm-up + timed region: EXACTLY K steps between barrier + synchronize on both sides
+    reset()
+    run(args.warmup)
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    tokens_per_s = B * dp * args.steps / elapsed
+
+    # ---- p50 step latency (separate pass, per-step events on the launch stream)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(33)]
+    evs[0].record()
+    for i in range(32):
+        run(1)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    p50 = statistics.median(evs[i].elapsed_time(evs[i + 1]) for i in range(32))
+
+    out = {
+        "metric": "decode tokens/sec + p50 latency, Qwen2-7B W4A16 b=1..64 @1/2/4/8 GPU" if args.workload == "qwen2-7b-w4a16"
+                  else f"decode tokens/sec + p50 latency ({args.workload})",
+        "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "p50_ms": round(p50, 4), "higher_is_better": True,
+        "scaling": "strong" if dp == 1 else "weak", "vs_baseline": None, "dtype": "f16",
+        "data": "synthetic (random-init weights of the named architecture, random KV cache, greedy decode)",
+        "config": {"workload": f"{args.workload}: {mname} decode, weights {kind}"
+                               f"{' GPTQ g128' if kind == 'w4' else ''}, KV {'int8' if kv_int8 else 'fp16'}, page {page}",
+                   "batch": B, "global_batch": B * dp, "seq_len": ctx, "parallelism": f"tp{tp}" + (f"dp{dp}" if dp > 1 else ""),
+                   "graph": bool(tp == 1 and not args.no_graph) or graph is not None},
+    }
+    if args.layers:
+        out["invalid"] = f"debug run with --layers {args.layers}"
+
+    if rank == 0 and tp == 1:
+        # ---- roofline of the dominant kernel (weight-only dequant GEMM): algorithmic bytes / HIP-event time
+        bps = bytes_per_step(cfg, eng, B, ctx, kv_int8)
+        reset()
+        prof = eng.profile(B, 4)
+        torch.cuda.synchronize()
+        gq = prof["gemm_quant"]
+        n_launch_step = 4 * cfg.num_layers
+        act_bytes = B * 2 * (cfg.hidden * 2 + cfg.nh * cfg.hd + (cfg.nh + 2 * cfg.nkv) * cfg.hd + 2 * cfg.inter) * cfg.num_layers
+        alg_bytes_launch = (bps["linears"] + act_bytes) / n_launch_step
+        avg_ms = gq["ms"] / max(1, gq["launches"])
+        ach = alg_bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": "gemm_wq_kernel (qkv/o/gate_up/down linears)", "achieved": round(ach, 1),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                           "bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_ms * 1e3, 3),
+                           "launches_timed": gq["launches"]}
+        total_b = sum(bps.values())
+        out["step_roofline"] = {"bytes_per_step": int(total_b), "achieved_GBs": round(total_b / (ms_per_step * 1e-3) / 1e9, 1),
+                                "frac_of_8TBs": round(total_b / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "breakdown_bytes": {k: int(v) for k, v in bps.items()},
+                                "eager_kernel_ms_per_step": {k: round(v["ms"] / 4, 4) for k, v in prof.items()}}
+        # ---- batch sweep of the metric (b = 1..64), same weights / cache
+        if not args.no_sweep and not args.no_graph:
+            sweep = []
+            for b in [x for x in (1, 2, 4, 8, 16, 32, 64) if x <= B]:
+                eng.capture(b)
+                reset(); eng.replay(b, 4); torch.cuda.synchronize()
+                t0 = time.perf_counter(); eng.replay(b, 32); torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / 32 * 1e3
+                bb = bytes_per_step(cfg, eng, b, ctx, kv_int8)
+                sweep.append({"batch": b, "tokens_per_s": round(b / ms * 1e3, 1), "ms_per_step": round(ms, 4),
+                              "hbm_frac": round(sum(bb.values()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+            out["sweep"] = sweep
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg_full, kind, kv_int8, B, ctx)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
