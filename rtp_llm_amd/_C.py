@@ -90,6 +90,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise Mi355Error(f"{LIB_PATH} not found - build it with `python -m rtp_llm_amd.build` "
                              "(the HIP extension is required; there is no CPU fallback)")
+        # PyTorch-ROCm bundles its own libamdhip64; it must be loaded first so that this library binds to the
+        # same HIP runtime instance (two runtimes in one process cannot share device pointers / streams).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the ABI lost a symbol

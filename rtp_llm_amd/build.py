@@ -22,7 +22,7 @@ HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "internal.h"), os.
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-CFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wno-unused-result", "-x", "hip"]
+CFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fno-slp-vectorize", "-Wno-unused-result", "-x", "hip"]
 
 
 def _stale(src, obj):

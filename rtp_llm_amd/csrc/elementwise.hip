@@ -32,10 +32,26 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const f16* __restrict_
             if (partials) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[t][e] = 0.f;
-                for (int s = 0; s < nsplit; ++s) {
-                    const float* src = partials + ((size_t)s * M + row) * ld + c0;
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(src);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
+                // slabs are summed in index order (deterministic); loads are issued 4 slabs at a time so the
+                // reduction costs ~nsplit/4 memory round trips instead of nsplit
+                const size_t sstride = (size_t)M * ld;
+                const float* src0 = partials + (size_t)row * ld + c0;
+                int s = 0;
+                for (; s + 4 <= nsplit; s += 4) {
+                    f32x4 a[4], b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        a[u] = *reinterpret_cast<const f32x4*>(src0 + (s + u) * sstride);
+                        b[u] = *reinterpret_cast<const f32x4*>(src0 + (s + u) * sstride + 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[t][e] += a[u][e]; v[t][4 + e] += b[u][e]; }
+                }
+                for (; s < nsplit; ++s) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(src0 + s * sstride);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(src0 + s * sstride + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[t][e] += a[e]; v[t][4 + e] += b[e]; }
                 }

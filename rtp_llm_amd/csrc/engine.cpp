@@ -250,10 +250,11 @@ extern "C" int mi355_decoder_step(mi355_decoder_t* d, int32_t B, mi355_stream_t 
 extern "C" int mi355_decoder_capture(mi355_decoder_t* d, int32_t B) {
     if (!d || B <= 0 || B > d->cfg.max_batch) { mi355_set_error("decoder_capture: B=%d", B); return MI355_ERR_ARG; }
     if (d->graphs.count(B)) return MI355_OK;
-    if (!d->cap_stream && hipStreamCreateWithFlags(&d->cap_stream, hipStreamNonBlocking) != hipSuccess) {
-        mi355_set_error("decoder_capture: stream create failed"); return MI355_ERR_HIP;
+    hipError_t e = hipSuccess;
+    if (!d->cap_stream && (e = hipStreamCreateWithFlags(&d->cap_stream, hipStreamNonBlocking)) != hipSuccess) {
+        mi355_set_error("decoder_capture: stream create failed: %s", hipGetErrorString(e)); return MI355_ERR_HIP;
     }
-    hipError_t e = hipStreamBeginCapture(d->cap_stream, hipStreamCaptureModeThreadLocal);
+    e = hipStreamBeginCapture(d->cap_stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { mi355_set_error("decoder_capture: begin: %s", hipGetErrorString(e)); return MI355_ERR_HIP; }
     const int rc = mi355_decoder_step(d, B, d->cap_stream);
     hipGraph_t g = nullptr;

@@ -48,161 +48,315 @@ __device__ __forceinline__ u32x4 bload128(__amdgpu_buffer_rsrc_t r, uint32_t off
     return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX);
 }
 
-template <int WBITS, int MB, int NBW, int GS, int D>
-__global__ __launch_bounds__(256) void gemm_wq_kernel(const GemmParams p) {
-    constexpr int LPC   = WBITS / 4;
-    constexpr int GSD   = (GS > 0) ? GS : 1; // divisor-safe
-    constexpr int NMETA = (GS > 0) ? 4 / GSD : 0;
-    constexpr int XSLOTS = 256 * MB; // 16-byte slots per x chunk tile
-    __shared__ u32x4 xs[2][XSLOTS];
+// ---- in-register widening of the packed codes to MFMA A-operands (no subtract, no scale: both move to
+// the accumulator side, see "zero / scale on the C side" below).
+//   W4: dword of step s -> 8 fp16:  (e0,e1) = 1024+u  (nibbles at mantissa bits 0-3, exponent of 1024.0)
+//                                   (e2,e3) =   64+u  (nibbles at mantissa bits 4-7, exponent of 64.0, ulp 1/16)
+//                                   (e4,e5), (e6,e7) the same after one shift by 8.   5 VALU per 8 weights.
+//   W8: 8 offset-binary bytes -> 8 fp16 1024+u via v_perm.                              4 VALU per 8 weights.
+// v_and_or_b32 is VOP3 (no literal operands on gfx9, one SGPR at most): the four constants live in VGPRs.
+struct W4Consts { uint32_t m0, m1, e0, e1; };
+__device__ __forceinline__ W4Consts w4_consts() {
+    W4Consts c = {0x000F000Fu, 0x00F000F0u, 0x64006400u, 0x54005400u};
+    asm volatile("" : "+v"(c.m0), "+v"(c.m1), "+v"(c.e0), "+v"(c.e1)); // keep them in VGPRs
+    return c;
+}
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t m, uint32_t o) {
+    return (a & m) | o; // selected as v_and_or_b32 once the constants are opaque VGPRs (no inline asm: its result
+                        // feeding an MFMA would need hand-placed wait states)
+}
+__device__ __forceinline__ f16x8 widen_w4(uint32_t w, const W4Consts& c) {
+    const uint32_t w8 = w >> 8;
+    u32x4 r;
+    r[0] = and_or(w, c.m0, c.e0);
+    r[1] = and_or(w, c.m1, c.e1);
+    r[2] = and_or(w8, c.m0, c.e0);
+    r[3] = and_or(w8, c.m1, c.e1);
+    return __builtin_bit_cast(f16x8, r);
+}
+__device__ __forceinline__ f16x8 widen_w8(uint32_t lo, uint32_t hi) {
+    const uint32_t C = 0x64646464u;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_perm(C, lo, 0x04010400u);
+    r[1] = __builtin_amdgcn_perm(C, lo, 0x04030402u);
+    r[2] = __builtin_amdgcn_perm(C, hi, 0x04010400u);
+    r[3] = __builtin_amdgcn_perm(C, hi, 0x04030402u);
+    return __builtin_bit_cast(f16x8, r);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// Block shape: NWN "n-waves" share one x tile and own NBW 16-column tiles each (BN = 16*NBW*NWN columns);
+// KG "k-groups" of NWN waves split the block's chunk range between them (intra-block split-K, merged
+// through LDS at the end).  Small M wants many waves in flight per CU (KG = 2, narrow BN); large M wants a
+// wide BN so the x tile (4*MB KiB per chunk) is amortised over >= as many weight bytes.
+//
+// Zero / scale on the C side.  The MFMA consumes the biased codes (1024+u or 64+u, exact in fp16) and
+// accumulates  S = sum_k (bias_k + u_k) x_k  per quantisation group in fp32 (products are exact: 11 x 11 bits).
+// With X0 / X1 the fp32 sums of x over the 1024-biased / 64-biased positions of the group (computed once
+// per chunk by the threads that stage x, kept in LDS):
+//     sum_k (u_k - z) x_k = S - (1024+z) X0 - (64+z) X1 = [S + 960 X1] + zneg (X0 + X1),   zneg = -(1024+z)
+//     y += scale * that.
+// Cost: 2 v_fma_mix per output element per group instead of 2 packed ops per weight pair — 2x fewer VALU
+// at M <= 16, where the dequant ALU work was the measured limiter (VALU issues 1 wave-instruction per 4 cycles).
+template <int WBITS, int MB, int NBW, int GS, int D, int NWN, int KG>
+__global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams p) {
+    constexpr int LPC    = WBITS / 4;              // wave-loads per (tile, chunk)
+    constexpr int NSUB   = (GS > 0) ? 4 / GS : 1;  // quantisation groups per chunk (per-channel: 1 pseudo group)
+    constexpr int SPG    = 4 / NSUB;               // MFMA k-steps per group
+    constexpr bool QUANT = WBITS != 16;
+    constexpr bool GROUPED = GS > 0;               // per-group scale (else one scale per column, applied at the end)
+    constexpr int GT     = 64 * NWN;               // threads per k-group
+    constexpr int XSLOTS = 256 * MB;               // 16-byte slots per x chunk tile
+    constexpr int UPT    = (XSLOTS + GT - 1) / GT; // x pieces per thread per chunk
+    constexpr int XR     = D;                      // x ring depth: x(c) is issued before w(c), so the in-order
+                                                   // vmcnt wait for x never drains newer weight loads
+    constexpr int PPG    = 16 / NSUB;              // 16-byte pieces of a row per group
+    __shared__ u32x4 xs[KG][2][XSLOTS];
+    __shared__ float xsum[QUANT ? KG : 1][2][NSUB * 2][16 * MB];
+    __shared__ f32x4 red[(KG > 1) ? NWN * NBW * MB * 64 : 1];
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn   = wave % NWN;                   // n-wave index
+    const int kg   = wave / NWN;                   // k-group
+    const int tg   = tid - kg * GT;                // thread index inside the k-group
     const int jj = lane & 15, q = lane >> 4;
 
-    const int nt_base = (blockIdx.x * 4 + wave) * NBW;
-    const int c_begin = blockIdx.y * p.cps;
-    const int n_ch    = min(p.cps, p.KC - c_begin);
+    const int nt_base = (blockIdx.x * NWN + wn) * NBW;
+    const int blk_c0  = blockIdx.y * p.cps;
+    const int blk_nch = min(p.cps, p.KC - blk_c0);
+    const int n_it    = (blk_nch + KG - 1) / KG;   // iterations = chunks of the longest k-group
+    const int c_begin = blk_c0 + kg * n_it;
+    const int n_ch    = max(0, min(n_it, blk_c0 + blk_nch - c_begin));
 
-    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.qw, 0, p.qw_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)p.meta, 0, p.meta_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-
-    const uint32_t OOB = 0xFFFFFFF0u;
-
-    // per-tile byte offsets (chunk 0 of this split), OOB when the tile does not exist
-    uint32_t woff[NBW];
-    uint32_t moff[NBW];
-    bool     tile_ok[NBW];
+    // Bounds do the tail handling: every tile gets its own buffer descriptor covering exactly the chunks of
+    // this k-group, so loads past its end (ring prefetch, short ranges) return 0 without memory traffic and
+    // the main loop carries no conditional loads (a uniform select makes hipcc branch around the load and
+    // drain vmcnt — measured: it serialised the whole ring).
+    constexpr uint32_t FLAGS = 0x00020000u;
+    __amdgpu_buffer_rsrc_t rw[NBW], rm[NBW];
+    bool tile_ok[NBW];
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         const int nt = nt_base + nb;
         tile_ok[nb]  = nt < p.NT;
-        woff[nb] = tile_ok[nb] ? (uint32_t)(((uint32_t)nt * p.KC + c_begin) * LPC * 1024u + lane * 16u) : OOB;
-        moff[nb] = tile_ok[nb] ? (uint32_t)((nt * 16 + jj) * 4) : OOB;
+        const char* wb = (const char*)p.qw + ((size_t)nt * p.KC + c_begin) * (LPC * 1024);
+        rw[nb] = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, tile_ok[nb] ? n_ch * LPC * 1024 : 0, FLAGS);
+        const char* mb = (const char*)p.meta + ((size_t)(GROUPED ? c_begin * NSUB : 0) * p.N_pad + nt * 16) * 4;
+        const int mbytes = GROUPED ? (n_ch > 0 ? ((n_ch * NSUB - 1) * p.N_pad + 16) * 4 : 0) : 64;
+        rm[nb] = __builtin_amdgcn_make_buffer_rsrc((void*)mb, 0, (tile_ok[nb] && QUANT) ? mbytes : 0, FLAGS);
     }
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, FLAGS);
+    const uint32_t OOBX = 0x80000000u; // x images are < 2 GiB: stays out of range after adding chunk offsets
 
     u32x4    wr[D][NBW][LPC];
-    uint32_t mr[D][NBW][NMETA > 0 ? NMETA : 1];
+    uint32_t mr[D][NBW][NSUB];                     // meta {zneg, scale} of column 16nt + jj, per group
     f32x4    acc[NBW][MB];
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const uint32_t lane16 = lane * 16u, jj4 = jj * 4u;
+    const W4Consts w4c = w4_consts();
     auto load_w = [&](int d, int ci) {
-        const bool ok = ci < n_ch;
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
-            const uint32_t base = (ok && tile_ok[nb]) ? woff[nb] + (uint32_t)ci * (LPC * 1024u) : OOB;
 #pragma unroll
-            for (int lp = 0; lp < LPC; ++lp) wr[d][nb][lp] = bload128<2 /*nt*/>(rw, base + lp * 1024u);
-            if (NMETA > 0) {
+            for (int lp = 0; lp < LPC; ++lp)
+                wr[d][nb][lp] = bload128<2 /*nt*/>(rw[nb], lane16 + (uint32_t)(ci * LPC + lp) * 1024u);
+            if (GROUPED) {
 #pragma unroll
-                for (int gi = 0; gi < NMETA; ++gi) {
-                    const int g = (c_begin + ci) * NMETA + gi;
-                    const uint32_t mo = (ok && tile_ok[nb]) ? moff[nb] + (uint32_t)g * (uint32_t)p.N_pad * 4u : OOB;
-                    mr[d][nb][gi] = __builtin_amdgcn_raw_buffer_load_b32(rm, mo, 0, 0);
+                for (int gi = 0; gi < NSUB; ++gi)
+                    mr[d][nb][gi] = __builtin_amdgcn_raw_buffer_load_b32(
+                        rm[nb], jj4 + (uint32_t)(ci * NSUB + gi) * (uint32_t)p.N_pad * 4u, 0, 0);
+            }
+        }
+    };
+
+    // x staging: the GT threads of a k-group own the 256*MB 16-byte pieces of its [16*MB rows][128 k] tile
+    uint32_t xoff[UPT];
+    int      xlim[UPT]; // number of chunks of this k-group for which the piece is inside [0, K) and the group's range
+    int      xslot[UPT], xsidx[UPT];
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+        const int pi = tg + GT * u;
+        const int j = pi >> 4, pp = pi & 15;
+        const int k0 = c_begin * 128 + pp * 8;
+        const bool ok = pi < XSLOTS && j < p.M && k0 < p.K;
+        xoff[u]  = (uint32_t)((j * p.K + k0) * 2);
+        xlim[u]  = ok ? min((p.K - k0 + 127) / 128, n_ch) : 0; // also zero past this k-group's range: OOB codes are not zero weights
+        xslot[u] = (pi < XSLOTS) ? pp * (16 * MB) + (j ^ (pp & 3)) : -1;
+        xsidx[u] = (pi < XSLOTS && (pp % PPG) == 0) ? (pp / PPG) * 2 * (16 * MB) + j : -1;
+    }
+    // x register ring: chunk c lives in xr[c % XR], loaded XR-1 iterations ahead, written to LDS one ahead
+    u32x4 xr[XR][UPT];
+    auto load_x = [&](int d, int ci) {
+#pragma unroll
+        for (int u = 0; u < UPT; ++u)   // per-lane select (v_cndmask): pieces past K / rows past M read as zero
+            xr[d][u] = bload128<0>(rx, (ci < xlim[u]) ? xoff[u] + (uint32_t)ci * 256u : OOBX);
+    };
+    auto store_x = [&](int d, int buf) {
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) {
+            if (UPT * GT == XSLOTS || xslot[u] >= 0) xs[kg][buf][xslot[u]] = xr[d][u];
+            if (QUANT) {
+                // group sums of x over the two code-bias classes; a row's 16 pieces sit in 16 adjacent lanes
+                const f16x2 ones = {(f16)1.f, (f16)1.f};
+                const u32x4 v = xr[d][u];
+                float s0, s1;
+                if (WBITS == 4) {
+                    s0 = __builtin_amdgcn_fdot2(as_h2(v[0]), ones, 0.f, false);
+                    s1 = __builtin_amdgcn_fdot2(as_h2(v[1]), ones, 0.f, false);
+                    s0 = __builtin_amdgcn_fdot2(as_h2(v[2]), ones, s0, false);
+                    s1 = __builtin_amdgcn_fdot2(as_h2(v[3]), ones, s1, false);
+                } else {
+                    s0 = __builtin_amdgcn_fdot2(as_h2(v[0]), ones, 0.f, false);
+                    s0 = __builtin_amdgcn_fdot2(as_h2(v[1]), ones, s0, false);
+                    s0 = __builtin_amdgcn_fdot2(as_h2(v[2]), ones, s0, false);
+                    s0 = __builtin_amdgcn_fdot2(as_h2(v[3]), ones, s0, false);
+                    s1 = 0.f;
+                }
+                s0 = dpp_add<0xB1>(s0); s0 = dpp_add<0x4E>(s0);           // quad: xor 1, xor 2
+                if (PPG >= 8) s0 = dpp_add<0x141>(s0);                     // row_half_mirror: 8 lanes
+                if (PPG >= 16) s0 = dpp_add<0x140>(s0);                    // row_mirror: 16 lanes
+                if (WBITS == 4) {
+                    s1 = dpp_add<0xB1>(s1); s1 = dpp_add<0x4E>(s1);
+                    if (PPG >= 8) s1 = dpp_add<0x141>(s1);
+                    if (PPG >= 16) s1 = dpp_add<0x140>(s1);
+                }
+                if (xsidx[u] >= 0) {
+                    (&xsum[kg][buf][0][0])[xsidx[u]] = s0;
+                    (&xsum[kg][buf][0][0])[xsidx[u] + 16 * MB] = s1;
                 }
             }
         }
     };
 
-    // x staging: thread owns MB 16-byte pieces of the [16*MB rows][128 k] chunk tile
-    uint32_t xoff[MB];
-    int      xslot[MB];
+    // prologue: x first, then weights (issue order matters for the in-order vmcnt)
 #pragma unroll
-    for (int u = 0; u < MB; ++u) {
-        const int pi = tid + 256 * u;
-        const int j = pi >> 4, pp = pi & 15;
-        xoff[u]  = (j < p.M) ? (uint32_t)((j * p.K + c_begin * 128 + pp * 8) * 2) : OOB;
-        xslot[u] = pp * (16 * MB) + (j ^ (pp & 3));
-    }
-    const int kpiece0 = c_begin * 128; // k of piece 0 in chunk 0
-    u32x4 xr[MB];
-    auto load_x = [&](int ci) {
-#pragma unroll
-        for (int u = 0; u < MB; ++u) {
-            const int pp = (tid + 256 * u) & 15;
-            const bool ok = (ci < n_ch) && (kpiece0 + ci * 128 + pp * 8 < p.K) && (xoff[u] != OOB);
-            xr[u] = bload128<0>(rx, ok ? xoff[u] + (uint32_t)ci * 256u : OOB);
-        }
-    };
-    auto store_x = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < MB; ++u) xs[buf][xslot[u]] = xr[u];
-    };
-
-    // per-channel mode: zero term is constant along K
-    uint32_t mch[NBW];
-    if (GS == 0 && WBITS != 16) {
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) mch[nb] = __builtin_amdgcn_raw_buffer_load_b32(rm, moff[nb], 0, 0);
-    }
-
-    // prologue
+    for (int d = 0; d < XR - 1; ++d) load_x(d, d);
 #pragma unroll
     for (int d = 0; d < D; ++d) load_w(d, d);
-    load_x(0);
-    store_x(0);
+    store_x(0, 0);
     __syncthreads();
 
     auto compute = [&](int d, int buf) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            f16x8 b[MB];
+        for (int gi = 0; gi < NSUB; ++gi) {
+            float XS[MB];
+            f32x4 ag[NBW][MB];
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                const u32x4 v = xs[buf][(s * 4 + q) * (16 * MB) + mb * 16 + (jj ^ q)];
-                b[mb] = __builtin_bit_cast(f16x8, v);
-            }
-#pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) {
-                f16x8 a;
-                if (WBITS == 16) {
-                    a = __builtin_bit_cast(f16x8, wr[d][nb][s % LPC]);
-                } else {
-                    const uint32_t m = (GS > 0) ? mr[d][nb][(GS > 0) ? s / GSD : 0] : mch[nb];
-                    const f16x2 zneg2 = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u));
-                    const f16x2 s2    = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
-                    if (WBITS == 4) {
-                        a = dequant_w4(wr[d][nb][0][s], zneg2, s2);
-                    } else {
-                        const u32x4 w = wr[d][nb][(s >> 1) % LPC];
-                        a = dequant_w8<(GS > 0)>(w[(s & 1) * 2], w[(s & 1) * 2 + 1], zneg2, s2);
-                    }
+                float xb = 0.f;
+                if (QUANT) {
+                    const float x0 = xsum[kg][buf][gi * 2 + 0][mb * 16 + jj];
+                    const float x1 = xsum[kg][buf][gi * 2 + 1][mb * 16 + jj];
+                    XS[mb] = x0 + x1;
+                    xb = 960.f * x1;
                 }
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = mfma16x16x32(a, b[mb], acc[nb][mb]);
+                for (int nb = 0; nb < NBW; ++nb) ag[nb][mb] = (f32x4){xb, xb, xb, xb};
+            }
+#pragma unroll
+            for (int ss = 0; ss < SPG; ++ss) {
+                const int s = gi * SPG + ss;
+                f16x8 b[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const u32x4 v = xs[kg][buf][(s * 4 + q) * (16 * MB) + mb * 16 + (jj ^ q)];
+                    b[mb] = __builtin_bit_cast(f16x8, v);
+                }
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    f16x8 a;
+                    if (WBITS == 16) {
+                        a = __builtin_bit_cast(f16x8, wr[d][nb][s % LPC]);
+                    } else if (WBITS == 4) {
+                        a = widen_w4(wr[d][nb][0][s], w4c);
+                    } else {
+                        const u32x4 w = wr[d][nb][(s >> 1) % LPC];
+                        a = widen_w8(w[(s & 1) * 2], w[(s & 1) * 2 + 1]);
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) ag[nb][mb] = mfma16x16x32(a, b[mb], ag[nb][mb]);
+                }
+            }
+            // ---- C side: rows of this lane are columns 16nt + 4q + r; their meta sits in lanes 4q + r
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                if (!QUANT) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) acc[nb][mb] += ag[nb][mb];
+                } else if (GROUPED) {
+                    f16x2 m4[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        m4[r] = as_h2((uint32_t)__builtin_amdgcn_ds_bpermute((q * 4 + r) * 4, (int)mr[d][nb][gi]));
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float t = __builtin_fmaf((float)m4[r][0], XS[mb], ag[nb][mb][r]);
+                            acc[nb][mb][r] = __builtin_fmaf((float)m4[r][1], t, acc[nb][mb][r]);
+                        }
+                } else { // per-channel int8: zero code 128 for every column, scale applied in the epilogue
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[nb][mb][r] += __builtin_fmaf(-1152.f, XS[mb], ag[nb][mb][r]);
+                }
             }
         }
     };
 
-    for (int it = 0; it < n_ch; it += D) {
+    auto slot = [&](int d, int ci) {
+        load_x((d + XR - 1) % XR, ci + XR - 1);  // OOB -> zeros past the end
+        compute(d, d & 1);                       // D is even, so ci & 1 == d & 1
+        load_w(d, ci + D);
+        store_x((d + 1) % XR, (d + 1) & 1);       // chunk ci+1, issued XR-2 iterations ago
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);         // keep slots apart: without it the scheduler hoists the widening
+                                                   // of all D ring entries to the top of the round and spills
+    };
+    // Rounds of D slots with NO per-slot guard (n_it is rounded up; slots past the end see zero x and OOB = 0
+    // weights).  With a guard inside the unrolled body hipcc's waitcnt pass must assume later slots may be
+    // skipped and emits vmcnt(1) for every ring read: each iteration then waits for a load issued one
+    // iteration earlier (measured: ~1 us per chunk).  Unguarded, the ring reads wait with vmcnt(3D - 4).
+    for (int it = 0; it < n_it; it += D) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int ci = it + d;
-            if (ci < n_ch) {
-                load_x(ci + 1);          // OOB -> zeros past the end
-                compute(d, d & 1);       // D is even, so (it + d) & 1 == d & 1
-                load_w(d, ci + D);
-                store_x((d + 1) & 1);
-                __syncthreads();
-            }
-        }
+        for (int d = 0; d < D; ++d) slot(d, it + d);
     }
 
-    // ------------------------------------------------------------ epilogue
+    // ------------------------------------------------------------ merge k-groups, epilogue
+    if (KG > 1) {
+        if (kg > 0) {
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) red[((wn * NBW + nb) * MB + mb) * 64 + lane] = acc[nb][mb];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[nb][mb] += red[((wn * NBW + nb) * MB + mb) * 64 + lane];
+    }
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         if (!tile_ok[nb]) continue;
         const int n0 = (nt_base + nb) * 16 + q * 4;
         f32x4 sc = {1.f, 1.f, 1.f, 1.f};
-        if (GS == 0 && WBITS != 16) {
+        if (QUANT && !GROUPED) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const uint32_t m = __builtin_amdgcn_raw_buffer_load_b32(rm, (uint32_t)(n0 + r) * 4u, 0, 0);
+                const uint32_t m = __builtin_amdgcn_raw_buffer_load_b32(rm[nb], (uint32_t)(q * 4 + r) * 4u, 0, 0);
                 sc[r] = (float)as_h2(m)[1];
             }
         }
@@ -278,32 +432,39 @@ __global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------ dispatch
-template <int WBITS, int GS, int D>
-int launch_gemm_t(const GemmParams& p, int MB, int NBW, hipStream_t st) {
-    dim3 grid(cdiv(p.NT, 4 * NBW), p.nsplit), block(256);
-#define L_(mb, nbw)                                                                           \
-    hipLaunchKernelGGL((gemm_wq_kernel<WBITS, mb, nbw, GS, D>), grid, block, 0, st, p);        \
-    break;
-    if (NBW == 1) {
-        switch (MB) { case 1: L_(1, 1) case 2: L_(2, 1) case 3: L_(3, 1) default: L_(4, 1) }
-    } else {
-        switch (MB) { case 1: L_(1, 2) case 2: L_(2, 2) case 3: L_(3, 2) default: L_(4, 2) }
+struct GemmPlan { int cfg, nsplit, cps, bn; };   // cfg: index into the block-shape table below
+
+int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // [1] nsplit override, [2] config override (+1)
+
+// block shapes: {MB, NBW, NWN, KG}
+//   cfg 0: M<=16, BN=64   (4 n-waves x 2 k-groups)      cfg 1: M<=16, BN=128 (huge N, e.g. lm_head)
+//   cfg 2: M<=32, BN=128  (8 n-waves)                   cfg 3: M<=48, BN=256   cfg 4: M<=64, BN=256
+constexpr int kCfgBN[5] = {64, 128, 128, 256, 256};
+
+template <int WBITS, int GS, int D1, int DN>
+int launch_gemm_t(const GemmParams& p, int cfg, hipStream_t st) {
+    dim3 grid(cdiv(p.NT * 16, kCfgBN[cfg]), p.nsplit);
+    switch (cfg) {
+        case 0: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 1, 1, GS, D1, 4, 2>), grid, dim3(512), 0, st, p); break;
+        case 1: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 1, 2, GS, D1, 4, 2>), grid, dim3(512), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 2, 1, GS, DN, 8, 1>), grid, dim3(512), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 3, 2, GS, DN, 8, 1>), grid, dim3(512), 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 2, GS, DN, 8, 1>), grid, dim3(512), 0, st, p); break;
     }
-#undef L_
     MI355_CHECK_LAUNCH("gemm_wq_kernel");
     return MI355_OK;
 }
 
-int launch_gemm(const GemmParams& p, int wbits, int group_size, int MB, int NBW, hipStream_t st) {
-    if (wbits == 16) return launch_gemm_t<16, 0, 2>(p, MB, NBW, st);
+int launch_gemm(const GemmParams& p, int wbits, int group_size, int cfg, hipStream_t st) {
+    if (wbits == 16) return launch_gemm_t<16, 0, 2, 2>(p, cfg, st);
     if (wbits == 4) {
-        if (group_size == 128) return launch_gemm_t<4, 4, 4>(p, MB, NBW, st);
-        if (group_size == 64) return launch_gemm_t<4, 2, 4>(p, MB, NBW, st);
-        if (group_size == 32) return launch_gemm_t<4, 1, 4>(p, MB, NBW, st);
+        if (group_size == 128) return launch_gemm_t<4, 4, 4, 2>(p, cfg, st);
+        if (group_size == 64) return launch_gemm_t<4, 2, 4, 2>(p, cfg, st);
+        if (group_size == 32) return launch_gemm_t<4, 1, 4, 2>(p, cfg, st);
     }
     if (wbits == 8) {
-        if (group_size == 0) return launch_gemm_t<8, 0, 4>(p, MB, NBW, st);
-        if (group_size == 128) return launch_gemm_t<8, 4, 4>(p, MB, NBW, st);
+        if (group_size == 0) return launch_gemm_t<8, 0, 4, 2>(p, cfg, st);
+        if (group_size == 128) return launch_gemm_t<8, 4, 4, 2>(p, cfg, st);
     }
     mi355_set_error("gemm: unsupported wbits=%d group_size=%d", wbits, group_size);
     return MI355_ERR_UNSUPPORTED;
@@ -330,33 +491,53 @@ void fill_params(GemmParams& p, const void* x, int M, const mi355_weight_t* w) {
     p.bias = nullptr; p.y = nullptr; p.partials = nullptr; p.ldy = 0;
 }
 
+// Block shape + split-K plan.  Aim at >= ~2 resident 8-wave blocks per CU (256 CUs) while keeping the
+// fp32 slab traffic (write + read, 8 B per element per split) below about half the weight bytes.
+GemmPlan plan_gemm(int M, const mi355_weight_t* w, int max_splits) {
+    const int NT = w->N_pad / 16, KC = w->K_pad / 128;
+    const int MB = cdiv(M, 16);
+    GemmPlan g;
+    g.cfg = (MB == 1) ? (NT >= 4096 ? 1 : 0) : (MB == 2 ? 2 : (MB == 3 ? 3 : 4));
+    if (g_debug[2] > 0) g.cfg = g_debug[2] - 1;
+    g.bn = kCfgBN[g.cfg];
+    const int blocks_n = cdiv(NT * 16, g.bn);
+    int nsplit = 512 / blocks_n;
+    if (nsplit < 1) nsplit = 1;
+    const double wbytes = (double)w->K_pad * w->N_pad * w->wbits / 8.0;
+    while (nsplit > 1 && (double)nsplit * M * w->N_pad * 8.0 > 0.5 * wbytes) --nsplit;
+    if (nsplit > max_splits) nsplit = max_splits;
+    const int min_chunks = (g.cfg <= 1) ? 4 : 2;   // k-grouped shapes want >= 2 chunks per group
+    if (nsplit > KC / min_chunks) nsplit = KC / min_chunks > 0 ? KC / min_chunks : 1;
+    if (g_debug[1] > 0) nsplit = g_debug[1] > max_splits ? max_splits : g_debug[1];
+    g.cps    = cdiv(KC, nsplit);
+    g.nsplit = cdiv(KC, g.cps);
+    return g;
+}
+
 } // namespace
 
-// Split-K plan shared with the engine: aim at ~2 blocks per CU, >= 2 chunks per split.
 extern "C" int mi355_gemm_plan(int M, const mi355_weight_t* w, int max_splits, int* nbw_out, int* cps_out) {
-    const int NT = w->N_pad / 16, KC = w->K_pad / 128;
-    int NBW = (NT >= 4096) ? 2 : 1;
-    const int blocks_n = cdiv(NT, 4 * NBW);
-    int target = 512;
-    int nsplit = target / blocks_n;
-    if (nsplit < 1) nsplit = 1;
-    // large M: slab traffic grows with M*nsplit, keep it below ~half the weight bytes
-    const double wbytes = (double)w->K_pad * w->N_pad * w->wbits / 8.0;
-    while (nsplit > 1 && (double)nsplit * (M < 16 ? 16 : M) * w->N_pad * 8.0 > wbytes) --nsplit;
-    if (nsplit > max_splits) nsplit = max_splits;
-    if (nsplit > KC / 2) nsplit = KC / 2 > 0 ? KC / 2 : 1;
-    int cps = cdiv(KC, nsplit);
-    nsplit  = cdiv(KC, cps);
-    *nbw_out = NBW; *cps_out = cps;
-    return nsplit;
+    const GemmPlan g = plan_gemm(M, w, max_splits);
+    if (nbw_out) *nbw_out = g.cfg;
+    if (cps_out) *cps_out = g.cps;
+    return g.nsplit;
+}
+
+// Tuning / experiment hook (tools/gemm_bench.py); not part of the public ABI.
+extern "C" void mi355_debug_set(int key, int value) {
+    if (key >= 0 && key < 8) g_debug[key] = value;
 }
 
 extern "C" size_t mi355_linear_workspace_bytes(int32_t M, const mi355_weight_t* w) {
     if (!w || M <= 0) return 0;
     const int Mc = M > 64 ? 64 : M;
-    int nbw, cps;
-    const int ns = mi355_gemm_plan(Mc, w, 64, &nbw, &cps);
-    return ns > 1 ? (size_t)ns * Mc * w->N_pad * sizeof(float) : 0;
+    size_t need = 0;
+    for (int m = 1; m <= Mc; ++m) { // forward() plans per slab of <= 64 rows; cover every possible slab height
+        const GemmPlan g = plan_gemm(m, w, 64);
+        const size_t b = g.nsplit > 1 ? (size_t)g.nsplit * m * w->N_pad * sizeof(float) : 0;
+        need = b > need ? b : need;
+    }
+    return need;
 }
 
 extern "C" int mi355_linear_partial(const void* x, int32_t M, const mi355_weight_t* w, float* partials,
@@ -364,10 +545,9 @@ extern "C" int mi355_linear_partial(const void* x, int32_t M, const mi355_weight
     if (int e = check_weight(w)) return e;
     MI355_CHECK_ARG(x && partials && M > 0 && M <= 64 && max_splits >= 1, "linear_partial: bad args (M=%d)", M);
     GemmParams p; fill_params(p, x, M, w);
-    int nbw, cps;
-    p.nsplit = mi355_gemm_plan(M, w, max_splits, &nbw, &cps);
-    p.cps = cps; p.mode = MODE_PARTIAL; p.partials = partials;
-    if (int e = launch_gemm(p, w->wbits, w->group_size, cdiv(M, 16), nbw, (hipStream_t)stream)) return e;
+    const GemmPlan g = plan_gemm(M, w, max_splits);
+    p.nsplit = g.nsplit; p.cps = g.cps; p.mode = MODE_PARTIAL; p.partials = partials;
+    if (int e = launch_gemm(p, w->wbits, w->group_size, g.cfg, (hipStream_t)stream)) return e;
     return p.nsplit;
 }
 
@@ -383,8 +563,8 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
     for (int m0 = 0; m0 < M; m0 += 64) {
         const int Mc = (M - m0) > 64 ? 64 : (M - m0);
         GemmParams p; fill_params(p, (const f16*)x + (size_t)m0 * w->K, Mc, w);
-        int nbw, cps;
-        int ns = mi355_gemm_plan(Mc, w, 64, &nbw, &cps);
+        const GemmPlan g = plan_gemm(Mc, w, 64);
+        const int ns = g.nsplit, cps = g.cps;
         if (ns > 1 && (size_t)ns * Mc * w->N_pad * sizeof(float) > workspace_bytes) {
             mi355_set_error("linear_forward: workspace %zu too small", workspace_bytes);
             return MI355_ERR_WORKSPACE;
@@ -393,10 +573,10 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
         p.nsplit = ns; p.cps = cps; p.ldy = ldy;
         if (ns == 1) {
             p.mode = mode; p.bias = (const f16*)bias; p.y = yc;
-            if (int e = launch_gemm(p, w->wbits, w->group_size, cdiv(Mc, 16), nbw, st)) return e;
+            if (int e = launch_gemm(p, w->wbits, w->group_size, g.cfg, st)) return e;
         } else {
             p.mode = MODE_PARTIAL; p.partials = (float*)workspace;
-            if (int e = launch_gemm(p, w->wbits, w->group_size, cdiv(Mc, 16), nbw, st)) return e;
+            if (int e = launch_gemm(p, w->wbits, w->group_size, g.cfg, st)) return e;
             const int total = Mc * (w->N_pad / 4);
             hipLaunchKernelGGL(reduce_epilogue_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)workspace,
                                ns, Mc, w->N, w->N_pad, (const f16*)bias, yc, ldy, mode);
@@ -413,9 +593,8 @@ extern "C" int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_
     MI355_CHECK_ARG(x && y && M > 0 && M <= 64, "linear_direct: bad args");
     const int mode = (epilogue & MI355_EPI_OUT_F32) ? MODE_F32 : (epilogue & MI355_EPI_SILU_MUL) ? MODE_SILU : MODE_F16;
     GemmParams p; fill_params(p, x, M, w);
-    int nbw, cps;
-    mi355_gemm_plan(M, w, 1, &nbw, &cps);
+    const GemmPlan g = plan_gemm(M, w, 1);
     p.nsplit = 1; p.cps = p.KC; p.mode = mode; p.bias = (const f16*)bias; p.y = y;
     p.ldy = (mode == MODE_SILU) ? w->N / 2 : w->N;
-    return launch_gemm(p, w->wbits, w->group_size, cdiv(M, 16), nbw, (hipStream_t)stream);
+    return launch_gemm(p, w->wbits, w->group_size, g.cfg, (hipStream_t)stream);
 }

@@ -42,10 +42,17 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const RopeParams p) 
     float x0 = 0.f, x1 = 0.f;
     if (act) {
         if (p.partials) {
-            for (int s = 0; s < p.nsplit; ++s) {
-                const float* src = p.partials + ((size_t)s * p.T + t) * p.ld;
-                x0 += src[col0]; x1 += src[col1];
+            const size_t sstride = (size_t)p.T * p.ld;
+            const float* src = p.partials + (size_t)t * p.ld;
+            int s = 0;
+            for (; s + 4 <= p.nsplit; s += 4) { // 4 slabs in flight per round trip, summed in index order
+                float a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a[u] = src[(s + u) * sstride + col0]; b[u] = src[(s + u) * sstride + col1]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { x0 += a[u]; x1 += b[u]; }
             }
+            for (; s < p.nsplit; ++s) { x0 += src[s * sstride + col0]; x1 += src[s * sstride + col1]; }
         } else {
             x0 = (float)p.qkv[(size_t)t * p.ld + col0];
             x1 = (float)p.qkv[(size_t)t * p.ld + col1];

@@ -250,7 +250,10 @@ def test_engine_greedy_decode_matches_oracle(kind, kv_int8):
         eng.replay(B, 1) if use_graph else eng.step(B)
         torch.cuda.synchronize()
         got = eng.logits[:B].cpu()
-        assert torch.allclose(got, ref_logits, **TOL), (step, (got - ref_logits).abs().max())
+        # INT8 KV: a 1-ulp fp16 difference in a rotated K can flip an int8 code (1/127 of the head's amax), so the
+        # end-to-end logits tolerance is 2.5e-2 there (convention "parity unpinned"); 1e-2 otherwise.
+        tol = dict(atol=2.5e-2, rtol=2.5e-2) if kv_int8 else TOL
+        assert torch.allclose(got, ref_logits, **tol), (step, (got - ref_logits).abs().max())
         ref_next = oracle.greedy(ref_logits)
         # greedy ids must agree wherever the oracle's top-2 margin exceeds the logits tolerance
         top2 = ref_logits.topk(2, dim=-1).values

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the weight-only GEMM through the C-ABI (HBM-resident weights: several copies rotated
+so the 256 MiB Infinity Cache cannot hold them).  usage: gemm_bench.py [--kinds w4,int8,fp16] [--ms 1,16,64]
+[--var V] [--nsplit S] [--nbw B]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rtp_llm_amd import _C, model, ops  # noqa: E402
+
+SHAPES = {"qkv": (3584, 4608), "o": (3584, 3584), "gate_up": (3584, 37888), "down": (18944, 3584), "lm_head": (3584, 152064)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kinds", default="w4")
+    ap.add_argument("--ms", default="1,16,64")
+    ap.add_argument("--shapes", default="qkv,o,gate_up,down")
+    ap.add_argument("--var", type=int, default=0)
+    ap.add_argument("--nsplit", type=int, default=0)
+    ap.add_argument("--nbw", type=int, default=0, help="block-shape cfg override + 1")
+    ap.add_argument("--iters", type=int, default=48)
+    a = ap.parse_args()
+    lib = _C.lib()
+    lib.mi355_debug_set.argtypes = [C.c_int, C.c_int]
+    lib.mi355_debug_set(0, a.var); lib.mi355_debug_set(1, a.nsplit); lib.mi355_debug_set(2, a.nbw)
+    dev = "cuda:0"
+    gen = torch.Generator(device=dev).manual_seed(0)
+    for kind in a.kinds.split(","):
+        for name in a.shapes.split(","):
+            K, N = SHAPES[name]
+            k = "fp16" if name == "lm_head" else kind
+            base = model.synth_linear(K, N, k, dev, gen).pack(gate_up=(name == "gate_up"))
+            ncopy = max(2, int(600e6 // base.nbytes) + 1)
+            copies = [base] + [type(base)(base.qweight.clone(), None if base.meta is None else base.meta.clone(), base.wbits,
+                                          base.K, base.N, base.K_pad, base.N_pad, base.group_size) for _ in range(ncopy - 1)]
+            for M in [int(m) for m in a.ms.split(",")]:
+                x = (torch.randn(M, K, device=dev, generator=gen) * 0.5).half()
+                epi = _C.EPI_SILU_MUL if name == "gate_up" else (_C.EPI_OUT_F32 if name == "lm_head" else 0)
+                outs = [ops.linear(x, c, None, epi) for c in copies[:2]]
+                torch.cuda.synchronize()
+                st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                st.record()
+                for i in range(a.iters):
+                    ops.linear(x, copies[i % ncopy], None, epi, out=outs[0])
+                en.record(); torch.cuda.synchronize()
+                us = st.elapsed_time(en) / a.iters * 1e3
+                print(f"{k:5s} {name:8s} M={M:3d}  {us:8.2f} us  {base.nbytes / us / 1e3:8.1f} GB/s   ({base.nbytes / 1e6:.1f} MB, {ncopy} copies)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
