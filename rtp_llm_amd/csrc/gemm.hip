@@ -109,6 +109,8 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
     constexpr int SPG    = 4 / NSUB;               // MFMA k-steps per group
     constexpr bool QUANT = WBITS != 16;
     constexpr bool GROUPED = GS > 0;               // per-group scale (else one scale per column, applied at the end)
+    constexpr bool CSIDE = QUANT && MB <= 2;       // zero/scale on the accumulator side (cheap for few row blocks);
+                                                   // MB >= 3: classic operand-side dequant, cost independent of MB
     constexpr int GT     = 64 * NWN;               // threads per k-group
     constexpr int XSLOTS = 256 * MB;               // 16-byte slots per x chunk tile
     constexpr int UPT    = (XSLOTS + GT - 1) / GT; // x pieces per thread per chunk
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
                                                    // vmcnt wait for x never drains newer weight loads
     constexpr int PPG    = 16 / NSUB;              // 16-byte pieces of a row per group
     __shared__ u32x4 xs[KG][2][XSLOTS];
-    __shared__ float xsum[QUANT ? KG : 1][2][NSUB * 2][16 * MB];
+    __shared__ float xsum[CSIDE ? KG : 1][2][NSUB * 2][16 * MB];
     __shared__ f32x4 red[(KG > 1) ? NWN * NBW * MB * 64 : 1];
 
     const int tid  = threadIdx.x;
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
 #pragma unroll
         for (int u = 0; u < UPT; ++u) {
             if (UPT * GT == XSLOTS || xslot[u] >= 0) xs[kg][buf][xslot[u]] = xr[d][u];
-            if (QUANT) {
+            if (CSIDE) {
                 // group sums of x over the two code-bias classes; a row's 16 pieces sit in 16 adjacent lanes
                 const f16x2 ones = {(f16)1.f, (f16)1.f};
                 const u32x4 v = xr[d][u];
@@ -238,6 +240,12 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
         }
     };
 
+    uint32_t mch[NBW]; // per-channel mode, operand-side path: the zero term is constant along K
+    if (QUANT && !GROUPED && !CSIDE) {
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) mch[nb] = __builtin_amdgcn_raw_buffer_load_b32(rm[nb], jj4, 0, 0);
+    }
+
     // prologue: x first, then weights (issue order matters for the in-order vmcnt)
 #pragma unroll
     for (int d = 0; d < XR - 1; ++d) load_x(d, d);
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 float xb = 0.f;
-                if (QUANT) {
+                if (CSIDE) {
                     const float x0 = xsum[kg][buf][gi * 2 + 0][mb * 16 + jj];
                     const float x1 = xsum[kg][buf][gi * 2 + 1][mb * 16 + jj];
                     XS[mb] = x0 + x1;
@@ -277,11 +285,23 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
                     f16x8 a;
                     if (WBITS == 16) {
                         a = __builtin_bit_cast(f16x8, wr[d][nb][s % LPC]);
-                    } else if (WBITS == 4) {
-                        a = widen_w4(wr[d][nb][0][s], w4c);
-                    } else {
-                        const u32x4 w = wr[d][nb][(s >> 1) % LPC];
-                        a = widen_w8(w[(s & 1) * 2], w[(s & 1) * 2 + 1]);
+                    } else if (CSIDE) {
+                        if (WBITS == 4) {
+                            a = widen_w4(wr[d][nb][0][s], w4c);
+                        } else {
+                            const u32x4 w = wr[d][nb][(s >> 1) % LPC];
+                            a = widen_w8(w[(s & 1) * 2], w[(s & 1) * 2 + 1]);
+                        }
+                    } else { // operand-side dequant: (code - z) [* scale] in fp16, exact subtract, one rounding
+                        const uint32_t m = GROUPED ? mr[d][nb][gi] : mch[nb];
+                        const f16x2 zneg2 = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u));
+                        const f16x2 sc2   = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
+                        if (WBITS == 4) {
+                            a = dequant_w4(wr[d][nb][0][s], zneg2, sc2);
+                        } else {
+                            const u32x4 w = wr[d][nb][(s >> 1) % LPC];
+                            a = dequant_w8<GROUPED>(w[(s & 1) * 2], w[(s & 1) * 2 + 1], zneg2, sc2);
+                        }
                     }
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) ag[nb][mb] = mfma16x16x32(a, b[mb], ag[nb][mb]);
@@ -290,7 +310,7 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
             // ---- C side: rows of this lane are columns 16nt + 4q + r; their meta sits in lanes 4q + r
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) {
-                if (!QUANT) {
+                if (!CSIDE) {
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) acc[nb][mb] += ag[nb][mb];
                 } else if (GROUPED) {
@@ -439,32 +459,38 @@ int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // [1] nsplit override, [2] con
 // block shapes: {MB, NBW, NWN, KG}
 //   cfg 0: M<=16, BN=64   (4 n-waves x 2 k-groups)      cfg 1: M<=16, BN=128 (huge N, e.g. lm_head)
 //   cfg 2: M<=32, BN=128  (8 n-waves)                   cfg 3: M<=48, BN=256   cfg 4: M<=64, BN=256
-constexpr int kCfgBN[5] = {64, 128, 128, 256, 256};
+//   cfg 5: M<=16, BN=64, 4 waves, no k-groups (experiment)   cfg 6/7: M<=64/48, BN=256 as 16 n-waves x 1 tile
+constexpr int kCfgBN[8] = {64, 128, 128, 256, 256, 64, 256, 256};
 
-template <int WBITS, int GS, int D1, int DN>
+// Ring depths per shape: D1 for the M<=16 shapes, D2 for BN=128 (M<=32), DW for the 16-wave BN=256 shapes.
+// Bytes in flight per CU = waves * NBW * D KiB; ~85 KiB per CU are needed to cover HBM latency at 6 TB/s.
+template <int WBITS, int GS, int D1, int D2, int DW>
 int launch_gemm_t(const GemmParams& p, int cfg, hipStream_t st) {
     dim3 grid(cdiv(p.NT * 16, kCfgBN[cfg]), p.nsplit);
     switch (cfg) {
         case 0: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 1, 1, GS, D1, 4, 2>), grid, dim3(512), 0, st, p); break;
         case 1: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 1, 2, GS, D1, 4, 2>), grid, dim3(512), 0, st, p); break;
-        case 2: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 2, 1, GS, DN, 8, 1>), grid, dim3(512), 0, st, p); break;
-        case 3: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 3, 2, GS, DN, 8, 1>), grid, dim3(512), 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 2, GS, DN, 8, 1>), grid, dim3(512), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 2, 1, GS, D2, 8, 1>), grid, dim3(512), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 3, 2, GS, DW, 8, 1>), grid, dim3(512), 0, st, p); break;
+        case 4: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 2, GS, DW, 8, 1>), grid, dim3(512), 0, st, p); break;
+        case 5: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 1, 1, GS, D1, 4, 1>), grid, dim3(256), 0, st, p); break;
+        case 6: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 1, GS, 2, 16, 1>), grid, dim3(1024), 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 3, 1, GS, 2, 16, 1>), grid, dim3(1024), 0, st, p); break;
     }
     MI355_CHECK_LAUNCH("gemm_wq_kernel");
     return MI355_OK;
 }
 
 int launch_gemm(const GemmParams& p, int wbits, int group_size, int cfg, hipStream_t st) {
-    if (wbits == 16) return launch_gemm_t<16, 0, 2, 2>(p, cfg, st);
+    if (wbits == 16) return launch_gemm_t<16, 0, 2, 2, 2>(p, cfg, st);
     if (wbits == 4) {
-        if (group_size == 128) return launch_gemm_t<4, 4, 4, 2>(p, cfg, st);
-        if (group_size == 64) return launch_gemm_t<4, 2, 4, 2>(p, cfg, st);
-        if (group_size == 32) return launch_gemm_t<4, 1, 4, 2>(p, cfg, st);
+        if (group_size == 128) return launch_gemm_t<4, 4, 4, 4, 4>(p, cfg, st);
+        if (group_size == 64) return launch_gemm_t<4, 2, 4, 4, 4>(p, cfg, st);
+        if (group_size == 32) return launch_gemm_t<4, 1, 4, 4, 4>(p, cfg, st);
     }
     if (wbits == 8) {
-        if (group_size == 0) return launch_gemm_t<8, 0, 4, 2>(p, cfg, st);
-        if (group_size == 128) return launch_gemm_t<8, 4, 4, 2>(p, cfg, st);
+        if (group_size == 0) return launch_gemm_t<8, 0, 4, 2, 2>(p, cfg, st);
+        if (group_size == 128) return launch_gemm_t<8, 4, 4, 2, 2>(p, cfg, st);
     }
     mi355_set_error("gemm: unsupported wbits=%d group_size=%d", wbits, group_size);
     return MI355_ERR_UNSUPPORTED;
@@ -491,23 +517,34 @@ void fill_params(GemmParams& p, const void* x, int M, const mi355_weight_t* w) {
     p.bias = nullptr; p.y = nullptr; p.partials = nullptr; p.ldy = 0;
 }
 
-// Block shape + split-K plan.  Aim at >= ~2 resident 8-wave blocks per CU (256 CUs) while keeping the
-// fp32 slab traffic (write + read, 8 B per element per split) below about half the weight bytes.
+// Block shape + split-K plan.  The kernel is a per-block pipeline of n_it chunk iterations (one barrier each);
+// with few blocks the iteration latency, not bandwidth, sets the time, so K is split until the machine is
+// full.  Split-K costs fp32 slab traffic (8 B per output element per split, write + read).  Pick the split
+// that minimises a small time model calibrated on MI355X (profiles/r01_*):
+//     t = ceil(blocks / resident) * n_it * t_it  +  slab_bytes / 3 TB/s
 GemmPlan plan_gemm(int M, const mi355_weight_t* w, int max_splits) {
     const int NT = w->N_pad / 16, KC = w->K_pad / 128;
     const int MB = cdiv(M, 16);
     GemmPlan g;
-    g.cfg = (MB == 1) ? (NT >= 4096 ? 1 : 0) : (MB == 2 ? 2 : (MB == 3 ? 3 : 4));
+    g.cfg = (MB == 1) ? (NT >= 4096 ? 1 : 5) : (MB == 2 ? 2 : (MB == 3 ? 3 : 4)); // measured best per row-block count
     if (g_debug[2] > 0) g.cfg = g_debug[2] - 1;
     g.bn = kCfgBN[g.cfg];
     const int blocks_n = cdiv(NT * 16, g.bn);
-    int nsplit = 512 / blocks_n;
-    if (nsplit < 1) nsplit = 1;
-    const double wbytes = (double)w->K_pad * w->N_pad * w->wbits / 8.0;
-    while (nsplit > 1 && (double)nsplit * M * w->N_pad * 8.0 > 0.5 * wbytes) --nsplit;
-    if (nsplit > max_splits) nsplit = max_splits;
-    const int min_chunks = (g.cfg <= 1) ? 4 : 2;   // k-grouped shapes want >= 2 chunks per group
-    if (nsplit > KC / min_chunks) nsplit = KC / min_chunks > 0 ? KC / min_chunks : 1;
+    static const double t_it_us[5]  = {0.0, 0.8, 1.0, 1.3, 1.5};   // per chunk iteration, by MB
+    static const int    resident[8] = {2, 2, 2, 1, 1, 4, 1, 1};     // blocks per CU, by shape
+    const bool kgrouped = g.cfg <= 1;
+    const int min_chunks = kgrouped ? 4 : 2;
+    int best = 1; double best_t = 1e30;
+    for (int ns = 1; ns <= max_splits && ns <= (KC / min_chunks > 0 ? KC / min_chunks : 1); ++ns) {
+        const int cps = cdiv(KC, ns), nsr = cdiv(KC, cps);
+        if (nsr != ns) continue;
+        const int n_it = kgrouped ? cdiv(cps, 2) : cps;
+        const int rounds = cdiv(blocks_n * ns, 256 * resident[g.cfg]);
+        const double slab = ns > 1 ? (double)ns * M * w->N_pad * 8.0 / 3.0e6 : 0.0; // us at 3 TB/s
+        const double t = rounds * (n_it * t_it_us[MB] + 2.0) + slab;
+        if (t < best_t - 1e-9) { best_t = t; best = ns; }
+    }
+    int nsplit = best;
     if (g_debug[1] > 0) nsplit = g_debug[1] > max_splits ? max_splits : g_debug[1];
     g.cps    = cdiv(KC, nsplit);
     g.nsplit = cdiv(KC, g.cps);
