@@ -274,8 +274,15 @@ def main():
         alg_bytes_launch = (bps["linears"] + act_bytes) / n_launch_step
         avg_ms = gq["ms"] / max(1, gq["launches"])
         ach = alg_bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        try:  # HBM read bytes per launch from the committed PMC pass of this workload (profiles/README.md)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(args.workload)
+            if tj and tj.get("batch") == B:
+                traffic = int(tj["gemm_quant_read_bytes_per_launch"])
+        except Exception:  # noqa: BLE001
+            traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": "gemm_wq_kernel (qkv/o/gate_up/down linears)", "achieved": round(ach, 1),
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_ms * 1e3, 3),
                            "launches_timed": gq["launches"]}
         total_b = sum(bps.values())
