@@ -13,47 +13,66 @@ namespace {
 // Reference numerics (rtp_llm/models_py/modules/base/common/norm.py:83-92):
 //   var = mean(x_f32^2); xn = (x_f32 * rsqrt(var + eps)).to(fp16); y = weight * xn
 // One block (256 threads) per row; each thread owns 8-element vectors.
-template <int VPT> // vectors (of 8 halfs) per thread
-__global__ __launch_bounds__(256) void add_rmsnorm_kernel(const f16* __restrict__ x, const float* __restrict__ partials,
+template <int VPT> // vectors (of 8 halfs) per thread; 512 threads per row
+__global__ __launch_bounds__(512) void add_rmsnorm_kernel(const f16* __restrict__ x, const float* __restrict__ partials,
                                                           int nsplit, int ld, int M, const f16* __restrict__ bias,
                                                           const f16* __restrict__ res_in, f16* __restrict__ res_out,
                                                           const f16* __restrict__ weight, float eps, int H,
                                                           f16* __restrict__ y) {
+    constexpr int NTH = 512;
     const int row = blockIdx.x;
     const int tid = threadIdx.x;
     const int nvec = H >> 3;
     float v[VPT][8];
+    f16x8 rin[VPT], bin[VPT], win[VPT];
+    // everything that does not depend on the slab sum is requested first (one memory round trip for all of it)
+#pragma unroll
+    for (int t = 0; t < VPT; ++t) {
+        const int vi = tid + t * NTH;
+        const int c0 = (vi < nvec ? vi : 0) * 8;
+        rin[t] = res_in ? *reinterpret_cast<const f16x8*>(res_in + (size_t)row * H + c0) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        bin[t] = bias ? *reinterpret_cast<const f16x8*>(bias + c0) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        win[t] = (y && weight) ? *reinterpret_cast<const f16x8*>(weight + c0) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
     float ss = 0.f;
 #pragma unroll
     for (int t = 0; t < VPT; ++t) {
-        const int vi = tid + t * 256;
+        const int vi = tid + t * NTH;
         if (vi < nvec) {
             const int c0 = vi * 8;
             if (partials) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[t][e] = 0.f;
-                // slabs are summed in index order (deterministic); loads are issued 4 slabs at a time so the
-                // reduction costs ~nsplit/4 memory round trips instead of nsplit
+                // slabs are summed in index order (deterministic); 8 slabs are in flight per memory round trip
                 const size_t sstride = (size_t)M * ld;
                 const float* src0 = partials + (size_t)row * ld + c0;
                 int s = 0;
-                for (; s + 4 <= nsplit; s += 4) {
-                    f32x4 a[4], b[4];
+                for (; s + 8 <= nsplit; s += 8) {
+                    f32x4 a[8], b[8];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 8; ++u) {
                         a[u] = *reinterpret_cast<const f32x4*>(src0 + (s + u) * sstride);
                         b[u] = *reinterpret_cast<const f32x4*>(src0 + (s + u) * sstride + 4);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < 8; ++u)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[t][e] += a[u][e]; v[t][4 + e] += b[u][e]; }
                 }
-                for (; s < nsplit; ++s) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(src0 + s * sstride);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(src0 + s * sstride + 4);
+                if (s < nsplit) { // tail: predicated loads, still one round trip
+                    f32x4 a[8], b[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[t][e] += a[e]; v[t][4 + e] += b[e]; }
+                    for (int u = 0; u < 7; ++u) {
+                        const bool ok = s + u < nsplit;
+                        const float* sp = src0 + (ok ? (s + u) : s) * sstride;
+                        a[u] = *reinterpret_cast<const f32x4*>(sp);
+                        b[u] = *reinterpret_cast<const f32x4*>(sp + 4);
+                        if (!ok) { a[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; b[u] = a[u]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 7; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[t][e] += a[u][e]; v[t][4 + e] += b[u][e]; }
                 }
             } else {
                 const f16x8 a = *reinterpret_cast<const f16x8*>(x + (size_t)row * H + c0);
@@ -61,18 +80,16 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const f16* __restrict_
                 for (int e = 0; e < 8; ++e) v[t][e] = (float)a[e];
             }
             if (bias) {
-                const f16x8 b = *reinterpret_cast<const f16x8*>(bias + c0);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[t][e] += (float)b[e];
+                for (int e = 0; e < 8; ++e) v[t][e] += (float)bin[t][e];
             }
             if (partials) { // the GEMM output is an fp16 tensor in the reference: round once
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[t][e] = (float)(f16)v[t][e];
             }
             if (res_in) {
-                const f16x8 r = *reinterpret_cast<const f16x8*>(res_in + (size_t)row * H + c0);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[t][e] = (float)(f16)(v[t][e] + (float)r[e]);
+                for (int e = 0; e < 8; ++e) v[t][e] = (float)(f16)(v[t][e] + (float)rin[t][e]);
             }
             if (res_out) {
                 f16x8 o;
@@ -84,22 +101,23 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const f16* __restrict_
             for (int e = 0; e < 8; ++e) ss += v[t][e] * v[t][e];
         }
     }
-    __shared__ float red[4];
+    __shared__ float red[NTH / 64];
     ss = wave_sum(ss);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
-    const float tot = red[0] + red[1] + red[2] + red[3];
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NTH / 64; ++i) tot += red[i];
     const float rs = rsqrtf(tot / (float)H + eps);
     if (!y) return;
 #pragma unroll
     for (int t = 0; t < VPT; ++t) {
-        const int vi = tid + t * 256;
+        const int vi = tid + t * NTH;
         if (vi < nvec) {
             const int c0 = vi * 8;
-            const f16x8 w = *reinterpret_cast<const f16x8*>(weight + c0);
             f16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = w[e] * (f16)(v[t][e] * rs);
+            for (int e = 0; e < 8; ++e) o[e] = win[t][e] * (f16)(v[t][e] * rs);
             *reinterpret_cast<f16x8*>(y + (size_t)row * H + c0) = o;
         }
     }
@@ -192,15 +210,15 @@ extern "C" int mi355_add_rmsnorm(const void* x_f16, const float* partials, int32
                                  const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M,
                                  int32_t H, void* y, mi355_stream_t stream) {
     MI355_CHECK_ARG((x_f16 != nullptr) != (partials != nullptr), "add_rmsnorm: exactly one of x_f16 / partials");
-    MI355_CHECK_ARG(M > 0 && H > 0 && H % 8 == 0 && H <= 8 * 256 * 4, "add_rmsnorm: M=%d H=%d (H %% 8 == 0, H <= 8192)", M, H);
+    MI355_CHECK_ARG(M > 0 && H > 0 && H % 8 == 0 && H <= 8 * 512 * 2, "add_rmsnorm: M=%d H=%d (H %% 8 == 0, H <= 8192)", M, H);
     MI355_CHECK_ARG(!partials || (nsplit >= 1 && ld >= H && ld % 4 == 0), "add_rmsnorm: nsplit=%d ld=%d", nsplit, ld);
     MI355_CHECK_ARG(!y || weight, "add_rmsnorm: weight required");
     hipStream_t st = (hipStream_t)stream;
-    const int vpt = cdiv(H / 8, 256);
+    const int vpt = cdiv(H / 8, 512);
 #define L_(V)                                                                                                        \
-    hipLaunchKernelGGL(add_rmsnorm_kernel<V>, dim3(M), dim3(256), 0, st, (const f16*)x_f16, partials, nsplit, ld, M, \
+    hipLaunchKernelGGL(add_rmsnorm_kernel<V>, dim3(M), dim3(512), 0, st, (const f16*)x_f16, partials, nsplit, ld, M, \
                        (const f16*)bias, (const f16*)residual_in, (f16*)residual_out, (const f16*)weight, eps, H, (f16*)y)
-    switch (vpt) { case 1: L_(1); break; case 2: L_(2); break; case 3: L_(3); break; default: L_(4); break; }
+    if (vpt <= 1) L_(1); else L_(2);
 #undef L_
     MI355_CHECK_LAUNCH("add_rmsnorm_kernel");
     return MI355_OK;

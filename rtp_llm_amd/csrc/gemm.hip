@@ -89,6 +89,21 @@ __device__ __forceinline__ float dpp_add(float v) {
     return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
+// Operand-side dequant (M > 32): scale * (u - z) in fp16 — exact subtract of the biased code, one rounding.
+// Even code pairs come out as 1024+u, odd pairs as 64+u (see widen_w4), so the subtract uses two exact
+// constants -(1024+z) and -(64+z).  1 shift + 4 v_and_or + 4 v_pk_add + 4 v_pk_mul = 13 VALU per 8 weights.
+__device__ __forceinline__ f16x8 dequant_w4_vc(uint32_t w, f16x2 zneg2, f16x2 zneg2b, f16x2 s2, const W4Consts& c) {
+    const uint32_t w8 = w >> 8;
+    const f16x2 h0 = (as_h2(and_or(w, c.m0, c.e0)) + zneg2) * s2;
+    const f16x2 h1 = (as_h2(and_or(w, c.m1, c.e1)) + zneg2b) * s2;
+    const f16x2 h2 = (as_h2(and_or(w8, c.m0, c.e0)) + zneg2) * s2;
+    const f16x2 h3 = (as_h2(and_or(w8, c.m1, c.e1)) + zneg2b) * s2;
+    f16x8 out;
+    out[0] = h0[0]; out[1] = h0[1]; out[2] = h1[0]; out[3] = h1[1];
+    out[4] = h2[0]; out[5] = h2[1]; out[6] = h3[0]; out[7] = h3[1];
+    return out;
+}
+
 // Block shape: NWN "n-waves" share one x tile and own NBW 16-column tiles each (BN = 16*NBW*NWN columns);
 // KG "k-groups" of NWN waves split the block's chunk range between them (intra-block split-K, merged
 // through LDS at the end).  Small M wants many waves in flight per CU (KG = 2, narrow BN); large M wants a
@@ -297,22 +312,25 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
                         const f16x2 zneg2 = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u));
                         const f16x2 sc2   = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
                         if (WBITS == 4) {
-                            a = dequant_w4(wr[d][nb][0][s], zneg2, sc2);
+                            const f16x2 c960 = {(f16)960.f, (f16)960.f};
+                            a = dequant_w4_vc(wr[d][nb][0][s], zneg2, zneg2 + c960, sc2, w4c);
                         } else {
                             const u32x4 w = wr[d][nb][(s >> 1) % LPC];
                             a = dequant_w8<GROUPED>(w[(s & 1) * 2], w[(s & 1) * 2 + 1], zneg2, sc2);
                         }
                     }
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) ag[nb][mb] = mfma16x16x32(a, b[mb], ag[nb][mb]);
+                    for (int mb = 0; mb < MB; ++mb) {
+                        if (CSIDE) ag[nb][mb] = mfma16x16x32(a, b[mb], ag[nb][mb]);
+                        else       acc[nb][mb] = mfma16x16x32(a, b[mb], acc[nb][mb]);
+                    }
                 }
             }
             // ---- C side: rows of this lane are columns 16nt + 4q + r; their meta sits in lanes 4q + r
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) {
                 if (!CSIDE) {
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) acc[nb][mb] += ag[nb][mb];
+                    // operand-side path accumulated straight into acc
                 } else if (GROUPED) {
                     f16x2 m4[4];
 #pragma unroll
@@ -335,9 +353,57 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
         }
     };
 
+    // Operand-side path (M > 32), software-pipelined by hand: the dequant of unit u+1 (13 VALU) is issued
+    // between the 4 MFMAs of unit u, so MFMA and VALU overlap inside one wave (a wave issues in order: four
+    // back-to-back MFMAs would otherwise block its own VALU for 64 cycles; PMC showed VALU 33% / MFMA 33% busy).
+    auto compute_os = [&](int d, int buf) {
+        constexpr int NS = 4 * NBW;
+        f16x2 zn[NBW][NSUB], znb[NBW][NSUB], scl[NBW][NSUB];
+        const f16x2 c960 = {(f16)960.f, (f16)960.f};
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int gi = 0; gi < NSUB; ++gi) {
+                const uint32_t m = GROUPED ? mr[d][nb][gi] : mch[nb];
+                zn[nb][gi]  = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u));
+                scl[nb][gi] = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
+                znb[nb][gi] = zn[nb][gi] + c960;
+            }
+        auto dq = [&](int u) -> f16x8 {
+            const int s = u / NBW, nb = u % NBW, gi = s / SPG;
+            if (WBITS == 4) return dequant_w4_vc(wr[d][nb][0][s], zn[nb][gi], znb[nb][gi], scl[nb][gi], w4c);
+            const u32x4 w = wr[d][nb][(s >> 1) % LPC];
+            return dequant_w8<GROUPED>(w[(s & 1) * 2], w[(s & 1) * 2 + 1], zn[nb][gi], scl[nb][gi]);
+        };
+        auto load_b = [&](f16x8 (&b)[MB], int s) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                b[mb] = __builtin_bit_cast(f16x8, xs[kg][buf][(s * 4 + q) * (16 * MB) + mb * 16 + (jj ^ q)]);
+        };
+        f16x8 b0[MB], b1[MB];
+        load_b(b0, 0);
+        f16x8 a_cur = dq(0), a_next = a_cur;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int s = u / NBW, nb = u % NBW;
+            if (nb == 0 && s + 1 < 4) { if (s & 1) load_b(b0, s + 1); else load_b(b1, s + 1); }
+            if (u + 1 < NS) a_next = dq(u + 1);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                acc[nb][mb] = mfma16x16x32(a_cur, (s & 1) ? b1[mb] : b0[mb], acc[nb][mb]);
+            a_cur = a_next;
+        }
+#pragma unroll
+        for (int g = 0; g < NS * MB; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); // 4 VALU
+        }
+    };
+
     auto slot = [&](int d, int ci) {
         load_x((d + XR - 1) % XR, ci + XR - 1);  // OOB -> zeros past the end
-        compute(d, d & 1);                       // D is even, so ci & 1 == d & 1
+        if (QUANT && !CSIDE) compute_os(d, d & 1);
+        else compute(d, d & 1);                  // D is even, so ci & 1 == d & 1
         load_w(d, ci + D);
         store_x((d + 1) % XR, (d + 1) & 1);       // chunk ci+1, issued XR-2 iterations ago
         __syncthreads();
@@ -460,7 +526,9 @@ int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // [1] nsplit override, [2] con
 //   cfg 0: M<=16, BN=64   (4 n-waves x 2 k-groups)      cfg 1: M<=16, BN=128 (huge N, e.g. lm_head)
 //   cfg 2: M<=32, BN=128  (8 n-waves)                   cfg 3: M<=48, BN=256   cfg 4: M<=64, BN=256
 //   cfg 5: M<=16, BN=64, 4 waves, no k-groups (experiment)   cfg 6/7: M<=64/48, BN=256 as 16 n-waves x 1 tile
-constexpr int kCfgBN[8] = {64, 128, 128, 256, 256, 64, 256, 256};
+//   cfg 8: M<=64 BN=128 8x1 tiles   cfg 9: M<=64 BN=128 4 waves x 2 tiles   cfg 10: M<=64 BN=256 4 waves x 4 tiles
+//   cfg 11: M<=64 BN=160 as 10 n-waves (237 gate_up blocks on 256 CUs)
+constexpr int kCfgBN[12] = {64, 128, 128, 256, 256, 64, 256, 256, 128, 128, 256, 160};
 
 // Ring depths per shape: D1 for the M<=16 shapes, D2 for BN=128 (M<=32), DW for the 16-wave BN=256 shapes.
 // Bytes in flight per CU = waves * NBW * D KiB; ~85 KiB per CU are needed to cover HBM latency at 6 TB/s.
@@ -475,7 +543,11 @@ int launch_gemm_t(const GemmParams& p, int cfg, hipStream_t st) {
         case 4: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 2, GS, DW, 8, 1>), grid, dim3(512), 0, st, p); break;
         case 5: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 1, 1, GS, D1, 4, 1>), grid, dim3(256), 0, st, p); break;
         case 6: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 1, GS, 2, 16, 1>), grid, dim3(1024), 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 3, 1, GS, 2, 16, 1>), grid, dim3(1024), 0, st, p); break;
+        case 7: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 3, 1, GS, 2, 16, 1>), grid, dim3(1024), 0, st, p); break;
+        case 8: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 1, GS, DW, 8, 1>), grid, dim3(512), 0, st, p); break;
+        case 9: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 2, GS, DW, 4, 1>), grid, dim3(256), 0, st, p); break;
+        case 10: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 4, GS, 2, 4, 1>), grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 1, GS, DW, 10, 1>), grid, dim3(640), 0, st, p); break;
     }
     MI355_CHECK_LAUNCH("gemm_wq_kernel");
     return MI355_OK;
@@ -531,7 +603,7 @@ GemmPlan plan_gemm(int M, const mi355_weight_t* w, int max_splits) {
     g.bn = kCfgBN[g.cfg];
     const int blocks_n = cdiv(NT * 16, g.bn);
     static const double t_it_us[5]  = {0.0, 0.8, 1.0, 1.3, 1.5};   // per chunk iteration, by MB
-    static const int    resident[8] = {2, 2, 2, 1, 1, 4, 1, 1};     // blocks per CU, by shape
+    static const int    resident[12] = {2, 2, 2, 1, 1, 4, 1, 1, 1, 2, 2, 1};     // blocks per CU, by shape
     const bool kgrouped = g.cfg <= 1;
     const int min_chunks = kgrouped ? 4 : 2;
     int best = 1; double best_t = 1e30;
