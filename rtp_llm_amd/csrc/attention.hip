@@ -78,52 +78,53 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
     for (int db = 0; db < NDB; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = NEG_BIG, l_run = 0.f;
 
-    for (int tb = pstart + wave * 32; tb < pend; tb += 128) {
-        // ---- addresses. K rows: lane row i=j -> token window (j>>2), V: window w.
-        const int kwin = tb + (j >> 2) * 8;             // first token of the 8-window of this K row
-        const int vwin = tb + w * 8;                    // first token of this lane's V / P window
-        const int last = seq_len - 1;
-        const int kw_c = min(kwin, last & ~7), vw_c = min(vwin, last & ~7); // clamp whole windows in range
-        const int kblk = bt[kw_c / p.page], vblk = bt[vw_c / p.page];
+    // One 32-token group of K/V in registers (+ the per-token INT8 scales of the lane's own 8 tokens).
+    struct Group {
+        u32x4 kf[2][INT8 ? NSTEP / 2 : NSTEP];
+        u32x4 vf16[INT8 ? 1 : NDB];
+        u32x2 vf8[INT8 ? NDB : 1];
+        f32x4 ksc[2], vsc[2];
+    };
+    const int last = seq_len - 1;
+    // block ids of the group starting at token tb: K rows use window (j>>2), V / scales / P use window w
+    auto lookup = [&](int tb, int& kblk, int& vblk) {
+        const int kw_c = min(tb + (j >> 2) * 8, last & ~7), vw_c = min(tb + w * 8, last & ~7);
+        kblk = bt[kw_c / p.page]; vblk = bt[vw_c / p.page];
+    };
+    auto load_group = [&](Group& g, int tb, int kblk, int vblk) {
+        const int kw_c = min(tb + (j >> 2) * 8, last & ~7), vw_c = min(tb + w * 8, last & ~7); // whole windows clamped in range
         const size_t khead = ((size_t)kblk * 2 + 0) * p.nkv + kh;
         const size_t vhead = ((size_t)vblk * 2 + 1) * p.nkv + kh;
-
-        // ---- K loads: tile tau row j -> token kw_c + (j&3) + 4*tau
-        u32x4 kf[2][INT8 ? NSTEP / 2 : NSTEP];
+        // K: tile tau row j -> token kw_c + (j&3) + 4*tau
 #pragma unroll
         for (int tau = 0; tau < 2; ++tau) {
             const int tok_in = (kw_c % p.page) + (j & 3) + 4 * tau;
             const char* krow = kvb + (khead * head_elems + (size_t)tok_in * HD) * ES;
             if (INT8) {
 #pragma unroll
-                for (int sp = 0; sp < NSTEP / 2; ++sp) kf[tau][sp] = *reinterpret_cast<const u32x4*>(krow + sp * 64 + w * 16);
+                for (int sp = 0; sp < NSTEP / 2; ++sp) g.kf[tau][sp] = *reinterpret_cast<const u32x4*>(krow + sp * 64 + w * 16);
             } else {
 #pragma unroll
-                for (int s = 0; s < NSTEP; ++s) kf[tau][s] = *reinterpret_cast<const u32x4*>(krow + (s * 32 + w * 8) * 2);
+                for (int s = 0; s < NSTEP; ++s) g.kf[tau][s] = *reinterpret_cast<const u32x4*>(krow + (s * 32 + w * 8) * 2);
             }
         }
-        // ---- V loads: d-block db row j (channel db*16+j), tokens vw_c .. vw_c+7
-        u32x4 vf16[INT8 ? 1 : NDB];
-        u32x2 vf8[INT8 ? NDB : 1];
-        {
-            const int tok_in = vw_c % p.page;
+        // V: d-block db row j (channel db*16+j), tokens vw_c .. vw_c+7
+        const int tok_in = vw_c % p.page;
 #pragma unroll
-            for (int db = 0; db < NDB; ++db) {
-                const char* vrow = kvb + (vhead * head_elems + (size_t)(db * 16 + j) * p.page + tok_in) * ES;
-                if (INT8) vf8[db] = *reinterpret_cast<const u32x2*>(vrow);
-                else      vf16[db] = *reinterpret_cast<const u32x4*>(vrow);
-            }
+        for (int db = 0; db < NDB; ++db) {
+            const char* vrow = kvb + (vhead * head_elems + (size_t)(db * 16 + j) * p.page + tok_in) * ES;
+            if (INT8) g.vf8[db] = *reinterpret_cast<const u32x2*>(vrow);
+            else      g.vf16[db] = *reinterpret_cast<const u32x4*>(vrow);
         }
-        // ---- INT8 scales: S rows of this lane are tokens vwin + {r, 4+r}; P slots the same 8 tokens
-        f32x4 ksc[2], vsc[2];
-        if (INT8) {
-            // scale plane: [blk][K|V][nkv][page]; this lane's S/P tokens sit in window w -> block vblk
-            const float* ks = p.scale_base + (((size_t)vblk * 2 + 0) * p.nkv + kh) * p.page + (vw_c % p.page);
-            const float* vs = p.scale_base + (((size_t)vblk * 2 + 1) * p.nkv + kh) * p.page + (vw_c % p.page);
-            ksc[0] = *reinterpret_cast<const f32x4*>(ks); ksc[1] = *reinterpret_cast<const f32x4*>(ks + 4);
-            vsc[0] = *reinterpret_cast<const f32x4*>(vs); vsc[1] = *reinterpret_cast<const f32x4*>(vs + 4);
+        if (INT8) { // scale plane [blk][K|V][nkv][page]: the lane's S rows / P slots are the 8 tokens of window w
+            const float* ks = p.scale_base + (((size_t)vblk * 2 + 0) * p.nkv + kh) * p.page + tok_in;
+            const float* vs = p.scale_base + (((size_t)vblk * 2 + 1) * p.nkv + kh) * p.page + tok_in;
+            g.ksc[0] = *reinterpret_cast<const f32x4*>(ks); g.ksc[1] = *reinterpret_cast<const f32x4*>(ks + 4);
+            g.vsc[0] = *reinterpret_cast<const f32x4*>(vs); g.vsc[1] = *reinterpret_cast<const f32x4*>(vs + 4);
         }
-
+    };
+    auto compute_group = [&](const Group& g, int tb) {
+        const int vwin = tb + w * 8; // first token of this lane's S rows / P slots
         // ---- S^T = K q^T
         f32x4 sacc[2];
 #pragma unroll
@@ -133,12 +134,12 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
             for (int s = 0; s < NSTEP; ++s) {
                 f16x8 a;
                 if (INT8) {
-                    const u32x4 kk = kf[tau][s >> 1];
+                    const u32x4 kk = g.kf[tau][s >> 1];
                     const uint32_t lo = kk[(s & 1) * 2] ^ 0x80808080u, hi = kk[(s & 1) * 2 + 1] ^ 0x80808080u;
                     const f16x2 zneg2 = {(f16)-1152.f, (f16)-1152.f};
                     a = dequant_w8<false>(lo, hi, zneg2, zneg2);
                 } else {
-                    a = __builtin_bit_cast(f16x8, kf[tau][s]);
+                    a = __builtin_bit_cast(f16x8, g.kf[tau][s]);
                 }
                 sacc[tau] = mfma16x16x32(a, qf[s], sacc[tau]);
             }
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = sacc[tau][r] * p.scale_log2;
-                if (INT8) v *= ksc[tau][r];
+                if (INT8) v *= g.ksc[tau][r];
                 const int tok = vwin + tau * 4 + r;
                 v = tok < seq_len ? v : NEG_BIG;
                 sv[tau * 4 + r] = v;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
             const bool valid = vwin + e < seq_len;
             float pe = valid ? __builtin_amdgcn_exp2f(sv[e] - m_new) : 0.f;
             psum += pe;
-            if (INT8) pe = valid ? pe * vsc[e >> 2][e & 3] : 0.f; // scale bytes past seq_len may be garbage
+            if (INT8) pe = valid ? pe * g.vsc[e >> 2][e & 3] : 0.f; // scale bytes past seq_len may be garbage
             pf[e] = (f16)pe;
         }
         l_run = l_run * alpha + psum;
@@ -179,9 +180,9 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
             f16x8 a;
             if (INT8) {
                 const f16x2 zneg2 = {(f16)-1152.f, (f16)-1152.f};
-                a = dequant_w8<false>(vf8[db][0] ^ 0x80808080u, vf8[db][1] ^ 0x80808080u, zneg2, zneg2);
+                a = dequant_w8<false>(g.vf8[db][0] ^ 0x80808080u, g.vf8[db][1] ^ 0x80808080u, zneg2, zneg2);
             } else {
-                a = __builtin_bit_cast(f16x8, vf16[db]);
+                a = __builtin_bit_cast(f16x8, g.vf16[db]);
             }
             // tokens past seq_len carry p = 0 but V bytes there may be garbage (NaN/Inf): zero them
             if (vwin + 7 >= seq_len) {
@@ -189,6 +190,26 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
                 for (int e = 0; e < 8; ++e) if (vwin + e >= seq_len) a[e] = (f16)0.f;
             }
             o[db] = mfma16x16x32(a, pf, o[db] * alpha);
+        }
+    };
+
+    // Two groups in flight per wave (registers ping-pong), block ids looked up one group further ahead:
+    // with one long partition per (sequence, kv head) a SIMD holds a single wave, so the wave itself has to
+    // keep >= 32 KB of K/V loads outstanding to cover HBM latency.
+    {
+        Group gA, gB;
+        int tb = pstart + wave * 32;
+        int kbA = 0, vbA = 0, kbB = 0, vbB = 0;
+        if (tb < pend) { lookup(tb, kbA, vbA); load_group(gA, tb, kbA, vbA); }
+        if (tb + 128 < pend) lookup(tb + 128, kbB, vbB);
+        for (; tb < pend; tb += 256) {
+            const bool hasB = tb + 128 < pend;
+            if (hasB) load_group(gB, tb + 128, kbB, vbB);
+            if (tb + 256 < pend) lookup(tb + 256, kbA, vbA);
+            compute_group(gA, tb);
+            if (tb + 256 < pend) load_group(gA, tb + 256, kbA, vbA);
+            if (tb + 384 < pend) lookup(tb + 384, kbB, vbB);
+            if (hasB) compute_group(gB, tb + 128);
         }
     }
 
@@ -258,15 +279,23 @@ __global__ __launch_bounds__(256) void attn_reduce_kernel(const AttnParams p) {
     for (int c = 0; c < CPL; ++c) dst[c] = (f16)(acc[c] * inv);
 }
 
+int g_attn_ps_override = 0; // tuning hook (tools/attn_bench.py)
+
 int plan_partitions(int B, int nkv, int max_seq_len, int* ps_out) {
-    // enough blocks to fill 256 CUs (~4 blocks per CU), partitions of 128..1024 tokens
-    int PS = 1024;
-    while (PS > 128 && (long)B * nkv * cdiv(max_seq_len, PS) < 1024) PS >>= 1;
+    if (g_attn_ps_override > 0) { *ps_out = g_attn_ps_override; return cdiv(max_seq_len, g_attn_ps_override); }
+    // Long partitions stream best (measured b=64, ctx 1024: one 1024-token partition per (seq, kv head) reaches
+    // 5.2 TB/s, five 256-token ones 4.0 TB/s and need the reduce kernel): split the sequence only as far as
+    // needed to put one block on every CU, never below 128 tokens.
+    int PS = 1 << 30;
+    while (PS > 128 && (long)B * nkv * cdiv(max_seq_len, PS) < 256) PS >>= 1;
+    if (PS > max_seq_len) PS = ((max_seq_len + 127) / 128) * 128;
     *ps_out = PS;
     return cdiv(max_seq_len, PS);
 }
 
 } // namespace
+
+extern "C" void mi355_debug_set_attn(int ps) { g_attn_ps_override = ps; }
 
 extern "C" size_t mi355_paged_attn_workspace_bytes(int32_t B, int32_t nh, int32_t hd, int32_t max_seq_len) {
     if (B <= 0 || nh <= 0 || hd <= 0 || max_seq_len <= 0) return 0;
