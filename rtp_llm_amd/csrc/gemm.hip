@@ -43,9 +43,11 @@ struct GemmParams {
 
 enum { MODE_PARTIAL = 0, MODE_F16 = 1, MODE_SILU = 2, MODE_F32 = 3 };
 
+// voff: per-lane byte offset (VGPR, loop invariant); soff: wave-uniform byte offset (SGPR).  The range check of a
+// raw buffer covers voff + soff on gfx950 (tools/probe/soffset_oob.hip), so chunk stepping costs no VALU.
 template <int AUX>
-__device__ __forceinline__ u32x4 bload128(__amdgpu_buffer_rsrc_t r, uint32_t off) {
-    return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX);
+__device__ __forceinline__ u32x4 bload128(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff = 0) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
 }
 
 // ---- in-register widening of the packed codes to MFMA A-operands (no subtract, no scale: both move to
@@ -186,12 +188,12 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
         for (int nb = 0; nb < NBW; ++nb) {
 #pragma unroll
             for (int lp = 0; lp < LPC; ++lp)
-                wr[d][nb][lp] = bload128<2 /*nt*/>(rw[nb], lane16 + (uint32_t)(ci * LPC + lp) * 1024u);
+                wr[d][nb][lp] = bload128<2 /*nt*/>(rw[nb], lane16, (uint32_t)(ci * LPC + lp) * 1024u);
             if (GROUPED) {
 #pragma unroll
                 for (int gi = 0; gi < NSUB; ++gi)
                     mr[d][nb][gi] = __builtin_amdgcn_raw_buffer_load_b32(
-                        rm[nb], jj4 + (uint32_t)(ci * NSUB + gi) * (uint32_t)p.N_pad * 4u, 0, 0);
+                        rm[nb], jj4, (uint32_t)(ci * NSUB + gi) * (uint32_t)p.N_pad * 4u, 0);
             }
         }
     };
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
     auto load_x = [&](int d, int ci) {
 #pragma unroll
         for (int u = 0; u < UPT; ++u)   // per-lane select (v_cndmask): pieces past K / rows past M read as zero
-            xr[d][u] = bload128<0>(rx, (ci < xlim[u]) ? xoff[u] + (uint32_t)ci * 256u : OOBX);
+            xr[d][u] = bload128<0>(rx, (ci < xlim[u]) ? xoff[u] : OOBX, (uint32_t)ci * 256u);
     };
     auto store_x = [&](int d, int buf) {
 #pragma unroll
@@ -528,7 +530,8 @@ int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // [1] nsplit override, [2] con
 //   cfg 5: M<=16, BN=64, 4 waves, no k-groups (experiment)   cfg 6/7: M<=64/48, BN=256 as 16 n-waves x 1 tile
 //   cfg 8: M<=64 BN=128 8x1 tiles   cfg 9: M<=64 BN=128 4 waves x 2 tiles   cfg 10: M<=64 BN=256 4 waves x 4 tiles
 //   cfg 11: M<=64 BN=160 as 10 n-waves (237 gate_up blocks on 256 CUs)
-constexpr int kCfgBN[12] = {64, 128, 128, 256, 256, 64, 256, 256, 128, 128, 256, 160};
+//   cfg 12: M<=64 BN=64 as 4 waves x 1 tile (592 gate_up blocks, several resident per CU)
+constexpr int kCfgBN[13] = {64, 128, 128, 256, 256, 64, 256, 256, 128, 128, 256, 160, 64};
 
 // Ring depths per shape: D1 for the M<=16 shapes, D2 for BN=128 (M<=32), DW for the 16-wave BN=256 shapes.
 // Bytes in flight per CU = waves * NBW * D KiB; ~85 KiB per CU are needed to cover HBM latency at 6 TB/s.
@@ -547,7 +550,8 @@ int launch_gemm_t(const GemmParams& p, int cfg, hipStream_t st) {
         case 8: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 1, GS, DW, 8, 1>), grid, dim3(512), 0, st, p); break;
         case 9: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 2, GS, DW, 4, 1>), grid, dim3(256), 0, st, p); break;
         case 10: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 4, GS, 2, 4, 1>), grid, dim3(256), 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 1, GS, DW, 10, 1>), grid, dim3(640), 0, st, p); break;
+        case 11: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 1, GS, DW, 10, 1>), grid, dim3(640), 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 1, GS, DW, 4, 1>), grid, dim3(256), 0, st, p); break;
     }
     MI355_CHECK_LAUNCH("gemm_wq_kernel");
     return MI355_OK;
@@ -603,7 +607,7 @@ GemmPlan plan_gemm(int M, const mi355_weight_t* w, int max_splits) {
     g.bn = kCfgBN[g.cfg];
     const int blocks_n = cdiv(NT * 16, g.bn);
     static const double t_it_us[5]  = {0.0, 0.8, 1.0, 1.3, 1.5};   // per chunk iteration, by MB
-    static const int    resident[12] = {2, 2, 2, 1, 1, 4, 1, 1, 1, 2, 2, 1};     // blocks per CU, by shape
+    static const int    resident[13] = {2, 2, 2, 1, 1, 4, 1, 1, 1, 2, 2, 1, 3};     // blocks per CU, by shape
     const bool kgrouped = g.cfg <= 1;
     const int min_chunks = kgrouped ? 4 : 2;
     int best = 1; double best_t = 1e30;
