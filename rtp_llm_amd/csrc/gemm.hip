@@ -21,75 +21,12 @@
 //    needs no branches).
 //  * split-K across blocks writes fp32 slabs; the consumer kernel (RoPE/KV-write,
 //    add+RMSNorm, or reduce_epilogue below) folds the reduction — deterministic order.
-#include "common.h"
-#include "internal.h"
+#include "gemm_common.h"
+
+extern "C" int mi355_gemm_smallm(const void* gp, int wbits, int group_size, int want_partial, int max_splits,
+                                 mi355_stream_t stream);
 
 namespace {
-
-struct GemmParams {
-    const f16*      x;
-    const void*     qw;
-    const uint32_t* meta;
-    const f16*      bias;
-    void*           y;        // direct mode output
-    float*          partials; // partial mode output
-    int M, K;                 // logical K (row stride of x)
-    int N, N_pad, NT, KC;     // NT = N_pad/16, KC = K_pad/128
-    int nsplit, cps;          // chunks per split
-    int mode;                 // 0 partial slabs, 1 fp16, 2 fp16 silu-mul, 3 fp32
-    int ldy;
-    uint32_t qw_bytes, meta_bytes, x_bytes;
-};
-
-enum { MODE_PARTIAL = 0, MODE_F16 = 1, MODE_SILU = 2, MODE_F32 = 3 };
-
-// voff: per-lane byte offset (VGPR, loop invariant); soff: wave-uniform byte offset (SGPR).  The range check of a
-// raw buffer covers voff + soff on gfx950 (tools/probe/soffset_oob.hip), so chunk stepping costs no VALU.
-template <int AUX>
-__device__ __forceinline__ u32x4 bload128(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff = 0) {
-    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
-}
-
-// ---- in-register widening of the packed codes to MFMA A-operands (no subtract, no scale: both move to
-// the accumulator side, see "zero / scale on the C side" below).
-//   W4: dword of step s -> 8 fp16:  (e0,e1) = 1024+u  (nibbles at mantissa bits 0-3, exponent of 1024.0)
-//                                   (e2,e3) =   64+u  (nibbles at mantissa bits 4-7, exponent of 64.0, ulp 1/16)
-//                                   (e4,e5), (e6,e7) the same after one shift by 8.   5 VALU per 8 weights.
-//   W8: 8 offset-binary bytes -> 8 fp16 1024+u via v_perm.                              4 VALU per 8 weights.
-// v_and_or_b32 is VOP3 (no literal operands on gfx9, one SGPR at most): the four constants live in VGPRs.
-struct W4Consts { uint32_t m0, m1, e0, e1; };
-__device__ __forceinline__ W4Consts w4_consts() {
-    W4Consts c = {0x000F000Fu, 0x00F000F0u, 0x64006400u, 0x54005400u};
-    asm volatile("" : "+v"(c.m0), "+v"(c.m1), "+v"(c.e0), "+v"(c.e1)); // keep them in VGPRs
-    return c;
-}
-__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t m, uint32_t o) {
-    return (a & m) | o; // selected as v_and_or_b32 once the constants are opaque VGPRs (no inline asm: its result
-                        // feeding an MFMA would need hand-placed wait states)
-}
-__device__ __forceinline__ f16x8 widen_w4(uint32_t w, const W4Consts& c) {
-    const uint32_t w8 = w >> 8;
-    u32x4 r;
-    r[0] = and_or(w, c.m0, c.e0);
-    r[1] = and_or(w, c.m1, c.e1);
-    r[2] = and_or(w8, c.m0, c.e0);
-    r[3] = and_or(w8, c.m1, c.e1);
-    return __builtin_bit_cast(f16x8, r);
-}
-__device__ __forceinline__ f16x8 widen_w8(uint32_t lo, uint32_t hi) {
-    const uint32_t C = 0x64646464u;
-    u32x4 r;
-    r[0] = __builtin_amdgcn_perm(C, lo, 0x04010400u);
-    r[1] = __builtin_amdgcn_perm(C, lo, 0x04030402u);
-    r[2] = __builtin_amdgcn_perm(C, hi, 0x04010400u);
-    r[3] = __builtin_amdgcn_perm(C, hi, 0x04030402u);
-    return __builtin_bit_cast(f16x8, r);
-}
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
 
 // Operand-side dequant (M > 32): scale * (u - z) in fp16 — exact subtract of the biased code, one rounding.
 // Even code pairs come out as 1024+u, odd pairs as 64+u (see widen_w4), so the subtract uses two exact
@@ -522,7 +459,7 @@ __global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* __res
 // ------------------------------------------------------------------ dispatch
 struct GemmPlan { int cfg, nsplit, cps, bn; };   // cfg: index into the block-shape table below
 
-int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // [1] nsplit override, [2] config override (+1)
+int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // [1] nsplit override, [2] config override (+1), [4] disable gemm_smallm
 
 // block shapes: {MB, NBW, NWN, KG}
 //   cfg 0: M<=16, BN=64   (4 n-waves x 2 k-groups)      cfg 1: M<=16, BN=128 (huge N, e.g. lm_head)
@@ -658,8 +595,13 @@ extern "C" int mi355_linear_partial(const void* x, int32_t M, const mi355_weight
     if (int e = check_weight(w)) return e;
     MI355_CHECK_ARG(x && partials && M > 0 && M <= 64 && max_splits >= 1, "linear_partial: bad args (M=%d)", M);
     GemmParams p; fill_params(p, x, M, w);
+    p.mode = MODE_PARTIAL; p.partials = partials;
+    if (M <= 8 && w->wbits != 16 && !g_debug[4]) { // persistent x-resident kernel (gemm_smallm.hip)
+        const int rc = mi355_gemm_smallm(&p, w->wbits, w->group_size, 1, max_splits, stream);
+        if (rc != MI355_ERR_UNSUPPORTED) return rc;
+    }
     const GemmPlan g = plan_gemm(M, w, max_splits);
-    p.nsplit = g.nsplit; p.cps = g.cps; p.mode = MODE_PARTIAL; p.partials = partials;
+    p.nsplit = g.nsplit; p.cps = g.cps;
     if (int e = launch_gemm(p, w->wbits, w->group_size, g.cfg, (hipStream_t)stream)) return e;
     return p.nsplit;
 }
@@ -676,6 +618,13 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
     for (int m0 = 0; m0 < M; m0 += 64) {
         const int Mc = (M - m0) > 64 ? 64 : (M - m0);
         GemmParams p; fill_params(p, (const f16*)x + (size_t)m0 * w->K, Mc, w);
+        if (Mc <= 8 && w->wbits != 16 && !g_debug[4]) { // persistent x-resident kernel, fused epilogue, no slabs
+            GemmParams ps; fill_params(ps, (const f16*)x + (size_t)m0 * w->K, Mc, w);
+            ps.mode = mode; ps.bias = (const f16*)bias; ps.y = (char*)y + (size_t)m0 * ldy * ysz; ps.ldy = ldy;
+            const int rc = mi355_gemm_smallm(&ps, w->wbits, w->group_size, 0, 1, stream);
+            if (rc >= 0) continue;
+            if (rc != MI355_ERR_UNSUPPORTED) return rc;
+        }
         const GemmPlan g = plan_gemm(Mc, w, 64);
         const int ns = g.nsplit, cps = g.cps;
         if (ns > 1 && (size_t)ns * Mc * w->N_pad * sizeof(float) > workspace_bytes) {
@@ -706,8 +655,14 @@ extern "C" int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_
     MI355_CHECK_ARG(x && y && M > 0 && M <= 64, "linear_direct: bad args");
     const int mode = (epilogue & MI355_EPI_OUT_F32) ? MODE_F32 : (epilogue & MI355_EPI_SILU_MUL) ? MODE_SILU : MODE_F16;
     GemmParams p; fill_params(p, x, M, w);
-    const GemmPlan g = plan_gemm(M, w, 1);
-    p.nsplit = 1; p.cps = p.KC; p.mode = mode; p.bias = (const f16*)bias; p.y = y;
+    p.mode = mode; p.bias = (const f16*)bias; p.y = y;
     p.ldy = (mode == MODE_SILU) ? w->N / 2 : w->N;
+    if (M <= 8 && w->wbits != 16 && !g_debug[4]) {
+        const int rc = mi355_gemm_smallm(&p, w->wbits, w->group_size, 0, 1, stream);
+        if (rc >= 0) return MI355_OK;
+        if (rc != MI355_ERR_UNSUPPORTED) return rc;
+    }
+    const GemmPlan g = plan_gemm(M, w, 1);
+    p.nsplit = 1; p.cps = p.KC;
     return launch_gemm(p, w->wbits, w->group_size, g.cfg, (hipStream_t)stream);
 }

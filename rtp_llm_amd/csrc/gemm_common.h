@@ -1,0 +1,105 @@
+// Shared pieces of the weight-only GEMM kernels (gemm.hip: staged-x kernels; gemm_smallm.hip: persistent
+// x-resident kernel for M <= 8).
+#pragma once
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+struct GemmParams {
+    const f16*      x;
+    const void*     qw;
+    const uint32_t* meta;
+    const f16*      bias;
+    void*           y;        // direct mode output
+    float*          partials; // partial mode output
+    int M, K;                 // logical K (row stride of x)
+    int N, N_pad, NT, KC;     // NT = N_pad/16, KC = K_pad/128
+    int nsplit, cps;          // chunks per split
+    int mode;                 // 0 partial slabs, 1 fp16, 2 fp16 silu-mul, 3 fp32
+    int ldy;
+    uint32_t qw_bytes, meta_bytes, x_bytes;
+};
+
+enum { MODE_PARTIAL = 0, MODE_F16 = 1, MODE_SILU = 2, MODE_F32 = 3 };
+
+// voff: per-lane byte offset (VGPR, loop invariant); soff: wave-uniform byte offset (SGPR).  The range check of a
+// raw buffer covers voff + soff on gfx950 (tools/probe/soffset_oob.hip), so chunk stepping costs no VALU.
+template <int AUX>
+__device__ __forceinline__ u32x4 bload128(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff = 0) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
+}
+
+// ---- in-register widening of the packed codes to MFMA A-operands (no subtract, no scale: both move to
+// the accumulator side, see "zero / scale on the C side" below).
+//   W4: dword of step s -> 8 fp16:  (e0,e1) = 1024+u  (nibbles at mantissa bits 0-3, exponent of 1024.0)
+//                                   (e2,e3) =   64+u  (nibbles at mantissa bits 4-7, exponent of 64.0, ulp 1/16)
+//                                   (e4,e5), (e6,e7) the same after one shift by 8.   5 VALU per 8 weights.
+//   W8: 8 offset-binary bytes -> 8 fp16 1024+u via v_perm.                              4 VALU per 8 weights.
+// v_and_or_b32 is VOP3 (no literal operands on gfx9, one SGPR at most): the four constants live in VGPRs.
+struct W4Consts { uint32_t m0, m1, e0, e1; };
+__device__ __forceinline__ W4Consts w4_consts() {
+    W4Consts c = {0x000F000Fu, 0x00F000F0u, 0x64006400u, 0x54005400u};
+    asm volatile("" : "+v"(c.m0), "+v"(c.m1), "+v"(c.e0), "+v"(c.e1)); // keep them in VGPRs
+    return c;
+}
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t m, uint32_t o) {
+    return (a & m) | o; // selected as v_and_or_b32 once the constants are opaque VGPRs (no inline asm: its result
+                        // feeding an MFMA would need hand-placed wait states)
+}
+__device__ __forceinline__ f16x8 widen_w4(uint32_t w, const W4Consts& c) {
+    const uint32_t w8 = w >> 8;
+    u32x4 r;
+    r[0] = and_or(w, c.m0, c.e0);
+    r[1] = and_or(w, c.m1, c.e1);
+    r[2] = and_or(w8, c.m0, c.e0);
+    r[3] = and_or(w8, c.m1, c.e1);
+    return __builtin_bit_cast(f16x8, r);
+}
+__device__ __forceinline__ f16x8 widen_w8(uint32_t lo, uint32_t hi) {
+    const uint32_t C = 0x64646464u;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_perm(C, lo, 0x04010400u);
+    r[1] = __builtin_amdgcn_perm(C, lo, 0x04030402u);
+    r[2] = __builtin_amdgcn_perm(C, hi, 0x04010400u);
+    r[3] = __builtin_amdgcn_perm(C, hi, 0x04030402u);
+    return __builtin_bit_cast(f16x8, r);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+
+// Epilogue for one lane's 4 consecutive output columns n0..n0+3 of batch row m (v already scaled).
+__device__ __forceinline__ void gemm_store(const GemmParams& p, f32x4 v, int m, int n0, int split) {
+    if (p.mode == MODE_PARTIAL) {
+        *reinterpret_cast<f32x4*>(p.partials + ((size_t)split * p.M + m) * p.N_pad + n0) = v;
+        return;
+    }
+    if (n0 >= p.N) return;
+    if (p.bias) {
+        const f16x4 bv = *reinterpret_cast<const f16x4*>(p.bias + n0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
+    }
+    if (p.mode == MODE_F32) {
+        *reinterpret_cast<f32x4*>((float*)p.y + (size_t)m * p.ldy + n0) = v;
+    } else if (p.mode == MODE_F16) {
+        f16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (f16)v[r];
+        *reinterpret_cast<f16x4*>((f16*)p.y + (size_t)m * p.ldy + n0) = o;
+    } else { // MODE_SILU: (gate, up) interleaved; round GEMM output to fp16 first
+        f16x2 o;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float g = (float)(f16)v[2 * t], u = (float)(f16)v[2 * t + 1];
+            o[t] = (f16)((g / (1.f + __expf(-g))) * u);
+        }
+        *reinterpret_cast<f16x2*>((f16*)p.y + (size_t)m * p.ldy + (n0 >> 1)) = o;
+    }
+}
+
+} // namespace
