@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--debug-set", default="", help="debug only: 'idx=val,...' forwarded to mi355_debug_set (kernel A/B switches)")
     args = ap.parse_args()
 
     from rtp_llm_amd import _C, distributed, model
@@ -136,6 +137,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _C.lib()  # fail loudly when the HIP extension is missing
+    for kv in filter(None, args.debug_set.split(",")):
+        _C.lib().mi355_debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
 
     mname, kind, kv_int8, dB, dctx, page = WORKLOADS[args.workload]
     B, ctx = args.batch or dB, args.ctx or dctx

@@ -25,23 +25,10 @@
 
 extern "C" int mi355_gemm_smallm(const void* gp, int wbits, int group_size, int want_partial, int max_splits,
                                  mi355_stream_t stream);
+extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int want_partial, int max_splits,
+                               mi355_stream_t stream);
 
 namespace {
-
-// Operand-side dequant (M > 32): scale * (u - z) in fp16 — exact subtract of the biased code, one rounding.
-// Even code pairs come out as 1024+u, odd pairs as 64+u (see widen_w4), so the subtract uses two exact
-// constants -(1024+z) and -(64+z).  1 shift + 4 v_and_or + 4 v_pk_add + 4 v_pk_mul = 13 VALU per 8 weights.
-__device__ __forceinline__ f16x8 dequant_w4_vc(uint32_t w, f16x2 zneg2, f16x2 zneg2b, f16x2 s2, const W4Consts& c) {
-    const uint32_t w8 = w >> 8;
-    const f16x2 h0 = (as_h2(and_or(w, c.m0, c.e0)) + zneg2) * s2;
-    const f16x2 h1 = (as_h2(and_or(w, c.m1, c.e1)) + zneg2b) * s2;
-    const f16x2 h2 = (as_h2(and_or(w8, c.m0, c.e0)) + zneg2) * s2;
-    const f16x2 h3 = (as_h2(and_or(w8, c.m1, c.e1)) + zneg2b) * s2;
-    f16x8 out;
-    out[0] = h0[0]; out[1] = h0[1]; out[2] = h1[0]; out[3] = h1[1];
-    out[4] = h2[0]; out[5] = h2[1]; out[6] = h3[0]; out[7] = h3[1];
-    return out;
-}
 
 // Block shape: NWN "n-waves" share one x tile and own NBW 16-column tiles each (BN = 16*NBW*NWN columns);
 // KG "k-groups" of NWN waves split the block's chunk range between them (intra-block split-K, merged
@@ -459,7 +446,7 @@ __global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* __res
 // ------------------------------------------------------------------ dispatch
 struct GemmPlan { int cfg, nsplit, cps, bn; };   // cfg: index into the block-shape table below
 
-int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // [1] nsplit override, [2] config override (+1), [4] disable gemm_smallm
+int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // [1] nsplit override, [2] config override (+1), [4] disable gemm_smallm, [5] disable gemm_wide
 
 // block shapes: {MB, NBW, NWN, KG}
 //   cfg 0: M<=16, BN=64   (4 n-waves x 2 k-groups)      cfg 1: M<=16, BN=128 (huge N, e.g. lm_head)
@@ -574,7 +561,9 @@ extern "C" int mi355_gemm_plan(int M, const mi355_weight_t* w, int max_splits, i
 }
 
 // Tuning / experiment hook (tools/gemm_bench.py); not part of the public ABI.
+extern int g_wide_dbg;
 extern "C" void mi355_debug_set(int key, int value) {
+    if (key == 0) g_wide_dbg = value;
     if (key >= 0 && key < 8) g_debug[key] = value;
 }
 
@@ -600,6 +589,10 @@ extern "C" int mi355_linear_partial(const void* x, int32_t M, const mi355_weight
         const int rc = mi355_gemm_smallm(&p, w->wbits, w->group_size, 1, max_splits, stream);
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
+    if (M > 16 && w->wbits != 16 && !g_debug[5]) { // register-resident activations, K split over the waves (gemm_wide.hip)
+        const int rc = mi355_gemm_wide(&p, w->wbits, w->group_size, 1, max_splits, stream);
+        if (rc != MI355_ERR_UNSUPPORTED) return rc;
+    }
     const GemmPlan g = plan_gemm(M, w, max_splits);
     p.nsplit = g.nsplit; p.cps = g.cps;
     if (int e = launch_gemm(p, w->wbits, w->group_size, g.cfg, (hipStream_t)stream)) return e;
@@ -622,6 +615,13 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
             GemmParams ps; fill_params(ps, (const f16*)x + (size_t)m0 * w->K, Mc, w);
             ps.mode = mode; ps.bias = (const f16*)bias; ps.y = (char*)y + (size_t)m0 * ldy * ysz; ps.ldy = ldy;
             const int rc = mi355_gemm_smallm(&ps, w->wbits, w->group_size, 0, 1, stream);
+            if (rc >= 0) continue;
+            if (rc != MI355_ERR_UNSUPPORTED) return rc;
+        }
+        if (Mc > 16 && w->wbits != 16 && !g_debug[5]) {
+            GemmParams ps; fill_params(ps, (const f16*)x + (size_t)m0 * w->K, Mc, w);
+            ps.mode = mode; ps.bias = (const f16*)bias; ps.y = (char*)y + (size_t)m0 * ldy * ysz; ps.ldy = ldy;
+            const int rc = mi355_gemm_wide(&ps, w->wbits, w->group_size, 0, 1, stream);
             if (rc >= 0) continue;
             if (rc != MI355_ERR_UNSUPPORTED) return rc;
         }
@@ -659,6 +659,11 @@ extern "C" int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_
     p.ldy = (mode == MODE_SILU) ? w->N / 2 : w->N;
     if (M <= 8 && w->wbits != 16 && !g_debug[4]) {
         const int rc = mi355_gemm_smallm(&p, w->wbits, w->group_size, 0, 1, stream);
+        if (rc >= 0) return MI355_OK;
+        if (rc != MI355_ERR_UNSUPPORTED) return rc;
+    }
+    if (M > 16 && w->wbits != 16 && !g_debug[5]) {
+        const int rc = mi355_gemm_wide(&p, w->wbits, w->group_size, 0, 1, stream);
         if (rc >= 0) return MI355_OK;
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }

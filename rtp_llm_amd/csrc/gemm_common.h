@@ -66,6 +66,21 @@ __device__ __forceinline__ f16x8 widen_w8(uint32_t lo, uint32_t hi) {
     return __builtin_bit_cast(f16x8, r);
 }
 
+// Operand-side dequant (M > 32): scale * (u - z) in fp16 — exact subtract of the biased code, one rounding.
+// Even code pairs come out as 1024+u, odd pairs as 64+u (see widen_w4), so the subtract uses two exact
+// constants -(1024+z) and -(64+z).  1 shift + 4 v_and_or + 4 v_pk_add + 4 v_pk_mul = 13 VALU per 8 weights.
+__device__ __forceinline__ f16x8 dequant_w4_vc(uint32_t w, f16x2 zneg2, f16x2 zneg2b, f16x2 s2, const W4Consts& c) {
+    const uint32_t w8 = w >> 8;
+    const f16x2 h0 = (as_h2(and_or(w, c.m0, c.e0)) + zneg2) * s2;
+    const f16x2 h1 = (as_h2(and_or(w, c.m1, c.e1)) + zneg2b) * s2;
+    const f16x2 h2 = (as_h2(and_or(w8, c.m0, c.e0)) + zneg2) * s2;
+    const f16x2 h3 = (as_h2(and_or(w8, c.m1, c.e1)) + zneg2b) * s2;
+    f16x8 out;
+    out[0] = h0[0]; out[1] = h0[1]; out[2] = h1[0]; out[3] = h1[1];
+    out[4] = h2[0]; out[5] = h2[1]; out[6] = h3[0]; out[7] = h3[1];
+    return out;
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
     return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));

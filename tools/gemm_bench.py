@@ -24,11 +24,12 @@ def main():
     ap.add_argument("--nsplit", type=int, default=0)
     ap.add_argument("--nbw", type=int, default=0, help="block-shape cfg override + 1")
     ap.add_argument("--iters", type=int, default=48)
+    ap.add_argument("--nowide", type=int, default=0, help="1: disable the register-resident wide-M kernel")
     ap.add_argument("--nosmall", type=int, default=0, help="1: disable the persistent small-M kernel")
     a = ap.parse_args()
     lib = _C.lib()
     lib.mi355_debug_set.argtypes = [C.c_int, C.c_int]
-    lib.mi355_debug_set(0, a.var); lib.mi355_debug_set(1, a.nsplit); lib.mi355_debug_set(2, a.nbw); lib.mi355_debug_set(4, a.nosmall)
+    lib.mi355_debug_set(0, a.var); lib.mi355_debug_set(1, a.nsplit); lib.mi355_debug_set(2, a.nbw); lib.mi355_debug_set(4, a.nosmall); lib.mi355_debug_set(5, a.nowide)
     dev = "cuda:0"
     gen = torch.Generator(device=dev).manual_seed(0)
     for kind in a.kinds.split(","):
