@@ -1,24 +1,32 @@
-// Weight-only dequant GEMM for 16 < M <= 64 rows ("wide" decode batches), gfx950.
+// Weight-only dequant GEMM for 32 < M <= 64 rows ("wide" decode batches), gfx950.
 //
 // Same contract and weight image as gemm.hip (reference slot: rtp_llm/models_py/modules/factory/linear/factory.py:106-119,
-// W4A16 / W8A16 strategies) but a different decomposition, because at M = 64 the staged-x kernel is bound by LDS
-// B-fragment reads (every wave re-reads the whole 16 KiB x chunk for 1-2 KiB of weights) and by its per-chunk barrier:
+// W4A16 / W8A16 strategies) but a different decomposition.  At M = 64 the staged-x kernel of gemm.hip is bound by LDS
+// B-fragment reads (every wave re-reads the whole 16 KiB x chunk for 1-2 KiB of weights), by its per-chunk barrier and
+// by running on 148 of 256 CUs (BN = 256).  Here:
 //
-//  * one 4-wave block per CU (one wave per SIMD, up to 512 registers each); the block owns <= T adjacent 16-column
-//    tiles and a K range; the four waves split the K range and each wave walks ALL T tiles for its own chunks;
-//  * the activations of a chunk (MB x 4 MFMA B-fragments, 64 VGPRs at MB = 4) are loaded straight from global/L2 in
-//    fragment layout, double buffered in registers, and reused for the T tiles: no LDS, no barrier in the main loop;
-//  * weights stream through a T-deep register ring (1 KiB wave-loads, non-temporal), dequantised on the operand side
-//    (13 VALU per 8 weights) while the previous unit's MFMAs run (software pipeline, one dword ahead);
-//  * the four partial accumulators meet once in LDS at the end; split-K across blocks (slabs) only where N alone
-//    cannot fill 256 CUs (qkv / o / down).
+//  * one 8-wave block per CU (two waves per SIMD, <= 256 registers each) owns <= 2T adjacent 16-column tiles and a K
+//    range.  Wave w = (K slice w & 3, tile half w >> 2): the four K slices split the block's chunks, the two halves
+//    split its tiles; the two waves of a SIMD cover each other's dependency / memory stalls;
+//  * a wave keeps the activations of its current chunk as MFMA B fragments in registers (MB x 4 fragments, 64 VGPRs at
+//    MB = 4) and reuses them for its T tiles; the next chunk's fragments are gathered from global/L2 in fragment
+//    layout by the two waves of the K slice (half each), parked in a double-buffered LDS region and read back right
+//    after the last use of the old ones.  One s_barrier per chunk, no LDS traffic per tile;
+//  * the fragment loads are issued a whole phase (T tiles) before they are written to LDS: vmcnt is an in-order
+//    queue, so waiting for a young L2 load would also force every older HBM weight load to have landed (measured:
+//    with a short wait distance the weight ring was effectively one tile deep);
+//  * weights stream through a T-deep register ring (1 KiB wave-loads, non-temporal), dequantised on the operand side;
+//    the (4 MFMA + 13 VALU) unit is a fixed hand-ordered instruction stream (WIDE_UNIT_W4): measured on MI355X a
+//    16x16x32 MFMA blocks its own wave's issue for ~12 of its 16 cycles, so order and wave count decide the rate
+//    (tools/probe/unit_rate.hip: 52 ns per unit with one wave per SIMD, 43 ns with two);
+//  * the four K slices meet once in LDS at the end; split-K across blocks (fp32 slabs) only where N alone cannot fill
+//    256 CUs (qkv / o / down).
 //
-// Tail handling is by buffer range checks only: offsets of tiles / chunks outside the block's share are pushed
-// past the end of the buffer (loads return 0 and cost nothing), so the main loop has no branches.
+// Tail handling is by buffer range checks only: offsets of tiles / chunks outside a wave's share are pushed past the
+// end of the buffer (loads return 0 and cost nothing), so the main loop has no branches and every wave of a block
+// runs the same number of phases (and barriers).
 #include "gemm_common.h"
 #include <type_traits>
-
-namespace {
 
 // One (tile, k-step) unit of the W4 / 64-row path as a fixed instruction stream: the 4 MFMAs of the unit (A = the
 // operand dequantised by the previous unit, in the fixed tuple AIN) interleaved with the 13 VALU that dequantise the
@@ -46,6 +54,8 @@ namespace {
     "v_pk_mul_f16 " N2 ", " N2 ", %[sc]\n\t"                                \
     "v_pk_mul_f16 " N3 ", " N3 ", %[sc]"
 
+namespace {
+
 // compile-time loop: the body sees its index as a constant expression (sched_group_barrier needs literal arguments)
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -60,33 +70,36 @@ struct WideParams {
     int G; // tile groups (grid.x)
 };
 
+// T = tiles per wave; a block owns 2T tiles.
 template <int WBITS, int MB, int GS, int T, int DBG = 0>
-__global__ __launch_bounds__(256) void gemm_wide_kernel(const WideParams wp) {
+__global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
     const GemmParams& p = wp.g;
-    constexpr int NW   = 4;
+    constexpr int NKS  = 4, NW = 8;                      // K slices, waves
     constexpr int LPC  = WBITS / 4;
     constexpr int NSUB = (GS > 0) ? 4 / GS : 1;
     constexpr int SPG  = 4 / NSUB;
     constexpr bool GROUPED = GS > 0;
-    constexpr int NBL  = 4 * MB;                         // activation loads per chunk
-    constexpr int BT   = (T < 4) ? T : 4;                // tiles over which the next chunk's activation loads are spread
-    constexpr int BPT  = (NBL + BT - 1) / BT;
+    constexpr int NBL  = 4 * MB;                         // activation fragments per chunk
+    constexpr int XF   = NBL / 2;                        // ... gathered by each of the two waves of a K slice
     constexpr int NU   = 4 * T;                          // (tile, k-step) units per chunk
     constexpr uint32_t INV  = 0x40000000u;               // images are <= 1 GiB: any sum with INV is out of range, no wrap
     constexpr uint32_t INVX = 0x80000000u;
+    constexpr bool HAND = (WBITS == 4 && MB == 4);      // hand-ordered unit (WIDE_UNIT_W4)
+    static_assert(XF <= NU - 8, "fragment writes, the barrier and the fragment reads must fit one phase");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ks = wave & 3, th = wave >> 2;
     const int i = lane & 15, q = lane >> 4;
 
     const int t0 = (int)(((long)blockIdx.x * p.NT) / wp.G), t1 = (int)(((long)(blockIdx.x + 1) * p.NT) / wp.G);
-    const int ntiles = t1 - t0;                          // <= T (host)
+    const int ntiles = t1 - t0;                          // <= 2T (host)
     const int c0  = blockIdx.y * p.cps;
     const int nch = min(p.cps, p.KC - c0);
-    const int per = (nch + NW - 1) / NW;
-    const int cw0 = c0 + wave * per;
-    const int ncw = max(0, min(per, c0 + nch - cw0));    // chunks of this wave
+    const int per = (nch + NKS - 1) / NKS;               // phases of every wave of the block
+    const int cw0 = c0 + ks * per;
+    const int ncw = max(0, min(per, c0 + nch - cw0));    // chunks of this K slice
 
     constexpr uint32_t FLAGS = 0x00020000u;
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.qw, 0, p.qw_bytes, FLAGS);
@@ -96,19 +109,23 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const WideParams wp) {
     uint32_t toff[T];                                    // wave-uniform byte offset of tile t's first chunk
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        const uint32_t ok = 0u - (uint32_t)(t < ntiles);
-        toff[t] = (((uint32_t)(t0 + t) * (uint32_t)p.KC * (LPC * 1024u)) & ok) | (INV & ~ok);
+        const uint32_t ok = 0u - (uint32_t)(th * T + t < ntiles);
+        toff[t] = (((uint32_t)(t0 + th * T + t) * (uint32_t)p.KC * (LPC * 1024u)) & ok) | (INV & ~ok);
     }
     const uint32_t lane16 = lane * 16u;
-    const uint32_t mvoff  = (uint32_t)(t0 * 16 + i) * 4u;           // + t * 64: meta of column 16 (t0 + t) + i
+    const uint32_t mvoff  = (uint32_t)((t0 + th * T) * 16 + i) * 4u;  // + t * 64: meta of column 16 (t0 + th T + t) + i
     const uint32_t mrow   = (uint32_t)p.N_pad * 4u;
-    uint32_t xvoff[MB];
+    uint32_t xvoff[XF];                                  // fragment j = th XF + jj: rows 16 (j / 4) + i, k-step j % 4
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) xvoff[mb] = (uint32_t)(((mb * 16 + i) * p.K + q * 8) * 2); // rows >= M: out of range
+    for (int jj = 0; jj < XF; ++jj) {
+        const int j = th * XF + jj;
+        xvoff[jj] = (uint32_t)((((j / 4) * 16 + i) * p.K + q * 8) * 2 + (j % 4) * 64); // rows >= M: out of range
+    }
 
-    u32x4    wr[2][T][LPC];                              // two ring sets: chunk k lives in set k & 1, refilled with chunk k + 2
-    uint32_t mr[2][T][NSUB];
+    u32x4    wr[T][LPC];                                 // weight ring: tile t of the current chunk, refilled with the next
+    uint32_t mr[T][NSUB];
     f16x8    bq[MB][4];                                  // B fragments of the current chunk: [row block][k-step]
+    u32x4    xt[XF];                                     // this wave's half of the fragments of chunk k + 2, in flight
     f32x4    acc[T][MB];
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -122,112 +139,113 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const WideParams wp) {
     auto m_soff = [&](int c, bool valid) { const uint32_t m = 0u - (uint32_t)valid; return (((uint32_t)c * NSUB * mrow) & m) | (INV & ~m); };
     auto x_soff = [&](int c, bool valid) { const uint32_t m = 0u - (uint32_t)valid; return (((uint32_t)c * 256u) & m) | (INVX & ~m); };
 
-    auto load_tile = [&](int r, int t, uint32_t ws, uint32_t ms) {
+    auto load_tile = [&](int t, uint32_t ws, uint32_t ms) {
 #pragma unroll
-        for (int lp = 0; lp < LPC; ++lp) wr[r][t][lp] = bload128<2 /*nt*/>(rw, lane16 + lp * 1024u, toff[t] + ws);
+        for (int lp = 0; lp < LPC; ++lp) wr[t][lp] = bload128<2 /*nt*/>(rw, lane16 + lp * 1024u, toff[t] + ws);
         if (GROUPED) {
 #pragma unroll
             for (int gi = 0; gi < NSUB; ++gi)
-                mr[r][t][gi] = __builtin_amdgcn_raw_buffer_load_b32(rm, mvoff + t * 64u, ms + gi * mrow, 0);
+                mr[t][gi] = __builtin_amdgcn_raw_buffer_load_b32(rm, mvoff + t * 64u, ms + gi * mrow, 0);
         }
     };
 
     // operand-side dequant of unit (t, s): column i of tile t, k = 32 s + 8 q .. + 7
-    constexpr bool HAND = (WBITS == 4 && MB == 4);      // hand-ordered unit (WIDE_UNIT_W4)
     f16x2 zn, znb, scl;
-    auto meta_of = [&](int r, int t, int s) {
-        const uint32_t m = mr[GROUPED ? r : 0][t][GROUPED ? s / SPG : 0];
+    auto meta_of = [&](int t, int s) {
+        const uint32_t m = mr[t][GROUPED ? s / SPG : 0];
         zn  = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u));
         scl = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
         if (WBITS == 4) znb = zn + c960;
     };
-    auto dq = [&](int r, int t, int s) -> f16x8 {
-        if (s % SPG == 0) meta_of(r, t, s);
-        if (WBITS == 4) return dequant_w4_vc(wr[r][t][0][s], zn, znb, scl, w4c);
-        const u32x4 w = wr[r][t][(s >> 1) % LPC];
+    auto dq = [&](int t, int s) -> f16x8 {
+        if (s % SPG == 0) meta_of(t, s);
+        if (WBITS == 4) return dequant_w4_vc(wr[t][0][s], zn, znb, scl, w4c);
+        const u32x4 w = wr[t][(s >> 1) % LPC];
         return dequant_w8<GROUPED>(w[(s & 1) * 2], w[(s & 1) * 2 + 1], zn, scl);
     };
 
     if (!GROUPED) { // per-channel: the meta row is constant along K
 #pragma unroll
-        for (int t = 0; t < T; ++t) mr[0][t][0] = __builtin_amdgcn_raw_buffer_load_b32(rm, mvoff + t * 64u, 0, 0);
+        for (int t = 0; t < T; ++t) mr[t][0] = __builtin_amdgcn_raw_buffer_load_b32(rm, mvoff + t * 64u, 0, 0);
     }
 
-    // ---- prologue: activations and weights of the first chunk
-    u32x4* xb = reinterpret_cast<u32x4*>(smem) + wave * (NBL * 64);  // wave-private staging of the NEXT chunk's activations
+    // LDS: fragments of chunk c of K slice ks live in xbuf[c & 1][ks][fragment][lane]
+    u32x4* xbuf = reinterpret_cast<u32x4*>(smem);
+    auto xregion = [&](int par) { return xbuf + (par * NKS + ks) * (NBL * 64); };
+    auto block_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }; // raw: no vmcnt drain
+
+    // ---- prologue: fragments of chunk 0 through LDS, chunk 1 in flight, weights of chunk 0 in the ring.  Issue order
+    // as in the steady state (fragments of the later chunk first, then the ring): the compiler merges the vmcnt state of
+    // this path into the loop head, and a shorter queue here would shorten every wait of the loop.
     {
-        const uint32_t xs0 = x_soff(cw0, ncw > 0);
-        // through LDS like every later chunk: fragment registers that were pending on VMEM on the entry path only
-        // would make the compiler add vmcnt waits for them at the loop head of every iteration
+        const uint32_t xs0 = x_soff(cw0, ncw > 0), xs1 = x_soff(cw0 + 1, !(DBG & 1) && ncw > 1);
+        u32x4 x0t[XF];
 #pragma unroll
-        for (int j = 0; j < NBL; ++j) xb[j * 64 + lane] = bload128<0>(rx, xvoff[j / 4] + (j % 4) * 64u, xs0);
+        for (int jj = 0; jj < XF; ++jj) xt[jj] = bload128<0>(rx, xvoff[jj], xs1);
 #pragma unroll
-        for (int j = 0; j < NBL; ++j) bq[j / 4][j % 4] = __builtin_bit_cast(f16x8, xb[j * 64 + lane]);
+        for (int jj = 0; jj < XF; ++jj) x0t[jj] = bload128<0>(rx, xvoff[jj], xs0);
         const uint32_t ws0 = w_soff(cw0, ncw > 0), ms0 = m_soff(cw0, ncw > 0);
 #pragma unroll
-        for (int t = 0; t < T; ++t) load_tile(0, t, ws0, ms0);
-        const uint32_t ws1 = w_soff(cw0 + 1, ncw > 1), ms1 = m_soff(cw0 + 1, ncw > 1);
+        for (int t = 0; t < T; ++t) load_tile(t, ws0, ms0);
+        u32x4* x0 = xregion(0);
 #pragma unroll
-        for (int t = 0; t < T; ++t) load_tile(1, t, ws1, ms1);
+        for (int jj = 0; jj < XF; ++jj) x0[(th * XF + jj) * 64 + lane] = x0t[jj];
+        block_sync();
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) bq[j / 4][j % 4] = __builtin_bit_cast(f16x8, x0[j * 64 + lane]);
     }
-    f16x8 a_cur = dq(0, 0, 0);
+    f16x8 a_cur = dq(0, 0);
     u32x4 aE = __builtin_bit_cast(u32x4, a_cur), aO = aE;   // HAND: operand of even / odd units (fixed register tuples)
 
-    // One chunk: MFMAs of unit u with a_cur while unit u+1 is dequantised; tile t's ring slot is refilled with the
-    // next chunk right after its last dword has been consumed.  The next chunk's activations are fetched early in the
-    // phase (so they are older than most refills in the in-order vmcnt queue), parked in LDS XD units later, and
-    // read back into the fragment registers of k-step s right after that k-step's last use (unit (T-1, s)): one set
-    // of fragment registers instead of two (double buffering them in VGPRs overflowed into AGPR copies and made the
-    // compiler wait for the youngest load at every loop head).
-    constexpr int XD = 6;                                // units between an activation load and its LDS write (L2 latency)
-    static_assert(NBL + XD <= NU - 4, "activation staging must finish before the fragment reads of the last tile");
-    u32x4 xt[XD];
-    // phase R consumes ring set R for chunk k, stages the activations of chunk k + 1 and refills set R with chunk k + 2
-    auto phase = [&](auto rc, int k) {
-        constexpr int R = decltype(rc)::value;
+    // ---- phase k: chunk k of the K slice.  Units 0..XF-1 park the fragments of chunk k+1 (loaded one phase ago) in LDS
+    // and fetch those of chunk k+2; the barrier follows; the last tile's units read chunk k+1 back into bq[..][s].
+    for (int k = 0; k < per; ++k) {
         // DBG (timing experiments only): out-of-range offsets keep the instruction stream but remove the memory traffic
-        const bool v1 = !(DBG & 1) && k + 1 < ncw, v2 = !(DBG & 2) && k + 2 < ncw;
-        const uint32_t ws = w_soff(cw0 + k + 2, v2), ms = m_soff(cw0 + k + 2, v2), xs = x_soff(cw0 + k + 1, v1);
+        const bool v1 = !(DBG & 2) && k + 1 < ncw, v2 = !(DBG & 1) && k + 2 < ncw;
+        const uint32_t ws = w_soff(cw0 + k + 1, v1), ms = m_soff(cw0 + k + 1, v1), xs = x_soff(cw0 + k + 2, v2);
+        u32x4* xn = xregion((k + 1) & 1);
         static_for<0, NU>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             constexpr int t = u / 4, s = u % 4;
-            if constexpr (u >= XD && u < NBL + XD) xb[(u - XD) * 64 + lane] = xt[(u - XD) % XD];   // frees the slot ...
-            if constexpr (u < NBL) xt[u % XD] = bload128<0>(rx, xvoff[u / 4] + (u % 4) * 64u, xs);  // ... fragment j = u reuses
-            if constexpr (s == 3) load_tile(R, t, ws, ms);                  // dq(R, t, 3) was issued in unit (t, 2)
-            constexpr int un = (u + 1) % NU, rn = (u + 1 < NU) ? R : 1 - R, tn = un / 4, sn = un % 4;
+            if constexpr (u < XF) {
+                xn[(th * XF + u) * 64 + lane] = xt[u];
+                xt[u] = bload128<0>(rx, xvoff[u], xs);
+            }
+            if constexpr (u == XF) block_sync();
+            if constexpr (s == 3) load_tile(t, ws, ms);                     // dq(t, 3) was issued in unit (t, 2)
+            constexpr int un = (u + 1) % NU, tn = un / 4, sn = un % 4;
             if constexpr (HAND) {
-                if constexpr (sn % SPG == 0) meta_of(rn, tn, sn);
-                const uint32_t wn = wr[rn][tn][0][sn];
+                if constexpr (sn % SPG == 0) meta_of(tn, sn);
+                const uint32_t wn = wr[tn][0][sn];
                 uint32_t tmp;
                 if constexpr (u % 2 == 0) {
-                    asm volatile(WIDE_UNIT_W4("v[248:251]", "v252", "v253", "v254", "v255")
-                                 : [t] "=&v"(tmp), "=&{v[252:255]}"(aO), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1]),
+                    asm volatile(WIDE_UNIT_W4("v[100:103]", "v104", "v105", "v106", "v107")
+                                 : [t] "=&v"(tmp), "=&{v[104:107]}"(aO), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1]),
                                    [c2] "+a"(acc[t][2]), [c3] "+a"(acc[t][3])
-                                 : "{v[248:251]}"(aE), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
+                                 : "{v[100:103]}"(aE), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
                                    [e1] "v"(w4c.e1), [zn] "v"(zn), [znb] "v"(znb), [sc] "v"(scl), [b0] "v"(bq[0][s]),
                                    [b1] "v"(bq[1][s]), [b2] "v"(bq[2][s]), [b3] "v"(bq[3][s]));
                 } else {
-                    asm volatile(WIDE_UNIT_W4("v[252:255]", "v248", "v249", "v250", "v251")
-                                 : [t] "=&v"(tmp), "=&{v[248:251]}"(aE), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1]),
+                    asm volatile(WIDE_UNIT_W4("v[104:107]", "v100", "v101", "v102", "v103")
+                                 : [t] "=&v"(tmp), "=&{v[100:103]}"(aE), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1]),
                                    [c2] "+a"(acc[t][2]), [c3] "+a"(acc[t][3])
-                                 : "{v[252:255]}"(aO), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
+                                 : "{v[104:107]}"(aO), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
                                    [e1] "v"(w4c.e1), [zn] "v"(zn), [znb] "v"(znb), [sc] "v"(scl), [b0] "v"(bq[0][s]),
                                    [b1] "v"(bq[1][s]), [b2] "v"(bq[2][s]), [b3] "v"(bq[3][s]));
                 }
             } else {
-                const f16x8 a_next = dq(rn, tn, sn);
+                const f16x8 a_next = dq(tn, sn);
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) acc[t][mb] = mfma16x16x32(a_cur, bq[mb][s], acc[t][mb]);
                 a_cur = a_next;
             }
             if constexpr (t == T - 1) {
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) bq[mb][s] = __builtin_bit_cast(f16x8, xb[(mb * 4 + s) * 64 + lane]);
+                for (int mb = 0; mb < MB; ++mb) bq[mb][s] = __builtin_bit_cast(f16x8, xn[(mb * 4 + s) * 64 + lane]);
             }
             // pin the memory operations of this unit where they were written (left free, the scheduler sinks a whole
             // phase of loads to its end and the ring reads then wait for loads issued a few cycles earlier)
-            if constexpr (u >= XD && u < NBL + XD) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            if constexpr (u < NBL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if constexpr (u < XF) { __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
             if constexpr (s == 3) __builtin_amdgcn_sched_group_barrier(0x020, LPC + (GROUPED ? NSUB : 0), 0);
             if constexpr (!HAND) {
 #pragma unroll
@@ -239,36 +257,30 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const WideParams wp) {
             if constexpr (t == T - 1) __builtin_amdgcn_sched_group_barrier(0x100, MB, 0);
             __builtin_amdgcn_sched_barrier(0);   // fence per unit: the groups above only order what is inside it
         });
-    };
-    // unguarded pairs of phases (an odd count runs one extra phase on zero activations and out-of-range weights)
-    for (int k = 0; k < ncw; k += 2) {
-        phase(std::integral_constant<int, 0>{}, k);
-        phase(std::integral_constant<int, 1>{}, k + 1);
     }
     if constexpr (HAND) asm volatile("s_nop 15" ::: "memory"); // the last MFMAs' results are read by compiler code below
-    __syncthreads(); // staging regions are reused by the merge below
+    __syncthreads(); // fragment regions are reused by the merge below
 
-    // ---- merge the four waves through LDS (two halves of the tile set), epilogue
-    constexpr int TH = (T + 1) / 2;
+    // ---- merge the four K slices through LDS (TR tiles per round), epilogue
+    constexpr int TR = 3;
     f32x4* red = reinterpret_cast<f32x4*>(smem);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (h) __syncthreads();
+    for (int r0 = 0; r0 < T; r0 += TR) {
+        if (r0) __syncthreads();
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            if (t / TH != h) continue;
+        for (int t = r0; t < r0 + TR && t < T; ++t)
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) red[((wave * TH + (t - h * TH)) * MB + mb) * 64 + lane] = acc[t][mb];
-        }
+            for (int mb = 0; mb < MB; ++mb) red[((wave * TR + (t - r0)) * MB + mb) * 64 + lane] = acc[t][mb];
         __syncthreads();
-        const int nth = (T - h * TH < TH) ? T - h * TH : TH;
-        for (int j = wave; j < nth * MB; j += NW) {
-            const int tt = j / MB, mb = j - tt * MB, t = h * TH + tt;
-            if (t >= ntiles) continue;
-            f32x4 v = red[((0 * TH + tt) * MB + mb) * 64 + lane];
+        const int ntr = (T - r0 < TR) ? T - r0 : TR;
+        for (int id = wave; id < 2 * ntr * MB; id += NW) {
+            const int h = id / (ntr * MB), rem = id - h * (ntr * MB), tt = rem / MB, mb = rem - tt * MB;
+            const int tb = h * T + r0 + tt;              // tile inside the block
+            if (tb >= ntiles) continue;
+            f32x4 v = red[(((h * NKS + 0) * TR + tt) * MB + mb) * 64 + lane];
 #pragma unroll
-            for (int w = 1; w < NW; ++w) v += red[((w * TH + tt) * MB + mb) * 64 + lane];
-            const int m = mb * 16 + i, n0 = (t0 + t) * 16 + q * 4;
+            for (int s = 1; s < NKS; ++s) v += red[(((h * NKS + s) * TR + tt) * MB + mb) * 64 + lane];
+            const int m = mb * 16 + i, n0 = (t0 + tb) * 16 + q * 4;
             if (WBITS != 16 && !GROUPED) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -284,14 +296,14 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const WideParams wp) {
 template <int WBITS, int MB, int GS, int T, int DBG = 0>
 int launch_wide_t(const WideParams& wp, hipStream_t st) {
     auto k = gemm_wide_kernel<WBITS, MB, GS, T, DBG>;
-    constexpr size_t red_b = (size_t)4 * ((T + 1) / 2) * MB * 1024, stage_b = (size_t)4 * 4 * MB * 1024;
+    constexpr size_t red_b = (size_t)8 * 3 * MB * 1024, stage_b = (size_t)2 * 4 * 4 * MB * 1024;
     constexpr size_t lds = red_b > stage_b ? red_b : stage_b;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k, dim3(wp.G, wp.g.nsplit), dim3(256), lds, st, wp);
+    hipLaunchKernelGGL(k, dim3(wp.G, wp.g.nsplit), dim3(512), lds, st, wp);
     MI355_CHECK_LAUNCH("gemm_wide_kernel");
     return MI355_OK;
 }
@@ -305,27 +317,30 @@ int g_wide_dbg = 0; // experiment switch (tools/gemm_bench.py --var): 1 no activ
 extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int want_partial, int max_splits,
                                mi355_stream_t stream) {
     GemmParams g = *reinterpret_cast<const GemmParams*>(gp);
-    constexpr int T = 10, CUS = 256;
+    constexpr int T = 5, TB = 2 * T, CUS = 256;     // tiles per wave / per block
     if (g.M <= 32 || g.M > 64) return MI355_ERR_UNSUPPORTED;
     if (!(wbits == 4 && group_size == 128)) return MI355_ERR_UNSUPPORTED;
     if (g.K % 128 != 0 || g.qw_bytes > 0x40000000u || g.meta_bytes > 0x40000000u) return MI355_ERR_UNSUPPORTED;
     WideParams wp;
-    int G = (g.NT + T - 1) / T;                     // fewest groups with <= T tiles each
+    int G = (g.NT + TB - 1) / TB;                   // fewest groups with <= TB tiles each
     int nsplit = 1;
+    // Split-K shapes (qkv / o / down at M = 64) measured equal to the staged-x kernel: short K ranges leave 1-4 phases per
+    // wave and the fixed prologue / merge dominates; they stay on gemm.hip unless the experiment switch asks otherwise.
+    if (want_partial && g_wide_dbg < 8) return MI355_ERR_UNSUPPORTED;
     if (want_partial) {
         nsplit = CUS / G;
         if (nsplit > max_splits) nsplit = max_splits;
-        if (nsplit > g.KC / 4) nsplit = g.KC / 4;   // >= one chunk per wave
+        if (nsplit > g.KC / 4) nsplit = g.KC / 4;   // >= one chunk per K slice
         if (nsplit < 1) nsplit = 1;
     } else {
-        if (G < CUS && g.NT >= CUS * (T - 3)) G = CUS;   // N alone fills the machine: spread tiles over all CUs
+        if (G < CUS && g.NT >= CUS * (TB - 3)) G = CUS;  // N alone fills the machine: spread tiles over all CUs
         if (G < CUS * 3 / 4) return MI355_ERR_UNSUPPORTED;
     }
     g.cps = (g.KC + nsplit - 1) / nsplit;
     g.nsplit = (g.KC + g.cps - 1) / g.cps;
     wp.g = g; wp.G = G;
     int rc;
-    switch (g_wide_dbg) {
+    switch (g_wide_dbg & 7) {
         case 1: rc = launch_wide_t<4, 4, 4, T, 1>(wp, (hipStream_t)stream); break;
         case 2: rc = launch_wide_t<4, 4, 4, T, 2>(wp, (hipStream_t)stream); break;
         case 3: rc = launch_wide_t<4, 4, 4, T, 3>(wp, (hipStream_t)stream); break;

@@ -88,6 +88,28 @@ def test_linear_silu_and_f32_epilogues(M):
     assert torch.allclose(y32.cpu(), oracle.linear(x, _dense(c16), out_f32=True), **TOL)
 
 
+@pytest.mark.parametrize("M", [33, 48, 64])
+@pytest.mark.parametrize("K,I", [(256, 18944), (640, 16000)])
+def test_linear_wide_batch_kernel(M, K, I):
+    """32 < M <= 64 with N wide enough to fill the machine takes the register-resident kernel (gemm_wide.hip):
+    plain, bias and fused SiLU epilogues, ragged tile groups (2 * 16000 / 16 tiles over 256 blocks), odd chunk counts."""
+    c = _canon_cpu(K, 2 * I, "w4", 21 + M)
+    x = _x(M, K, 2)
+    dense = _dense(c)
+    y = ops.linear(x.to(DEV), c.pack(gate_up=True).to(DEV), epilogue=_C.EPI_SILU_MUL)
+    assert torch.allclose(y.cpu().float(), oracle.silu_mul(oracle.linear(x, dense)).float(), **TOL)
+    bias = (torch.randn(2 * I, generator=_gen(4)) * 0.1).half()
+    y2 = ops.linear(x.to(DEV), c.pack().to(DEV), bias.to(DEV))
+    ref2 = oracle.linear(x, dense, bias)
+    assert torch.allclose(y2.cpu().float(), ref2.float(), **TOL), (y2.cpu().float() - ref2.float()).abs().max()
+    _C.lib().mi355_debug_set(5, 1)                      # same call through the staged-x kernel: both within tolerance
+    try:
+        y3 = ops.linear(x.to(DEV), c.pack().to(DEV), bias.to(DEV))
+    finally:
+        _C.lib().mi355_debug_set(5, 0)
+    assert torch.allclose(y3.cpu().float(), ref2.float(), **TOL)
+
+
 def test_linear_is_deterministic():
     c = _canon_cpu(3584, 512, "w4", 9)
     x, p = _x(16, 3584, 4).to(DEV), c.pack().to(DEV)

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--nsplit", type=int, default=0)
     ap.add_argument("--nbw", type=int, default=0, help="block-shape cfg override + 1")
     ap.add_argument("--iters", type=int, default=48)
+    ap.add_argument("--partial", type=int, default=0, help="1: qkv/o/down through mi355_linear_partial (split-K slabs, as the engine)")
     ap.add_argument("--nowide", type=int, default=0, help="1: disable the register-resident wide-M kernel")
     ap.add_argument("--nosmall", type=int, default=0, help="1: disable the persistent small-M kernel")
     a = ap.parse_args()
@@ -43,12 +44,22 @@ def main():
             for M in [int(m) for m in a.ms.split(",")]:
                 x = (torch.randn(M, K, device=dev, generator=gen) * 0.5).half()
                 epi = _C.EPI_SILU_MUL if name == "gate_up" else (_C.EPI_OUT_F32 if name == "lm_head" else 0)
-                outs = [ops.linear(x, c, None, epi) for c in copies[:2]]
+                partial = a.partial and name not in ("gate_up", "lm_head")
+                if partial:
+                    slabs = torch.empty(16 * M * base.N_pad, dtype=torch.float32, device=dev)
+                    structs = [ops.weight_struct(c) for c in copies]
+                    stream = torch.cuda.current_stream().cuda_stream
+                    run = lambda i: lib.mi355_linear_partial(x.data_ptr(), M, C.byref(structs[i % ncopy]), slabs.data_ptr(), 16, stream)
+                    ns = run(0)
+                    assert ns > 0, _C.last_error() if hasattr(_C, "last_error") else ns
+                else:
+                    outs = [ops.linear(x, c, None, epi) for c in copies[:2]]
+                    run = lambda i: ops.linear(x, copies[i % ncopy], None, epi, out=outs[0])
                 torch.cuda.synchronize()
                 st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 st.record()
                 for i in range(a.iters):
-                    ops.linear(x, copies[i % ncopy], None, epi, out=outs[0])
+                    run(i)
                 en.record(); torch.cuda.synchronize()
                 us = st.elapsed_time(en) / a.iters * 1e3
                 print(f"{k:5s} {name:8s} M={M:3d}  {us:8.2f} us  {base.nbytes / us / 1e3:8.1f} GB/s   ({base.nbytes / 1e6:.1f} MB, {ncopy} copies)", flush=True)
