@@ -68,6 +68,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 struct WideParams {
     GemmParams g;
     int G; // tile groups (grid.x)
+    unsigned long long* stamps; // DBG & 4: wall_clock64 at start / after prologue / after the main loop / at the end, per wave
 };
 
 // T = tiles per wave; a block owns 2T tiles.
@@ -91,6 +92,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ks = wave & 3, th = wave >> 2;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if constexpr (DBG & 4) st0 = wall_clock64();
     const int i = lane & 15, q = lane >> 4;
 
     const int t0 = (int)(((long)blockIdx.x * p.NT) / wp.G), t1 = (int)(((long)(blockIdx.x + 1) * p.NT) / wp.G);
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
         for (int j = 0; j < NBL; ++j) bq[j / 4][j % 4] = __builtin_bit_cast(f16x8, x0[j * 64 + lane]);
     }
     f16x8 a_cur = dq(0, 0);
+    if constexpr (DBG & 4) st1 = wall_clock64();
     u32x4 aE = __builtin_bit_cast(u32x4, a_cur), aO = aE;   // HAND: operand of even / odd units (fixed register tuples)
 
     // ---- phase k: chunk k of the K slice.  Units 0..XF-1 park the fragments of chunk k+1 (loaded one phase ago) in LDS
@@ -258,6 +262,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
             __builtin_amdgcn_sched_barrier(0);   // fence per unit: the groups above only order what is inside it
         });
     }
+    if constexpr (DBG & 4) st2 = wall_clock64();
     if constexpr (HAND) asm volatile("s_nop 15" ::: "memory"); // the last MFMAs' results are read by compiler code below
     __syncthreads(); // fragment regions are reused by the merge below
 
@@ -291,6 +296,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
             if (m < p.M) gemm_store(p, v, m, n0, blockIdx.y);
         }
     }
+    if constexpr (DBG & 4) {
+        if (lane == 0 && wp.stamps) {
+            unsigned long long* d = wp.stamps + ((size_t)blockIdx.x * NW + wave) * 4;
+            d[0] = st0; d[1] = st1; d[2] = st2; d[3] = wall_clock64();
+        }
+    }
 }
 
 template <int WBITS, int MB, int GS, int T, int DBG = 0>
@@ -310,7 +321,10 @@ int launch_wide_t(const WideParams& wp, hipStream_t st) {
 
 } // namespace
 
+unsigned long long* g_wide_stamps = nullptr; // device buffer for DBG & 4 (mi355_debug_ptr)
 int g_wide_dbg = 0; // experiment switch (tools/gemm_bench.py --var): 1 no activation reloads, 2 no weight refills, 3 both
+
+extern "C" void mi355_debug_ptr(void* p) { g_wide_stamps = (unsigned long long*)p; }
 
 // Plan + launch.  Returns the number of slabs written (partial mode), MI355_OK (direct mode), or
 // MI355_ERR_UNSUPPORTED when the shape does not fit this kernel (the caller falls back to gemm.hip).
@@ -338,12 +352,13 @@ extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int wa
     }
     g.cps = (g.KC + nsplit - 1) / nsplit;
     g.nsplit = (g.KC + g.cps - 1) / g.cps;
-    wp.g = g; wp.G = G;
+    wp.g = g; wp.G = G; wp.stamps = g_wide_stamps;
     int rc;
     switch (g_wide_dbg & 7) {
         case 1: rc = launch_wide_t<4, 4, 4, T, 1>(wp, (hipStream_t)stream); break;
         case 2: rc = launch_wide_t<4, 4, 4, T, 2>(wp, (hipStream_t)stream); break;
         case 3: rc = launch_wide_t<4, 4, 4, T, 3>(wp, (hipStream_t)stream); break;
+        case 4: rc = launch_wide_t<4, 4, 4, T, 4>(wp, (hipStream_t)stream); break;
         default: rc = launch_wide_t<4, 4, 4, T>(wp, (hipStream_t)stream);
     }
     if (rc != MI355_OK) return rc;

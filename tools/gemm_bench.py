@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rtp_llm_amd import _C, model, ops  # noqa: E402
 
-SHAPES = {"qkv": (3584, 4608), "o": (3584, 3584), "gate_up": (3584, 37888), "down": (18944, 3584), "lm_head": (3584, 152064)}
+SHAPES = {"gu_k1792": (1792, 37888), "gu_k7168": (7168, 37888), "gu_k14336": (14336, 37888), "qkv": (3584, 4608), "o": (3584, 3584), "gate_up": (3584, 37888), "down": (18944, 3584), "lm_head": (3584, 152064)}
 
 
 def main():
@@ -37,13 +37,13 @@ def main():
         for name in a.shapes.split(","):
             K, N = SHAPES[name]
             k = "fp16" if name == "lm_head" else kind
-            base = model.synth_linear(K, N, k, dev, gen).pack(gate_up=(name == "gate_up"))
+            base = model.synth_linear(K, N, k, dev, gen).pack(gate_up=(name == "gate_up" or name.startswith("gu_")))
             ncopy = max(2, int(600e6 // base.nbytes) + 1)
             copies = [base] + [type(base)(base.qweight.clone(), None if base.meta is None else base.meta.clone(), base.wbits,
                                           base.K, base.N, base.K_pad, base.N_pad, base.group_size) for _ in range(ncopy - 1)]
             for M in [int(m) for m in a.ms.split(",")]:
                 x = (torch.randn(M, K, device=dev, generator=gen) * 0.5).half()
-                epi = _C.EPI_SILU_MUL if name == "gate_up" else (_C.EPI_OUT_F32 if name == "lm_head" else 0)
+                epi = _C.EPI_SILU_MUL if name in ("gate_up", "gu_k1792", "gu_k7168", "gu_k14336") else (_C.EPI_OUT_F32 if name == "lm_head" else 0)
                 partial = a.partial and name not in ("gate_up", "lm_head")
                 if partial:
                     slabs = torch.empty(16 * M * base.N_pad, dtype=torch.float32, device=dev)
