@@ -28,32 +28,6 @@
 #include "gemm_common.h"
 #include <type_traits>
 
-// One (tile, k-step) unit of the W4 / 64-row path as a fixed instruction stream: the 4 MFMAs of the unit (A = the
-// operand dequantised by the previous unit, in the fixed tuple AIN) interleaved with the 13 VALU that dequantise the
-// next dword into N0..N3 (the other fixed tuple).  One wave per SIMD issues in order, so the order IS the schedule:
-// every MFMA is followed by >= 3 independent VALU (its 16 cycles in the matrix pipe are covered), dependent VALU are
-// >= 4 slots apart, and the two leading VALU give the 2 wait states a VALU-written MFMA operand needs (the previous
-// unit ends with writes to AIN).  hipcc's own schedule of the same work ran at ~10 cycles per instruction
-// (dependent v_pk chains back to back with s_nop between them, accumulators renamed through v_accvgpr moves).
-#define WIDE_UNIT_W4(AIN, N0, N1, N2, N3)                                   \
-    "v_lshrrev_b32 %[t], 8, %[w]\n\t"                                       \
-    "v_and_or_b32 " N0 ", %[w], %[m0], %[e0]\n\t"                           \
-    "v_mfma_f32_16x16x32_f16 %[c0], " AIN ", %[b0], %[c0]\n\t"              \
-    "v_and_or_b32 " N1 ", %[w], %[m1], %[e1]\n\t"                           \
-    "v_and_or_b32 " N2 ", %[t], %[m0], %[e0]\n\t"                           \
-    "v_and_or_b32 " N3 ", %[t], %[m1], %[e1]\n\t"                           \
-    "v_mfma_f32_16x16x32_f16 %[c1], " AIN ", %[b1], %[c1]\n\t"              \
-    "v_pk_add_f16 " N0 ", " N0 ", %[zn]\n\t"                                \
-    "v_pk_add_f16 " N1 ", " N1 ", %[znb]\n\t"                               \
-    "v_pk_add_f16 " N2 ", " N2 ", %[zn]\n\t"                                \
-    "v_mfma_f32_16x16x32_f16 %[c2], " AIN ", %[b2], %[c2]\n\t"              \
-    "v_pk_add_f16 " N3 ", " N3 ", %[znb]\n\t"                               \
-    "v_pk_mul_f16 " N0 ", " N0 ", %[sc]\n\t"                                \
-    "v_pk_mul_f16 " N1 ", " N1 ", %[sc]\n\t"                                \
-    "v_mfma_f32_16x16x32_f16 %[c3], " AIN ", %[b3], %[c3]\n\t"              \
-    "v_pk_mul_f16 " N2 ", " N2 ", %[sc]\n\t"                                \
-    "v_pk_mul_f16 " N3 ", " N3 ", %[sc]"
-
 namespace {
 
 // compile-time loop: the body sees its index as a constant expression (sched_group_barrier needs literal arguments)
