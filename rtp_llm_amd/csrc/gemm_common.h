@@ -30,6 +30,24 @@
     "v_pk_mul_f16 " N2 ", " N2 ", %[sc]\n\t"                                \
     "v_pk_mul_f16 " N3 ", " N3 ", %[sc]"
 
+// Same for 32 rows (2 MFMAs per unit): VALU-issue bound, the MFMAs sit where >= 5 independent VALU follow.
+#define WIDE_UNIT_W4_MB2(AIN, N0, N1, N2, N3)                               \
+    "v_lshrrev_b32 %[t], 8, %[w]\n\t"                                       \
+    "v_and_or_b32 " N0 ", %[w], %[m0], %[e0]\n\t"                           \
+    "v_mfma_f32_16x16x32_f16 %[c0], " AIN ", %[b0], %[c0]\n\t"              \
+    "v_and_or_b32 " N1 ", %[w], %[m1], %[e1]\n\t"                           \
+    "v_and_or_b32 " N2 ", %[t], %[m0], %[e0]\n\t"                           \
+    "v_and_or_b32 " N3 ", %[t], %[m1], %[e1]\n\t"                           \
+    "v_pk_add_f16 " N0 ", " N0 ", %[zn]\n\t"                                \
+    "v_pk_add_f16 " N1 ", " N1 ", %[znb]\n\t"                               \
+    "v_mfma_f32_16x16x32_f16 %[c1], " AIN ", %[b1], %[c1]\n\t"              \
+    "v_pk_add_f16 " N2 ", " N2 ", %[zn]\n\t"                                \
+    "v_pk_add_f16 " N3 ", " N3 ", %[znb]\n\t"                               \
+    "v_pk_mul_f16 " N0 ", " N0 ", %[sc]\n\t"                                \
+    "v_pk_mul_f16 " N1 ", " N1 ", %[sc]\n\t"                                \
+    "v_pk_mul_f16 " N2 ", " N2 ", %[sc]\n\t"                                \
+    "v_pk_mul_f16 " N3 ", " N3 ", %[sc]"
+
 namespace {
 
 struct GemmParams {

@@ -1,4 +1,4 @@
-// Weight-only dequant GEMM for 32 < M <= 64 rows ("wide" decode batches), gfx950.
+// Weight-only dequant GEMM for 16 < M <= 64 rows ("wide" decode batches), gfx950.
 //
 // Same contract and weight image as gemm.hip (reference slot: rtp_llm/models_py/modules/factory/linear/factory.py:106-119,
 // W4A16 / W8A16 strategies) but a different decomposition.  At M = 64 the staged-x kernel of gemm.hip is bound by LDS
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
     constexpr int NU   = 4 * T;                          // (tile, k-step) units per chunk
     constexpr uint32_t INV  = 0x40000000u;               // images are <= 1 GiB: any sum with INV is out of range, no wrap
     constexpr uint32_t INVX = 0x80000000u;
-    constexpr bool HAND = (WBITS == 4 && MB == 4);      // hand-ordered unit (WIDE_UNIT_W4)
+    constexpr bool HAND = (WBITS == 4 && (MB == 4 || MB == 2)); // hand-ordered unit (WIDE_UNIT_W4 / _MB2)
     static_assert(XF <= NU - 8, "fragment writes, the barrier and the fragment reads must fit one phase");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -196,20 +196,36 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
                 if constexpr (sn % SPG == 0) meta_of(tn, sn);
                 const uint32_t wn = wr[tn][0][sn];
                 uint32_t tmp;
-                if constexpr (u % 2 == 0) {
-                    asm volatile(WIDE_UNIT_W4("v[100:103]", "v104", "v105", "v106", "v107")
-                                 : [t] "=&v"(tmp), "=&{v[104:107]}"(aO), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1]),
-                                   [c2] "+a"(acc[t][2]), [c3] "+a"(acc[t][3])
-                                 : "{v[100:103]}"(aE), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
-                                   [e1] "v"(w4c.e1), [zn] "v"(zn), [znb] "v"(znb), [sc] "v"(scl), [b0] "v"(bq[0][s]),
-                                   [b1] "v"(bq[1][s]), [b2] "v"(bq[2][s]), [b3] "v"(bq[3][s]));
+                if constexpr (MB == 4) {
+                    if constexpr (u % 2 == 0) {
+                        asm volatile(WIDE_UNIT_W4("v[100:103]", "v104", "v105", "v106", "v107")
+                                     : [t] "=&v"(tmp), "=&{v[104:107]}"(aO), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1]),
+                                       [c2] "+a"(acc[t][2]), [c3] "+a"(acc[t][3])
+                                     : "{v[100:103]}"(aE), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
+                                       [e1] "v"(w4c.e1), [zn] "v"(zn), [znb] "v"(znb), [sc] "v"(scl), [b0] "v"(bq[0][s]),
+                                       [b1] "v"(bq[1][s]), [b2] "v"(bq[2][s]), [b3] "v"(bq[3][s]));
+                    } else {
+                        asm volatile(WIDE_UNIT_W4("v[104:107]", "v100", "v101", "v102", "v103")
+                                     : [t] "=&v"(tmp), "=&{v[100:103]}"(aE), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1]),
+                                       [c2] "+a"(acc[t][2]), [c3] "+a"(acc[t][3])
+                                     : "{v[104:107]}"(aO), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
+                                       [e1] "v"(w4c.e1), [zn] "v"(zn), [znb] "v"(znb), [sc] "v"(scl), [b0] "v"(bq[0][s]),
+                                       [b1] "v"(bq[1][s]), [b2] "v"(bq[2][s]), [b3] "v"(bq[3][s]));
+                    }
                 } else {
-                    asm volatile(WIDE_UNIT_W4("v[104:107]", "v100", "v101", "v102", "v103")
-                                 : [t] "=&v"(tmp), "=&{v[100:103]}"(aE), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1]),
-                                   [c2] "+a"(acc[t][2]), [c3] "+a"(acc[t][3])
-                                 : "{v[104:107]}"(aO), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
-                                   [e1] "v"(w4c.e1), [zn] "v"(zn), [znb] "v"(znb), [sc] "v"(scl), [b0] "v"(bq[0][s]),
-                                   [b1] "v"(bq[1][s]), [b2] "v"(bq[2][s]), [b3] "v"(bq[3][s]));
+                    if constexpr (u % 2 == 0) {
+                        asm volatile(WIDE_UNIT_W4_MB2("v[100:103]", "v104", "v105", "v106", "v107")
+                                     : [t] "=&v"(tmp), "=&{v[104:107]}"(aO), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1])
+                                     : "{v[100:103]}"(aE), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
+                                       [e1] "v"(w4c.e1), [zn] "v"(zn), [znb] "v"(znb), [sc] "v"(scl), [b0] "v"(bq[0][s]),
+                                       [b1] "v"(bq[1][s]));
+                    } else {
+                        asm volatile(WIDE_UNIT_W4_MB2("v[104:107]", "v100", "v101", "v102", "v103")
+                                     : [t] "=&v"(tmp), "=&{v[100:103]}"(aE), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1])
+                                     : "{v[104:107]}"(aO), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
+                                       [e1] "v"(w4c.e1), [zn] "v"(zn), [znb] "v"(znb), [sc] "v"(scl), [b0] "v"(bq[0][s]),
+                                       [b1] "v"(bq[1][s]));
+                    }
                 }
             } else {
                 const f16x8 a_next = dq(tn, sn);
@@ -306,7 +322,7 @@ extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int wa
                                mi355_stream_t stream) {
     GemmParams g = *reinterpret_cast<const GemmParams*>(gp);
     constexpr int T = 5, TB = 2 * T, CUS = 256;     // tiles per wave / per block
-    if (g.M <= 32 || g.M > 64) return MI355_ERR_UNSUPPORTED;
+    if (g.M <= 16 || g.M > 64) return MI355_ERR_UNSUPPORTED;
     if (!(wbits == 4 && group_size == 128)) return MI355_ERR_UNSUPPORTED;
     if (g.K % 128 != 0 || g.qw_bytes > 0x40000000u || g.meta_bytes > 0x40000000u) return MI355_ERR_UNSUPPORTED;
     WideParams wp;
@@ -328,6 +344,8 @@ extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int wa
     g.nsplit = (g.KC + g.cps - 1) / g.cps;
     wp.g = g; wp.G = G; wp.stamps = g_wide_stamps;
     int rc;
+    if (g.M <= 32 && (g_wide_dbg & 7) == 0) rc = launch_wide_t<4, 2, 4, T>(wp, (hipStream_t)stream);
+    else
     switch (g_wide_dbg & 7) {
         case 1: rc = launch_wide_t<4, 4, 4, T, 1>(wp, (hipStream_t)stream); break;
         case 2: rc = launch_wide_t<4, 4, 4, T, 2>(wp, (hipStream_t)stream); break;

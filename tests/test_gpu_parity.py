@@ -88,10 +88,10 @@ def test_linear_silu_and_f32_epilogues(M):
     assert torch.allclose(y32.cpu(), oracle.linear(x, _dense(c16), out_f32=True), **TOL)
 
 
-@pytest.mark.parametrize("M", [33, 48, 64])
+@pytest.mark.parametrize("M", [17, 33, 48, 64])
 @pytest.mark.parametrize("K,I", [(256, 18944), (640, 16000)])
 def test_linear_wide_batch_kernel(M, K, I):
-    """32 < M <= 64 with N wide enough to fill the machine takes the register-resident kernel (gemm_wide.hip):
+    """16 < M <= 64 with N wide enough to fill the machine takes the register-resident kernel (gemm_wide.hip):
     plain, bias and fused SiLU epilogues, ragged tile groups (2 * 16000 / 16 tiles over 256 blocks), odd chunk counts."""
     c = _canon_cpu(K, 2 * I, "w4", 21 + M)
     x = _x(M, K, 2)
