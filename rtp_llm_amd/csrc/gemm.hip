@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* __res
 // ------------------------------------------------------------------ dispatch
 struct GemmPlan { int cfg, nsplit, cps, bn; };   // cfg: index into the block-shape table below
 
-int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // [1] nsplit override, [2] config override (+1), [4] disable gemm_smallm, [5] disable gemm_wide
+int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // [1] nsplit override, [2] config override (+1), [4] gemm_smallm: 1 never, 2 also inside the decode step, [5] disable gemm_wide
 
 // block shapes: {MB, NBW, NWN, KG}
 //   cfg 0: M<=16, BN=64   (4 n-waves x 2 k-groups)      cfg 1: M<=16, BN=128 (huge N, e.g. lm_head)
@@ -592,7 +592,9 @@ extern "C" int mi355_linear_partial(const void* x, int32_t M, const mi355_weight
     MI355_CHECK_ARG(x && partials && M > 0 && M <= 64 && max_splits >= 1, "linear_partial: bad args (M=%d)", M);
     GemmParams p; fill_params(p, x, M, w);
     p.mode = MODE_PARTIAL; p.partials = partials;
-    if (M <= 8 && w->wbits != 16 && !g_debug[4]) { // persistent x-resident kernel (gemm_smallm.hip)
+    // (gemm_smallm.hip is not used here: inside the decode step, where the consumer kernel folds the slabs anyway,
+    // it measured 3-8 % behind the staged kernel -- b=1 linears 1.55 vs 1.48 ms/step; g_debug[4] = 2 re-enables it)
+    if (M <= 8 && w->wbits != 16 && g_debug[4] == 2) {
         const int rc = mi355_gemm_smallm(&p, w->wbits, w->group_size, 1, max_splits, stream);
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
@@ -618,7 +620,8 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
     for (int m0 = 0; m0 < M; m0 += 64) {
         const int Mc = (M - m0) > 64 ? 64 : (M - m0);
         GemmParams p; fill_params(p, (const f16*)x + (size_t)m0 * w->K, Mc, w);
-        if (Mc <= 8 && w->wbits != 16 && !g_debug[4]) { // persistent x-resident kernel, fused epilogue, no slabs
+        if (Mc <= 8 && w->wbits != 16 && g_debug[4] != 1) { // persistent x-resident kernel: fused epilogue, no slabs, no
+                                                             // reduce launch (stand-alone call: qkv 9.1 vs 14.6 us at M = 1)
             GemmParams ps; fill_params(ps, (const f16*)x + (size_t)m0 * w->K, Mc, w);
             ps.mode = mode; ps.bias = (const f16*)bias; ps.y = (char*)y + (size_t)m0 * ldy * ysz; ps.ldy = ldy;
             const int rc = mi355_gemm_smallm(&ps, w->wbits, w->group_size, 0, 1, stream);
@@ -664,7 +667,7 @@ extern "C" int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_
     GemmParams p; fill_params(p, x, M, w);
     p.mode = mode; p.bias = (const f16*)bias; p.y = y;
     p.ldy = (mode == MODE_SILU) ? w->N / 2 : w->N;
-    if (M <= 8 && w->wbits != 16 && !g_debug[4]) {
+    if (M <= 8 && w->wbits != 16 && g_debug[4] == 2) {
         const int rc = mi355_gemm_smallm(&p, w->wbits, w->group_size, 0, 1, stream);
         if (rc >= 0) return MI355_OK;
         if (rc != MI355_ERR_UNSUPPORTED) return rc;

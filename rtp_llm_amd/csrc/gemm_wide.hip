@@ -328,9 +328,10 @@ extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int wa
     WideParams wp;
     int G = (g.NT + TB - 1) / TB;                   // fewest groups with <= TB tiles each
     int nsplit = 1;
-    // Split-K shapes (qkv / o / down at M = 64) measured equal to the staged-x kernel: short K ranges leave 1-4 phases per
-    // wave and the fixed prologue / merge dominates; they stay on gemm.hip unless the experiment switch asks otherwise.
-    if (want_partial && g_wide_dbg < 8) return MI355_ERR_UNSUPPORTED;
+    // Split-K shapes: measured equal or behind the staged-x kernel at M = 64 (short K ranges leave 1-4 phases per wave
+    // and the fixed prologue / merge dominates) and for short K at M <= 32 (qkv 9.0 vs 7.5 us); ahead for deep K at
+    // M <= 32 (down 14.9 vs 20.0 us).  The rest stays on gemm.hip unless the experiment switch asks otherwise.
+    if (want_partial && !(g.M <= 32 && g.KC >= 64) && g_wide_dbg < 8) return MI355_ERR_UNSUPPORTED;
     if (want_partial) {
         nsplit = CUS / G;
         if (nsplit > max_splits) nsplit = max_splits;
