@@ -208,6 +208,26 @@ int mi355_paged_decode_attn(const void* q, const mi355_kv_layer_t* kv, const int
 int mi355_argmax(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t* ids,
                  void* workspace, size_t workspace_bytes, mi355_stream_t stream);
 
+/* Speculative decoding, target-verify step.
+ * mi355_rejection_sample: chain rejection sampling of gamma draft tokens per row against the target model, argument
+ * for argument invokeRejectionSampling<float,int>
+ * (rtp_llm/models_py/bindings/rocm/speculative_sampling/sampling.cu:306-530):
+ *   draft_probs   [B][gamma][V] fp32 (ignored when draft_probs_point_mass != 0: p = 1 at the draft token)
+ *   draft_token_ids [B][gamma], uniform_samples [B][gamma+1] in [0,1)
+ *   target_probs  [B][gamma+1][V] fp32, target_token_ids [B][gamma+1][stride] (the LAST element of each record is used)
+ *   do_sample     [B] bytes: 0 = greedy row (accept iff draft == target token), 1 = accept iff u * p < q, on rejection
+ *                 draw from relu(q - p) with the next uniform (first index whose prefix sum exceeds u * sum)
+ *   output_token_ids [B][gamma+1]: accepted drafts, then the correction / bonus token, then -1 padding
+ *   output_accepted_token_num [B]: accepted drafts + 1.
+ * mi355_softmax_rows: probs[r][:] = softmax(logits[r][:] / temperature) in fp32 (the rows the sampler hands over). */
+int mi355_softmax_rows(const float* logits, int32_t rows, int32_t V, int32_t ld, float temperature, float* probs,
+                       mi355_stream_t stream);
+int mi355_rejection_sample(const float* draft_probs, const int32_t* draft_token_ids, const float* uniform_samples,
+                           const float* target_probs, const int32_t* target_token_ids, int32_t target_token_stride,
+                           int32_t* output_token_ids, int32_t* output_accepted_token_num, const uint8_t* do_sample,
+                           int32_t batch_size, int32_t num_speculative_tokens, int32_t vocab_size,
+                           int32_t draft_probs_point_mass, mi355_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Decode-step driver (C++): owns no tensors, only pointers.  It enqueues the
  * whole decode step of a Qwen2/Llama-style decoder (the body of

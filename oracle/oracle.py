@@ -199,3 +199,62 @@ class OracleDecoder:
         hn = rmsnorm(h, w["final_norm"], eps)
         logits = linear(hn, w["lm_head"], out_f32=True)
         return hn, logits
+
+
+# --------------------------------------------------------------------------- speculative verify
+def rejection_sample(draft_token_ids, target_token_ids, target_probs, uniform_samples, do_sample, draft_probs=None):
+    """CPU restatement of rejection_sampling_kernel (models_py/bindings/rocm/speculative_sampling/sampling.cu:306-475),
+    plain Python loops (small cases only).  draft_token_ids [B,g], target_token_ids [B,g+1], target_probs [B,g+1,V],
+    uniform_samples [B,g+1], do_sample [B], draft_probs [B,g,V] or None (point mass at the draft token).
+    Returns (output_token_ids [B,g+1] padded with -1, accepted [B] = accepted drafts + 1).  The residual draw is the
+    first index whose inclusive fp32 prefix sum of relu(q - p), taken in index order, exceeds u * sum (sampling.cu:421-463)."""
+    import numpy as np
+    d = np.asarray(draft_token_ids); t = np.asarray(target_token_ids)
+    q = np.asarray(target_probs, dtype=np.float32); u = np.asarray(uniform_samples, dtype=np.float32)
+    B, G = d.shape
+    V = q.shape[-1]
+    out = np.full((B, G + 1), -1, dtype=np.int32)
+    acc = np.zeros(B, dtype=np.int32)
+    for b in range(B):
+        sample = bool(do_sample[b])
+        pos, fallback = G, False
+        for i in range(G):
+            qi = q[b, i, d[b, i]]
+            pi = np.float32(1.0) if draft_probs is None else np.float32(draft_probs[b][i][d[b, i]])
+            accept = (np.float32(u[b, i] * pi) < qi) if sample else (t[b, i] == d[b, i])   # sampling.cu:352
+            if accept:
+                out[b, i] = d[b, i]
+            else:
+                pos = i
+                if not sample:
+                    out[b, i] = t[b, i]
+                    fallback = True
+                break
+        acc[b] = pos + 1
+        if pos == G:
+            out[b, G] = t[b, G]
+        if fallback or pos == G:
+            continue
+        p = np.zeros(V, dtype=np.float32)
+        if draft_probs is None:
+            p[d[b, pos]] = 1.0
+        else:
+            p = np.asarray(draft_probs[b][pos], dtype=np.float32)
+        r = np.maximum(q[b, pos] - p, np.float32(0))
+        total = np.float32(0)
+        for x in r:
+            total = np.float32(total + x)
+        thr = np.float32(u[b, min(pos + 1, G)] * total)
+        c, found = np.float32(0), V - 1
+        for j in range(V):
+            c = np.float32(c + r[j])
+            if r[j] > 0 and c > thr:
+                found = j
+                break
+        out[b, pos] = found
+    return torch.from_numpy(out), torch.from_numpy(acc)
+
+
+def softmax_rows(logits: torch.Tensor, temperature: float = 1.0) -> torch.Tensor:
+    """softmax(logits / T) per row in fp32 (the distribution handed to rejection sampling)."""
+    return torch.softmax(logits.float() / temperature, dim=-1)

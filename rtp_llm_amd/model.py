@@ -329,6 +329,16 @@ class DecoderEngine:
     def step(self, B: int):
         _C.check(self.lib.mi355_decoder_step(self.handle, B, self._st()), "decoder_step")
 
+    def forward(self, B: int):
+        """The decode step without sampling: logits of the B rows stay in `self.logits`, token_ids / positions are not
+        advanced (speculative verify, scoring)."""
+        st, h, lib = self._st(), self.handle, self.lib
+        _C.check(lib.mi355_decoder_begin(h, B, st), "decoder_begin")
+        for l in range(self.cfg.num_layers):
+            _C.check(lib.mi355_decoder_layer_attn(h, l, st), "decoder_layer_attn")
+            _C.check(lib.mi355_decoder_layer_mlp(h, l, st), "decoder_layer_mlp")
+        _C.check(lib.mi355_decoder_finish(h, 0, st), "decoder_finish")
+
     def capture(self, B: int):
         _C.check(self.lib.mi355_decoder_capture(self.handle, B), "decoder_capture")
 

@@ -120,6 +120,43 @@ def argmax(logits: torch.Tensor) -> torch.Tensor:
     return ids
 
 
+def softmax_rows(logits: torch.Tensor, temperature: float = 1.0) -> torch.Tensor:
+    """probs = softmax(logits / temperature) per row, fp32 (input of rejection sampling)."""
+    _chk(logits, torch.float32, "softmax_rows.logits")
+    R, V = logits.shape
+    probs = torch.empty_like(logits)
+    _C.check(_C.lib().mi355_softmax_rows(logits.data_ptr(), R, V, V, float(temperature), probs.data_ptr(), _stream()), "softmax_rows")
+    return probs
+
+
+def rejection_sample(draft_token_ids: torch.Tensor, target_token_ids: torch.Tensor, target_probs: torch.Tensor,
+                     uniform_samples: torch.Tensor, do_sample: torch.Tensor, draft_probs: Optional[torch.Tensor] = None):
+    """Chain rejection sampling (bindings/rocm/speculative_sampling/sampling.cu:306): draft_token_ids [B,g] int32,
+    target_token_ids [B,g+1] or [B,g+1,stride] int32, target_probs [B,g+1,V] fp32, uniform_samples [B,g+1] fp32,
+    do_sample [B] bool/uint8, draft_probs [B,g,V] fp32 or None (point mass).  -> (output_token_ids [B,g+1], accepted [B])."""
+    _chk(draft_token_ids, torch.int32, "rejection_sample.draft_token_ids")
+    _chk(target_token_ids, torch.int32, "rejection_sample.target_token_ids")
+    _chk(target_probs, torch.float32, "rejection_sample.target_probs")
+    _chk(uniform_samples, torch.float32, "rejection_sample.uniform_samples")
+    B, G = draft_token_ids.shape
+    V = target_probs.shape[-1]
+    if target_probs.shape != (B, G + 1, V) or uniform_samples.shape != (B, G + 1) or target_token_ids.shape[:2] != (B, G + 1):
+        raise _C.Mi355Error("rejection_sample: inconsistent shapes")
+    stride = 1 if target_token_ids.dim() == 2 else target_token_ids.shape[2]
+    ds = do_sample.to(torch.uint8).contiguous()
+    if draft_probs is not None:
+        _chk(draft_probs, torch.float32, "rejection_sample.draft_probs")
+        if draft_probs.shape != (B, G, V):
+            raise _C.Mi355Error("rejection_sample: draft_probs shape")
+    out = torch.empty(B, G + 1, dtype=torch.int32, device=draft_token_ids.device)
+    acc = torch.empty(B, dtype=torch.int32, device=draft_token_ids.device)
+    _C.check(_C.lib().mi355_rejection_sample(_p(draft_probs), draft_token_ids.data_ptr(), uniform_samples.data_ptr(),
+                                             target_probs.data_ptr(), target_token_ids.data_ptr(), stride, out.data_ptr(),
+                                             acc.data_ptr(), ds.data_ptr(), B, G, V, 1 if draft_probs is None else 0, _stream()),
+             "rejection_sample")
+    return out, acc
+
+
 # ------------------------------------------------------------------ attention
 def rope_kv_write(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], cos_sin: torch.Tensor, positions: torch.Tensor,
                   block_table: torch.Tensor, kv_base: torch.Tensor, scale_base: Optional[torch.Tensor], nh: int, nkv: int,

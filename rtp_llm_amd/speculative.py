@@ -1,0 +1,112 @@
+"""Speculative decoding over the decode path: separate draft model proposes, the target verifies.
+
+The reference's "vanilla" mode (cpp/config/ConfigModules.h:305-312; wiring
+cpp/engine_base/ProposeModelEngineInitParams.h:16-30): a small draft model (BASELINE config 5: Qwen2-0.5B) proposes
+`gamma` tokens, the target scores gamma+1 tokens per sequence in ONE step over the paged cache (`is_target_verify`,
+models_py/bindings/OpDefs.h:283) and chain rejection sampling keeps the longest accepted prefix plus one corrected /
+bonus token (cpp/normal_engine/speculative/SpeculativeSampler.cc:214, kernel
+bindings/rocm/speculative_sampling/sampling.cu:306).
+
+MI355X design: the verify step needs no new attention kernel.  A verify row (sequence b, draft position t) is a decode
+row with its own position ctx_b + t and sequence b's block table: `mi355_rope_kv_write` stores the K/V of all gamma+1
+tokens first, `mi355_paged_decode_attn` then gives row t a context of ctx_b + t + 1 tokens, which IS the causal mask.
+The linears see M = B * (gamma + 1) rows (<= 64: the wide-batch GEMM shapes), so verifying 5 tokens costs about one
+decode step of a 5x larger batch.  Rejected tokens leave stale K/V beyond the accepted length; they are overwritten
+by the next step's tokens at the same positions.
+"""
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _C, ops
+from .model import DecoderEngine
+
+
+class SpeculativeDecoder:
+    """Greedy (or sampled) speculative decoding on two DecoderEngines that share nothing but the token stream.
+
+    State per sequence: `last` (newest token, not yet in the target cache), `ctx` (tokens in the target cache), and for
+    the draft cache `dctx` plus the list of tokens it has not processed yet (`pending`, ends with `last`)."""
+
+    def __init__(self, target: DecoderEngine, draft: DecoderEngine, gamma: int):
+        if gamma < 1:
+            raise ValueError("gamma >= 1")
+        self.target, self.draft, self.gamma = target, draft, gamma
+        self.B = 0
+
+    def start(self, last_tokens: Sequence[int], ctx_lens: Sequence[int], target_block_table: torch.Tensor,
+              draft_block_table: torch.Tensor, draft_ctx_lens: Optional[Sequence[int]] = None,
+              draft_pending: Optional[List[List[int]]] = None):
+        """Both caches already hold `ctx_lens[b]` tokens of sequence b (or `draft_ctx_lens` + `draft_pending` when the
+        draft lags); `last_tokens[b]` is the next input token."""
+        B = len(last_tokens)
+        if B * (self.gamma + 1) > self.target.max_batch or 2 * B > self.draft.max_batch:
+            raise _C.Mi355Error(f"speculative: batch {B} x (gamma+1) exceeds the engines' max_batch")
+        self.B = B
+        self.last = [int(t) for t in last_tokens]
+        self.ctx = [int(c) for c in ctx_lens]
+        self.dctx = [int(c) for c in (draft_ctx_lens if draft_ctx_lens is not None else ctx_lens)]
+        self.pending = [list(p) for p in draft_pending] if draft_pending is not None else [[t] for t in self.last]
+        self.tbt = torch.as_tensor(target_block_table, dtype=torch.int32)
+        self.dbt = torch.as_tensor(draft_block_table, dtype=torch.int32)
+        self.accepted_hist: List[List[int]] = []
+
+    # one engine forward over `rows` = [(sequence, token, position)], logits stay in engine.logits[:len(rows)]
+    @staticmethod
+    def _forward(eng: DecoderEngine, rows, table: torch.Tensor):
+        seqs = [r[0] for r in rows]
+        eng.set_inputs([r[1] for r in rows], [r[2] for r in rows], table[seqs])
+        eng.forward(len(rows))
+
+    def step(self, do_sample: Optional[Sequence[bool]] = None, temperature: float = 1.0,
+             uniform: Optional[torch.Tensor] = None) -> List[List[int]]:
+        """One propose + verify round; returns the tokens emitted per sequence (1 .. gamma + 1 each)."""
+        B, G = self.B, self.gamma
+        dev = self.target.device
+        # ---- draft: catch up on the pending tokens (1 or 2 per sequence), then gamma - 1 single-token steps
+        rows, last_row = [], []
+        for b in range(B):
+            for k, tok in enumerate(self.pending[b]):
+                rows.append((b, tok, self.dctx[b] + k))
+            last_row.append(len(rows) - 1)
+            self.dctx[b] += len(self.pending[b])
+        self._forward(self.draft, rows, self.dbt)
+        nxt = ops.argmax(self.draft.logits[: len(rows)])[torch.tensor(last_row, device=dev)]
+        drafts = [nxt]
+        for _ in range(G - 1):
+            cur = drafts[-1].tolist()
+            self._forward(self.draft, [(b, cur[b], self.dctx[b]) for b in range(B)], self.dbt)
+            for b in range(B):
+                self.dctx[b] += 1
+            drafts.append(ops.argmax(self.draft.logits[:B]).clone())
+        draft_ids = torch.stack(drafts, dim=1).to(torch.int32).contiguous()          # [B, G]
+        dl = draft_ids.tolist()
+        # ---- target: gamma + 1 decode rows per sequence = causal verify over the paged cache
+        rows = []
+        for b in range(B):
+            toks = [self.last[b]] + dl[b]
+            rows += [(b, toks[t], self.ctx[b] + t) for t in range(G + 1)]
+        self._forward(self.target, rows, self.tbt)
+        R = B * (G + 1)
+        logits = self.target.logits[:R]
+        target_ids = ops.argmax(logits).reshape(B, G + 1).contiguous()
+        probs = ops.softmax_rows(logits, temperature).reshape(B, G + 1, -1)
+        ds = torch.zeros(B, dtype=torch.uint8, device=dev) if do_sample is None else torch.as_tensor(do_sample, device=dev).to(torch.uint8)
+        if uniform is None:
+            uniform = torch.rand(B, G + 1, device=dev, dtype=torch.float32)
+        out, acc = ops.rejection_sample(draft_ids, target_ids, probs, uniform.to(dev), ds)   # draft = point mass (greedy draft)
+        out_l, acc_l = out.tolist(), acc.tolist()
+        # ---- advance: target cache now holds `last` and the accepted drafts; the draft cache holds last + d_1..d_{G-1}
+        emitted = []
+        for b in range(B):
+            n = acc_l[b]
+            toks = out_l[b][:n]
+            emitted.append(toks)
+            old_ctx = self.ctx[b]
+            self.ctx[b] += n
+            self.last[b] = toks[-1]
+            valid_draft = old_ctx + 1 + min(n - 1, G - 1)          # last_old + accepted drafts the draft model has seen
+            self.dctx[b] = valid_draft
+            self.pending[b] = ([dl[b][G - 1]] if n - 1 == G else []) + [toks[-1]]
+        self.accepted_hist.append(acc_l)
+        return emitted
