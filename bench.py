@@ -66,7 +66,9 @@ def cpu_baseline(cfg, kind, kv_int8, B, ctx, budget_s=25.0):
     (the reference's own perf knob hack_layer_num, docs/benchmark/benchmark.md)."""
     from oracle import oracle
     from rtp_llm_amd import model
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the oracle works on per-sequence tensors (small ops): beyond ~16 threads torch's intra-op pool only adds overhead
+    # (measured on the 256-core GPU host: 61 s per layer at 256 threads vs ~1 s at 8-16)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     nl = 2
     small = model.ModelConfig(cfg.name, nl, cfg.hidden, cfg.nh, cfg.nkv, cfg.hd, cfg.inter, cfg.vocab, cfg.rope_theta,
                               cfg.rms_eps, cfg.qkv_bias, ctx + 8)
@@ -278,13 +280,13 @@ def main():
         avg_ms = gq["ms"] / max(1, gq["launches"])
         ach = alg_bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
-        try:  # HBM read bytes per launch from the committed PMC pass of this workload (profiles/README.md)
+        try:  # HBM read + write bytes per launch from the committed PMC passes of this workload (profiles/README.md)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(args.workload)
             if tj and tj.get("batch") == B:
-                traffic = int(tj["gemm_quant_read_bytes_per_launch"])
+                traffic = int(tj["gemm_quant_bytes_per_launch"])
         except Exception:  # noqa: BLE001
             traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "gemm_wq_kernel (qkv/o/gate_up/down linears)", "achieved": round(ach, 1),
+        out["roofline"] = {"bound": "hbm", "kernel": "gemm_wq_kernel / gemm_wide_kernel (the four quantised linears of a layer: qkv, o, gate_up, down)", "achieved": round(ach, 1),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_ms * 1e3, 3),
                            "launches_timed": gq["launches"]}
