@@ -13,6 +13,8 @@ this path, each function citing the reference lines it follows.  Pinning status
   * RMSNorm / RoPE / SiLU-mul / paged attention (fp16 KV) / greedy: restated from the
     reference's own torch test references (cited per function); those references are
     what the reference's ROCm unit tests compare against at atol=rtol=1e-2.
+  * Chain rejection sampling (speculative verify): PINNED against the reference's own known-answer kernel tests
+    (bindings/cuda/test/CudaSpeculativeSamplingTest.cc:36-366, transcribed in tests/spec_vectors.py).
   * W4A16 / W8A16 GEMM results and INT8 KV-cache numerics: PARITY UNPINNED — the reference
     snapshot contains no kernel, test or golden vector for them; the oracle
     defines them from the loader formulas (W = scale*(q - z - gptq_flag), W = q*scale_col)
