@@ -323,7 +323,7 @@ extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int wa
     GemmParams g = *reinterpret_cast<const GemmParams*>(gp);
     constexpr int T = 5, TB = 2 * T, CUS = 256;     // tiles per wave / per block
     if (g.M <= 16 || g.M > 64) return MI355_ERR_UNSUPPORTED;
-    if (!(wbits == 4 && group_size == 128)) return MI355_ERR_UNSUPPORTED;
+    if (!(wbits == 4 && (group_size == 128 || group_size == 64 || group_size == 32))) return MI355_ERR_UNSUPPORTED;
     if (g.K % 128 != 0 || g.qw_bytes > 0x40000000u || g.meta_bytes > 0x40000000u) return MI355_ERR_UNSUPPORTED;
     WideParams wp;
     int G = (g.NT + TB - 1) / TB;                   // fewest groups with <= TB tiles each
@@ -345,15 +345,19 @@ extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int wa
     g.nsplit = (g.KC + g.cps - 1) / g.cps;
     wp.g = g; wp.G = G; wp.stamps = g_wide_stamps;
     int rc;
-    if (g.M <= 32 && (g_wide_dbg & 7) == 0) rc = launch_wide_t<4, 2, 4, T>(wp, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    const bool mb2 = g.M <= 32;
+    if (group_size == 64)      rc = mb2 ? launch_wide_t<4, 2, 2, T>(wp, st) : launch_wide_t<4, 4, 2, T>(wp, st);
+    else if (group_size == 32) rc = mb2 ? launch_wide_t<4, 2, 1, T>(wp, st) : launch_wide_t<4, 4, 1, T>(wp, st);
+    else if (mb2 && (g_wide_dbg & 7) == 0) rc = launch_wide_t<4, 2, 4, T>(wp, st);
     else
-    switch (g_wide_dbg & 7) {
-        case 1: rc = launch_wide_t<4, 4, 4, T, 1>(wp, (hipStream_t)stream); break;
-        case 2: rc = launch_wide_t<4, 4, 4, T, 2>(wp, (hipStream_t)stream); break;
-        case 3: rc = launch_wide_t<4, 4, 4, T, 3>(wp, (hipStream_t)stream); break;
-        case 4: rc = launch_wide_t<4, 4, 4, T, 4>(wp, (hipStream_t)stream); break;
-        default: rc = launch_wide_t<4, 4, 4, T>(wp, (hipStream_t)stream);
-    }
+        switch (g_wide_dbg & 7) {
+            case 1: rc = launch_wide_t<4, 4, 4, T, 1>(wp, st); break;
+            case 2: rc = launch_wide_t<4, 4, 4, T, 2>(wp, st); break;
+            case 3: rc = launch_wide_t<4, 4, 4, T, 3>(wp, st); break;
+            case 4: rc = launch_wide_t<4, 4, 4, T, 4>(wp, st); break;
+            default: rc = launch_wide_t<4, 4, 4, T>(wp, st);
+        }
     if (rc != MI355_OK) return rc;
     return want_partial ? g.nsplit : MI355_OK;
 }

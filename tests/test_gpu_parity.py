@@ -89,11 +89,11 @@ def test_linear_silu_and_f32_epilogues(M):
 
 
 @pytest.mark.parametrize("M", [17, 33, 48, 64])
-@pytest.mark.parametrize("K,I", [(256, 18944), (640, 16000)])
-def test_linear_wide_batch_kernel(M, K, I):
+@pytest.mark.parametrize("K,I,group", [(256, 18944, 128), (640, 16000, 128), (384, 16000, 64), (256, 18944, 32)])
+def test_linear_wide_batch_kernel(M, K, I, group):
     """16 < M <= 64 with N wide enough to fill the machine takes the register-resident kernel (gemm_wide.hip):
     plain, bias and fused SiLU epilogues, ragged tile groups (2 * 16000 / 16 tiles over 256 blocks), odd chunk counts."""
-    c = _canon_cpu(K, 2 * I, "w4", 21 + M)
+    c = _canon_cpu(K, 2 * I, "w4", 21 + M, group)
     x = _x(M, K, 2)
     dense = _dense(c)
     y = ops.linear(x.to(DEV), c.pack(gate_up=True).to(DEV), epilogue=_C.EPI_SILU_MUL)
