@@ -339,6 +339,38 @@ class DecoderEngine:
             _C.check(lib.mi355_decoder_layer_mlp(h, l, st), "decoder_layer_mlp")
         _C.check(lib.mi355_decoder_finish(h, 0, st), "decoder_finish")
 
+    # ---- whole-request helpers (prompt ingestion rides on the decode path: no prefill kernels in this build)
+    def ingest(self, prompts: List[List[int]], block_table) -> List[int]:
+        """Write the K/V of every prompt token except the last into the paged cache and return the context lengths.
+        A prompt token is a decode row with its own position and its sequence's block table, so up to `max_batch`
+        tokens (of any mix of sequences) go through one step and causality holds by construction: row (b, p) attends to
+        positions <= p of sequence b, all written by this or an earlier step (rope_kv_write precedes attention).
+        This is chunked prefill at decode-kernel efficiency (KV re-read per row) -- SURVEY 8f n4 is the real thing."""
+        bt = torch.as_tensor(block_table, dtype=torch.int32)
+        rows = [(b, tok, pos) for b, pr in enumerate(prompts) for pos, tok in enumerate(pr[:-1])]
+        # a row may only run once all earlier positions of its sequence are in the cache or in the same step: order by
+        # position, so every step holds a prefix-closed set
+        rows.sort(key=lambda r: r[2])
+        for i in range(0, len(rows), self.max_batch):
+            chunk = rows[i:i + self.max_batch]
+            self.set_inputs([r[1] for r in chunk], [r[2] for r in chunk], bt[[r[0] for r in chunk]])
+            self.forward(len(chunk))
+        return [len(pr) - 1 for pr in prompts]
+
+    def generate(self, prompts: List[List[int]], block_table, max_new_tokens: int) -> List[List[int]]:
+        """Greedy generation for a batch of prompts (tp = 1): ingest, then graph-replayed decode steps."""
+        B = len(prompts)
+        if B > self.max_batch or any(len(pr) < 1 for pr in prompts):
+            raise _C.Mi355Error("generate: batch exceeds max_batch or empty prompt")
+        ctx = self.ingest(prompts, block_table)
+        self.set_inputs([pr[-1] for pr in prompts], ctx, block_table)
+        self.capture(B)
+        out = []
+        for _ in range(max_new_tokens):
+            self.replay(B, 1)
+            out.append(self.token_ids[:B].clone())
+        return torch.stack(out, 1).cpu().tolist()
+
     def capture(self, B: int):
         _C.check(self.lib.mi355_decoder_capture(self.handle, B), "decoder_capture")
 
