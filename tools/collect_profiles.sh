@@ -27,6 +27,6 @@ pmc fetch_gate_up FETCH_SIZE python tools/gemm_bench.py --ms 64 --shapes gate_up
 pmc write_gate_up WRITE_SIZE python tools/gemm_bench.py --ms 64 --shapes gate_up --iters 12
 pmc sq_wide "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU" python tools/gemm_bench.py --ms 64 --shapes gate_up --iters 12
 pmc sq_wide2 "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" python tools/gemm_bench.py --ms 64 --shapes gate_up --iters 12
-( cd $R && ./tools/probe/unit_rate > $O/probe_unit_rate.txt 2>&1; python tools/wide_stamps.py 3584 > $O/wide_stamps.txt 2>&1; python tools/spec_bench.py > $O/spec_round.txt 2>&1 )
+( cd $R && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -Wno-unused-result -o tools/probe/unit_rate tools/probe/unit_rate.hip && ./tools/probe/unit_rate > $O/probe_unit_rate.txt 2>&1; python tools/wide_stamps.py 3584 > $O/wide_stamps.txt 2>&1; python tools/spec_bench.py > $O/spec_round.txt 2>&1 )
 ( cd $R && python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log > $O/bench_default.json )
 ls -la $O
