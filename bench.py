@@ -12,7 +12,9 @@ One JSON line on stdout (rank 0): BASELINE.json's metric (decode tokens/s + p50 
 Qwen2-7B W4A16, seq 1024), plus `roofline` (dominant kernel = the weight-only dequant GEMM,
 algorithmic bytes / HIP-event time) and `cpu_baseline` (the CPU oracle timed on this host).
 Data: synthetic (random-init weights of the named architecture, random KV) — there is no
-network for checkpoints.  N > 1: tensor parallel over RCCL (one process per GPU, torchrun env).
+network for checkpoints.  N > 1 (one process per GPU, torchrun env): the headline is N replicas of the model, each
+decoding its own `batch` sequences (requests are independent: no data-path collective, weak scaling); the
+tensor-parallel layout over RCCL is measured right after and reported in `tp_layout`.
 """
 import argparse
 import json
@@ -123,6 +125,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--ctx", type=int, default=None)
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then labelled invalid)")
+    ap.add_argument("--shard-of", type=int, default=0, help="debug only: run ONE rank's shard of a tp=N layout without the collectives "
+                    "(per-rank kernel shapes on a 1-GPU box; result is labelled invalid)")
+    ap.add_argument("--no-tp", action="store_true", help="N > 1: skip the tensor-parallel layout measured after the replica headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -136,6 +141,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
+    if os.environ.get("MI355_BENCH_ONE_GPU") == "1":   # debug: several ranks on device 0 (control-plane check on a 1-GPU box)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _C.lib()  # fail loudly when the HIP extension is missing
@@ -147,127 +154,109 @@ def main():
     cfg_full = model.MODELS[mname]
     if args.layers:
         cfg_full = model.ModelConfig(**{**cfg_full.__dict__, "num_layers": args.layers})
-    # ---- parallel layout: TP over the largest divisor of the head counts, data-parallel replicas for the rest
-    tp = 1
-    if world > 1:
-        distributed.init_distributed("nccl")
-        tp = max(t for t in range(1, world + 1) if world % t == 0 and cfg_full.nh % t == 0 and cfg_full.nkv % t == 0
-                 and cfg_full.inter % (t * 128) == 0)
-        dp = world // tp
-        import torch.distributed as dist
-        for r0 in range(0, world, tp):   # every rank creates every group (torch.distributed contract)
-            grp = dist.new_group(list(range(r0, r0 + tp)))
-            if r0 <= rank < r0 + tp:
-                distributed.set_tp_group(grp)
-    dp = world // tp
-    tp_rank = rank % tp
-    cfg = cfg_full.per_rank(tp)
     total_steps = args.steps + args.warmup + 8
     max_seq_len = ctx + total_steps + 64
     blocks_per_seq = (max_seq_len + page - 1) // page
     num_blocks = B * blocks_per_seq
 
-    # ---- synthetic weights, generated per rank directly at per-rank shapes (random init: the TP split of
-    # random tensors is random tensors; norms/embedding use the same seed on every rank)
-    t0 = time.time()
-    wseed = 1000 + tp_rank
-    gen = torch.Generator(device=dev).manual_seed(wseed)
-    layers = [model.synth_layer(cfg, kind, dev, gen) for _ in range(cfg.num_layers)]
-    gshared = torch.Generator(device=dev).manual_seed(7)
-    for L in layers:  # replicated tensors must be identical on all TP ranks
-        L["input_norm"] = (1.0 + 0.1 * torch.randn(cfg.hidden, device=dev, generator=gshared)).half()
-        L["post_norm"] = (1.0 + 0.1 * torch.randn(cfg.hidden, device=dev, generator=gshared)).half()
-    weights = {
-        "layers": layers,
-        "embedding": (torch.randn(cfg_full.vocab, cfg.hidden, device=dev, generator=gshared) * 0.5).half(),
-        "final_norm": (1.0 + 0.1 * torch.randn(cfg.hidden, device=dev, generator=gshared)).half(),
-        "lm_head": model.synth_linear(cfg.hidden, cfg.vocab, "fp16", dev, gen),
-    }
-    eng = model.DecoderEngine(cfg, weights, kv_int8=kv_int8, page=page, num_blocks=num_blocks, max_batch=B,
-                              max_seq_len=max_seq_len, device=dev, tp_size=tp, vocab_full=cfg_full.vocab)
-    del weights, layers
-    torch.cuda.empty_cache()
-    fill_kv_random(eng, B, ctx, seed=2 + rank)
-    gi = torch.Generator().manual_seed(1 + rank // tp)
-    ids0 = torch.randint(0, cfg_full.vocab, (B,), generator=gi, dtype=torch.int32)
-    bt = torch.randperm(num_blocks, generator=torch.Generator().manual_seed(2)).reshape(B, blocks_per_seq).to(torch.int32)
-
-    def reset():
-        eng.set_inputs(ids0.tolist(), [ctx - 1] * B, bt)
-
-    reset()
-    torch.cuda.synchronize()
-    log(f"[rank {rank}] setup {time.time() - t0:.1f}s: {args.workload} B={B} ctx={ctx} tp={tp} dp={dp} "
-        f"weights {eng.packed_bytes / 1e9:.2f} GB + lm_head {eng.packed_bytes_lm_head / 1e9:.2f} GB")
-
-    # ---- step runner
-    graph = None
-    if tp == 1:
-        if not args.no_graph:
-            eng.capture(B)
-        run = (lambda n: eng.replay(B, n)) if not args.no_graph else (lambda n: [eng.step(B) for _ in range(n)])
-    else:
-        run_eager = lambda n: [eng.step_tp(B) for _ in range(n)]
-        run = run_eager
-        if not args.no_graph and os.environ.get("MI355_TP_GRAPH", "1") == "1":
-            try:  # capture the TP step (RCCL collectives included) into one graph; fall back to eager on any failure
-                run_eager(2)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    eng.step_tp(B)
-                graph = g
-                run = lambda n: [graph.replay() for _ in range(n)]
-                log(f"[rank {rank}] TP step captured in a hipGraph")
-            except Exception as e:  # noqa: BLE001
-                log(f"[rank {rank}] TP graph capture failed ({type(e).__name__}: {e}); running eager")
-                graph = None
-                run = run_eager
+    # ---- control plane for N > 1: gloo (CPU tensors) for the barrier and the max-over-ranks; RCCL only carries the
+    # data-path collectives of the TP layout below, so the headline does not hang on it
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
 
-    # ---- warm-up + timed region: EXACTLY K steps between barrier + synchronize on both sides
+    def max_over_ranks(x: float) -> float:
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
+
+    def build_engine(tp, tp_rank, replica):
+        """Synthetic weights generated per rank directly at per-rank shapes (the TP split of random tensors is random
+        tensors; norms / embedding use the same seed on every rank)."""
+        cfg = cfg_full.per_rank(tp)
+        if args.shard_of > 1 and world == 1:
+            cfg = cfg_full.per_rank(args.shard_of)
+        gen = torch.Generator(device=dev).manual_seed(1000 + tp_rank)
+        layers = [model.synth_layer(cfg, kind, dev, gen) for _ in range(cfg.num_layers)]
+        gshared = torch.Generator(device=dev).manual_seed(7)
+        for L in layers:  # replicated tensors must be identical on all TP ranks
+            L["input_norm"] = (1.0 + 0.1 * torch.randn(cfg.hidden, device=dev, generator=gshared)).half()
+            L["post_norm"] = (1.0 + 0.1 * torch.randn(cfg.hidden, device=dev, generator=gshared)).half()
+        weights = {
+            "layers": layers,
+            "embedding": (torch.randn(cfg_full.vocab, cfg.hidden, device=dev, generator=gshared) * 0.5).half(),
+            "final_norm": (1.0 + 0.1 * torch.randn(cfg.hidden, device=dev, generator=gshared)).half(),
+            "lm_head": model.synth_linear(cfg.hidden, cfg.vocab, "fp16", dev, gen),
+        }
+        eng = model.DecoderEngine(cfg, weights, kv_int8=kv_int8, page=page, num_blocks=num_blocks, max_batch=B,
+                                  max_seq_len=max_seq_len, device=dev, tp_size=tp, vocab_full=cfg_full.vocab)
+        del weights, layers
+        torch.cuda.empty_cache()
+        fill_kv_random(eng, B, ctx, seed=2 + rank)
+        ids0 = torch.randint(0, cfg_full.vocab, (B,), generator=torch.Generator().manual_seed(1 + replica), dtype=torch.int32)
+        bt = torch.randperm(num_blocks, generator=torch.Generator().manual_seed(2)).reshape(B, blocks_per_seq).to(torch.int32)
+        return cfg, eng, (lambda: eng.set_inputs(ids0.tolist(), [ctx - 1] * B, bt))
+
+    def timed(run, reset):
+        """W warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; max over ranks."""
+        reset()
+        run(args.warmup)
+        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        # p50 step latency (separate pass, per-step events on the launch stream)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(33)]
+        evs[0].record()
+        for i in range(32):
+            run(1)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        return elapsed, statistics.median(evs[i].elapsed_time(evs[i + 1]) for i in range(32))
+
+    # ---- headline layout: every GPU is a replica of the whole model with its own `batch` sequences (decode requests
+    # are independent units: no data-path collective, weak scaling).  The TP layout is measured after it.
+    tp, dp = 1, world
+    t0 = time.time()
+    cfg, eng, reset = build_engine(1, 0, rank)
     reset()
-    run(args.warmup)
-    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    torch.cuda.synchronize()
+    log(f"[rank {rank}] setup {time.time() - t0:.1f}s: {args.workload} B={B} ctx={ctx} replicas={dp} "
+        f"weights {eng.packed_bytes / 1e9:.2f} GB + lm_head {eng.packed_bytes_lm_head / 1e9:.2f} GB")
+    graph = None
+    if not args.no_graph:
+        eng.capture(B)
+    run = (lambda n: eng.replay(B, n)) if not args.no_graph else (lambda n: [eng.step(B) for _ in range(n)])
+    elapsed, p50 = timed(run, reset)
     ms_per_step = elapsed / args.steps * 1e3
     tokens_per_s = B * dp * args.steps / elapsed
-
-    # ---- p50 step latency (separate pass, per-step events on the launch stream)
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(33)]
-    evs[0].record()
-    for i in range(32):
-        run(1)
-        evs[i + 1].record()
-    torch.cuda.synchronize()
-    p50 = statistics.median(evs[i].elapsed_time(evs[i + 1]) for i in range(32))
 
     out = {
         "metric": "decode tokens/sec + p50 latency, Qwen2-7B W4A16 b=1..64 @1/2/4/8 GPU" if args.workload == "qwen2-7b-w4a16"
                   else f"decode tokens/sec + p50 latency ({args.workload})",
         "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "p50_ms": round(p50, 4), "higher_is_better": True,
-        "scaling": "strong" if dp == 1 else "weak", "vs_baseline": None, "dtype": "f16",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16",
         "data": "synthetic (random-init weights of the named architecture, random KV cache, greedy decode)",
         "config": {"workload": f"{args.workload}: {mname} decode, weights {kind}"
                                f"{' GPTQ g128' if kind == 'w4' else ''}, KV {'int8' if kv_int8 else 'fp16'}, page {page}",
-                   "batch": B, "global_batch": B * dp, "seq_len": ctx, "parallelism": f"tp{tp}" + (f"dp{dp}" if dp > 1 else ""),
-                   "graph": bool(tp == 1 and not args.no_graph) or graph is not None},
+                   "batch": B, "global_batch": B * dp, "seq_len": ctx, "parallelism": "tp1" if dp == 1 else f"dp{dp} (one full replica per GPU, {B} sequences each)",
+                   "graph": not args.no_graph},
     }
     if args.layers:
         out["invalid"] = f"debug run with --layers {args.layers}"
+    if args.shard_of > 1:
+        out["invalid"] = f"debug run: one rank's shard of tp={args.shard_of}, collectives omitted"
 
-    if rank == 0 and tp == 1:
+    if rank == 0 and world == 1:
         # ---- roofline of the dominant kernel (weight-only dequant GEMM): algorithmic bytes / HIP-event time
         bps = bytes_per_step(cfg, eng, B, ctx, kv_int8)
         reset()
@@ -309,6 +298,45 @@ def main():
             out["sweep"] = sweep
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg_full, kind, kv_int8, B, ctx)
+    # ---- N > 1: the tensor-parallel layout of the same job (Megatron split, two all-reduces per layer over RCCL/xGMI):
+    # what TP buys is step latency, not aggregate throughput, for a model that fits one GPU.  Measured after the
+    # headline and reported beside it; a failure here is recorded, it does not take the headline down.
+    if world > 1 and not args.no_tp:
+        tp_info = {}
+        try:
+            import torch.distributed as dist
+            tpn = max(t for t in range(1, world + 1) if world % t == 0 and cfg_full.nh % t == 0 and cfg_full.nkv % t == 0
+                      and cfg_full.inter % (t * 128) == 0)
+            dpn = world // tpn
+            del eng
+            torch.cuda.empty_cache()
+            for r0 in range(0, world, tpn):   # every rank creates every group (torch.distributed contract)
+                grp = dist.new_group(list(range(r0, r0 + tpn)), backend="nccl")
+                if r0 <= rank < r0 + tpn:
+                    distributed.set_tp_group(grp)
+            _, teng, treset = build_engine(tpn, rank % tpn, rank // tpn)
+            treset()
+            run_eager = lambda n: [teng.step_tp(B) for _ in range(n)]
+            trun, captured = run_eager, False
+            if not args.no_graph and os.environ.get("MI355_TP_GRAPH", "1") == "1":
+                try:  # capture the TP step (RCCL collectives included) into one graph; eager on any failure
+                    run_eager(2)
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        teng.step_tp(B)
+                    trun, captured = (lambda n: [g.replay() for _ in range(n)]), True
+                except Exception as e:  # noqa: BLE001
+                    log(f"[rank {rank}] TP graph capture failed ({type(e).__name__}: {e}); running eager")
+                    trun = run_eager
+            t_el, t_p50 = timed(trun, treset)
+            tp_info = {"parallelism": f"tp{tpn}" + (f" x dp{dpn}" if dpn > 1 else ""), "global_batch": B * dpn,
+                       "tokens_per_s": round(B * dpn * args.steps / t_el, 1), "ms_per_step": round(t_el / args.steps * 1e3, 4),
+                       "p50_ms": round(t_p50, 4), "graph": captured, "collectives": "RCCL all-reduce x2 per layer + logits all-gather"}
+        except Exception as e:  # noqa: BLE001
+            tp_info = {"error": f"{type(e).__name__}: {e}"}
+            log(f"[rank {rank}] TP layout failed: {tp_info['error']}")
+        out["tp_layout"] = tp_info
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -14,6 +14,7 @@
 // (already the next layer's input norm).  No standalone reduce / add / activation kernels.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <algorithm>
 #include <string.h>
 #include <map>
 #include <new>
@@ -36,7 +37,7 @@ struct mi355_decoder {
     // carved workspace
     void *resid, *xn, *q_buf, *attn_out, *act, *attn_ws, *argmax_ws;
     float* partials;
-    size_t attn_ws_bytes, argmax_ws_bytes;
+    size_t attn_ws_bytes, argmax_ws_bytes, partials_bytes;
     int    B;
     // graphs
     hipStream_t                    cap_stream;
@@ -70,14 +71,16 @@ size_t carve_all(mi355_decoder* d, const mi355_model_config_t& c, void* base) {
     void* q_buf    = cv.take(MB_ * qdim * 2);
     void* attn_out = cv.take(MB_ * qdim * 2);
     void* act      = cv.take(MB_ * c.inter * 2);
-    void* partials = cv.take((size_t)kMaxSplits * MB_ * npad * 4);
+    // split-K slabs: qkv / o / down use up to kMaxSplits of [max_batch, npad]; a K-split gate_up (TP shards) up to 4 of [max_batch, 2 inter]
+    const size_t pbytes = std::max((size_t)kMaxSplits * MB_ * npad * 4, (size_t)4 * MB_ * ((2 * c.inter + 15) & ~15) * 4);
+    void* partials = cv.take(pbytes);
     const size_t aw = mi355_paged_attn_workspace_bytes(c.max_batch, c.nh, c.hd, c.max_seq_len);
     void* attn_ws  = cv.take(aw);
     const size_t gw = MB_ * 64 * 8;
     void* argmax_ws = cv.take(gw);
     if (d) {
         d->resid = resid; d->xn = xn; d->q_buf = q_buf; d->attn_out = attn_out; d->act = act;
-        d->partials = (float*)partials; d->attn_ws = attn_ws; d->attn_ws_bytes = aw;
+        d->partials = (float*)partials; d->partials_bytes = pbytes; d->attn_ws = attn_ws; d->attn_ws_bytes = aw;
         d->argmax_ws = argmax_ws; d->argmax_ws_bytes = gw;
     }
     return cv.off;
@@ -206,7 +209,8 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(d->bufs.ar_buf, nullptr, 0, 0, nullptr, d->resid, d->resid, L.post_norm, c.rms_eps,
                                              B, c.hidden, d->xn, st));
     }
-    RUN(MI355_KC_GEMM_QUANT, mi355_linear_direct(d->xn, B, &L.gate_up, nullptr, d->act, MI355_EPI_SILU_MUL, st));
+    RUN(MI355_KC_GEMM_QUANT, mi355_linear_direct(d->xn, B, &L.gate_up, nullptr, d->act, MI355_EPI_SILU_MUL, d->partials,
+                                                 d->partials_bytes, st));
     int ns = 0;
     RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->act, B, &L.down, d->partials, kMaxSplits, st));
     if (c.tp_size == 1) {
@@ -228,7 +232,7 @@ extern "C" int mi355_decoder_finish(mi355_decoder_t* d, int32_t sample, mi355_st
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(d->bufs.ar_buf, nullptr, 0, 0, nullptr, d->resid, d->resid, d->model.final_norm,
                                              c.rms_eps, B, c.hidden, d->xn, st));
     }
-    RUN(MI355_KC_GEMM_LMHEAD, mi355_linear_direct(d->xn, B, &d->model.lm_head, nullptr, d->bufs.logits, MI355_EPI_OUT_F32, st));
+    RUN(MI355_KC_GEMM_LMHEAD, mi355_linear_direct(d->xn, B, &d->model.lm_head, nullptr, d->bufs.logits, MI355_EPI_OUT_F32, nullptr, 0, st));
     if (sample) {
         RUN(MI355_KC_OTHER, mi355_argmax_ex(d->bufs.logits, B, c.vocab, c.vocab, d->bufs.token_ids, d->bufs.positions,
                                             d->argmax_ws, d->argmax_ws_bytes, st));

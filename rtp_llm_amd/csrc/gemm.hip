@@ -658,9 +658,11 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
     return MI355_OK;
 }
 
-// Engine-internal: direct (nsplit = 1) GEMM with fused epilogue, no workspace.
+// Engine-internal: GEMM with fused epilogue.  Without a workspace: one launch, nsplit = 1.  With one (the step driver's
+// slab buffer): shapes that would leave most CUs without a block in a single launch (column-parallel shards under TP:
+// gate_up of Qwen2-7B at tp = 4 is 37-74 blocks) are split along K into slabs and finished by reduce_epilogue_kernel.
 extern "C" int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_t* w, const void* bias, void* y,
-                                   int32_t epilogue, mi355_stream_t stream) {
+                                   int32_t epilogue, void* workspace, size_t workspace_bytes, mi355_stream_t stream) {
     if (int e = check_weight(w)) return e;
     MI355_CHECK_ARG(x && y && M > 0 && M <= 64, "linear_direct: bad args");
     const int mode = (epilogue & MI355_EPI_OUT_F32) ? MODE_F32 : (epilogue & MI355_EPI_SILU_MUL) ? MODE_SILU : MODE_F16;
@@ -677,7 +679,21 @@ extern "C" int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_
         if (rc >= 0) return MI355_OK;
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
-    const GemmPlan g = plan_gemm(M, w, 1);
-    p.nsplit = 1; p.cps = p.KC;
-    return launch_gemm(p, w->wbits, w->group_size, g.cfg, (hipStream_t)stream);
+    int max_splits = 1;
+    if (workspace && w->wbits != 16) {
+        const size_t per_split = (size_t)M * w->N_pad * sizeof(float);
+        const size_t fit = workspace_bytes / per_split;
+        max_splits = fit > 16 ? 16 : (int)fit;
+        if (max_splits < 1) max_splits = 1;
+    }
+    const GemmPlan g = plan_gemm(M, w, max_splits);
+    p.nsplit = g.nsplit; p.cps = g.cps;
+    if (g.nsplit == 1) return launch_gemm(p, w->wbits, w->group_size, g.cfg, (hipStream_t)stream);
+    p.mode = MODE_PARTIAL; p.partials = (float*)workspace; p.bias = nullptr; p.y = nullptr;
+    if (int e = launch_gemm(p, w->wbits, w->group_size, g.cfg, (hipStream_t)stream)) return e;
+    const int total = M * (w->N_pad / 4);
+    hipLaunchKernelGGL(reduce_epilogue_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+                       g.nsplit, M, w->N, w->N_pad, (const f16*)bias, y, (mode == MODE_SILU) ? w->N / 2 : w->N, mode);
+    MI355_CHECK_LAUNCH("reduce_epilogue_kernel");
+    return MI355_OK;
 }

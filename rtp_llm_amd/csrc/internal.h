@@ -7,7 +7,7 @@ extern "C" {
 #endif
 int mi355_gemm_plan(int M, const mi355_weight_t* w, int max_splits, int* nbw_out, int* cps_out);
 int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_t* w, const void* bias, void* y, int32_t epilogue,
-                        mi355_stream_t stream);
+                        void* workspace, size_t workspace_bytes, mi355_stream_t stream);
 int mi355_argmax_ex(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t* ids, int32_t* positions, void* workspace,
                     size_t workspace_bytes, mi355_stream_t stream);
 /* seq_lens_minus_one != 0: seq_lens[] holds tokens already cached (decode "positions"), context = value + 1 */
