@@ -309,6 +309,31 @@ def test_generate_with_ragged_prompts_matches_oracle():
                 assert logits[0, nxt] >= logits[0].max() - 2e-2, (b, pos, nxt, int(logits[0].argmax()))
 
 
+def test_engine_wide_hidden_mid_batch_matches_oracle():
+    """A layer shape with long K and narrow N at a 33-row batch: the step driver splits the gate_up GEMM along K into its
+    slab buffer and finishes it with the reduce + SiLU epilogue kernel (the path column-parallel TP shards take)."""
+    cfg = model.ModelConfig("wide-hidden", 2, 2048, 16, 4, 128, 1024, 1024, max_pos=256)
+    w = model.synth_model(cfg, "w4", "cpu", seed=13)
+    B, page = 33, 16
+    import ctypes
+    ws = ops.weight_struct(w["layers"][0]["gate_up"].pack(gate_up=True))
+    assert _C.lib().mi355_gemm_plan(ctypes.c_int(B), ctypes.byref(ws), ctypes.c_int(4), None, None) > 1   # the planner does split it
+    odec = oracle.OracleDecoder({**cfg.__dict__}, _oracle_weights(w))
+    okv = oracle.OracleKV(cfg.num_layers, B, False)
+    eng = model.DecoderEngine(cfg, model.weights_to(w, DEV), kv_int8=False, page=page, num_blocks=B * 2, max_batch=B, max_seq_len=32, device=DEV)
+    bt = torch.arange(B * 2, dtype=torch.int32).reshape(B, 2)
+    tok = torch.randint(0, cfg.vocab, (B,), generator=_gen(4), dtype=torch.int32)
+    eng.set_inputs(tok.tolist(), [0] * B, bt)
+    for step in range(3):
+        pos = torch.full((B,), step, dtype=torch.int32)
+        _, ref_logits = odec.forward_tokens(tok, pos, okv, list(range(B)))
+        eng.step(B)
+        torch.cuda.synchronize()
+        assert torch.allclose(eng.logits[:B].cpu(), ref_logits, **TOL), (step, (eng.logits[:B].cpu() - ref_logits).abs().max())
+        tok = oracle.greedy(ref_logits)
+        eng.token_ids[:B].copy_(tok)
+
+
 def test_module_graph_matches_engine():
     """The reference-shaped Python module graph (LinearFactory / FMHA impl / RMSNorm modules) and the C++ step
     driver run the same kernels: hidden states agree to fp16 rounding of the fused epilogues."""
