@@ -37,6 +37,8 @@ WORKLOADS = {
     "qwen2-7b-w8a16": ("qwen2-7b", "int8", False, 16, 1024, 16),         # configs[1]
     "qwen2-7b-w4a16-kv8": ("qwen2-7b", "w4", True, 64, 4096, 16),        # configs[2]
     "qwen2-0.5b-fp16": ("qwen2-0.5b", "fp16", False, 1, 128, 16),        # configs[0] shape (GPU run of the plumbing config)
+    "llama3-70b-awq": ("llama3-70b", "w4", False, 32, 2048, 16),         # configs[3]: needs --gpus 8 (tp8) or --shard-of 8
+    "qwen2-72b-w4a16": ("qwen2-72b", "w4", False, 8, 1024, 16),          # configs[4] target model: --gpus 8 or --shard-of 8
 }
 
 
