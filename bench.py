@@ -308,7 +308,7 @@ def main():
         try:
             import torch.distributed as dist
             tpn = max(t for t in range(1, world + 1) if world % t == 0 and cfg_full.nh % t == 0 and cfg_full.nkv % t == 0
-                      and cfg_full.inter % (t * 128) == 0)
+                      and cfg_full.vocab % t == 0)
             dpn = world // tpn
             del eng
             torch.cuda.empty_cache()

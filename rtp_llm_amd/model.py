@@ -48,9 +48,16 @@ class ModelConfig:
         K/V heads split by tp when divisible, utils/model_weight.py:447-466)."""
         if tp == 1:
             return self
-        assert self.nh % tp == 0 and self.nkv % tp == 0 and self.inter % tp == 0 and self.vocab % tp == 0, \
-            f"{self.name}: nh={self.nh} nkv={self.nkv} inter={self.inter} vocab={self.vocab} not divisible by tp={tp}"
-        return replace(self, nh=self.nh // tp, nkv=self.nkv // tp, inter=self.inter // tp, vocab=self.vocab // tp)
+        assert self.nh % tp == 0 and self.nkv % tp == 0 and self.vocab % tp == 0, \
+            f"{self.name}: nh={self.nh} nkv={self.nkv} vocab={self.vocab} not divisible by tp={tp}"
+        return replace(self, nh=self.nh // tp, nkv=self.nkv // tp, inter=self.padded_inter(tp) // tp, vocab=self.vocab // tp)
+
+    def padded_inter(self, tp: int) -> int:
+        """FFN width padded so that every rank gets a whole number of 128-row quantisation groups / K chunks
+        (the reference's align_size = tp * group_size, utils/model_weight.py:234-250): Qwen2-72B's 29568 = 231 * 128
+        becomes 29696 at tp = 8.  Padded columns / rows carry zero weights."""
+        a = tp * 128
+        return (self.inter + a - 1) // a * a
 
 
 # dims from the HF config.json values quoted in SURVEY section 8 (models/qwen_v2.py:338-399 reads them)
@@ -96,6 +103,24 @@ class CanonLinear:
             return CanonLinear(self.kind, hi - lo, self.N, None, s(self.q), self.scales[lo // g: hi // g].contiguous(),
                                self.z_eff[lo // g: hi // g].contiguous(), g)
         return CanonLinear(self.kind, hi - lo, self.N, s(self.w), s(self.q), self.scales, None, 0)
+
+    def pad_cols(self, n: int) -> "CanonLinear":
+        """Append n output columns of zero weight (code 0, zero 0, scale 0)."""
+        if n == 0:
+            return self
+        z = lambda t: None if t is None else torch.cat([t, torch.zeros(*t.shape[:-1], n, dtype=t.dtype, device=t.device)], dim=-1)
+        return CanonLinear(self.kind, self.K, self.N + n, z(self.w), z(self.q), z(self.scales), z(self.z_eff), self.group_size)
+
+    def pad_rows(self, n: int) -> "CanonLinear":
+        """Append n input rows of zero weight; for w4 n must be a multiple of the group size (new groups: scale 0)."""
+        if n == 0:
+            return self
+        z = lambda t, k: None if t is None else torch.cat([t, torch.zeros(k, *t.shape[1:], dtype=t.dtype, device=t.device)], dim=0)
+        if self.kind == "w4":
+            assert n % self.group_size == 0
+            return CanonLinear(self.kind, self.K + n, self.N, None, z(self.q, n), z(self.scales, n // self.group_size),
+                               z(self.z_eff, n // self.group_size), self.group_size)
+        return CanonLinear(self.kind, self.K + n, self.N, z(self.w, n), z(self.q, n), self.scales, None, 0)
 
     @staticmethod
     def cat_cols(parts: List["CanonLinear"]) -> "CanonLinear":
@@ -165,17 +190,21 @@ def split_layer_tp(layer: Dict, cfg: ModelConfig, tp: int, rank: int) -> Dict:
     QKV bias split like the QKV columns."""
     if tp == 1:
         return layer
-    hd, nh, nkv, I = cfg.hd, cfg.nh, cfg.nkv, cfg.inter
+    hd, nh, nkv, I0 = cfg.hd, cfg.nh, cfg.nkv, cfg.inter
+    I = cfg.padded_inter(tp)                      # align_size padding: zero columns of gate / up, zero rows of down
     nh_r, nkv_r, I_r = nh // tp, nkv // tp, I // tp
     qkv = layer["qkv"]
     q_lo, k_lo, v_lo = rank * nh_r * hd, nh * hd + rank * nkv_r * hd, (nh + nkv) * hd + rank * nkv_r * hd
     parts = [qkv.cols(q_lo, q_lo + nh_r * hd), qkv.cols(k_lo, k_lo + nkv_r * hd), qkv.cols(v_lo, v_lo + nkv_r * hd)]
-    gu = layer["gate_up"]
+    gu, down = layer["gate_up"], layer["down"]
+    if I != I0:
+        gu = CanonLinear.cat_cols([gu.cols(0, I0).pad_cols(I - I0), gu.cols(I0, 2 * I0).pad_cols(I - I0)])
+        down = down.pad_rows(I - I0)
     out = {
         "qkv": CanonLinear.cat_cols(parts),
         "o": layer["o"].rows(rank * nh_r * hd, (rank + 1) * nh_r * hd),
         "gate_up": CanonLinear.cat_cols([gu.cols(rank * I_r, (rank + 1) * I_r), gu.cols(I + rank * I_r, I + (rank + 1) * I_r)]),
-        "down": layer["down"].rows(rank * I_r, (rank + 1) * I_r),
+        "down": down.rows(rank * I_r, (rank + 1) * I_r),
         "input_norm": layer["input_norm"], "post_norm": layer["post_norm"], "qkv_bias": None,
     }
     if layer["qkv_bias"] is not None:

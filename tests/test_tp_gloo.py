@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, inter):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,8 +33,10 @@ def _worker(rank, world, port, q):
         g = distributed.all_gather(torch.full((2, 3), float(rank)), distributed.Group.TP)
         assert g.shape == (2, 3 * world) and all(torch.equal(g[:, 3 * r:3 * r + 3], torch.full((2, 3), float(r))) for r in range(world))
         assert distributed.tp_size() == world and distributed.tp_rank() == rank
-        # ---- one TP decoder layer: split weights per rank, all_reduce after O-proj and down-proj
-        cfg = model.ModelConfig("t", 1, 256, 8, 4, 64, 512, 64, max_pos=64)
+        # ---- one TP decoder layer: split weights per rank, all_reduce after O-proj and down-proj.  inter = 384 is not
+        # a multiple of tp * 128: the split pads it to 512 with zero weights (the reference's align_size = tp * g)
+        cfg = model.ModelConfig("t", 1, 256, 8, 4, 64, inter, 64, max_pos=64)
+        assert cfg.per_rank(world).inter == (256 if inter == 384 else inter // world)
         gen = torch.Generator().manual_seed(0)                      # same full weights on every rank
         L = model.synth_layer(cfg, "w4", "cpu", gen)
         dense = lambda c: oracle.dequant_groupwise(c.q, c.z_eff, c.scales, c.group_size)
@@ -70,11 +72,12 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(180)
-def test_tp2_gloo_layer_and_collectives():
+@pytest.mark.parametrize("inter", [512, 384])
+def test_tp2_gloo_layer_and_collectives(inter):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, inter)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=150) for _ in range(world)]
