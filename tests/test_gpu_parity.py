@@ -368,8 +368,8 @@ def _gpu_canon(K, N, kind, seed):
     return model.synth_linear(K, N, kind, DEV, torch.Generator(device=DEV).manual_seed(seed))
 
 
-@pytest.mark.parametrize("kind", ["w4", "int8"])
-@pytest.mark.parametrize("K,N", [(3584, 37888), (18944, 3584)])
+@pytest.mark.parametrize("kind,K,N", [("w4", 3584, 37888), ("w4", 18944, 3584), ("int8", 3584, 37888), ("int8", 18944, 3584),
+                                      ("w4", 8192, 57344), ("w4", 28672, 8192)])   # Qwen2-7B and Llama-3-70B FFN shapes
 def test_linear_full_size_properties(kind, K, N):
     c = _gpu_canon(K, N, kind, 3)
     p = c.pack()
