@@ -33,6 +33,7 @@ class SpeculativeDecoder:
             raise ValueError("gamma >= 1")
         self.target, self.draft, self.gamma = target, draft, gamma
         self.B = 0
+        self.profile = None      # set to {} to collect per-phase wall times (synchronises at every phase boundary)
 
     def start(self, last_tokens: Sequence[int], ctx_lens: Sequence[int], target_block_table: torch.Tensor,
               draft_block_table: torch.Tensor, draft_ctx_lens: Optional[Sequence[int]] = None,
@@ -63,6 +64,15 @@ class SpeculativeDecoder:
         """One propose + verify round; returns the tokens emitted per sequence (1 .. gamma + 1 each)."""
         B, G = self.B, self.gamma
         dev = self.target.device
+        import time
+        t_last = [time.perf_counter()]
+
+        def mark(name):
+            if self.profile is not None:
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                self.profile[name] = self.profile.get(name, 0.0) + (now - t_last[0]) * 1e3
+                t_last[0] = now
         # ---- draft: catch up on the pending tokens (1 or 2 per sequence), then gamma - 1 single-token steps
         rows, last_row = [], []
         for b in range(B):
@@ -73,14 +83,22 @@ class SpeculativeDecoder:
         self._forward(self.draft, rows, self.dbt)
         nxt = ops.argmax(self.draft.logits[: len(rows)])[torch.tensor(last_row, device=dev)]
         drafts = [nxt]
-        for _ in range(G - 1):
-            cur = drafts[-1].tolist()
-            self._forward(self.draft, [(b, cur[b], self.dctx[b]) for b in range(B)], self.dbt)
+        mark("draft_catch_up")
+        if G > 1:
+            # the remaining gamma - 1 draft steps never leave the device: one token per sequence, greedy feedback and
+            # position increment inside the captured step (DecoderEngine.replay), no host round trip per token
+            self.draft.token_ids[:B].copy_(nxt)
+            self.draft.positions[:B].copy_(torch.tensor(self.dctx, dtype=torch.int32))
+            self.draft.block_table[:B, : self.dbt.shape[1]].copy_(self.dbt)
+            self.draft.capture(B)
+            for _ in range(G - 1):
+                self.draft.replay(B, 1)
+                drafts.append(self.draft.token_ids[:B].clone())
             for b in range(B):
-                self.dctx[b] += 1
-            drafts.append(ops.argmax(self.draft.logits[:B]).clone())
+                self.dctx[b] += G - 1
         draft_ids = torch.stack(drafts, dim=1).to(torch.int32).contiguous()          # [B, G]
         dl = draft_ids.tolist()
+        mark("draft_steps")
         # ---- target: gamma + 1 decode rows per sequence = causal verify over the paged cache
         rows = []
         for b in range(B):
@@ -88,6 +106,7 @@ class SpeculativeDecoder:
             rows += [(b, toks[t], self.ctx[b] + t) for t in range(G + 1)]
         self._forward(self.target, rows, self.tbt)
         R = B * (G + 1)
+        mark("target_verify")
         logits = self.target.logits[:R]
         target_ids = ops.argmax(logits).reshape(B, G + 1).contiguous()
         probs = ops.softmax_rows(logits, temperature).reshape(B, G + 1, -1)
@@ -96,6 +115,7 @@ class SpeculativeDecoder:
             uniform = torch.rand(B, G + 1, device=dev, dtype=torch.float32)
         out, acc = ops.rejection_sample(draft_ids, target_ids, probs, uniform.to(dev), ds)   # draft = point mass (greedy draft)
         out_l, acc_l = out.tolist(), acc.tolist()
+        mark("sample")
         # ---- advance: target cache now holds `last` and the accepted drafts; the draft cache holds last + d_1..d_{G-1}
         emitted = []
         for b in range(B):

@@ -48,6 +48,10 @@ for _ in range(5):
     spec.step()
 torch.cuda.synchronize()
 t_round = (time.perf_counter() - t0) / 5 * 1e3
+spec.profile = {}
+for _ in range(5):
+    spec.step()
+print("phases (ms per round, synchronised):", {k: round(v / 5, 3) for k, v in spec.profile.items()})
 dev_round = G * t_draft + t_verify
 print(f"B={B} gamma={G} ctx={ctx}: target decode step (eager, {B} rows) {t_plain:.3f} ms; verify step ({rows} rows) {t_verify:.3f} ms; "
       f"draft step {t_draft:.3f} ms")
