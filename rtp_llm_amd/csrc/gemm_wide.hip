@@ -301,7 +301,11 @@ int launch_wide_t(const WideParams& wp, hipStream_t st) {
     constexpr size_t lds = red_b > stage_b ? red_b : stage_b;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            mi355_set_error("%s: cannot raise the dynamic LDS limit: %s", "gemm_wide", hipGetErrorString(e));
+            return MI355_ERR_HIP;
+        }
         attr_set = true;
     }
     hipLaunchKernelGGL(k, dim3(wp.G, wp.g.nsplit), dim3(512), lds, st, wp);
