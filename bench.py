@@ -17,6 +17,7 @@ decoding its own `batch` sequences (requests are independent: no data-path colle
 tensor-parallel layout over RCCL is measured right after and reported in `tp_layout`.
 """
 import argparse
+import ctypes as C
 import json
 import math
 import os
@@ -313,28 +314,38 @@ def main():
             del eng
             torch.cuda.empty_cache()
             for r0 in range(0, world, tpn):   # every rank creates every group (torch.distributed contract)
-                grp = dist.new_group(list(range(r0, r0 + tpn)), backend="nccl")
+                grp = dist.new_group(list(range(r0, r0 + tpn)), backend=os.environ.get("MI355_TP_BACKEND", "nccl"))  # gloo: 1-GPU dry run (eager)
                 if r0 <= rank < r0 + tpn:
                     distributed.set_tp_group(grp)
             _, teng, treset = build_engine(tpn, rank % tpn, rank // tpn)
             treset()
             run_eager = lambda n: [teng.step_tp(B) for _ in range(n)]
             trun, captured = run_eager, False
-            if not args.no_graph and os.environ.get("MI355_TP_GRAPH", "1") == "1":
+            tp_backend = os.environ.get("MI355_TP_BACKEND", "nccl")
+            if not args.no_graph and tp_backend == "nccl" and os.environ.get("MI355_TP_GRAPH", "1") == "1":
+                cap_stream = torch.cuda.Stream()
                 try:  # capture the TP step (RCCL collectives included) into one graph; eager on any failure
                     run_eager(2)
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with torch.cuda.graph(g, stream=cap_stream):
                         teng.step_tp(B)
                     trun, captured = (lambda n: [g.replay() for _ in range(n)]), True
                 except Exception as e:  # noqa: BLE001
-                    log(f"[rank {rank}] TP graph capture failed ({type(e).__name__}: {e}); running eager")
+                    log(f"[rank {rank}] TP graph capture failed ({type(e).__name__}: {str(e).splitlines()[0]}); running eager")
+                    # an invalidated capture leaves the stream capturing: end it, or every later launch fails
+                    _C.lib().mi355_abort_capture(C.c_void_p(cap_stream.cuda_stream))
+                    torch.cuda.set_stream(torch.cuda.default_stream())
+                    try:
+                        torch.cuda.synchronize()
+                    except Exception:  # noqa: BLE001
+                        pass
                     trun = run_eager
             t_el, t_p50 = timed(trun, treset)
             tp_info = {"parallelism": f"tp{tpn}" + (f" x dp{dpn}" if dpn > 1 else ""), "global_batch": B * dpn,
                        "tokens_per_s": round(B * dpn * args.steps / t_el, 1), "ms_per_step": round(t_el / args.steps * 1e3, 4),
-                       "p50_ms": round(t_p50, 4), "graph": captured, "collectives": "RCCL all-reduce x2 per layer + logits all-gather"}
+                       "p50_ms": round(t_p50, 4), "graph": captured,
+                       "collectives": ("RCCL" if tp_backend == "nccl" else tp_backend) + " all-reduce x2 per layer + logits all-gather"}
         except Exception as e:  # noqa: BLE001
             tp_info = {"error": f"{type(e).__name__}: {e}"}
             log(f"[rank {rank}] TP layout failed: {tp_info['error']}")

@@ -273,6 +273,18 @@ extern "C" int mi355_decoder_capture(mi355_decoder_t* d, int32_t B) {
     return MI355_OK;
 }
 
+// Host-side helper for drivers that capture the TP step (collectives included) with their framework's graph API: if that
+// capture is invalidated half way (an un-capturable collective), the stream is left capturing and every later launch
+// fails.  Ends whatever capture is active on `stream`, discarding the partial graph.  Not part of the public ABI.
+extern "C" int mi355_abort_capture(mi355_stream_t stream) {
+    (void)hipGetLastError();   // the status query itself fails on an invalidated capture: just try to end it
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture((hipStream_t)stream, &g);
+    if (g) hipGraphDestroy(g);
+    (void)hipGetLastError();
+    return MI355_OK;
+}
+
 extern "C" int mi355_decoder_replay(mi355_decoder_t* d, int32_t B, int32_t nsteps, mi355_stream_t stream) {
     if (!d || !d->graphs.count(B)) { mi355_set_error("decoder_replay: no graph for B=%d", B); return MI355_ERR_ARG; }
     hipGraphExec_t ge = d->graphs[B];
