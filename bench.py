@@ -306,6 +306,16 @@ def main():
     # headline and reported beside it; a failure here is recorded, it does not take the headline down.
     if world > 1 and not args.no_tp:
         tp_info = {}
+        # watchdog: a hang in the collectives (never exercised on the 1-GPU development boxes) must not cost the headline
+        import threading
+
+        def _tp_timeout():
+            if rank == 0:
+                print(json.dumps({**out, "tp_layout": {"error": "timed out after 300 s"}}), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(300.0, _tp_timeout)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             import torch.distributed as dist
             tpn = max(t for t in range(1, world + 1) if world % t == 0 and cfg_full.nh % t == 0 and cfg_full.nkv % t == 0
@@ -349,6 +359,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             tp_info = {"error": f"{type(e).__name__}: {e}"}
             log(f"[rank {rank}] TP layout failed: {tp_info['error']}")
+        watchdog.cancel()
         out["tp_layout"] = tp_info
     if rank == 0:
         print(json.dumps(out), flush=True)
