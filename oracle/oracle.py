@@ -10,9 +10,11 @@ this path, each function citing the reference lines it follows.  Pinning status
   * GPTQ/AWQ canonicalisation + INT8 autoquant: PINNED against golden vectors generated
     by importing the reference's own rtp_llm/device/device_impl.py (tests/golden/quant_*.npz,
     generator oracle/gen_golden.py).
-  * RMSNorm / RoPE / SiLU-mul / paged attention (fp16 KV) / greedy: restated from the
-    reference's own torch test references (cited per function); those references are
-    what the reference's ROCm unit tests compare against at atol=rtol=1e-2.
+  * RMSNorm / NeoX RoPE / paged decode attention (fp16 KV, and per-token-scaled 8-bit KV) / SiLU-gate MLP: PINNED against
+    outputs of the reference's own torch reference implementations (RMSNormTorch, _torch_reference, run_native /
+    ref_masked_attention, DenseMLP -- the functions its ROCm unit tests compare the native kernels with at
+    atol=rtol=1e-2), executed unmodified by oracle/gen_golden.py -> tests/golden/ref_layers.npz, checked by
+    tests/test_oracle_pinned.py (bit-equal, or within one fp16 ulp where the fp32 contraction order differs).
   * Chain rejection sampling (speculative verify): PINNED against the reference's own known-answer kernel tests
     (bindings/cuda/test/CudaSpeculativeSamplingTest.cc:36-366, transcribed in tests/spec_vectors.py).
   * W4A16 / W8A16 GEMM results and INT8 KV-cache numerics: PARITY UNPINNED — the reference
