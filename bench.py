@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--debug-set", default="", help="debug only: 'idx=val,...' forwarded to mi355_debug_set (kernel A/B switches)")
     args = ap.parse_args()
 
+    if args.debug_set:   # kernel A/B switches exist only in the tuning build (python -m rtp_llm_amd.build --tuning)
+        os.environ["MI355_TUNING_LIB"] = "1"
     from rtp_llm_amd import _C, distributed, model
 
     rank = int(os.environ.get("RANK", "0"))
@@ -256,6 +258,8 @@ def main():
     }
     if args.layers:
         out["invalid"] = f"debug run with --layers {args.layers}"
+    if args.debug_set:
+        out["invalid"] = f"debug run with --debug-set {args.debug_set} (tuning build of the library)"
     if args.shard_of > 1:
         out["invalid"] = f"debug run: one rank's shard of tp={args.shard_of}, collectives omitted"
 

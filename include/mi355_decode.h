@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 1
+#define MI355_ABI_VERSION 2
 
 typedef void* mi355_stream_t; /* hipStream_t */
 
@@ -95,7 +95,10 @@ typedef struct {
 enum {
     MI355_EPI_NONE     = 0,
     MI355_EPI_SILU_MUL = 1, /* columns are interleaved (gate,up) pairs; y is [M, N/2] */
-    MI355_EPI_OUT_F32  = 2  /* y is fp32 [M, N] (lm_head logits) */
+    MI355_EPI_OUT_F32  = 2, /* y is fp32 [M, N] (lm_head logits) */
+    /* kernel-family hints (per call, for A/B tests; results stay within the same tolerance): */
+    MI355_HINT_STAGED        = 0x100, /* 16 < M <= 64: take the LDS-staged kernel instead of the register-resident one */
+    MI355_HINT_NO_PERSISTENT = 0x200  /* M <= 8: skip the persistent x-resident kernel */
 };
 
 /* Workspace needed by mi355_linear_forward for a given (M, weight). */
@@ -182,12 +185,16 @@ typedef struct {
  * per sequence) through block_table[t][pos / page].
  * INT8 cache: scale = max|x| / 127 per (token, kv head) fp32, q = rne_sat(x / scale)
  * (rounding of rocm_utils/_cast_to_int8.h:5-24).
+ * Range checks (device side; the reference's kernel has none): a token whose position is outside
+ * [0, min(max_pos, max_blocks_per_seq * page)) or whose block id is outside [0, kv->num_blocks) is NOT written to the
+ * cache (its q row is still produced, rotated with the clamped position) and *oob_count (dev, may be NULL) is
+ * incremented once per such token, so a stale position cannot overwrite another sequence's pages.
  */
 int mi355_rope_kv_write(const void* qkv_f16, const float* partials, int32_t nsplit, int32_t ld,
-                        const void* qkv_bias, const float* cos_sin, int32_t rope_dim,
+                        const void* qkv_bias, const float* cos_sin, int32_t rope_dim, int32_t max_pos,
                         const int32_t* positions, const int32_t* block_table,
                         int32_t max_blocks_per_seq, int32_t T, int32_t nh,
-                        const mi355_kv_layer_t* kv, void* q_out, mi355_stream_t stream);
+                        const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count, mi355_stream_t stream);
 
 /*
  * Paged decode attention (flash-decoding, split over the sequence) — replaces
@@ -195,6 +202,8 @@ int mi355_rope_kv_write(const void* qkv_f16, const float* partials, int32_t nspl
  * (factory/attention/rocm_impl/aiter.py:1340-1561, bindings/rocm/atrexPA.cc:444-496).
  * out[B][nh*hd] = softmax(scale * q.K^T) . V over seq_lens[b] tokens gathered
  * through block_table[b][*]; fp32 logits/softmax; GQA group nh/nkv <= 16.
+ * seq_lens[b] is clamped to [1, max_seq_len] and block ids to [0, kv->num_blocks) on the device: out-of-range inputs give
+ * a wrong row, never an out-of-bounds access.
  */
 size_t mi355_paged_attn_workspace_bytes(int32_t B, int32_t nh, int32_t hd, int32_t max_seq_len);
 
@@ -318,6 +327,10 @@ enum {
 };
 int mi355_decoder_profile(mi355_decoder_t* d, int32_t B, int32_t nsteps, float* out_ms,
                           int32_t* out_launches, mi355_stream_t stream);
+
+/* Number of tokens the step driver refused to write to the KV cache since creation because their position or block id
+ * was out of range (see mi355_rope_kv_write).  Synchronises `stream`.  0 on a healthy run; < 0 = error. */
+int64_t mi355_decoder_oob_count(mi355_decoder_t* d, mi355_stream_t stream);
 
 #ifdef __cplusplus
 }

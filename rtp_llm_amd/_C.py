@@ -7,12 +7,17 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmi355_decode.so")
+# MI355_TUNING_LIB=1 (set by tools/ and bench.py --debug-set only) selects the tuning build, which adds process-global
+# experiment switches (mi355_debug_set & co); the product library has none.
+TUNING = os.environ.get("MI355_TUNING_LIB") == "1"
+LIB_PATH = os.path.join(_HERE, "lib", "libmi355_decode_tuning.so" if TUNING else "libmi355_decode.so")
 
 OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_WORKSPACE = 0, -1, -2, -3, -4
 W4, W8, W16 = 4, 8, 16
 KV_FP16, KV_INT8 = 0, 1
 EPI_NONE, EPI_SILU_MUL, EPI_OUT_F32 = 0, 1, 2
+HINT_STAGED, HINT_NO_PERSISTENT = 0x100, 0x200
+ABI_VERSION = 2
 KC_NAMES = ["gemm_quant", "gemm_lmhead", "attn", "rope_kv", "norm", "other"]
 
 vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
@@ -59,7 +64,7 @@ SIGNATURES = {
     "mi355_add_rmsnorm": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, vp]),
     "mi355_silu_mul": (i32, [vp, i32, i32, vp, vp]),
     "mi355_embedding": (i32, [vp, i32, vp, i32, i32, vp, vp]),
-    "mi355_rope_kv_write": (i32, [vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, C.POINTER(KVLayer), vp, vp]),
+    "mi355_rope_kv_write": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
     "mi355_paged_attn_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "mi355_paged_decode_attn": (i32, [vp, C.POINTER(KVLayer), vp, i32, vp, i32, i32, f32, i32, vp, vp, sz, vp]),
     "mi355_argmax": (i32, [vp, i32, i32, i32, vp, vp, sz, vp]),
@@ -76,6 +81,7 @@ SIGNATURES = {
     "mi355_decoder_capture": (i32, [vp, i32]),
     "mi355_decoder_replay": (i32, [vp, i32, i32, vp]),
     "mi355_decoder_profile": (i32, [vp, i32, i32, C.POINTER(f32), C.POINTER(i32), vp]),
+    "mi355_decoder_oob_count": (C.c_int64, [vp, vp]),
 }
 
 _lib = None
@@ -99,7 +105,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
-        if l.mi355_abi_version() != 1:
+        if l.mi355_abi_version() != ABI_VERSION:
             raise Mi355Error("libmi355_decode.so ABI version mismatch")
         _lib = l
     return _lib

@@ -1,9 +1,11 @@
 """Build libmi355_decode.so (gfx950) in-tree with hipcc.
 
-    python -m rtp_llm_amd.build [--force]
+    python -m rtp_llm_amd.build [--force] [--tuning]
 
 Objects go to rtp_llm_amd/csrc/build/, the library to rtp_llm_amd/lib/.  Only
 stale translation units are recompiled (mtime of source + headers).
+--tuning additionally builds lib/libmi355_decode_tuning.so (-DMI355_TUNING: process-global experiment
+switches for tools/; never loaded by the product path or the tests).
 """
 import os
 import subprocess
@@ -32,23 +34,24 @@ def _stale(src, obj):
     return any(os.path.getmtime(p) > t for p in [src] + HEADERS)
 
 
-def _compile(name, force):
+def _compile(name, force, tuning=False):
     src = os.path.join(CSRC, name)
-    obj = os.path.join(OBJ, os.path.splitext(name)[0] + ".o")
+    obj = os.path.join(OBJ, os.path.splitext(name)[0] + ("_tuning.o" if tuning else ".o"))
     if not force and not _stale(src, obj):
         return obj, False
-    cmd = [HIPCC] + CFLAGS + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + CFLAGS + (["-DMI355_TUNING"] if tuning else []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {name}:\n{r.stdout}\n{r.stderr}")
     return obj, True
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, tuning=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
+    LIB = os.path.join(LIBDIR, "libmi355_decode_tuning.so" if tuning else "libmi355_decode.so")
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
-        res = list(ex.map(lambda s: _compile(s, force), SOURCES))
+        res = list(ex.map(lambda s: _compile(s, force, tuning), SOURCES))
     objs = [o for o, _ in res]
     rebuilt = any(ch for _, ch in res)
     if rebuilt or not os.path.exists(LIB):
@@ -65,3 +68,5 @@ def build(force=False, verbose=True):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    if "--tuning" in sys.argv:
+        build(force="--force" in sys.argv, tuning=True)

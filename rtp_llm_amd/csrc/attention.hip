@@ -35,7 +35,7 @@ struct AttnParams {
     f16*           out;
     float*         tmp_out; // [B][nh][P][hd]
     float*         tmp_ml;  // [B][nh][P][2]
-    int B, nh, nkv, G, page, max_blocks, P, PS, seq_add;
+    int B, nh, nkv, G, page, max_blocks, P, PS, seq_add, max_seq, num_blocks;
     float scale_log2; // softmax scale * log2(e)
 };
 
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
     constexpr int NSTEP = HD / 32; // QK k-steps
     constexpr int NDB   = HD / 16; // PV d-blocks
     const int part = blockIdx.x, kh = blockIdx.y, b = blockIdx.z;
-    const int seq_len = p.seq_lens[b] + p.seq_add;
+    const int seq_len = min(max(p.seq_lens[b] + p.seq_add, 1), p.max_seq);   // clamped: block table / workspace stay in range
     const int pstart = part * p.PS;
     if (pstart >= seq_len) return;
     const int pend = min(seq_len, pstart + p.PS);
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
     // block ids of the group starting at token tb: K rows use window (j>>2), V / scales / P use window w
     auto lookup = [&](int tb, int& kblk, int& vblk) {
         const int kw_c = min(tb + (j >> 2) * 8, last & ~7), vw_c = min(tb + w * 8, last & ~7);
-        kblk = bt[kw_c / p.page]; vblk = bt[vw_c / p.page];
+        kblk = min(max(bt[kw_c / p.page], 0), p.num_blocks - 1); vblk = min(max(bt[vw_c / p.page], 0), p.num_blocks - 1);
     };
     auto load_group = [&](Group& g, int tb, int kblk, int vblk) {
         const int kw_c = min(tb + (j >> 2) * 8, last & ~7), vw_c = min(tb + w * 8, last & ~7); // whole windows clamped in range
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void attn_reduce_kernel(const AttnParams p) {
     const int gid = blockIdx.x * 4 + (threadIdx.x >> 6); // (b, h)
     if (gid >= p.B * p.nh) return;
     const int b = gid / p.nh;
-    const int np = (p.seq_lens[b] + p.seq_add + p.PS - 1) / p.PS;
+    const int np = (min(max(p.seq_lens[b] + p.seq_add, 1), p.max_seq) + p.PS - 1) / p.PS;
     const float* ml = p.tmp_ml + (size_t)gid * p.P * 2;
     float mstar = NEG_BIG;
     for (int i = 0; i < np; ++i) mstar = fmaxf(mstar, ml[i * 2]);
@@ -279,10 +279,15 @@ __global__ __launch_bounds__(256) void attn_reduce_kernel(const AttnParams p) {
     for (int c = 0; c < CPL; ++c) dst[c] = (f16)(acc[c] * inv);
 }
 
-int g_attn_ps_override = 0; // tuning hook (tools/attn_bench.py)
+#ifdef MI355_TUNING
+int g_attn_ps_override = 0; // tuning hook (tools/attn_bench.py), tuning build only
+#define ATTN_PS_OVERRIDE g_attn_ps_override
+#else
+#define ATTN_PS_OVERRIDE 0
+#endif
 
 int plan_partitions(int B, int nkv, int max_seq_len, int* ps_out) {
-    if (g_attn_ps_override > 0) { *ps_out = g_attn_ps_override; return cdiv(max_seq_len, g_attn_ps_override); }
+    if (ATTN_PS_OVERRIDE > 0) { *ps_out = ATTN_PS_OVERRIDE; return cdiv(max_seq_len, ATTN_PS_OVERRIDE); }
     // Long partitions stream best (measured b=64, ctx 1024: one 1024-token partition per (seq, kv head) reaches
     // 5.2 TB/s, five 256-token ones 4.0 TB/s and need the reduce kernel): split the sequence only as far as
     // needed to put one block on every CU, never below 128 tokens.
@@ -295,7 +300,9 @@ int plan_partitions(int B, int nkv, int max_seq_len, int* ps_out) {
 
 } // namespace
 
+#ifdef MI355_TUNING
 extern "C" void mi355_debug_set_attn(int ps) { g_attn_ps_override = ps; }
+#endif
 
 extern "C" size_t mi355_paged_attn_workspace_bytes(int32_t B, int32_t nh, int32_t hd, int32_t max_seq_len) {
     if (B <= 0 || nh <= 0 || hd <= 0 || max_seq_len <= 0) return 0;
@@ -320,6 +327,7 @@ extern "C" int mi355_paged_decode_attn_ex(const void* q, const mi355_kv_layer_t*
     MI355_CHECK_ARG(kv->page >= 16 && kv->page % 8 == 0, "paged_decode_attn: page=%d (>= 16, multiple of 8)", kv->page);
     MI355_CHECK_ARG(B > 0 && nh > 0 && kv->nkv > 0 && nh % kv->nkv == 0 && nh / kv->nkv <= 16,
                     "paged_decode_attn: nh=%d nkv=%d (group <= 16)", nh, kv->nkv);
+    MI355_CHECK_ARG(kv->num_blocks > 0, "paged_decode_attn: num_blocks=%d", kv->num_blocks);
     MI355_CHECK_ARG(max_seq_len > 0 && (long)max_blocks_per_seq * kv->page >= max_seq_len,
                     "paged_decode_attn: max_seq_len=%d exceeds block table", max_seq_len);
     const bool int8 = kv->kv_dtype == MI355_KV_INT8;
@@ -328,6 +336,7 @@ extern "C" int mi355_paged_decode_attn_ex(const void* q, const mi355_kv_layer_t*
     p.q = (const f16*)q; p.kv_base = kv->kv_base; p.scale_base = kv->scale_base; p.block_table = block_table;
     p.seq_lens = seq_lens; p.out = (f16*)out; p.B = B; p.nh = nh; p.nkv = kv->nkv; p.G = nh / kv->nkv;
     p.page = kv->page; p.max_blocks = max_blocks_per_seq; p.seq_add = seq_lens_minus_one ? 1 : 0;
+    p.max_seq = max_seq_len; p.num_blocks = kv->num_blocks;
     p.P = plan_partitions(B, kv->nkv, max_seq_len, &p.PS);
     p.scale_log2 = scale * 1.4426950408889634f;
     const size_t need = p.P > 1 ? (size_t)B * nh * p.P * (kv->hd + 2) * sizeof(float) : 0;

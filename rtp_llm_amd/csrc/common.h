@@ -18,6 +18,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // host-side error plumbing -------------------------------------------------
 void mi355_set_error(const char* fmt, ...);
+int  mi355_raise_dynamic_lds(const void* func, const char* name); // once per (kernel, device); error.cpp
+#define raise_dynamic_lds mi355_raise_dynamic_lds
 
 #define MI355_CHECK_ARG(cond, ...)            \
     do {                                      \

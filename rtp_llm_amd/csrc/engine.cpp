@@ -36,6 +36,7 @@ struct mi355_decoder {
     mi355_step_buffers_t               bufs;
     // carved workspace
     void *resid, *xn, *q_buf, *attn_out, *act, *attn_ws, *argmax_ws;
+    int32_t* oob_count; // tokens refused by the KV writer (stale position / block id)
     float* partials;
     size_t attn_ws_bytes, argmax_ws_bytes, partials_bytes;
     int    B;
@@ -78,7 +79,9 @@ size_t carve_all(mi355_decoder* d, const mi355_model_config_t& c, void* base) {
     void* attn_ws  = cv.take(aw);
     const size_t gw = MB_ * 64 * 8;
     void* argmax_ws = cv.take(gw);
+    void* oob = cv.take(256);
     if (d) {
+        d->oob_count = (int32_t*)oob;
         d->resid = resid; d->xn = xn; d->q_buf = q_buf; d->attn_out = attn_out; d->act = act;
         d->partials = (float*)partials; d->partials_bytes = pbytes; d->attn_ws = attn_ws; d->attn_ws_bytes = aw;
         d->argmax_ws = argmax_ws; d->argmax_ws_bytes = gw;
@@ -133,6 +136,12 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
         mi355_set_error("decoder_create: nh=%d nkv=%d hd=%d unsupported", cfg->nh, cfg->nkv, cfg->hd);
         return nullptr;
     }
+    if (cfg->max_seq_len <= 0 || cfg->max_seq_len > cfg->max_pos || cfg->page <= 0 ||
+        (long)cfg->max_blocks_per_seq * cfg->page < cfg->max_seq_len || cfg->num_blocks <= 0) {
+        mi355_set_error("decoder_create: max_seq_len=%d must be <= max_pos=%d (rotation table) and <= max_blocks_per_seq*page=%ld",
+                        cfg->max_seq_len, cfg->max_pos, (long)cfg->max_blocks_per_seq * cfg->page);
+        return nullptr;
+    }
     const size_t need = carve_all(nullptr, *cfg, nullptr);
     if (!bufs->workspace || bufs->workspace_bytes < need) {
         mi355_set_error("decoder_create: workspace %zu < %zu", bufs->workspace_bytes, need);
@@ -149,6 +158,7 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     carve_all(d, *cfg, bufs->workspace);
     d->xn = bufs->hidden; // the normed hidden state lives in the caller-visible buffer
     d->B = 0; d->cap_stream = nullptr; d->prof_on = false; d->ev_used = 0;
+    if (hipMemset(d->oob_count, 0, 256) != hipSuccess) { mi355_set_error("decoder_create: cannot clear the workspace"); delete d; return nullptr; }
     return d;
 }
 
@@ -185,8 +195,8 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
     RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->xn, B, &L.qkv, d->partials, kMaxSplits, st));
     mi355_kv_layer_t kv = kv_of(d, l);
     RUN(MI355_KC_ROPE_KV, mi355_rope_kv_write(nullptr, d->partials, ns, L.qkv.N_pad, L.qkv_bias, d->model.cos_sin, c.rope_dim,
-                                              d->bufs.positions, d->bufs.block_table, c.max_blocks_per_seq, B, c.nh, &kv,
-                                              d->q_buf, st));
+                                              c.max_pos, d->bufs.positions, d->bufs.block_table, c.max_blocks_per_seq, B, c.nh,
+                                              &kv, d->q_buf, d->oob_count, st));
     RUN(MI355_KC_ATTN, mi355_paged_decode_attn_ex(d->q_buf, &kv, d->bufs.block_table, c.max_blocks_per_seq, d->bufs.positions,
                                                   1, B, c.nh, 1.0f / sqrtf((float)c.hd), c.max_seq_len, d->attn_out,
                                                   d->attn_ws, d->attn_ws_bytes, st));
@@ -293,6 +303,17 @@ extern "C" int mi355_decoder_replay(mi355_decoder_t* d, int32_t B, int32_t nstep
         if (e != hipSuccess) { mi355_set_error("decoder_replay: %s", hipGetErrorString(e)); return MI355_ERR_HIP; }
     }
     return MI355_OK;
+}
+
+extern "C" int64_t mi355_decoder_oob_count(mi355_decoder_t* d, mi355_stream_t stream) {
+    if (!d) { mi355_set_error("decoder_oob_count: null decoder"); return MI355_ERR_ARG; }
+    int32_t v = 0;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
+        hipMemcpy(&v, d->oob_count, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) {
+        mi355_set_error("decoder_oob_count: %s", hipGetErrorString(hipGetLastError()));
+        return MI355_ERR_HIP;
+    }
+    return v;
 }
 
 extern "C" int mi355_decoder_profile(mi355_decoder_t* d, int32_t B, int32_t nsteps, float* out_ms, int32_t* out_launches,

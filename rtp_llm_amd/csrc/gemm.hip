@@ -28,6 +28,10 @@ extern "C" int mi355_gemm_smallm(const void* gp, int wbits, int group_size, int 
 extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int want_partial, int max_splits,
                                mi355_stream_t stream);
 
+#ifdef MI355_TUNING
+int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
 namespace {
 
 // Block shape: NWN "n-waves" share one x tile and own NBW 16-column tiles each (BN = 16*NBW*NWN columns);
@@ -446,7 +450,9 @@ __global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* __res
 // ------------------------------------------------------------------ dispatch
 struct GemmPlan { int cfg, nsplit, cps, bn; };   // cfg: index into the block-shape table below
 
-int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // [1] nsplit override, [2] config override (+1), [4] gemm_smallm: 1 never, 2 also inside the decode step, [5] disable gemm_wide
+// Tuning switches exist only in the MI355_TUNING build (lib/libmi355_decode_tuning.so, used by tools/): the product library
+// has no mutable process-global state.  [1] nsplit override, [2] config override (+1), [4] == 2: gemm_smallm also inside
+// the decode step.  Per-call kernel-family hints travel in the `epilogue` word instead (MI355_HINT_*).
 
 // block shapes: {MB, NBW, NWN, KG}
 //   cfg 0: M<=16, BN=64   (4 n-waves x 2 k-groups)      cfg 1: M<=16, BN=128 (huge N, e.g. lm_head)
@@ -527,7 +533,7 @@ GemmPlan plan_gemm(int M, const mi355_weight_t* w, int max_splits) {
     const int MB = cdiv(M, 16);
     GemmPlan g;
     g.cfg = (MB == 1) ? (NT >= 4096 ? 1 : 5) : (MB == 2 ? 2 : (MB == 3 ? 3 : 4)); // measured best per row-block count
-    if (g_debug[2] > 0) g.cfg = g_debug[2] - 1;
+    if (TUNE(2) > 0) g.cfg = TUNE(2) - 1;
     g.bn = kCfgBN[g.cfg];
     const int blocks_n = cdiv(NT * 16, g.bn);
     static const double t_it_us[5]  = {0.0, 0.8, 1.0, 1.3, 1.5};   // per chunk iteration, by MB
@@ -545,13 +551,13 @@ GemmPlan plan_gemm(int M, const mi355_weight_t* w, int max_splits) {
         if (t < best_t - 1e-9) { best_t = t; best = ns; }
     }
     int nsplit = best;
-    if (g_debug[1] > 0) nsplit = g_debug[1] > max_splits ? max_splits : g_debug[1];
+    if (TUNE(1) > 0) nsplit = TUNE(1) > max_splits ? max_splits : TUNE(1);
     g.cps    = cdiv(KC, nsplit);
     g.nsplit = cdiv(KC, g.cps);
     // Short-K / narrow-N shapes at M > 32 (qkv, o): BN = 256 leaves < 2/3 of the CUs with a block even after the
     // split; the BN = 128 shape (8 n-waves x 1 tile) doubles the block count at the same slab traffic
     // (measured M = 64: qkv 10.97 -> 9.45 us, o 10.91 -> 9.17 us; down stays on BN = 256, 21.0 vs 23.2 us).
-    if (MB >= 3 && g_debug[2] == 0 && w->wbits != 16 && blocks_n * g.nsplit <= 160) {
+    if (MB >= 3 && TUNE(2) == 0 && w->wbits != 16 && blocks_n * g.nsplit <= 160) {
         g.cfg = 8;
         g.bn  = kCfgBN[8];
     }
@@ -567,12 +573,14 @@ extern "C" int mi355_gemm_plan(int M, const mi355_weight_t* w, int max_splits, i
     return g.nsplit;
 }
 
-// Tuning / experiment hook (tools/gemm_bench.py); not part of the public ABI.
+#ifdef MI355_TUNING
+// Tuning / experiment hook (tools/gemm_bench.py); only in the tuning build, not part of the ABI.
 extern int g_wide_dbg;
 extern "C" void mi355_debug_set(int key, int value) {
     if (key == 0) g_wide_dbg = value;
-    if (key >= 0 && key < 8) g_debug[key] = value;
+    if (key >= 0 && key < 8) g_tune[key] = value;
 }
+#endif
 
 extern "C" size_t mi355_linear_workspace_bytes(int32_t M, const mi355_weight_t* w) {
     if (!w || M <= 0) return 0;
@@ -593,12 +601,12 @@ extern "C" int mi355_linear_partial(const void* x, int32_t M, const mi355_weight
     GemmParams p; fill_params(p, x, M, w);
     p.mode = MODE_PARTIAL; p.partials = partials;
     // (gemm_smallm.hip is not used here: inside the decode step, where the consumer kernel folds the slabs anyway,
-    // it measured 3-8 % behind the staged kernel -- b=1 linears 1.55 vs 1.48 ms/step; g_debug[4] = 2 re-enables it)
-    if (M <= 8 && w->wbits != 16 && g_debug[4] == 2) {
+    // it measured 3-8 % behind the staged kernel -- b=1 linears 1.55 vs 1.48 ms/step; tuning switch 4 = 2 re-enables it)
+    if (M <= 8 && w->wbits != 16 && TUNE(4) == 2) {
         const int rc = mi355_gemm_smallm(&p, w->wbits, w->group_size, 1, max_splits, stream);
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
-    if (M > 16 && w->wbits != 16 && !g_debug[5]) { // register-resident activations, K split over the waves (gemm_wide.hip)
+    if (M > 16 && w->wbits != 16 && !TUNE(5)) { // register-resident activations, K split over the waves (gemm_wide.hip)
         const int rc = mi355_gemm_wide(&p, w->wbits, w->group_size, 1, max_splits, stream);
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
@@ -620,7 +628,7 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
     for (int m0 = 0; m0 < M; m0 += 64) {
         const int Mc = (M - m0) > 64 ? 64 : (M - m0);
         GemmParams p; fill_params(p, (const f16*)x + (size_t)m0 * w->K, Mc, w);
-        if (Mc <= 8 && w->wbits != 16 && g_debug[4] != 1) { // persistent x-resident kernel: fused epilogue, no slabs, no
+        if (Mc <= 8 && w->wbits != 16 && !(epilogue & MI355_HINT_NO_PERSISTENT) && TUNE(4) != 1) { // persistent x-resident kernel: fused epilogue, no slabs, no
                                                              // reduce launch (stand-alone call: qkv 9.1 vs 14.6 us at M = 1)
             GemmParams ps; fill_params(ps, (const f16*)x + (size_t)m0 * w->K, Mc, w);
             ps.mode = mode; ps.bias = (const f16*)bias; ps.y = (char*)y + (size_t)m0 * ldy * ysz; ps.ldy = ldy;
@@ -628,7 +636,7 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
             if (rc >= 0) continue;
             if (rc != MI355_ERR_UNSUPPORTED) return rc;
         }
-        if (Mc > 16 && w->wbits != 16 && !g_debug[5]) {
+        if (Mc > 16 && w->wbits != 16 && !(epilogue & MI355_HINT_STAGED) && !TUNE(5)) {
             GemmParams ps; fill_params(ps, (const f16*)x + (size_t)m0 * w->K, Mc, w);
             ps.mode = mode; ps.bias = (const f16*)bias; ps.y = (char*)y + (size_t)m0 * ldy * ysz; ps.ldy = ldy;
             const int rc = mi355_gemm_wide(&ps, w->wbits, w->group_size, 0, 1, stream);
@@ -669,12 +677,12 @@ extern "C" int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_
     GemmParams p; fill_params(p, x, M, w);
     p.mode = mode; p.bias = (const f16*)bias; p.y = y;
     p.ldy = (mode == MODE_SILU) ? w->N / 2 : w->N;
-    if (M <= 8 && w->wbits != 16 && g_debug[4] == 2) {
+    if (M <= 8 && w->wbits != 16 && TUNE(4) == 2) {
         const int rc = mi355_gemm_smallm(&p, w->wbits, w->group_size, 0, 1, stream);
         if (rc >= 0) return MI355_OK;
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
-    if (M > 16 && w->wbits != 16 && !g_debug[5]) {
+    if (M > 16 && w->wbits != 16 && !(epilogue & MI355_HINT_STAGED) && !TUNE(5)) {
         const int rc = mi355_gemm_wide(&p, w->wbits, w->group_size, 0, 1, stream);
         if (rc >= 0) return MI355_OK;
         if (rc != MI355_ERR_UNSUPPORTED) return rc;

@@ -204,15 +204,7 @@ template <int WBITS, int GS>
 int launch_t(const SmallMParams& sp, size_t lds, hipStream_t st) {
     constexpr int NW = 16, D = 4;
     auto k = gemm_smallm_kernel<WBITS, GS, D, NW>;
-    static bool attr_set = false;
-    if (!attr_set) { // allow > 64 KiB of dynamic LDS
-        const hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            mi355_set_error("%s: cannot raise the dynamic LDS limit: %s", "gemm_smallm", hipGetErrorString(e));
-            return MI355_ERR_HIP;
-        }
-        attr_set = true;
-    }
+    if (int e = raise_dynamic_lds((const void*)k, "gemm_smallm")) return e; // allow > 64 KiB of dynamic LDS
     hipLaunchKernelGGL(k, dim3(sp.GT, sp.g.nsplit), dim3(64 * NW), lds, st, sp);
     MI355_CHECK_LAUNCH("gemm_smallm_kernel");
     return MI355_OK;

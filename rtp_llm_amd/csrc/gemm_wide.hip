@@ -299,15 +299,7 @@ int launch_wide_t(const WideParams& wp, hipStream_t st) {
     auto k = gemm_wide_kernel<WBITS, MB, GS, T, DBG>;
     constexpr size_t red_b = (size_t)8 * 3 * MB * 1024, stage_b = (size_t)2 * 4 * 4 * MB * 1024;
     constexpr size_t lds = red_b > stage_b ? red_b : stage_b;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            mi355_set_error("%s: cannot raise the dynamic LDS limit: %s", "gemm_wide", hipGetErrorString(e));
-            return MI355_ERR_HIP;
-        }
-        attr_set = true;
-    }
+    if (int e = raise_dynamic_lds((const void*)k, "gemm_wide")) return e;
     hipLaunchKernelGGL(k, dim3(wp.G, wp.g.nsplit), dim3(512), lds, st, wp);
     MI355_CHECK_LAUNCH("gemm_wide_kernel");
     return MI355_OK;
@@ -315,10 +307,16 @@ int launch_wide_t(const WideParams& wp, hipStream_t st) {
 
 } // namespace
 
+#ifdef MI355_TUNING   // experiment switches of the tuning build only (tools/gemm_bench.py --var, tools/wide_stamps.py)
 unsigned long long* g_wide_stamps = nullptr; // device buffer for DBG & 4 (mi355_debug_ptr)
-int g_wide_dbg = 0; // experiment switch (tools/gemm_bench.py --var): 1 no activation reloads, 2 no weight refills, 3 both
-
+int g_wide_dbg = 0; // 1 no activation reloads, 2 no weight refills, 3 both, 4 per-wave timestamps, +8 also for split-K shapes
 extern "C" void mi355_debug_ptr(void* p) { g_wide_stamps = (unsigned long long*)p; }
+#define WIDE_DBG g_wide_dbg
+#define WIDE_STAMPS g_wide_stamps
+#else
+#define WIDE_DBG 0
+#define WIDE_STAMPS nullptr
+#endif
 
 // Plan + launch.  Returns the number of slabs written (partial mode), MI355_OK (direct mode), or
 // MI355_ERR_UNSUPPORTED when the shape does not fit this kernel (the caller falls back to gemm.hip).
@@ -335,7 +333,7 @@ extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int wa
     // Split-K shapes: measured equal or behind the staged-x kernel at M = 64 (short K ranges leave 1-4 phases per wave
     // and the fixed prologue / merge dominates) and for short K at M <= 32 (qkv 9.0 vs 7.5 us); ahead for deep K at
     // M <= 32 (down 14.9 vs 20.0 us).  The rest stays on gemm.hip unless the experiment switch asks otherwise.
-    if (want_partial && !(g.M <= 32 && g.KC >= 64) && g_wide_dbg < 8) return MI355_ERR_UNSUPPORTED;
+    if (want_partial && !(g.M <= 32 && g.KC >= 64) && WIDE_DBG < 8) return MI355_ERR_UNSUPPORTED;
     if (want_partial) {
         nsplit = CUS / G;
         if (nsplit > max_splits) nsplit = max_splits;
@@ -347,19 +345,21 @@ extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int wa
     }
     g.cps = (g.KC + nsplit - 1) / nsplit;
     g.nsplit = (g.KC + g.cps - 1) / g.cps;
-    wp.g = g; wp.G = G; wp.stamps = g_wide_stamps;
+    wp.g = g; wp.G = G; wp.stamps = WIDE_STAMPS;
     int rc;
     hipStream_t st = (hipStream_t)stream;
     const bool mb2 = g.M <= 32;
     if (group_size == 64)      rc = mb2 ? launch_wide_t<4, 2, 2, T>(wp, st) : launch_wide_t<4, 4, 2, T>(wp, st);
     else if (group_size == 32) rc = mb2 ? launch_wide_t<4, 2, 1, T>(wp, st) : launch_wide_t<4, 4, 1, T>(wp, st);
-    else if (mb2 && (g_wide_dbg & 7) == 0) rc = launch_wide_t<4, 2, 4, T>(wp, st);
+    else if (mb2 && (WIDE_DBG & 7) == 0) rc = launch_wide_t<4, 2, 4, T>(wp, st);
     else
-        switch (g_wide_dbg & 7) {
+        switch (WIDE_DBG & 7) {
+#ifdef MI355_TUNING
             case 1: rc = launch_wide_t<4, 4, 4, T, 1>(wp, st); break;
             case 2: rc = launch_wide_t<4, 4, 4, T, 2>(wp, st); break;
             case 3: rc = launch_wide_t<4, 4, 4, T, 3>(wp, st); break;
             case 4: rc = launch_wide_t<4, 4, 4, T, 4>(wp, st); break;
+#endif
             default: rc = launch_wide_t<4, 4, 4, T>(wp, st);
         }
     if (rc != MI355_OK) return rc;

@@ -22,7 +22,8 @@ struct RopeParams {
     const float*   cos_sin;
     const int32_t* positions;
     const int32_t* block_table;
-    int            max_blocks, T, nh, nkv, hd, page;
+    int            max_blocks, T, nh, nkv, hd, page, max_pos, num_blocks;
+    int32_t*       oob_count;
     void*          kv_base;
     float*         scale_base;
     int            kv_int8;
@@ -61,7 +62,9 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const RopeParams p) 
         // the QKV linear's output is an fp16 tensor in the reference
         x0 = (float)(f16)x0; x1 = (float)(f16)x1;
     }
-    const int pos = p.positions[t];
+    const int pos_in = p.positions[t];
+    const int pos_lim = min(p.max_pos, p.max_blocks * p.page);
+    const int pos = min(max(pos_in, 0), pos_lim - 1);       // clamped: the rotation table and the block table stay in range
     const bool is_v = h >= p.nh + p.nkv;
     if (!is_v && act) {
         const float2 cs = *reinterpret_cast<const float2*>(p.cos_sin + ((size_t)pos * half + lane) * 2);
@@ -79,6 +82,10 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const RopeParams p) 
     // ---- K / V into the paged cache
     const int kh  = is_v ? h - p.nh - p.nkv : h - p.nh;
     const int blk = p.block_table[(size_t)t * p.max_blocks + pos / p.page];
+    if (pos != pos_in || blk < 0 || blk >= p.num_blocks) {   // stale position / block id: never write somebody else's page
+        if (h == p.nh && lane == 0 && p.oob_count) atomicAdd(p.oob_count, 1);
+        return;
+    }
     const int tok = pos % p.page;
     const size_t head_elems = (size_t)p.page * p.hd;
     const size_t blk_base   = ((size_t)blk * 2 + (is_v ? 1 : 0)) * p.nkv + kh; // in units of heads
@@ -107,14 +114,16 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const RopeParams p) 
 } // namespace
 
 extern "C" int mi355_rope_kv_write(const void* qkv_f16, const float* partials, int32_t nsplit, int32_t ld,
-                                   const void* qkv_bias, const float* cos_sin, int32_t rope_dim, const int32_t* positions,
-                                   const int32_t* block_table, int32_t max_blocks_per_seq, int32_t T, int32_t nh,
-                                   const mi355_kv_layer_t* kv, void* q_out, mi355_stream_t stream) {
+                                   const void* qkv_bias, const float* cos_sin, int32_t rope_dim, int32_t max_pos,
+                                   const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq,
+                                   int32_t T, int32_t nh, const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count,
+                                   mi355_stream_t stream) {
     MI355_CHECK_ARG((qkv_f16 != nullptr) != (partials != nullptr), "rope_kv_write: exactly one of qkv_f16 / partials");
     MI355_CHECK_ARG(kv && kv->kv_base && cos_sin && positions && block_table && q_out, "rope_kv_write: null pointer");
     MI355_CHECK_ARG(kv->hd == 64 || kv->hd == 128, "rope_kv_write: hd=%d (64 or 128)", kv->hd);
     MI355_CHECK_ARG(rope_dim == kv->hd, "rope_kv_write: rope_dim=%d must equal hd=%d", rope_dim, kv->hd);
-    MI355_CHECK_ARG(kv->page > 0 && T > 0 && nh > 0 && kv->nkv > 0, "rope_kv_write: bad dims");
+    MI355_CHECK_ARG(kv->page > 0 && T > 0 && nh > 0 && kv->nkv > 0 && max_pos > 0 && max_blocks_per_seq > 0 && kv->num_blocks > 0,
+                    "rope_kv_write: bad dims");
     MI355_CHECK_ARG(kv->kv_dtype == MI355_KV_FP16 || (kv->kv_dtype == MI355_KV_INT8 && kv->scale_base),
                     "rope_kv_write: int8 cache needs scale_base");
     const int nheads = nh + 2 * kv->nkv;
@@ -123,6 +132,7 @@ extern "C" int mi355_rope_kv_write(const void* qkv_f16, const float* partials, i
     p.qkv = (const f16*)qkv_f16; p.partials = partials; p.nsplit = nsplit; p.ld = ld; p.bias = (const f16*)qkv_bias;
     p.cos_sin = cos_sin; p.positions = positions; p.block_table = block_table; p.max_blocks = max_blocks_per_seq;
     p.T = T; p.nh = nh; p.nkv = kv->nkv; p.hd = kv->hd; p.page = kv->page; p.kv_base = kv->kv_base;
+    p.max_pos = max_pos; p.num_blocks = kv->num_blocks; p.oob_count = oob_count;
     p.scale_base = kv->scale_base; p.kv_int8 = kv->kv_dtype == MI355_KV_INT8; p.q_out = (f16*)q_out;
     hipLaunchKernelGGL(rope_kv_write_kernel, dim3(T, cdiv(nheads, 4)), dim3(256), 0, (hipStream_t)stream, p);
     MI355_CHECK_LAUNCH("rope_kv_write_kernel");

@@ -54,6 +54,7 @@ class _PackedLinear(LinearBase):
     """Common forward: one C-ABI call on the packed weight (bias fused in the GEMM epilogue,
     as the reference applies Qwen2's QKV bias inside the linear, causal_attention.py:42-51)."""
     packed: PackedWeight
+    kernel_hints: int = 0   # _C.HINT_* bits forwarded with every call (A/B tests); 0 = let the library choose
 
     def _finish_init(self, packed: PackedWeight, bias: Optional[torch.Tensor]):
         self.packed = packed
@@ -61,12 +62,12 @@ class _PackedLinear(LinearBase):
         self.in_features, self.out_features = packed.K, packed.N
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
-        return ops.linear(input.contiguous(), self.packed, self.bias)
+        return ops.linear(input.contiguous(), self.packed, self.bias, epilogue=self.kernel_hints)
 
     def forward_silu_mul(self, input: torch.Tensor) -> torch.Tensor:
         """gate_up projection + SiLU-gate in one kernel; requires interleaved (gate, up) columns."""
         assert getattr(self, "gate_up_interleaved", False), "weight was not packed with interleaved gate/up columns"
-        return ops.linear(input.contiguous(), self.packed, self.bias, epilogue=_C.EPI_SILU_MUL)
+        return ops.linear(input.contiguous(), self.packed, self.bias, epilogue=_C.EPI_SILU_MUL | self.kernel_hints)
 
 
 class Mi355F16Linear(_PackedLinear):

@@ -64,7 +64,7 @@ def linear(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None
     M = x.numel() // w.K
     if x.shape[-1] != w.K:
         raise _C.Mi355Error(f"linear: x last dim {x.shape[-1]} != K {w.K}")
-    n_out = w.N // 2 if epilogue & _C.EPI_SILU_MUL else w.N
+    n_out = w.N // 2 if epilogue & _C.EPI_SILU_MUL else w.N   # (HINT_* bits of `epilogue` only select the kernel family)
     dt = torch.float32 if epilogue & _C.EPI_OUT_F32 else torch.float16
     if out is None:
         out = torch.empty(*x.shape[:-1], n_out, dtype=dt, device=x.device)
@@ -160,16 +160,18 @@ def rejection_sample(draft_token_ids: torch.Tensor, target_token_ids: torch.Tens
 # ------------------------------------------------------------------ attention
 def rope_kv_write(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], cos_sin: torch.Tensor, positions: torch.Tensor,
                   block_table: torch.Tensor, kv_base: torch.Tensor, scale_base: Optional[torch.Tensor], nh: int, nkv: int,
-                  hd: int, page: int) -> torch.Tensor:
-    """RoPE + bias + Q-extract + paged KV write for decode tokens; returns q [T, nh, hd]."""
+                  hd: int, page: int, oob_count: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """RoPE + bias + Q-extract + paged KV write for decode tokens; returns q [T, nh, hd].  Tokens with a position or
+    block id out of range are not written; `oob_count` (int32 [1], device) counts them."""
     _chk(qkv, torch.float16, "rope_kv_write.qkv"); _chk(cos_sin, torch.float32, "rope_kv_write.cos_sin")
     _chk(positions, torch.int32, "rope_kv_write.positions"); _chk(block_table, torch.int32, "rope_kv_write.block_table")
     T = qkv.shape[0]
     q_out = torch.empty(T, nh, hd, dtype=torch.float16, device=qkv.device)
     kv = kv_struct(kv_base, scale_base, page, nkv, hd)
     _C.check(_C.lib().mi355_rope_kv_write(qkv.data_ptr(), None, 0, qkv.shape[1], _p(qkv_bias), cos_sin.data_ptr(), hd,
-                                          positions.data_ptr(), block_table.data_ptr(), block_table.shape[1], T, nh,
-                                          C.byref(kv), q_out.data_ptr(), _stream()), "rope_kv_write")
+                                          cos_sin.shape[0], positions.data_ptr(), block_table.data_ptr(),
+                                          block_table.shape[1], T, nh, C.byref(kv), q_out.data_ptr(), _p(oob_count), _stream()),
+             "rope_kv_write")
     return q_out
 
 

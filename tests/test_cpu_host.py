@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mi355_decode.h but not exported"
     assert set(declared) == set(_C.SIGNATURES), "ctypes SIGNATURES out of sync with the header"
-    assert _C.lib().mi355_abi_version() == 1
+    assert _C.lib().mi355_abi_version() == _C.ABI_VERSION
 
 
 def test_argument_errors_are_reported_without_a_gpu():

@@ -1,0 +1,149 @@
+"""GPU parity at the BASELINE.json shapes, against the CPU oracle directly (no property stand-ins).
+
+  * every linear of Qwen2-7B and Llama-3-70B (W4 g128; Qwen2-7B also W8 per-channel) at the batch heights where the
+    kernel selection changes (M = 1, 8, 16, 17, 32, 33, 48, 64): HIP GEMM vs oracle.linear on the dequantised weights;
+  * a full-width 2-layer Qwen2-7B engine step, hipGraph-replayed, against oracle.OracleDecoder:
+      - W4 g128, B = 64, ctx 1024, fp16 KV        (the configuration BASELINE.json's metric is quoted on)
+      - W4 g128, B = 64, ctx 4096, INT8 KV        (configs[2])
+      - W8 per-channel, B = 16, ctx 1024, fp16 KV (configs[1])
+    logits within 1e-2 (north_star's tolerance), greedy ids identical wherever the oracle's top-2 margin exceeds it.
+
+The oracle computes M = 64 rows once per weight and every smaller M is checked against its leading rows (rows of a GEMM
+are independent), so the CPU side stays at a few seconds per shape.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import oracle
+from rtp_llm_amd import _C, kvcache, model, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = dict(atol=1e-2, rtol=1e-2)
+MS = (1, 8, 16, 17, 32, 33, 48, 64)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_native():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    _C.lib()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+
+
+def _dense(c):
+    if c.kind == "fp16":
+        return c.w.float()
+    if c.kind == "int8":
+        return oracle.dequant_int8(c.q, c.scales)
+    return oracle.dequant_groupwise(c.q, c.z_eff, c.scales, c.group_size)
+
+
+def _shapes(cfg):
+    qkv = (cfg.nh + 2 * cfg.nkv) * cfg.hd
+    return {"qkv": (cfg.hidden, qkv), "o": (cfg.nh * cfg.hd, cfg.hidden), "gate_up": (cfg.hidden, 2 * cfg.inter),
+            "down": (cfg.inter, cfg.hidden)}
+
+
+LINEAR_CASES = [(m, k, name) for m, kinds in ((model.QWEN2_7B, ("w4", "int8")), (model.LLAMA3_70B, ("w4",)))
+                for k in kinds for name in ("qkv", "o", "gate_up", "down")]
+
+
+@pytest.mark.parametrize("cfg,kind,name", LINEAR_CASES, ids=[f"{m.name}-{k}-{n}" for m, k, n in LINEAR_CASES])
+def test_linear_baseline_shape_vs_oracle(cfg, kind, name):
+    K, N = _shapes(cfg)[name]
+    gen = torch.Generator(device=DEV).manual_seed(K * 7 + N)
+    c_dev = model.synth_linear(K, N, kind, DEV, gen)
+    packed = c_dev.pack(gate_up=(name == "gate_up"))
+    c = model.weights_to({"w": c_dev}, "cpu")["w"]
+    W = _dense(c)
+    del c
+    x = (torch.randn(64, K, generator=torch.Generator().manual_seed(3)) * 0.5).half()
+    bias = (torch.randn(N, generator=torch.Generator().manual_seed(4)) * 0.1).half() if name == "qkv" else None
+    ref = oracle.linear(x, W, bias)
+    if name == "gate_up":
+        ref = oracle.silu_mul(ref)
+    del W
+    xd, bd = x.to(DEV), None if bias is None else bias.to(DEV)
+    for M in MS:
+        y = ops.linear(xd[:M].contiguous(), packed, bd, epilogue=_C.EPI_SILU_MUL if name == "gate_up" else _C.EPI_NONE)
+        torch.cuda.synchronize()
+        err = (y.cpu().float() - ref[:M].float()).abs().max()
+        assert torch.allclose(y.cpu().float(), ref[:M].float(), **TOL), f"{name} M={M}: max err {err}"
+
+
+def test_linear_partial_slabs_baseline_shapes_vs_oracle():
+    """The split-K entry the step driver uses for qkv / o / down (fp32 slabs summed by the consumer): the slab sum must be
+    the oracle's fp32 product at the Qwen2-7B shapes for every batch height class."""
+    import ctypes as C
+    cfg = model.QWEN2_7B
+    for name in ("qkv", "o", "down"):
+        K, N = _shapes(cfg)[name]
+        c_dev = model.synth_linear(K, N, "w4", DEV, torch.Generator(device=DEV).manual_seed(11 + K))
+        packed = c_dev.pack()
+        W = _dense(model.weights_to({"w": c_dev}, "cpu")["w"])
+        x = (torch.randn(64, K, generator=torch.Generator().manual_seed(5)) * 0.5).half()
+        ref = x.float() @ W
+        ws = ops.weight_struct(packed)
+        slabs = torch.zeros(16, 64, packed.N_pad, dtype=torch.float32, device=DEV)
+        for M in MS:
+            slabs.fill_(float("nan"))
+            ns = _C.lib().mi355_linear_partial(x[:M].to(DEV).contiguous().data_ptr(), M, C.byref(ws), slabs.data_ptr(), 16,
+                                               torch.cuda.current_stream().cuda_stream)
+            assert ns >= 1, _C.lib().mi355_last_error()
+            got = slabs.view(-1)[: ns * M * packed.N_pad].view(ns, M, packed.N_pad).sum(0)[:, :N].cpu()
+            assert torch.allclose(got, ref[:M], atol=5e-3, rtol=2e-3), f"{name} M={M} ns={ns}: {(got - ref[:M]).abs().max()}"
+
+
+# ------------------------------------------------------------------ full-width engine step
+def _oracle_weights(w):
+    return {"embedding": w["embedding"], "final_norm": w["final_norm"], "lm_head": _dense(w["lm_head"]),
+            "layers": [{"input_norm": L["input_norm"], "post_norm": L["post_norm"], "qkv_bias": L["qkv_bias"],
+                        **{k: _dense(L[k]) for k in ("qkv", "o", "gate_up", "down")}} for L in w["layers"]]}
+
+
+@pytest.mark.parametrize("kind,kv_int8,B,ctx", [("w4", False, 64, 1024), ("w4", True, 64, 4096), ("int8", False, 16, 1024)],
+                         ids=["w4-b64-ctx1024-kvf16", "w4-b64-ctx4096-kvint8", "w8-b16-ctx1024-kvf16"])
+def test_engine_full_width_step_vs_oracle(kind, kv_int8, B, ctx):
+    cfg = model.ModelConfig("qwen2-7b-2l", 2, 3584, 28, 4, 128, 18944, 152064, max_pos=ctx + 16)
+    w_dev = model.synth_model(cfg, kind, DEV, seed=21)
+    w = model.weights_to(w_dev, "cpu")
+    page, steps = 16, 2
+    mb = (ctx + steps + page - 1) // page
+    eng = model.DecoderEngine(cfg, w_dev, kv_int8=kv_int8, page=page, num_blocks=B * mb, max_batch=B,
+                              max_seq_len=ctx + steps, device=DEV)
+    del w_dev
+    odec = oracle.OracleDecoder({**cfg.__dict__}, _oracle_weights(w))
+    okv = oracle.OracleKV(cfg.num_layers, B, kv_int8)
+    g = torch.Generator().manual_seed(5)
+    bt = torch.randperm(B * mb, generator=g).reshape(B, mb).to(torch.int32)
+    # the same ctx-1 cached tokens on both sides ("allocate KV without prefill", the reference's batch-decode protocol)
+    for l in range(cfg.num_layers):
+        for b in range(B):
+            K = torch.randn(ctx - 1, cfg.nkv, cfg.hd, generator=g).half()
+            V = torch.randn(ctx - 1, cfg.nkv, cfg.hd, generator=g).half()
+            if kv_int8:
+                Kq, ks = oracle.quant_kv_int8(K); Vq, vs = oracle.quant_kv_int8(V)
+                kvcache.write_tokens(eng.kv[l], eng.kv_scale[l], bt[b], 0, Kq, Vq, ks, vs)
+                okv.k[l][b], okv.v[l][b], okv.ks[l][b], okv.vs[l][b] = list(Kq), list(Vq), list(ks), list(vs)
+            else:
+                kvcache.write_tokens(eng.kv[l], None, bt[b], 0, K, V)
+                okv.k[l][b], okv.v[l][b] = list(K), list(V)
+    tok = torch.randint(0, cfg.vocab, (B,), generator=g, dtype=torch.int32)
+    eng.set_inputs(tok.tolist(), [ctx - 1] * B, bt)
+    eng.capture(B)
+    for step in range(steps):
+        pos = torch.full((B,), ctx - 1 + step, dtype=torch.int32)
+        _, ref_logits = odec.forward_tokens(tok, pos, okv, list(range(B)))
+        eng.replay(B, 1)
+        torch.cuda.synchronize()
+        got = eng.logits[:B].cpu()
+        assert torch.allclose(got, ref_logits, **TOL), (step, float((got - ref_logits).abs().max()))
+        ref_next = oracle.greedy(ref_logits)
+        top2 = ref_logits.topk(2, dim=-1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-2
+        assert int(safe.sum()) >= B // 2
+        assert torch.equal(eng.token_ids[:B].cpu()[safe], ref_next[safe])
+        tok = ref_next
+        eng.token_ids[:B].copy_(tok)

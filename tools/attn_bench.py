@@ -3,6 +3,7 @@
 usage: attn_bench.py [--batch 64 --ctx 1024 --int8 --ps N]"""
 import argparse, ctypes as C, os, sys
 import torch
+os.environ["MI355_TUNING_LIB"] = "1"   # experiment switches live in the tuning build only (python -m rtp_llm_amd.build --tuning)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rtp_llm_amd import _C, kvcache, ops  # noqa: E402
 

@@ -9,6 +9,7 @@ import sys
 
 import torch
 
+os.environ["MI355_TUNING_LIB"] = "1"   # experiment switches live in the tuning build only (python -m rtp_llm_amd.build --tuning)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rtp_llm_amd import _C, model, ops  # noqa: E402
 

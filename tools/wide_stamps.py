@@ -3,6 +3,7 @@
 prologue, after the main loop and at the end (debug variant 4).  usage: wide_stamps.py [K]"""
 import ctypes as C, os, sys
 import torch
+os.environ["MI355_TUNING_LIB"] = "1"   # experiment switches live in the tuning build only (python -m rtp_llm_amd.build --tuning)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rtp_llm_amd import _C, model, ops
 
