@@ -231,6 +231,11 @@ int mi355_argmax(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t*
  * mi355_softmax_rows: probs[r][:] = softmax(logits[r][:] / temperature) in fp32 (the rows the sampler hands over). */
 int mi355_softmax_rows(const float* logits, int32_t rows, int32_t V, int32_t ld, float temperature, float* probs,
                        mi355_stream_t stream);
+/* ids[r] = first index whose inclusive fp32 prefix sum of probs[r, :] (index order) exceeds uniform_samples[r] * sum --
+ * sampling from the probabilities, the top_k = 0 / top_p = 1 branch of the sampler (bindings/core/CudaSampleOp.cc:702-737);
+ * gives the target model's own sampled token per verify row (target_token_ids of mi355_rejection_sample). */
+int mi355_sample_rows(const float* probs, int32_t rows, int32_t V, int32_t ld, const float* uniform_samples, int32_t* ids,
+                      mi355_stream_t stream);
 int mi355_rejection_sample(const float* draft_probs, const int32_t* draft_token_ids, const float* uniform_samples,
                            const float* target_probs, const int32_t* target_token_ids, int32_t target_token_stride,
                            int32_t* output_token_ids, int32_t* output_accepted_token_num, const uint8_t* do_sample,

@@ -259,6 +259,27 @@ def rejection_sample(draft_token_ids, target_token_ids, target_probs, uniform_sa
     return torch.from_numpy(out), torch.from_numpy(acc)
 
 
+def sample_rows(probs, uniform):
+    """ids[r] = first index whose inclusive fp32 prefix sum of probs[r] (index order) exceeds uniform[r] * sum(probs[r]) --
+    sampling from the probabilities (bindings/core/CudaSampleOp.cc:702-737, top_k = 0 / top_p = 1 branch)."""
+    import numpy as np
+    q = np.asarray(probs, dtype=np.float32); u = np.asarray(uniform, dtype=np.float32)
+    out = np.zeros(q.shape[0], dtype=np.int32)
+    for r in range(q.shape[0]):
+        total = np.float32(0)
+        for x in q[r]:
+            total = np.float32(total + max(x, np.float32(0)))
+        thr, c, found = np.float32(u[r] * total), np.float32(0), q.shape[1] - 1
+        for j, x in enumerate(q[r]):
+            x = max(x, np.float32(0))
+            c = np.float32(c + x)
+            if x > 0 and c > thr:
+                found = j
+                break
+        out[r] = found
+    return torch.from_numpy(out)
+
+
 def softmax_rows(logits: torch.Tensor, temperature: float = 1.0) -> torch.Tensor:
     """softmax(logits / T) per row in fp32 (the distribution handed to rejection sampling)."""
     return torch.softmax(logits.float() / temperature, dim=-1)

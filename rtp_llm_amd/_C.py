@@ -69,6 +69,7 @@ SIGNATURES = {
     "mi355_paged_decode_attn": (i32, [vp, C.POINTER(KVLayer), vp, i32, vp, i32, i32, f32, i32, vp, vp, sz, vp]),
     "mi355_argmax": (i32, [vp, i32, i32, i32, vp, vp, sz, vp]),
     "mi355_softmax_rows": (i32, [vp, i32, i32, i32, f32, vp, vp]),
+    "mi355_sample_rows": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "mi355_rejection_sample": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mi355_decoder_workspace_bytes": (sz, [C.POINTER(ModelConfig)]),
     "mi355_decoder_create": (vp, [C.POINTER(ModelConfig), C.POINTER(LayerWeights), C.POINTER(ModelWeights), C.POINTER(StepBuffers)]),

@@ -30,6 +30,43 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
     return r;
 }
 
+// Inverse-CDF draw from the unnormalised non-negative weights f(0..V-1): the first index j with f(j) > 0 whose inclusive
+// prefix sum, taken in index order, exceeds u01 * sum (V - 1 when rounding leaves none: sampling.cu:418).  Thread tx owns
+// the contiguous segment [lo, hi), so the block-level prefix over threads is the prefix over indices.  Result in *s_found
+// (valid for every thread after the call).
+template <class F>
+__device__ __forceinline__ void block_draw(F&& f, int V, float u01, float* s_red, float* s_scan, int* s_found) {
+    const int tx = threadIdx.x;
+    const int seg = (V + kThreads - 1) / kThreads;
+    const int lo = min(V, tx * seg), hi = min(V, lo + seg);
+    float local = 0.f;
+    for (int j = lo; j < hi; ++j) local += f(j);
+    const float total = block_sum(local, s_red);
+    const float u = u01 * total;
+    // inclusive prefix over threads (Hillis-Steele in LDS; 1024 entries)
+    s_scan[tx] = local;
+    if (tx == 0) *s_found = V - 1;
+    __syncthreads();
+    for (int off = 1; off < kThreads; off <<= 1) {
+        const float add = (tx >= off) ? s_scan[tx - off] : 0.f;
+        __syncthreads();
+        s_scan[tx] += add;
+        __syncthreads();
+    }
+    const float incl = s_scan[tx], excl = incl - local;
+    if (local > 0.f && excl <= u && incl > u) {   // the prefix crosses u inside this segment (at most one thread)
+        float c = excl;
+        int found = hi - 1;
+        for (int j = lo; j < hi; ++j) {
+            const float r = f(j);
+            c += r;
+            if (r > 0.f && c > u) { found = j; break; }
+        }
+        *s_found = found;
+    }
+    __syncthreads();
+}
+
 struct RejectParams {
     const float*   draft_probs;
     const int32_t* draft_ids;
@@ -87,39 +124,11 @@ __global__ __launch_bounds__(kThreads) void rejection_sample_kernel(const Reject
     const float* q = p.target_probs + (size_t)(row * G1 + pos) * p.V;
     const float* dp = p.point_mass ? nullptr : p.draft_probs + (size_t)(row * G + pos) * p.V;
     const int dtok = p.draft_ids[row * G + pos];
-    const int seg = (p.V + kThreads - 1) / kThreads;
-    const int lo = min(p.V, tx * seg), hi = min(p.V, lo + seg);
     auto resid = [&](int j) {
         const float pv = dp ? dp[j] : (j == dtok ? 1.0f : 0.0f);
         return fmaxf(q[j] - pv, 0.f);
     };
-    float local = 0.f;
-    for (int j = lo; j < hi; ++j) local += resid(j);
-    const float total = block_sum(local, s_red);
-    const float u = p.uniform[row * G1 + min(pos + 1, G)] * total;
-
-    // exclusive prefix over threads (Hillis-Steele in LDS; 1024 entries)
-    s_scan[tx] = local;
-    if (tx == 0) s_found = p.V - 1;     // "init the first rejected token to vocab_size - 1" (sampling.cu:418)
-    __syncthreads();
-    for (int off = 1; off < kThreads; off <<= 1) {
-        const float add = (tx >= off) ? s_scan[tx - off] : 0.f;
-        __syncthreads();
-        s_scan[tx] += add;
-        __syncthreads();
-    }
-    const float incl = s_scan[tx], excl = incl - local;
-    if (local > 0.f && excl <= u && incl > u) {   // the prefix crosses u inside this segment (at most one thread)
-        float c = excl;
-        int found = hi - 1;
-        for (int j = lo; j < hi; ++j) {
-            const float r = resid(j);
-            c += r;
-            if (r > 0.f && c > u) { found = j; break; }
-        }
-        s_found = found;
-    }
-    __syncthreads();
+    block_draw(resid, p.V, p.uniform[row * G1 + min(pos + 1, G)], s_red, s_scan, &s_found);
     if (tx == 0) {
         p.out_ids[row * G1 + pos] = s_found;
         for (int n = pos + 1; n < G1; ++n) p.out_ids[row * G1 + n] = -1;
@@ -148,7 +157,27 @@ __global__ __launch_bounds__(kThreads) void softmax_rows_kernel(const float* __r
     for (int j = threadIdx.x; j < V; j += kThreads) y[j] = __expf((x[j] - m) * inv_temp) * inv;
 }
 
+// ids[r] = inverse-CDF sample of probs[r, :] with uniform[r] (the top_k = 0 / top_p = 1 branch of the sampler:
+// softmax, then sampling from the probabilities, bindings/core/CudaSampleOp.cc:702-737)
+__global__ __launch_bounds__(kThreads) void sample_rows_kernel(const float* __restrict__ probs, int V, int ld,
+                                                               const float* __restrict__ uniform, int32_t* __restrict__ ids) {
+    __shared__ float s_red[kThreads / 64];
+    __shared__ float s_scan[kThreads];
+    __shared__ int   s_found;
+    const float* q = probs + (size_t)blockIdx.x * ld;
+    block_draw([&](int j) { return fmaxf(q[j], 0.f); }, V, uniform[blockIdx.x], s_red, s_scan, &s_found);
+    if (threadIdx.x == 0) ids[blockIdx.x] = s_found;
+}
+
 } // namespace
+
+extern "C" int mi355_sample_rows(const float* probs, int32_t rows, int32_t V, int32_t ld, const float* uniform_samples,
+                                 int32_t* ids, mi355_stream_t stream) {
+    MI355_CHECK_ARG(probs && uniform_samples && ids && rows > 0 && V > 0 && ld >= V, "sample_rows: bad args");
+    hipLaunchKernelGGL(sample_rows_kernel, dim3(rows), dim3(kThreads), 0, (hipStream_t)stream, probs, V, ld, uniform_samples, ids);
+    MI355_CHECK_LAUNCH("sample_rows_kernel");
+    return MI355_OK;
+}
 
 extern "C" int mi355_softmax_rows(const float* logits, int32_t rows, int32_t V, int32_t ld, float temperature, float* probs,
                                   mi355_stream_t stream) {

@@ -9,6 +9,10 @@ The decode-path slice of the reference's loader stack:
     supported — the reference never reads it (SURVEY 8f n2) — and a non-trivial g_idx is rejected here;
   * `--quantization int8`: load-time per-channel autoquant of the fp16 linears (weight_only_quant_weight.py:94-105).
 
+With quantization="int8" the per-channel scales are computed on the full [K, N] weight BEFORE the row-parallel TP split
+(the reference autoquantises each rank's shard; both are valid per-channel quantisations, this one makes every rank's
+codes a slice of the tp = 1 codes).  bf16 / fp32 checkpoint tensors are converted to fp16 at load time.
+
 Pure host code (safetensors + torch on CPU); the result feeds model.DecoderEngine / Qwen2DecoderModel unchanged.
 """
 import json
@@ -60,19 +64,38 @@ def config_from_hf(cfg: dict, name: str = "hf-model") -> Tuple[ModelConfig, dict
                      inter=cfg["intermediate_size"], vocab=cfg["vocab_size"], rope_theta=float(cfg.get("rope_theta", 10000.0)),
                      rms_eps=float(cfg.get("rms_norm_eps", 1e-6)), qkv_bias=False,
                      max_pos=int(cfg.get("max_position_embeddings", 8192)))
+    rs = cfg.get("rope_scaling") or {}
+    if rs and rs.get("rope_type", rs.get("type", "default")) not in ("default", None):
+        raise NotImplementedError(f"rope_scaling={rs}: only the base RoPE style is on this decode path (linear / dynamic / yarn / "
+                                  "llama3 scaling would decode with wrong rotations)")
+    if cfg.get("use_sliding_window"):
+        raise NotImplementedError("sliding-window attention is not on this decode path")
     q = cfg.get("quantization_config") or {}
     qc = {"method": q.get("quant_method", "none"), "bits": int(q.get("bits", 16)), "group_size": int(q.get("group_size", 0)),
           "desc_act": bool(q.get("desc_act", False))}
     return mc, qc
 
 
+def _f16(t: torch.Tensor, name: str) -> torch.Tensor:
+    """Checkpoint tensor -> fp16, the activation type of this path.  bf16 / fp32 checkpoints (Qwen2 ships bf16) are
+    converted once at load time; a value outside the fp16 range would become inf silently, so it is an error."""
+    if t.dtype == torch.float16:
+        return t
+    if t.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError(f"{name}: unsupported tensor dtype {t.dtype}")
+    o = t.to(torch.float16)
+    if not bool(torch.isfinite(o).all()):
+        raise ValueError(f"{name}: {t.dtype} values exceed the fp16 range")
+    return o
+
+
 def _linear_fp16(sh: _Shards, prefix: str) -> CanonLinear:
-    w = sh.get(prefix + ".weight").to(torch.float16)        # HF stores [out, in]
+    w = _f16(sh.get(prefix + ".weight"), prefix)           # HF stores [out, in]
     return CanonLinear("fp16", w.shape[1], w.shape[0], w=w.t().contiguous())
 
 
 def _linear_quant(sh: _Shards, prefix: str, method: str, group_size: int) -> CanonLinear:
-    qw, qz, sc = sh.get(prefix + ".qweight"), sh.get(prefix + ".qzeros"), sh.get(prefix + ".scales").to(torch.float16)
+    qw, qz, sc = sh.get(prefix + ".qweight"), sh.get(prefix + ".qzeros"), _f16(sh.get(prefix + ".scales"), prefix + ".scales")
     if sh.has(prefix + ".g_idx"):
         gidx = sh.get(prefix + ".g_idx")
         K = gidx.numel()
@@ -105,7 +128,7 @@ def load_hf_checkpoint(path: str, quantization: Optional[str] = None, tp: int = 
         return c
 
     def bias(name):
-        return sh.get(name + ".bias").to(torch.float16) if sh.has(name + ".bias") else None
+        return _f16(sh.get(name + ".bias"), name + ".bias") if sh.has(name + ".bias") else None
 
     layers = []
     has_bias = False
@@ -119,20 +142,23 @@ def load_hf_checkpoint(path: str, quantization: Optional[str] = None, tp: int = 
             "gate_up": CanonLinear.cat_cols([lin(p + "mlp.gate_proj"), lin(p + "mlp.up_proj")]),
             "down": lin(p + "mlp.down_proj"),
             "qkv_bias": torch.cat(b).contiguous() if b[0] is not None else None,
-            "input_norm": sh.get(p + "input_layernorm.weight").to(torch.float16),
-            "post_norm": sh.get(p + "post_attention_layernorm.weight").to(torch.float16),
+            "input_norm": _f16(sh.get(p + "input_layernorm.weight"), p + "input_layernorm"),
+            "post_norm": _f16(sh.get(p + "post_attention_layernorm.weight"), p + "post_attention_layernorm"),
         }
         layers.append(split_layer_tp(layer, mc, tp, rank))
-    emb = sh.get(pre + "embed_tokens.weight").to(torch.float16)
+    emb = _f16(sh.get(pre + "embed_tokens.weight"), "embed_tokens")
     if sh.has("lm_head.weight"):
-        head = sh.get("lm_head.weight").to(torch.float16)
+        head = _f16(sh.get("lm_head.weight"), "lm_head")
     else:                                                   # tie_word_embeddings (e.g. Qwen2-0.5B)
         head = emb
-    V = head.shape[0]
+    V = head.shape[0]                                       # padded-vocab checkpoints: the tensor, not config.json, decides
+    if V < mc.vocab or emb.shape[0] < mc.vocab:
+        raise ValueError(f"lm_head / embedding rows ({V}, {emb.shape[0]}) < vocab_size {mc.vocab}")
     if tp > 1:                                              # vocab-split lm_head (PyWrappedModel.cc:915-936)
-        assert V % tp == 0
+        if V % tp:
+            raise ValueError(f"lm_head rows {V} not divisible by tp={tp}")
         head = head[rank * (V // tp):(rank + 1) * (V // tp)]
-    mc = ModelConfig(**{**mc.__dict__, "num_layers": L, "qkv_bias": has_bias})
-    weights = {"layers": layers, "embedding": emb, "final_norm": sh.get(pre + "norm.weight").to(torch.float16),
+    mc = ModelConfig(**{**mc.__dict__, "num_layers": L, "qkv_bias": has_bias, "vocab": V})
+    weights = {"layers": layers, "embedding": emb, "final_norm": _f16(sh.get(pre + "norm.weight"), "norm"),
                "lm_head": CanonLinear("fp16", head.shape[1], head.shape[0], w=head.t().contiguous())}
     return (mc.per_rank(tp) if tp > 1 else mc), weights

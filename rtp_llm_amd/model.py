@@ -48,9 +48,21 @@ class ModelConfig:
         K/V heads split by tp when divisible, utils/model_weight.py:447-466)."""
         if tp == 1:
             return self
-        assert self.nh % tp == 0 and self.nkv % tp == 0 and self.vocab % tp == 0, \
-            f"{self.name}: nh={self.nh} nkv={self.nkv} vocab={self.vocab} not divisible by tp={tp}"
-        return replace(self, nh=self.nh // tp, nkv=self.nkv // tp, inter=self.padded_inter(tp) // tp, vocab=self.vocab // tp)
+        if self.nh % tp or self.vocab % tp or (self.nkv % tp and tp % self.nkv):
+            raise ValueError(f"{self.name}: nh={self.nh} / vocab={self.vocab} must be divisible by tp={tp}, and nkv={self.nkv} "
+                             f"must divide or be divisible by it")
+        return replace(self, nh=self.nh // tp, nkv=self.kv_heads_per_rank(tp), inter=self.padded_inter(tp) // tp,
+                       vocab=self.vocab // tp)
+
+    def kv_heads_per_rank(self, tp: int) -> int:
+        """K/V heads are split by tp while there are enough of them and replicated beyond that (get_sp_tensor splits
+        K/V by gcd(nkv, tp), utils/model_weight.py:447-466): Qwen2-7B (nkv = 4) at tp = 8 keeps one kv head per rank,
+        shared by the two ranks that own its query heads."""
+        return self.nkv // tp if self.nkv >= tp else 1
+
+    def kv_head_of_rank(self, tp: int, rank: int) -> int:
+        """First kv head of `rank` (the only one when heads are replicated)."""
+        return rank * self.nkv // tp
 
     def padded_inter(self, tp: int) -> int:
         """FFN width padded so that every rank gets a whole number of 128-row quantisation groups / K chunks
@@ -192,9 +204,10 @@ def split_layer_tp(layer: Dict, cfg: ModelConfig, tp: int, rank: int) -> Dict:
         return layer
     hd, nh, nkv, I0 = cfg.hd, cfg.nh, cfg.nkv, cfg.inter
     I = cfg.padded_inter(tp)                      # align_size padding: zero columns of gate / up, zero rows of down
-    nh_r, nkv_r, I_r = nh // tp, nkv // tp, I // tp
+    nh_r, nkv_r, I_r = nh // tp, cfg.kv_heads_per_rank(tp), I // tp
     qkv = layer["qkv"]
-    q_lo, k_lo, v_lo = rank * nh_r * hd, nh * hd + rank * nkv_r * hd, (nh + nkv) * hd + rank * nkv_r * hd
+    kv0 = cfg.kv_head_of_rank(tp, rank)           # tp > nkv: the kv head is replicated over tp / nkv ranks
+    q_lo, k_lo, v_lo = rank * nh_r * hd, (nh + kv0) * hd, (nh + nkv + kv0) * hd
     parts = [qkv.cols(q_lo, q_lo + nh_r * hd), qkv.cols(k_lo, k_lo + nkv_r * hd), qkv.cols(v_lo, v_lo + nkv_r * hd)]
     gu, down = layer["gate_up"], layer["down"]
     if I != I0:
@@ -354,6 +367,30 @@ class DecoderEngine:
     def _st(self) -> int:
         return torch.cuda.current_stream().cuda_stream
 
+    def capacity(self, block_table=None) -> int:
+        """Tokens one sequence may hold: bounded by the engine's max_seq_len, the rotation table and the block table."""
+        cap = min(self.max_seq_len, self.cfg.max_pos, self.max_blocks_per_seq * self.page)
+        if block_table is not None:
+            cap = min(cap, int(torch.as_tensor(block_table).shape[1]) * self.page)
+        return cap
+
+    def check_room(self, ctx_lens, new_tokens: int, block_table=None, what: str = "decode"):
+        """Raise before anything is enqueued if some sequence would outgrow its cache (graph replay advances positions on
+        the device, so nothing else would notice; the KV writer drops out-of-range tokens and counts them, see
+        oob_count())."""
+        cap = self.capacity(block_table)
+        worst = max(int(c) for c in ctx_lens) + int(new_tokens)
+        if worst > cap:
+            raise _C.Mi355Error(f"{what}: a sequence would reach {worst} tokens, capacity is {cap} "
+                                f"(max_seq_len {self.max_seq_len}, max_pos {self.cfg.max_pos}, block table {self.max_blocks_per_seq} x {self.page})")
+
+    def oob_count(self) -> int:
+        """Tokens the KV writer refused since creation (stale position / block id).  Synchronises."""
+        n = self.lib.mi355_decoder_oob_count(self.handle, self._st())
+        if n < 0:
+            _C.check(int(n), "decoder_oob_count")
+        return int(n)
+
     # ---- tp = 1
     def step(self, B: int):
         _C.check(self.lib.mi355_decoder_step(self.handle, B, self._st()), "decoder_step")
@@ -376,6 +413,7 @@ class DecoderEngine:
         positions <= p of sequence b, all written by this or an earlier step (rope_kv_write precedes attention).
         This is chunked prefill at decode-kernel efficiency (KV re-read per row) -- SURVEY 8f n4 is the real thing."""
         bt = torch.as_tensor(block_table, dtype=torch.int32)
+        self.check_room([len(pr) for pr in prompts], 0, bt, "ingest")
         rows = [(b, tok, pos) for b, pr in enumerate(prompts) for pos, tok in enumerate(pr[:-1])]
         # a row may only run once all earlier positions of its sequence are in the cache or in the same step: order by
         # position, so every step holds a prefix-closed set
@@ -391,6 +429,7 @@ class DecoderEngine:
         B = len(prompts)
         if B > self.max_batch or any(len(pr) < 1 for pr in prompts):
             raise _C.Mi355Error("generate: batch exceeds max_batch or empty prompt")
+        self.check_room([len(pr) for pr in prompts], max_new_tokens - 1, block_table, "generate")
         ctx = self.ingest(prompts, block_table)
         self.set_inputs([pr[-1] for pr in prompts], ctx, block_table)
         self.capture(B)
@@ -398,7 +437,10 @@ class DecoderEngine:
         for _ in range(max_new_tokens):
             self.replay(B, 1)
             out.append(self.token_ids[:B].clone())
-        return torch.stack(out, 1).cpu().tolist()
+        toks = torch.stack(out, 1).cpu().tolist()
+        if self.oob_count():
+            raise _C.Mi355Error("generate: the KV writer dropped out-of-range tokens (corrupt block table?)")
+        return toks
 
     def capture(self, B: int):
         _C.check(self.lib.mi355_decoder_capture(self.handle, B), "decoder_capture")

@@ -129,6 +129,17 @@ def softmax_rows(logits: torch.Tensor, temperature: float = 1.0) -> torch.Tensor
     return probs
 
 
+def sample_rows(probs: torch.Tensor, uniform: torch.Tensor) -> torch.Tensor:
+    """ids[r] ~ probs[r, :] by inverse CDF with uniform[r] in [0, 1) (fp32 prefix sums in index order)."""
+    _chk(probs, torch.float32, "sample_rows.probs"); _chk(uniform, torch.float32, "sample_rows.uniform")
+    R, V = probs.shape
+    if uniform.numel() != R:
+        raise _C.Mi355Error("sample_rows: one uniform per row")
+    ids = torch.empty(R, dtype=torch.int32, device=probs.device)
+    _C.check(_C.lib().mi355_sample_rows(probs.data_ptr(), R, V, V, uniform.data_ptr(), ids.data_ptr(), _stream()), "sample_rows")
+    return ids
+
+
 def rejection_sample(draft_token_ids: torch.Tensor, target_token_ids: torch.Tensor, target_probs: torch.Tensor,
                      uniform_samples: torch.Tensor, do_sample: torch.Tensor, draft_probs: Optional[torch.Tensor] = None):
     """Chain rejection sampling (bindings/rocm/speculative_sampling/sampling.cu:306): draft_token_ids [B,g] int32,

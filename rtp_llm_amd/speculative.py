@@ -23,7 +23,10 @@ from .model import DecoderEngine
 
 
 class SpeculativeDecoder:
-    """Greedy (or sampled) speculative decoding on two DecoderEngines that share nothing but the token stream.
+    """Greedy or sampled speculative decoding on two DecoderEngines that share nothing but the token stream.  For rows
+    with do_sample set the target's own token at every verify position is SAMPLED from its distribution (the reference
+    hands rejection sampling the target sampler's outputs, SpeculativeSampler.cc:214), so the bonus token after gamma
+    accepted drafts is a sample too and the output distribution is the target's; greedy rows use the argmax.
 
     State per sequence: `last` (newest token, not yet in the target cache), `ctx` (tokens in the target cache), and for
     the draft cache `dctx` plus the list of tokens it has not processed yet (`pending`, ends with `last`)."""
@@ -51,6 +54,12 @@ class SpeculativeDecoder:
         self.tbt = torch.as_tensor(target_block_table, dtype=torch.int32)
         self.dbt = torch.as_tensor(draft_block_table, dtype=torch.int32)
         self.accepted_hist: List[List[int]] = []
+        self._check_room()
+
+    def _check_room(self):
+        """A round writes positions ctx .. ctx + gamma of every sequence in both caches."""
+        self.target.check_room(self.ctx, self.gamma + 1, self.tbt, "speculative verify")
+        self.draft.check_room([d + len(p) for d, p in zip(self.dctx, self.pending)], self.gamma, self.dbt, "speculative draft")
 
     # one engine forward over `rows` = [(sequence, token, position)], logits stay in engine.logits[:len(rows)]
     @staticmethod
@@ -60,10 +69,12 @@ class SpeculativeDecoder:
         eng.forward(len(rows))
 
     def step(self, do_sample: Optional[Sequence[bool]] = None, temperature: float = 1.0,
-             uniform: Optional[torch.Tensor] = None) -> List[List[int]]:
-        """One propose + verify round; returns the tokens emitted per sequence (1 .. gamma + 1 each)."""
+             uniform: Optional[torch.Tensor] = None, uniform_target: Optional[torch.Tensor] = None) -> List[List[int]]:
+        """One propose + verify round; returns the tokens emitted per sequence (1 .. gamma + 1 each).
+        uniform [B, gamma+1]: accept / residual draws; uniform_target [B, gamma+1]: the target's own samples (sampled rows)."""
         B, G = self.B, self.gamma
         dev = self.target.device
+        self._check_room()
         import time
         t_last = [time.perf_counter()]
 
@@ -113,6 +124,11 @@ class SpeculativeDecoder:
         ds = torch.zeros(B, dtype=torch.uint8, device=dev) if do_sample is None else torch.as_tensor(do_sample, device=dev).to(torch.uint8)
         if uniform is None:
             uniform = torch.rand(B, G + 1, device=dev, dtype=torch.float32)
+        if bool(ds.any()):   # sampled rows: the target's token at each position is a draw from its distribution
+            if uniform_target is None:
+                uniform_target = torch.rand(B, G + 1, device=dev, dtype=torch.float32)
+            sampled = ops.sample_rows(probs.reshape(R, -1), uniform_target.to(dev).reshape(R).contiguous()).reshape(B, G + 1)
+            target_ids = torch.where(ds.bool().unsqueeze(1), sampled, target_ids).contiguous()
         out, acc = ops.rejection_sample(draft_ids, target_ids, probs, uniform.to(dev), ds)   # draft = point mass (greedy draft)
         out_l, acc_l = out.tolist(), acc.tolist()
         mark("sample")

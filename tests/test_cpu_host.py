@@ -131,3 +131,31 @@ def test_kvcache_layout_roundtrip_cpu():
     assert kv[5, 0].reshape(2, 16, 64)[1, 3, 10] == K[3, 1, 10]
     assert kv[5, 1].reshape(2, 64, 16)[1, 10, 3] == V[3, 1, 10]
     assert kv[2, 1].reshape(2, 64, 16)[0, 7, 4] == V[16 + 4, 0, 7]
+
+
+def test_kv_head_replication_when_tp_exceeds_kv_heads():
+    """Qwen2-7B (nkv = 4) at tp = 8: one kv head per rank, shared by the two ranks that own its query heads
+    (get_sp_tensor splits K/V by gcd(nkv, tp), utils/model_weight.py:447-466)."""
+    from rtp_llm_amd import model
+    cfg = model.ModelConfig("t", 1, 256, 8, 2, 32, 512, 1024)
+    assert cfg.per_rank(4).nkv == 1 and cfg.per_rank(4).nh == 2 and cfg.per_rank(2).nkv == 1
+    L = model.synth_layer(cfg, "fp16", "cpu", torch.Generator().manual_seed(0))
+    W, b = L["qkv"].w, L["qkv_bias"]
+    for rank in range(4):
+        S = model.split_layer_tp(L, cfg, 4, rank)
+        kvh = rank // 2                                              # ranks (0,1) share kv head 0, (2,3) kv head 1
+        q = W[:, rank * 64:(rank + 1) * 64]
+        k = W[:, 256 + kvh * 32: 256 + (kvh + 1) * 32]
+        v = W[:, 320 + kvh * 32: 320 + (kvh + 1) * 32]
+        assert torch.equal(S["qkv"].w, torch.cat([q, k, v], 1))
+        assert torch.equal(S["qkv_bias"], torch.cat([b[rank * 64:(rank + 1) * 64], b[256 + kvh * 32: 256 + (kvh + 1) * 32],
+                                                     b[320 + kvh * 32: 320 + (kvh + 1) * 32]]))
+    with pytest.raises(ValueError):
+        model.ModelConfig("t", 1, 256, 12, 3, 32, 512, 1024).per_rank(2)   # 3 kv heads over 2 ranks: neither divides
+
+
+def test_oracle_sample_rows_is_inverse_cdf():
+    from oracle import oracle
+    p = torch.tensor([[0.25, 0.0, 0.5, 0.25], [0.0, 0.0, 1.0, 0.0]])
+    assert oracle.sample_rows(p, torch.tensor([0.0, 0.3])).tolist() == [0, 2]
+    assert oracle.sample_rows(p[:1].repeat(4, 1), torch.tensor([0.24, 0.25, 0.74, 0.99])).tolist() == [0, 2, 2, 3]

@@ -107,3 +107,50 @@ def test_greedy_speculative_decoding_is_lossless(same_draft):
         assert all(a == G + 1 for r in spec.accepted_hist for a in r) and rounds == -(-gen // (G + 1))
     else:
         assert rounds > gen // (G + 1)
+
+
+@pytest.mark.parametrize("R,V", [(7, 97), (4, 4099), (3, 152064)])
+def test_sample_rows_matches_oracle_bit_exact(R, V):
+    """Dyadic probabilities (multiples of 2^-12) and uniforms (2^-10): fp32 prefix sums are exact in any order."""
+    case = spec_vectors.random_case(R, 1, V, 7 + R)
+    probs, u = case["target_probs"][:, 0].contiguous(), case["uniform"][:, 0].contiguous()
+    got = ops.sample_rows(probs.to(DEV), u.to(DEV)).cpu()
+    assert torch.equal(got, oracle.sample_rows(probs, u))
+
+
+def test_sampled_speculative_rows_preserve_the_target_distribution():
+    """Rejection sampling fed with the target's SAMPLED tokens (as the reference's SpeculativeSampler does): the first
+    emitted token of a sampled row is distributed as the target's first-position distribution q0 whatever the draft
+    proposes -- accepted draft with probability min(1, q0[d]/p0[d]), residual draw otherwise, and q-samples as bonus.
+    Statistical check over 60k independent rows on a 12-token vocabulary (chi-square-like bound, 5 sigma)."""
+    R, G, V = 60000, 2, 12
+    g = torch.Generator().manual_seed(17)
+    q = torch.softmax(torch.randn(G + 1, V, generator=g) * 1.5, -1)
+    pd = torch.softmax(torch.randn(G, V, generator=g) * 1.5, -1)
+    tp = q.unsqueeze(0).expand(R, G + 1, V).contiguous()
+    dp = pd.unsqueeze(0).expand(R, G, V).contiguous()
+    draft_ids = torch.stack([torch.multinomial(pd[i], R, replacement=True, generator=g) for i in range(G)], 1).int()
+    u = torch.rand(R, G + 1, generator=g)
+    ut = torch.rand(R * (G + 1), generator=g)
+    target_ids = ops.sample_rows(tp.reshape(-1, V).to(DEV), ut.to(DEV)).reshape(R, G + 1)
+    out, acc = ops.rejection_sample(draft_ids.to(DEV), target_ids, tp.to(DEV), u.to(DEV),
+                                    torch.ones(R, dtype=torch.bool, device=DEV), dp.to(DEV))
+    first = out[:, 0].cpu().long()
+    emp = torch.bincount(first, minlength=V).float() / R
+    sigma = torch.sqrt(q[0] * (1 - q[0]) / R)
+    assert bool(((emp - q[0]).abs() < 5 * sigma + 1e-4).all()), (emp, q[0])
+    # bonus token (all drafts accepted): distributed as q[G]
+    full = acc.cpu() == G + 1
+    n = int(full.sum())
+    assert n > 2000
+    empb = torch.bincount(out[:, G].cpu().long()[full], minlength=V).float() / n
+    sb = torch.sqrt(q[G] * (1 - q[G]) / n)
+    assert bool(((empb - q[G]).abs() < 5 * sb + 1e-4).all()), (empb, q[G])
+
+
+def test_speculative_refuses_to_outgrow_the_cache():
+    cfg, target, draft, _ = _engines(3, 11, False)
+    spec = SpeculativeDecoder(target, draft, 4)
+    bt = torch.arange(3 * 8, dtype=torch.int32).reshape(3, 8)       # 8 blocks x 16 = 128 tokens
+    with pytest.raises(_C.Mi355Error):
+        spec.start([1, 2, 3], [10, 125, 3], bt, bt)                  # 125 + gamma + 1 > 128
