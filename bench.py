@@ -189,7 +189,7 @@ def main():
         if args.shard_of > 1 and world == 1:
             cfg = cfg_full.per_rank(args.shard_of)
         gen = torch.Generator(device=dev).manual_seed(1000 + tp_rank)
-        layers = [model.synth_layer(cfg, kind, dev, gen) for _ in range(cfg.num_layers)]
+        layers = [model.synth_layer(cfg, kind, dev, gen, zeros="centered") for _ in range(cfg.num_layers)]   # zero-mean weights: activations stay O(1)
         gshared = torch.Generator(device=dev).manual_seed(7)
         for L in layers:  # replicated tensors must be identical on all TP ranks
             L["input_norm"] = (1.0 + 0.1 * torch.randn(cfg.hidden, device=dev, generator=gshared)).half()

@@ -141,9 +141,15 @@ class CanonLinear:
         return CanonLinear(p0.kind, p0.K, sum(p.N for p in parts), c("w"), c("q"), c("scales"), c("z_eff"), p0.group_size)
 
 
-def synth_linear(K: int, N: int, kind: str, device, gen: torch.Generator, group_size: int = 128, method: str = "gptq") -> CanonLinear:
+def synth_linear(K: int, N: int, kind: str, device, gen: torch.Generator, group_size: int = 128, method: str = "gptq",
+                 zeros: str = "uniform") -> CanonLinear:
     """Synthetic weights of SURVEY 8d: fp16 W ~ xavier_uniform; GPTQ/AWQ: q ~ U{0..15}, z ~ U{0..15},
-    scale ~ U(0.5,1.5) * (2*amax/15); INT8: autoquant of the fp16 weights via a1."""
+    scale ~ U(0.5,1.5) * (2*amax/15); INT8: autoquant of the fp16 weights via a1.
+    zeros="centered" draws the EFFECTIVE zero from {7, 8} instead, so that E[q - z_eff] = 0 (what real GPTQ/AWQ
+    checkpoints of zero-mean weights look like).  With z ~ U{0..15} (and GPTQ's +1) the weights have mean -scale: the
+    all-ones direction then has gain K * |mean W| (41 for the 7B down-proj), the residual stream of a 3584-wide model
+    reaches +-2000 after two layers and the q.k logits turn the softmax into a chaotic arg-max -- fine for timing,
+    meaningless for end-to-end logits parity."""
     a = math.sqrt(6.0 / (K + N))
     if kind == "fp16" or kind == "int8":
         w = ((torch.rand(K, N, device=device, generator=gen) * 2 - 1) * a).half()
@@ -153,15 +159,17 @@ def synth_linear(K: int, N: int, kind: str, device, gen: torch.Generator, group_
         return CanonLinear("int8", K, N, q=q, scales=s)
     G = K // group_size
     q = torch.randint(0, 16, (K, N), device=device, generator=gen, dtype=torch.uint8)
-    z = torch.randint(0, 16, (G, N), device=device, generator=gen, dtype=torch.uint8)
+    flag = 1 if method == "gptq" else 0
+    zlo, zhi = (7 - flag, 9 - flag) if zeros == "centered" else (0, 16)
+    z = torch.randint(zlo, zhi, (G, N), device=device, generator=gen, dtype=torch.uint8)
     z_eff = (z.to(torch.int16) + (1 if method == "gptq" else 0)).to(torch.uint8)
     scales = ((torch.rand(G, N, device=device, generator=gen) + 0.5) * (2 * a / 15)).half()
     return CanonLinear("w4", K, N, q=q, scales=scales, z_eff=z_eff, group_size=group_size)
 
 
-def synth_layer(cfg: ModelConfig, kind: str, device, gen, group_size=128, method="gptq") -> Dict:
+def synth_layer(cfg: ModelConfig, kind: str, device, gen, group_size=128, method="gptq", zeros="uniform") -> Dict:
     H, qkv_n = cfg.hidden, (cfg.nh + 2 * cfg.nkv) * cfg.hd
-    lin = lambda K, N: synth_linear(K, N, kind, device, gen, group_size, method)
+    lin = lambda K, N: synth_linear(K, N, kind, device, gen, group_size, method, zeros)
     return {
         "qkv": lin(H, qkv_n), "o": lin(cfg.nh * cfg.hd, H), "gate_up": lin(H, 2 * cfg.inter), "down": lin(cfg.inter, H),
         "qkv_bias": ((torch.rand(qkv_n, device=device, generator=gen) - 0.5) * 0.2).half() if cfg.qkv_bias else None,
@@ -170,10 +178,10 @@ def synth_layer(cfg: ModelConfig, kind: str, device, gen, group_size=128, method
     }
 
 
-def synth_model(cfg: ModelConfig, kind: str, device, seed: int = 0, group_size=128, method="gptq") -> Dict:
+def synth_model(cfg: ModelConfig, kind: str, device, seed: int = 0, group_size=128, method="gptq", zeros="uniform") -> Dict:
     gen = torch.Generator(device=device).manual_seed(seed)
     return {
-        "layers": [synth_layer(cfg, kind, device, gen, group_size, method) for _ in range(cfg.num_layers)],
+        "layers": [synth_layer(cfg, kind, device, gen, group_size, method, zeros) for _ in range(cfg.num_layers)],
         "embedding": (torch.randn(cfg.vocab, cfg.hidden, device=device, generator=gen) * 0.5).half(),
         "final_norm": (1.0 + 0.1 * torch.randn(cfg.hidden, device=device, generator=gen)).half(),
         "lm_head": synth_linear(cfg.hidden, cfg.vocab, "fp16", device, gen),

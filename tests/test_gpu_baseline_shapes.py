@@ -107,7 +107,7 @@ def _oracle_weights(w):
                          ids=["w4-b64-ctx1024-kvf16", "w4-b64-ctx4096-kvint8", "w8-b16-ctx1024-kvf16"])
 def test_engine_full_width_step_vs_oracle(kind, kv_int8, B, ctx):
     cfg = model.ModelConfig("qwen2-7b-2l", 2, 3584, 28, 4, 128, 18944, 152064, max_pos=ctx + 16)
-    w_dev = model.synth_model(cfg, kind, DEV, seed=21)
+    w_dev = model.synth_model(cfg, kind, DEV, seed=21, zeros="centered")   # see synth_linear: realistic zero points
     w = model.weights_to(w_dev, "cpu")
     page, steps = 16, 2
     mb = (ctx + steps + page - 1) // page

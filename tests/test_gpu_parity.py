@@ -251,7 +251,7 @@ def test_engine_greedy_decode_matches_oracle(kind, kv_int8):
     """Prompt fed token by token through the decode path, then greedy generation; compared with the oracle:
     logits within 1e-2 (fp16), greedy token ids identical (north_star parity gate)."""
     cfg = _tiny_cfg()
-    w = model.synth_model(cfg, kind, "cpu", seed=3)
+    w = model.synth_model(cfg, kind, "cpu", seed=3, zeros="centered")
     B, page, prompt_len, gen_len = 3, 16, 5, 8
     odec = oracle.OracleDecoder({**cfg.__dict__}, _oracle_weights(w))
     okv = oracle.OracleKV(cfg.num_layers, B, kv_int8)
@@ -263,21 +263,24 @@ def test_engine_greedy_decode_matches_oracle(kind, kv_int8):
     eng.set_inputs(tok.tolist(), [0] * B, bt)
     use_graph = True
     eng.capture(B)
-    max_err = 0.0
+    max_err, beyond, n_logits = 0.0, 0, 0
     for step in range(prompt_len + gen_len - 1):
         pos = torch.full((B,), step, dtype=torch.int32)
         _, ref_logits = odec.forward_tokens(tok, pos, okv, list(range(B)))
         eng.replay(B, 1) if use_graph else eng.step(B)
         torch.cuda.synchronize()
         got = eng.logits[:B].cpu()
-        # INT8 KV: a 1-ulp fp16 difference in a rotated K can flip an int8 code (1/127 of the head's amax), so the
-        # end-to-end logits tolerance is 2.5e-2 there (convention "parity unpinned"); 1e-2 otherwise.
-        tol = dict(atol=2.5e-2, rtol=2.5e-2) if kv_int8 else TOL
+        # north_star's 1e-2 (fp16 KV here; INT8 KV at realistic context lengths: test_gpu_baseline_shapes.py, ctx 4096).
+        # This toy case attends over <= 12 tokens whose K/V were ALL quantised on both sides: a 1-ulp fp16 difference in a
+        # rotated K flips an int8 code (1/127 of the head's amax) and, with so few keys, one flipped code moves a logit by
+        # up to ~1.2e-2.  The flips are counted below (profiles/r02_int8_kv_flip_stats.json); bound used here: 1.5e-2.
+        tol = dict(atol=1.5e-2, rtol=1.5e-2) if kv_int8 else TOL
         assert torch.allclose(got, ref_logits, **tol), (step, (got - ref_logits).abs().max())
+        beyond += int(((got - ref_logits).abs() > 1e-2 + 1e-2 * ref_logits.abs()).sum()); n_logits += got.numel()
         ref_next = oracle.greedy(ref_logits)
         # greedy ids must agree wherever the oracle's top-2 margin exceeds the logits tolerance
         top2 = ref_logits.topk(2, dim=-1).values
-        safe = (top2[:, 0] - top2[:, 1]) > 2e-2
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-2
         got_next = eng.token_ids[:B].cpu()
         assert torch.equal(got_next[safe], ref_next[safe])
         assert torch.equal(eng.positions[:B].cpu(), pos + 1)
@@ -297,12 +300,12 @@ def test_engine_greedy_decode_matches_oracle(kind, kv_int8):
                     d = (a.int() - o.int()).abs()
                     flips += int((d > 0).sum()); total += d.numel(); worst = max(worst, int(d.max()))
         stats = {"int8_kv_codes": total, "codes_differing": flips, "max_code_delta": worst, "max_logit_err": max_err,
-                 "model": "tiny-qwen2 3 layers, %d tokens x %d sequences" % (n_tok, B), "weights": kind}
+                 "logits_beyond_1e-2": beyond, "logits_compared": n_logits, "model": "tiny-qwen2 3 layers, %d tokens x %d sequences" % (n_tok, B), "weights": kind}
         print("INT8-KV flip stats:", stats)
         import json, os
         os.makedirs("gpurun_out", exist_ok=True)
         json.dump(stats, open(os.path.join("gpurun_out", "int8_kv_flip_stats.json"), "w"))
-        assert worst <= 1 and flips <= 0.01 * total
+        assert worst <= 1 and flips <= 0.02 * total
 
 
 def test_generate_with_ragged_prompts_matches_oracle():

@@ -29,7 +29,7 @@ def _worker(rank, world, port, q, kv_int8):
         distributed.init_distributed("gloo")
         # inter = 768 is not a multiple of tp * 128: exercises the align_size padding too
         cfg = model.ModelConfig("tiny-tp", 2, 512, 8, 2, 64, 768, 1024, max_pos=256)
-        w = model.synth_model(cfg, "w4", "cpu", seed=21)                       # same full weights on every rank
+        w = model.synth_model(cfg, "w4", "cpu", seed=21, zeros="centered")     # same full weights on every rank
         V = cfg.vocab
         layers = [model.split_layer_tp(L, cfg, world, rank) for L in w["layers"]]
         head = w["lm_head"].cols(rank * (V // world), (rank + 1) * (V // world))   # vocab-split lm_head
@@ -46,7 +46,7 @@ def _worker(rank, world, port, q, kv_int8):
         bt = torch.arange(B * 2, dtype=torch.int32).reshape(B, 2)
         tok = torch.randint(0, V, (B,), generator=torch.Generator().manual_seed(3), dtype=torch.int32)
         eng.set_inputs(tok.tolist(), [0] * B, bt)
-        tol = dict(atol=2.5e-2, rtol=2.5e-2) if kv_int8 else dict(atol=1e-2, rtol=1e-2)
+        tol = dict(atol=1e-2, rtol=1e-2)                                         # north_star, fp16 and INT8 KV alike
         for step in range(4):
             pos = torch.full((B,), step, dtype=torch.int32)
             _, ref = odec.forward_tokens(tok, pos, okv, list(range(B)))
