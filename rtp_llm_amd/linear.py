@@ -33,11 +33,17 @@ class QuantConfig:
 
 
 class LinearBase(nn.Module, ABC):
+    """Same abstract surface as the reference's LinearBase (linear_base.py:16-102)."""
+
     @classmethod
     @abstractmethod
     def can_handle(cls, quant_config, weight, weight_scales, hw_kernel_config=None, weight_scale_2=None,
                    input_scale=None) -> bool:
         ...
+
+    @abstractmethod
+    def __init__(self, weight, weight_scales=None, input_scales=None, bias=None, quant_config=None, weight_scale_2=None):
+        super().__init__()
 
     @abstractmethod
     def forward(self, input: torch.Tensor) -> torch.Tensor:
@@ -50,9 +56,11 @@ class LinearBase(nn.Module, ABC):
         return self.__class__.__name__
 
 
-class _PackedLinear(LinearBase):
-    """Common forward: one C-ABI call on the packed weight (bias fused in the GEMM epilogue,
-    as the reference applies Qwen2's QKV bias inside the linear, causal_attention.py:42-51)."""
+# ---- strategy implementations: plain mixins, so the same code binds to this package's LinearBase (below) and to the
+# reference's own LinearBase (rtp_llm_amd/reference_plugin.py) without a second copy
+class _PackedImpl:
+    """Common forward: one C-ABI call on the packed weight (bias fused in the GEMM epilogue, as the reference applies
+    Qwen2's QKV bias inside the linear, causal_attention.py:42-51)."""
     packed: PackedWeight
     kernel_hints: int = 0   # _C.HINT_* bits forwarded with every call (A/B tests); 0 = let the library choose
 
@@ -70,7 +78,7 @@ class _PackedLinear(LinearBase):
         return ops.linear(input.contiguous(), self.packed, self.bias, epilogue=_C.EPI_SILU_MUL | self.kernel_hints)
 
 
-class Mi355F16Linear(_PackedLinear):
+class _F16Impl(_PackedImpl):
     """fp16 weights [K, N] (the reference stores [K, N] and calls hipb_mm, f16_linear.py:100-112)."""
 
     @classmethod
@@ -78,11 +86,11 @@ class Mi355F16Linear(_PackedLinear):
         return weight_scales is None and weight.dtype == torch.float16
 
     def __init__(self, weight, weight_scales=None, input_scales=None, bias=None, quant_config=None, weight_scale_2=None):
-        super().__init__()
+        super().__init__(weight, weight_scales, input_scales, bias, quant_config, weight_scale_2)
         self._finish_init(quant.pack_fp16(weight.contiguous()), bias)
 
 
-class Mi355W8A16Linear(_PackedLinear):
+class _W8A16Impl(_PackedImpl):
     """INT8 weight-only, per-output-channel scale (load-time autoquant, device_impl.py:183-222).
     weight int8 [K, N], weight_scales [N]."""
 
@@ -91,26 +99,64 @@ class Mi355W8A16Linear(_PackedLinear):
         return weight_scales is not None and weight.dtype == torch.int8 and weight_scales.dim() == 1
 
     def __init__(self, weight, weight_scales=None, input_scales=None, bias=None, quant_config=None, weight_scale_2=None):
-        super().__init__()
+        super().__init__(weight, weight_scales, input_scales, bias, quant_config, weight_scale_2)
         self._finish_init(quant.pack_int8_per_channel(weight.contiguous(), weight_scales), bias)
 
 
-class Mi355W4A16Linear(_PackedLinear):
-    """INT4 group-wise (GPTQ / AWQ after canonicalisation).  weight: uint8 codes [K, N] in 0..15,
-    weight_scales fp16 [K/g, N], weight_zeros: effective zero codes [K/g, N] (z+1 for GPTQ)."""
+def _is_reference_w4_kernel(weight, weight_scales) -> bool:
+    """int8 [K/2, N] + scales [K/g, N], g in {32, 64, 128}: the tensors RocmImpl.preprocess_groupwise_weight_params emits."""
+    if weight_scales is None or weight.dtype != torch.int8 or weight_scales.dim() != 2 or weight.dim() != 2:
+        return False
+    K, G = 2 * weight.shape[0], weight_scales.shape[0]
+    return weight.shape[1] == weight_scales.shape[1] and G > 0 and K % G == 0 and K // G in (32, 64, 128)
+
+
+class _W4A16Impl(_PackedImpl):
+    """INT4 group-wise (GPTQ / AWQ).  Two input forms:
+      * canonical: weight uint8 codes [K, N] in 0..15, weight_scales fp16 [K/g, N], weight_zeros = effective zero codes
+        [K/g, N] (z + 1 for GPTQ);
+      * what the reference's ROCm loader hands its factory (device_impl.py:797-868): weight int8 [K/2, N] CK-permuted
+        nibble pairs, weight_scales [K/g, N], and zeros_x_scales [K/g, N] fp16.  The reference factory never forwards the
+        zeros (factory.py:86-93; SURVEY 8b "Gap"), so they are taken from, in this order: the `weight_zeros` keyword (the
+        small factory extension of INTEGRATION.md), the `weight_scale_2` slot (forwarded by the UNMODIFIED reference
+        factory: pass weight_scale_2_key=W.*_z at the call site), or a `zeros_x_scales` attribute set on the weight tensor."""
 
     @classmethod
     def can_handle(cls, quant_config, weight, weight_scales, hw_kernel_config=None, weight_scale_2=None, input_scale=None):
-        return weight_scales is not None and weight.dtype == torch.uint8 and weight_scales.dim() == 2
+        if weight_scales is None or weight_scales.dim() != 2:
+            return False
+        return weight.dtype == torch.uint8 or _is_reference_w4_kernel(weight, weight_scales)
 
     def __init__(self, weight, weight_scales=None, input_scales=None, bias=None, quant_config=None, weight_scale_2=None,
                  weight_zeros=None):
-        super().__init__()
-        K = weight.shape[0]
-        gs = K // weight_scales.shape[0]
+        super().__init__(weight, weight_scales, input_scales, bias, quant_config, weight_scale_2)
+        if weight.dtype == torch.int8:     # reference loader format
+            zs = weight_zeros if weight_zeros is not None else weight_scale_2 if weight_scale_2 is not None \
+                else getattr(weight, "zeros_x_scales", None)
+            if zs is None or tuple(zs.shape) != tuple(weight_scales.shape):
+                raise ValueError("W4A16: zeros_x_scales [K/g, N] is required with the reference's packed int4 kernel "
+                                 "(weight_zeros=, the weight_scale_2 slot, or weight.zeros_x_scales)")
+            self._finish_init(quant.pack_reference_rocm_w4(weight, weight_scales, zs), bias)
+            return
+        gs = weight.shape[0] // weight_scales.shape[0]
         if weight_zeros is None:  # symmetric: stored code = q_s + 8
             weight_zeros = torch.full_like(weight_scales, 8, dtype=torch.int16)
         self._finish_init(quant.pack_groupwise_w4(weight, weight_zeros, weight_scales, gs), bias)
+
+
+class Mi355F16Linear(_F16Impl, LinearBase):
+    pass
+
+
+class Mi355W8A16Linear(_W8A16Impl, LinearBase):
+    pass
+
+
+class Mi355W4A16Linear(_W4A16Impl, LinearBase):
+    pass
+
+
+STRATEGY_IMPLS = (("Mi355F16Linear", _F16Impl), ("Mi355W8A16Linear", _W8A16Impl), ("Mi355W4A16Linear", _W4A16Impl))
 
 
 class LinearFactory:

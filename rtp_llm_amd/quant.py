@@ -214,6 +214,52 @@ def autoquant_int8(weight_kn: torch.Tensor) -> PackedWeight:
     return pack_int8_per_channel(q, s)
 
 
+# --------------------------------------------------------------------------- reference-format import
+CK_NIBBLE_PERM = (2, 0, 6, 4, 3, 1, 7, 5)   # device_impl.py:751
+
+
+def unpack_reference_rocm_w4(kernel: torch.Tensor) -> torch.Tensor:
+    """The tensor the reference's ROCm loader hands the linear factory as ``W.*_w`` for a 4-bit layer -> canonical codes.
+
+    RocmImpl.preprocess_groupwise_weight_params (device_impl.py:797-868) emits int8 [K/2, N] (column-major strides): two
+    codes per byte along K (even k in the high nibble), XOR 0x88 (so the byte holds the ORIGINAL unsigned codes),
+    then the CK nibble permutation [2,0,6,4,3,1,7,5] per 8 nibbles of the column-major byte stream (device_impl.py:729-771).
+    Returns q uint8 [K, N] in 0..15."""
+    assert kernel.dtype == torch.int8 and kernel.dim() == 2
+    K2, N = kernel.shape
+    storage = kernel.t().contiguous().view(torch.uint8).reshape(-1)           # bytes in column-major order: [N][K/2]
+    nib = torch.stack([storage >> 4, storage & 0xF], dim=1).reshape(-1, 8)    # permuted nibbles
+    orig = torch.empty_like(nib)
+    orig[:, list(CK_NIBBLE_PERM)] = nib                                       # permuted[j] = orig[perm[j]]
+    return orig.reshape(N, 2 * K2).t().contiguous()
+
+
+def zeros_from_reference_folded(zeros_x_scales: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
+    """Invert zeros_x_scales = fp16((8 - z_eff) * scale) (device_impl.py:836-840): the quotient is within 2^-11 of an
+    integer, so rounding recovers z_eff exactly; zero-scale groups carry no information (weights are 0): z_eff = 8."""
+    s = scales.float()
+    ratio = torch.where(s != 0, zeros_x_scales.float() / torch.where(s != 0, s, torch.ones_like(s)), torch.zeros_like(s))
+    z = 8 - torch.round(ratio)
+    assert bool(((z >= 0) & (z <= 16)).all()), "zeros_x_scales is not (8 - z) * scale for integer z in 0..16"
+    return z.to(torch.uint8)
+
+
+def pack_reference_rocm_w4(kernel: torch.Tensor, scales: torch.Tensor, zeros_x_scales: torch.Tensor) -> "PackedWeight":
+    """(W.*_w, W.*_s, W.*_z) exactly as the reference's ROCm loader produces them -> the MI355-native image; bit-equal to
+    pack_gptq / pack_awq on the checkpoint tensors they came from."""
+    q = unpack_reference_rocm_w4(kernel)
+    K = q.shape[0]
+    G = scales.shape[0]
+    assert K % G == 0 and K // G in (32, 64, 128), f"group size {K}/{G}"
+    return pack_groupwise_w4(q, zeros_from_reference_folded(zeros_x_scales, scales), scales.contiguous().to(torch.float16), K // G)
+
+
+def cat_groupwise_cols(parts):
+    """Column-concatenate (weight-codes, scales, zeros) triples -- the scale AND zero concat the reference's
+    create_merged_linear lacks for GPTQ/AWQ (it concatenates scales for FP8/FP4 only, factory.py:172-176)."""
+    return tuple(torch.cat([p[i] for p in parts], dim=-1) for i in range(3))
+
+
 # --------------------------------------------------------------------------- reference-format export
 def reference_folded_zeros(z_eff: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
     """The reference's kernel-side representation (device_impl.py:283-289):
