@@ -1,6 +1,6 @@
 """Build libmi355_decode.so (gfx950) in-tree with hipcc.
 
-    python -m rtp_llm_amd.build [--force] [--tuning]
+    python -m rtp_llm_amd.build [--force] [--tuning] [--pybind]
 
 Objects go to rtp_llm_amd/csrc/build/, the library to rtp_llm_amd/lib/.  Only
 stale translation units are recompiled (mtime of source + headers).
@@ -66,7 +66,47 @@ def build(force=False, verbose=True, tuning=False):
     return LIB
 
 
+PYBIND_SRC = os.path.join(CSRC, "pybind", "register_ops.cc")
+
+
+def pybind_module_path():
+    import sysconfig
+    return os.path.join(LIBDIR, "mi355_compute_ops" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_pybind(force=False, verbose=True):
+    """The native registration shim (csrc/pybind/register_ops.cc): a pybind11 / torch-extension module exporting
+    rtp_llm::registerPyModuleOps on top of the C-ABI library.  Host code only; compiled with hipcc so that the HIP and
+    torch-ROCm headers see their usual configuration."""
+    import sysconfig
+    import torch
+    out = pybind_module_path()
+    lib = os.path.join(LIBDIR, "libmi355_decode.so")
+    deps = [PYBIND_SRC, os.path.join(INCLUDE, "mi355_decode.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        if verbose:
+            print(f"[rtp_llm_amd.build] up to date: {out}")
+        return out
+    if not os.path.exists(lib):
+        build(verbose=verbose)
+    T = os.path.dirname(torch.__file__)
+    cmd = [HIPCC, "-x", "hip", f"--offload-arch={ARCH}", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-DTORCH_EXTENSION_NAME=mi355_compute_ops", "-DUSE_ROCM",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           f"-I{T}/include", f"-I{T}/include/torch/csrc/api/include", f"-I{sysconfig.get_paths()['include']}",
+           PYBIND_SRC, "-o", out, f"-L{T}/lib", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-ltorch_python",
+           f"-L{LIBDIR}", "-lmi355_decode", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{T}/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"pybind shim build failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}")
+    if verbose:
+        print(f"[rtp_llm_amd.build] built {out}")
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     if "--tuning" in sys.argv:
         build(force="--force" in sys.argv, tuning=True)
+    if "--pybind" in sys.argv:
+        build_pybind(force="--force" in sys.argv)

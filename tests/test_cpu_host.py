@@ -159,3 +159,23 @@ def test_oracle_sample_rows_is_inverse_cdf():
     p = torch.tensor([[0.25, 0.0, 0.5, 0.25], [0.0, 0.0, 1.0, 0.0]])
     assert oracle.sample_rows(p, torch.tensor([0.0, 0.3])).tolist() == [0, 2]
     assert oracle.sample_rows(p[:1].repeat(4, 1), torch.tensor([0.24, 0.25, 0.74, 0.99])).tolist() == [0, 2, 2, 3]
+
+
+def test_native_registration_shim_exports_the_reference_hook():
+    """csrc/pybind/register_ops.cc: the module must export rtp_llm::registerPyModuleOps(pybind11::module&) -- the one
+    symbol the reference links per build flavour (bindings/RegisterOps.h:9) -- and expose the op classes / functions."""
+    import subprocess
+    from rtp_llm_amd import native_ops
+    from rtp_llm_amd.build import build_pybind
+    path = build_pybind(verbose=False)
+    syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    assert "_ZN7rtp_llm19registerPyModuleOpsERN8pybind117module_E" in syms
+    ops = native_ops.load()
+    for name in ("Mi355RopeKVCacheDecodeOp", "Mi355PagedAttnDecodeOp", "Mi355WeightOnlyLinear", "Mi355AttnParams", "AttentionConfigs",
+                 "LayerKVCache", "PyAttentionInputs", "rmsnorm", "fused_add_rmsnorm", "silu_and_mul", "embedding", "greedy_argmax"):
+        assert hasattr(ops, name), name
+    for cls in (ops.Mi355RopeKVCacheDecodeOp, ops.Mi355PagedAttnDecodeOp):
+        assert callable(getattr(cls, "prepare")) and callable(getattr(cls, "forward"))
+    assert callable(ops.Mi355AttnParams.update_kv_cache_offset) and callable(ops.Mi355AttnParams.prepare_in_place)
+    with pytest.raises(RuntimeError):                     # TORCH_CHECK -> RuntimeError, and no CPU path
+        ops.rmsnorm(torch.zeros(2, 8).half(), torch.zeros(2, 8).half(), torch.ones(8).half(), 1e-6)
