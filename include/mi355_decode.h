@@ -243,6 +243,48 @@ int mi355_rejection_sample(const float* draft_probs, const int32_t* draft_token_
                            int32_t draft_probs_point_mass, mi355_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Tensor-parallel all-reduce over peer-mapped memory (xGMI) -- replaces the reference's custom one-shot all-reduce
+ * TrtllmArFusionHandle (bindings/rocm/TrtllmAllReduceFusion.h:14-55; kernels trtllm_allreduce_fusion.cu:431-540) and,
+ * at the call sites all_reduce(x, Group.TP) of causal_attention.py:91-92 / dense_mlp.py:104-105, RCCL for the decode
+ * message sizes.  One process per GPU: every rank creates a context (which allocates and IPC-exports its buffers and
+ * fills an opaque handle blob), the host gathers the `world` blobs in rank order by any means (torch.distributed
+ * all_gather_object, as base/rocm/trt_allreduce.py:51-230 does) and every rank opens them.  Numerics: fp32 sum of the
+ * fp16 copies in rank order 0..N-1, one rounding -- bit-identical on every rank (trtllm_allreduce_fusion.cu:228-246).
+ * All calls only enqueue one kernel: graph-capturable; epochs advance on the device.  A peer that never arrives makes the
+ * kernel give up after ~2 s and sets a status word (mi355_allreduce_status != 0) instead of hanging the GPU.
+ * ---------------------------------------------------------------------- */
+typedef struct mi355_allreduce mi355_allreduce_t;
+
+size_t             mi355_allreduce_handle_bytes(void);
+/* max_bytes: largest fp16 message (T * H * 2).  handle_out: mi355_allreduce_handle_bytes() bytes. */
+mi355_allreduce_t* mi355_allreduce_create(int32_t rank, int32_t world, size_t max_bytes, void* handle_out);
+/* all_handles: world blobs, rank order. */
+int                mi355_allreduce_open(mi355_allreduce_t* ar, const void* all_handles);
+void               mi355_allreduce_destroy(mi355_allreduce_t* ar);
+int                mi355_allreduce_status(mi355_allreduce_t* ar, mi355_stream_t stream); /* synchronises; 0 = healthy */
+
+/* out[T,H] = sum over ranks of x[T,H] (fp16).  out may alias x. */
+int mi355_allreduce_sum(mi355_allreduce_t* ar, const void* x_f16, void* out_f16, int32_t T, int32_t H, mi355_stream_t stream);
+
+/* The fused form (allreduce_fusion_kernel_1stage + the split-K reduce of the producing row-parallel GEMM):
+ *   local   = fp16(x_f16 | sum of nsplit fp32 slabs [nsplit][T][ld] (+ bias on rank 0))
+ *   s       = fp16(sum over ranks of local)                       (rank order, fp32)
+ *   h       = residual_in ? fp16(s + residual_in) : s ;  residual_out = h (if non-NULL)
+ *   y       = weight * fp16(h * rsqrt(mean(h^2) + eps))            (if y non-NULL)
+ * i.e. bit for bit mi355_allreduce_sum followed by mi355_add_rmsnorm. */
+int mi355_allreduce_fused(mi355_allreduce_t* ar, const void* x_f16, const float* partials, int32_t nsplit, int32_t ld,
+                          const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
+                          int32_t T, int32_t H, void* y, mi355_stream_t stream);
+
+/* Greedy sampling under a vocab-split lm_head: ids[b] = argmax over ALL ranks' logit slices (this rank holds columns
+ * [vocab_offset, vocab_offset + V_local)), lowest global index on ties; identical on every rank.  Exchanges 8 bytes per
+ * row instead of gathering the logits (PyWrappedModel.cc:915-936).  positions (may be NULL) += 1.
+ * workspace >= B * 64 * 8 bytes. */
+int mi355_allreduce_argmax(mi355_allreduce_t* ar, const float* logits, int32_t B, int32_t V_local, int32_t ld,
+                           int32_t vocab_offset, int32_t* ids, int32_t* positions, void* workspace, size_t workspace_bytes,
+                           mi355_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Decode-step driver (C++): owns no tensors, only pointers.  It enqueues the
  * whole decode step of a Qwen2/Llama-style decoder (the body of
  * Qwen3Model.forward, rtp_llm/models_py/model_desc/qwen3.py:57-79,124-138,
@@ -315,6 +357,12 @@ int mi355_decoder_step(mi355_decoder_t* d, int32_t B, mi355_stream_t stream);
 
 /* hipGraph: capture one full step for batch B on an internal stream, then replay
  * `nsteps` times back-to-back on `stream` (greedy feedback stays on device). */
+/* Attach an opened all-reduce context (tp_size > 1): the two all-reduce points of every layer then run inside the step as
+ * mi355_allreduce_fused (split-K reduce + all-reduce + residual + next RMSNorm in one launch) and greedy sampling as
+ * mi355_allreduce_argmax, so mi355_decoder_step / _capture / _replay drive the whole tensor-parallel step from C++ with
+ * no host round trip per layer.  vocab_offset: first vocabulary column of this rank's lm_head slice. */
+int mi355_decoder_attach_allreduce(mi355_decoder_t* d, mi355_allreduce_t* ar, int32_t vocab_offset);
+
 int mi355_decoder_capture(mi355_decoder_t* d, int32_t B);
 int mi355_decoder_replay(mi355_decoder_t* d, int32_t B, int32_t nsteps, mi355_stream_t stream);
 
@@ -328,7 +376,8 @@ enum {
     MI355_KC_ROPE_KV    = 3,
     MI355_KC_NORM       = 4,
     MI355_KC_OTHER      = 5,
-    MI355_KC_COUNT      = 6
+    MI355_KC_COMM       = 6, /* fused all-reduce launches (tp_size > 1) */
+    MI355_KC_COUNT      = 7
 };
 int mi355_decoder_profile(mi355_decoder_t* d, int32_t B, int32_t nsteps, float* out_ms,
                           int32_t* out_launches, mi355_stream_t stream);

@@ -18,7 +18,7 @@ KV_FP16, KV_INT8 = 0, 1
 EPI_NONE, EPI_SILU_MUL, EPI_OUT_F32 = 0, 1, 2
 HINT_STAGED, HINT_NO_PERSISTENT = 0x100, 0x200
 ABI_VERSION = 2
-KC_NAMES = ["gemm_quant", "gemm_lmhead", "attn", "rope_kv", "norm", "other"]
+KC_NAMES = ["gemm_quant", "gemm_lmhead", "attn", "rope_kv", "norm", "other", "comm"]
 
 vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
 
@@ -71,6 +71,15 @@ SIGNATURES = {
     "mi355_softmax_rows": (i32, [vp, i32, i32, i32, f32, vp, vp]),
     "mi355_sample_rows": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "mi355_rejection_sample": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mi355_allreduce_handle_bytes": (sz, []),
+    "mi355_allreduce_create": (vp, [i32, i32, sz, vp]),
+    "mi355_allreduce_open": (i32, [vp, vp]),
+    "mi355_allreduce_destroy": (None, [vp]),
+    "mi355_allreduce_status": (i32, [vp, vp]),
+    "mi355_allreduce_sum": (i32, [vp, vp, vp, i32, i32, vp]),
+    "mi355_allreduce_fused": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, vp]),
+    "mi355_allreduce_argmax": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
+    "mi355_decoder_attach_allreduce": (i32, [vp, vp, i32]),
     "mi355_decoder_workspace_bytes": (sz, [C.POINTER(ModelConfig)]),
     "mi355_decoder_create": (vp, [C.POINTER(ModelConfig), C.POINTER(LayerWeights), C.POINTER(ModelWeights), C.POINTER(StepBuffers)]),
     "mi355_decoder_destroy": (None, [vp]),

@@ -1,0 +1,448 @@
+// One-shot all-reduce over peer-mapped memory (xGMI on a multi-GPU node), fused with the split-K reduce of the producing
+// GEMM, the residual add and the RMSNorm of the consumer.  gfx950.
+//
+// Replaces the reference's custom all-reduce for the decode message sizes: TrtllmArFusionHandle
+// (rtp_llm/models_py/bindings/rocm/TrtllmAllReduceFusion.h:14-55), kernels allreduce_kernel_1stage
+// (bindings/rocm/kernels/trtllm_allreduce_fusion.cu:474-540), the fused all-reduce + residual + RMSNorm form
+// allreduce_fusion_kernel_1stage (:431-471), the per-block flag barrier SyncComm (:285-316) and its numerics: peers are
+// summed in fp32 in rank order 0..N-1 and rounded once, so every rank obtains bit-identical results (:228-246,488-506).
+// Handle exchange mirrors base/rocm/trt_allreduce.py:51-230 (hipIpcGetMemHandle blobs gathered by the host).
+//
+// MI355X design.  8 GPUs are fully connected by point-to-point xGMI links, so for <= 1 MiB messages the cheapest
+// all-reduce is "everybody reads everybody": each rank publishes its fp16 tensor in an IPC-exported buffer, raises a
+// flag in every peer's flag table, waits for the peers' flags and then reads the N-1 remote copies concurrently over its
+// 7 links while summing them.  One kernel per all-reduce point of the layer does ALL of:
+//     stage 0   row <- sum of the local split-K slabs (+ bias), rounded to fp16      (what add_rmsnorm_kernel does at tp = 1)
+//               published to this rank's registered buffer (double-buffered by the epoch's parity)
+//     barrier   per block: block b only needs the rows block b of every peer published, so there is no grid-wide
+//               synchronisation and no assumption about co-residency beyond "block b of every rank eventually runs"
+//     stage 1   s = fp16(sum_r fp32(row_r)) in rank order; h = fp16(s + residual) -> residual stream; y = w * rmsnorm(h)
+// Epochs live in device memory and advance inside the kernel, so a captured graph replays correctly; every spin is
+// bounded (wall clock) and reports through a status word instead of hanging the GPU.
+// Greedy sampling under a vocab-split lm_head uses the same transport for (max logit, global index) pairs instead of
+// gathering the logits (PyWrappedModel.cc:915-936 gathers [B, V/tp] fp32 per rank; only 8 bytes per row are needed when
+// every top_k == 1).
+#include <string.h>
+#include <unistd.h>
+#include <new>
+
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+constexpr int kMaxWorld  = 8;
+constexpr int kMaxBlocks = 256;            // flag rows; grid of an all-reduce launch <= kMaxBlocks
+constexpr int kFlagRow   = 16;             // dwords per block row (8 used): one 64-byte line per block
+constexpr unsigned long long kSpinTicks = 200000000ull;   // 2 s of the 100 MHz wall clock
+constexpr size_t kAuxBytes = 32768;        // per parity, after the tensor region: 8-byte records of the argmax exchange.
+// Every location of a registered buffer has ONE owner block for all time (tensor row r and record r belong to block
+// r % kMaxBlocks whatever T is), and a block alternates parities with its own epoch: a location is rewritten two of its
+// owner's calls after it was last read, and a peer can only have raised the flag of the call in between after finishing
+// every earlier kernel on its stream.
+
+struct ArDev {                             // device-visible part of the context (passed by value to kernels)
+    f16*            my_data;               // registered buffer: 2 parities x max_elems
+    const f16*      peer_data[kMaxWorld];
+    uint32_t*       peer_flags[kMaxWorld]; // [kMaxBlocks][kFlagRow]; slot [b][r] is written by rank r
+    uint32_t*       epoch;                 // [kMaxBlocks] this rank's call counter per block (ordinary device memory)
+    int32_t*        status;                // != 0: a spin timed out (results invalid)
+    size_t          parity_elems;          // elements between the two parities
+    size_t          aux_elems;             // element offset of the record region inside a parity
+    uint32_t        data_bytes;            // bytes of one peer buffer (both parities): buffer range of the remote loads
+    int             rank, world;
+};
+
+struct FusedParams {
+    ArDev        ar;
+    const f16*   x;            // fp16 [T][H] local tensor, or
+    const float* partials;     // split-K slabs [nsplit][T][ld]
+    int          nsplit, ld;
+    const f16*   bias;         // added by rank 0 only (a row-parallel linear has one bias for the sum); may be null
+    const f16*   res_in;       // residual stream in (may be null: plain all-reduce)
+    f16*         res_out;      // residual stream out / plain all-reduce result
+    const f16*   weight;       // RMSNorm weight (null: no norm)
+    f16*         y;            // normed output
+    float        eps;
+    int          T, H;
+};
+
+// system-scope 16-byte load from a peer buffer (sc0 sc1: served by the owner's memory, never by a stale local line)
+__device__ __forceinline__ u32x4 load_sys(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 17 /* sc0 | sc1 */);
+}
+
+// Raise this block's flag at every peer, then wait for every peer's flag of the same epoch.  Executed by the whole block.
+__device__ __forceinline__ void peer_barrier(const ArDev& ar, int b, uint32_t epoch) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: this block's published rows first
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < ar.world) {
+        __hip_atomic_store(ar.peer_flags[t] + b * kFlagRow + ar.rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t* mine = ar.peer_flags[ar.rank] + b * kFlagRow + t;
+        const unsigned long long t0 = wall_clock64();
+        // monotonic epochs: a peer may already be one call ahead (its next call's flag), never behind once it arrived
+        while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > kSpinTicks) { atomicExch(ar.status, 1 + t); break; }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+template <int VPT>
+__global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams p) {
+    constexpr int NTH = 512;
+    const ArDev& ar = p.ar;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nvec = p.H >> 3;
+    const uint32_t epoch = ar.epoch[b] + 1;
+    const size_t par = (epoch & 1) * ar.parity_elems;
+    // ---- stage 0: local row (split-K reduce + bias), fp16, into the registered buffer
+    for (int row = b; row < p.T; row += gridDim.x) {
+#pragma unroll
+        for (int t = 0; t < VPT; ++t) {
+            const int vi = tid + t * NTH;
+            if (vi >= nvec) continue;
+            const int c0 = vi * 8;
+            f16x8 o;
+            if (p.partials) {
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const size_t sstride = (size_t)p.T * p.ld;
+                const float* src0 = p.partials + (size_t)row * p.ld + c0;
+                int s = 0;
+                for (; s + 4 <= p.nsplit; s += 4) {            // 4 slabs per memory round trip, summed in index order
+                    f32x4 a[4], c[4];                          // (as add_rmsnorm_kernel: same fp32 result, bit for bit)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        a[u] = *reinterpret_cast<const f32x4*>(src0 + (s + u) * sstride);
+                        c[u] = *reinterpret_cast<const f32x4*>(src0 + (s + u) * sstride + 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += a[u][e]; v[4 + e] += c[u][e]; }
+                }
+                for (; s < p.nsplit; ++s) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(src0 + s * sstride);
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(src0 + s * sstride + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += c[e]; }
+                }
+                if (p.bias && ar.rank == 0) {
+                    const f16x8 bv = *reinterpret_cast<const f16x8*>(p.bias + c0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)bv[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+            } else {
+                o = *reinterpret_cast<const f16x8*>(p.x + (size_t)row * p.H + c0);
+            }
+            *reinterpret_cast<f16x8*>(ar.my_data + par + (size_t)row * p.H + c0) = o;
+        }
+    }
+    peer_barrier(ar, b, epoch);
+    // ---- stage 1: rank-ordered fp32 sum of the N copies, residual add, RMSNorm
+    __amdgpu_buffer_rsrc_t rp[kMaxWorld];
+#pragma unroll
+    for (int r = 0; r < kMaxWorld; ++r)
+        rp[r] = __builtin_amdgcn_make_buffer_rsrc((void*)ar.peer_data[r < ar.world ? r : 0], 0, ar.data_bytes, 0x00020000u);
+    __shared__ float red[NTH / 64];
+    for (int row = b; row < p.T; row += gridDim.x) {
+        float v[VPT][8];
+        f16x8 win[VPT];
+        float ss = 0.f;
+#pragma unroll
+        for (int t = 0; t < VPT; ++t) {
+            const int vi = tid + t * NTH;
+            if (vi >= nvec) continue;
+            const int c0 = vi * 8;
+            const uint32_t off = (uint32_t)((par + (size_t)row * p.H + c0) * 2);
+            u32x4 in[kMaxWorld];
+#pragma unroll
+            for (int r = 0; r < kMaxWorld; ++r)
+                if (r < ar.world) in[r] = load_sys(rp[r], off);            // all peers in flight together
+            f16x8 rin = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (p.res_in) rin = *reinterpret_cast<const f16x8*>(p.res_in + (size_t)row * p.H + c0);
+            win[t] = (p.y && p.weight) ? *reinterpret_cast<const f16x8*>(p.weight + c0) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[t][e] = 0.f;
+#pragma unroll
+            for (int r = 0; r < kMaxWorld; ++r) {                           // rank order 0..N-1 on every rank
+                if (r < ar.world) {
+                    const f16x8 h = __builtin_bit_cast(f16x8, in[r]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[t][e] += (float)h[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[t][e] = (float)(f16)v[t][e];     // the all-reduced tensor is fp16: round once
+            if (p.res_in) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[t][e] = (float)(f16)(v[t][e] + (float)rin[e]);
+            }
+            if (p.res_out) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)v[t][e];
+                *reinterpret_cast<f16x8*>(p.res_out + (size_t)row * p.H + c0) = o;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += v[t][e] * v[t][e];
+        }
+        if (!p.y) continue;
+        ss = wave_sum(ss);                                                  // same reduction tree as add_rmsnorm_kernel
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NTH / 64; ++i) tot += red[i];
+        const float rs = rsqrtf(tot / (float)p.H + p.eps);
+#pragma unroll
+        for (int t = 0; t < VPT; ++t) {
+            const int vi = tid + t * NTH;
+            if (vi >= nvec) continue;
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = win[t][e] * (f16)(v[t][e] * rs);
+            *reinterpret_cast<f16x8*>(p.y + (size_t)row * p.H + vi * 8) = o;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) ar.epoch[b] = epoch;
+}
+
+// Greedy argmax across a vocab-split lm_head: every rank publishes (best local logit, global index) per row, then picks
+// the overall best -- highest value, lowest global index on ties (torch.argmax semantics on the gathered row).
+struct ArgmaxParams {
+    ArDev        ar;
+    const float* cand_v;       // [B][nparts] local candidates (argmax_stage1 of elementwise.hip)
+    const int*   cand_i;
+    int          nparts, B, vocab_offset;
+    int32_t*     ids;
+    int32_t*     positions;    // += 1 when non-null
+};
+
+__global__ __launch_bounds__(64) void allreduce_argmax_kernel(const ArgmaxParams p) {
+    const ArDev& ar = p.ar;
+    const int b = blockIdx.x, l = threadIdx.x;
+    const uint32_t epoch = ar.epoch[b] + 1;
+    const size_t par = (epoch & 1) * ar.parity_elems;
+    for (int row = b; row < p.B; row += gridDim.x) {
+        float bv = l < p.nparts ? p.cand_v[row * p.nparts + l] : -INFINITY;
+        int   bi = l < p.nparts ? p.cand_i[row * p.nparts + l] : 0x7FFFFFFF;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (l == 0) {
+            u32x2 rec = {__builtin_bit_cast(uint32_t, bv), (uint32_t)(bi + p.vocab_offset)};
+            *reinterpret_cast<u32x2*>(ar.my_data + par + ar.aux_elems + (size_t)row * 4) = rec;   // 8 bytes per row
+        }
+    }
+    peer_barrier(ar, b, epoch);
+    for (int row = b; row < p.B; row += gridDim.x) {
+        float bv = -INFINITY; int bi = 0x7FFFFFFF;
+        if (l < ar.world) {
+            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)ar.peer_data[l], 0, ar.data_bytes, 0x00020000u);
+            const u32x2 rec = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (uint32_t)((par + ar.aux_elems + (size_t)row * 4) * 2), 0, 17));
+            bv = __builtin_bit_cast(float, rec[0]); bi = (int)rec[1];
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) {                                   // world <= 8 lanes
+            const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (l == 0) {
+            p.ids[row] = bi;
+            if (p.positions) p.positions[row] += 1;
+        }
+    }
+    __syncthreads();
+    if (l == 0) ar.epoch[b] = epoch;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------ host side
+struct mi355_allreduce {
+    int     rank, world;
+    size_t  max_bytes;                 // largest message (one parity)
+    void*   data;                      // 2 x max_bytes, IPC-exported
+    void*   flags;                     // kMaxBlocks x kFlagRow dwords, IPC-exported
+    void*   peer_data[kMaxWorld];
+    void*   peer_flags[kMaxWorld];
+    bool    opened[kMaxWorld];
+    uint32_t* epoch;
+    int32_t*  status;
+    bool    ready;
+};
+
+namespace {
+
+struct HandleBlob {                    // what ranks exchange (host bytes)
+    hipIpcMemHandle_t data, flags;
+    int32_t           rank, world;
+    uint64_t          max_bytes;
+    int32_t           pid;
+    int32_t           device;
+};
+
+// IPC-exportable device memory, zeroed.  Preferred: uncached (fine-grained) memory, whose stores are visible to peers
+// without relying on a kernel boundary; if the runtime cannot export that kind, ordinary device memory (the kernels use
+// system-scope fences and sc0 sc1 accesses on everything shared, so both kinds are correct).
+void* alloc_shared(size_t bytes, hipIpcMemHandle_t* handle) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        void* p = nullptr;
+        const hipError_t e = attempt == 0 ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) : hipMalloc(&p, bytes);
+        if (e == hipSuccess && p) {
+            if (hipMemset(p, 0, bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipIpcGetMemHandle(handle, p) == hipSuccess)
+                return p;
+            (void)hipFree(p);
+        }
+        (void)hipGetLastError();
+    }
+    return nullptr;
+}
+
+ArDev dev_view(const mi355_allreduce* a) {
+    ArDev d;
+    d.my_data = (f16*)a->data;
+    for (int r = 0; r < kMaxWorld; ++r) {
+        d.peer_data[r]  = (const f16*)a->peer_data[r < a->world ? r : 0];
+        d.peer_flags[r] = (uint32_t*)a->peer_flags[r < a->world ? r : 0];
+    }
+    d.epoch = a->epoch; d.status = a->status;
+    d.parity_elems = (a->max_bytes + kAuxBytes) / 2;
+    d.aux_elems = a->max_bytes / 2;
+    d.data_bytes = (uint32_t)(2 * (a->max_bytes + kAuxBytes));
+    d.rank = a->rank; d.world = a->world;
+    return d;
+}
+
+} // namespace
+
+extern "C" size_t mi355_allreduce_handle_bytes(void) { return sizeof(HandleBlob); }
+
+extern "C" mi355_allreduce_t* mi355_allreduce_create(int32_t rank, int32_t world, size_t max_bytes, void* handle_out) {
+    if (rank < 0 || world < 1 || world > kMaxWorld || rank >= world || !handle_out || max_bytes == 0 ||
+        2 * (max_bytes + kAuxBytes) >= 0xFFFFFF00ull) {
+        mi355_set_error("allreduce_create: rank=%d world=%d (1..%d) max_bytes=%zu", rank, world, kMaxWorld, max_bytes);
+        return nullptr;
+    }
+    mi355_allreduce* a = new (std::nothrow) mi355_allreduce();
+    if (!a) return nullptr;
+    a->rank = rank; a->world = world; a->ready = false;
+    a->max_bytes = (max_bytes + 255) & ~(size_t)255;
+    for (int r = 0; r < kMaxWorld; ++r) { a->peer_data[r] = a->peer_flags[r] = nullptr; a->opened[r] = false; }
+    HandleBlob hb;
+    memset(&hb, 0, sizeof(hb));
+    a->data  = alloc_shared(2 * (a->max_bytes + kAuxBytes), &hb.data);
+    a->flags = alloc_shared((size_t)kMaxBlocks * kFlagRow * 4, &hb.flags);
+    a->epoch = nullptr; a->status = nullptr;
+    if (!a->data || !a->flags || hipMalloc((void**)&a->epoch, kMaxBlocks * 4 + 256) != hipSuccess ||
+        hipMemset(a->epoch, 0, kMaxBlocks * 4 + 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        mi355_set_error("allreduce_create: cannot allocate / export the shared buffers: %s", hipGetErrorString(hipGetLastError()));
+        mi355_allreduce_destroy(a);
+        return nullptr;
+    }
+    a->status = (int32_t*)(a->epoch + kMaxBlocks);
+    hb.rank = rank; hb.world = world; hb.max_bytes = a->max_bytes; hb.pid = (int32_t)getpid();
+    (void)hipGetDevice(&hb.device);
+    memcpy(handle_out, &hb, sizeof(hb));
+    a->peer_data[rank] = a->data; a->peer_flags[rank] = a->flags;
+    return a;
+}
+
+extern "C" int mi355_allreduce_open(mi355_allreduce_t* a, const void* all_handles) {
+    MI355_CHECK_ARG(a && all_handles, "allreduce_open: null argument");
+    const HandleBlob* hb = (const HandleBlob*)all_handles;
+    for (int r = 0; r < a->world; ++r) {
+        MI355_CHECK_ARG(hb[r].rank == r && hb[r].world == a->world && hb[r].max_bytes == a->max_bytes,
+                        "allreduce_open: handle %d is from rank %d / world %d / %llu bytes", r, hb[r].rank, hb[r].world,
+                        (unsigned long long)hb[r].max_bytes);
+        if (r == a->rank) continue;
+        if (hipIpcOpenMemHandle(&a->peer_data[r], hb[r].data, hipIpcMemLazyEnablePeerAccess) != hipSuccess ||
+            hipIpcOpenMemHandle(&a->peer_flags[r], hb[r].flags, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+            mi355_set_error("allreduce_open: hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(hipGetLastError()));
+            return MI355_ERR_HIP;
+        }
+        a->opened[r] = true;
+    }
+    a->ready = true;
+    return MI355_OK;
+}
+
+extern "C" void mi355_allreduce_destroy(mi355_allreduce_t* a) {
+    if (!a) return;
+    for (int r = 0; r < kMaxWorld; ++r) {
+        if (a->opened[r]) { if (a->peer_data[r]) hipIpcCloseMemHandle(a->peer_data[r]); if (a->peer_flags[r]) hipIpcCloseMemHandle(a->peer_flags[r]); }
+    }
+    if (a->data) hipFree(a->data);
+    if (a->flags) hipFree(a->flags);
+    if (a->epoch) hipFree(a->epoch);
+    (void)hipGetLastError();
+    delete a;
+}
+
+extern "C" int mi355_allreduce_status(mi355_allreduce_t* a, mi355_stream_t stream) {
+    MI355_CHECK_ARG(a, "allreduce_status: null");
+    int32_t v = 0;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(&v, a->status, 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        mi355_set_error("allreduce_status: %s", hipGetErrorString(hipGetLastError()));
+        return MI355_ERR_HIP;
+    }
+    return v;
+}
+
+extern "C" int mi355_allreduce_fused(mi355_allreduce_t* a, const void* x_f16, const float* partials, int32_t nsplit, int32_t ld,
+                                     const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
+                                     int32_t T, int32_t H, void* y, mi355_stream_t stream) {
+    MI355_CHECK_ARG(a && a->ready, "allreduce: context not opened (mi355_allreduce_open)");
+    MI355_CHECK_ARG((x_f16 != nullptr) != (partials != nullptr), "allreduce: exactly one of x_f16 / partials");
+    MI355_CHECK_ARG(T > 0 && H > 0 && H % 8 == 0 && H <= 8192, "allreduce: T=%d H=%d (H %% 8 == 0, H <= 8192)", T, H);
+    MI355_CHECK_ARG((size_t)T * H * 2 <= a->max_bytes, "allreduce: message %zu bytes > registered %zu", (size_t)T * H * 2, a->max_bytes);
+    MI355_CHECK_ARG(!partials || (nsplit >= 1 && ld >= H && ld % 4 == 0), "allreduce: nsplit=%d ld=%d", nsplit, ld);
+    MI355_CHECK_ARG(residual_out || y, "allreduce: no output");
+    MI355_CHECK_ARG(!y || weight, "allreduce: RMSNorm weight required with y");
+    FusedParams p;
+    p.ar = dev_view(a);
+    p.x = (const f16*)x_f16; p.partials = partials; p.nsplit = nsplit; p.ld = ld; p.bias = (const f16*)bias;
+    p.res_in = (const f16*)residual_in; p.res_out = (f16*)residual_out; p.weight = (const f16*)weight; p.y = (f16*)y;
+    p.eps = eps; p.T = T; p.H = H;
+    const int grid = T < kMaxBlocks ? T : kMaxBlocks;
+    hipStream_t st = (hipStream_t)stream;
+    if (H / 8 <= 512) hipLaunchKernelGGL(allreduce_fused_kernel<1>, dim3(grid), dim3(512), 0, st, p);
+    else              hipLaunchKernelGGL(allreduce_fused_kernel<2>, dim3(grid), dim3(512), 0, st, p);
+    MI355_CHECK_LAUNCH("allreduce_fused_kernel");
+    return MI355_OK;
+}
+
+extern "C" int mi355_allreduce_sum(mi355_allreduce_t* a, const void* x_f16, void* out_f16, int32_t T, int32_t H,
+                                   mi355_stream_t stream) {
+    return mi355_allreduce_fused(a, x_f16, nullptr, 0, 0, nullptr, nullptr, out_f16, nullptr, 0.f, T, H, nullptr, stream);
+}
+
+extern "C" int mi355_allreduce_argmax(mi355_allreduce_t* a, const float* logits, int32_t B, int32_t V_local, int32_t ld,
+                                      int32_t vocab_offset, int32_t* ids, int32_t* positions, void* workspace,
+                                      size_t workspace_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(a && a->ready, "allreduce_argmax: context not opened");
+    MI355_CHECK_ARG(logits && ids && workspace && B > 0 && V_local > 0 && ld >= V_local && ld % 4 == 0, "allreduce_argmax: bad args");
+    MI355_CHECK_ARG((size_t)B * 8 <= kAuxBytes, "allreduce_argmax: batch %d too large for the record region", B);
+    const int nparts = 64;
+    if (workspace_bytes < (size_t)B * nparts * 8) { mi355_set_error("allreduce_argmax: workspace too small"); return MI355_ERR_WORKSPACE; }
+    // stage 1 of the local argmax (candidates per row), then the cross-rank pick
+    if (int e = mi355_argmax_candidates(logits, B, V_local, ld, workspace, workspace_bytes, stream)) return e;
+    ArgmaxParams p;
+    p.ar = dev_view(a);
+    p.cand_v = (const float*)workspace; p.cand_i = (const int*)((const float*)workspace + (size_t)B * nparts);
+    p.nparts = nparts; p.B = B; p.vocab_offset = vocab_offset; p.ids = ids; p.positions = positions;
+    const int grid = B < kMaxBlocks ? B : kMaxBlocks;
+    hipLaunchKernelGGL(allreduce_argmax_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, p);
+    MI355_CHECK_LAUNCH("allreduce_argmax_kernel");
+    return MI355_OK;
+}

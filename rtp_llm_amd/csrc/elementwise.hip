@@ -262,6 +262,18 @@ extern "C" int mi355_argmax_ex(const float* logits, int32_t B, int32_t V, int32_
     return MI355_OK;
 }
 
+// stage 1 only: per-row candidates (value, local index) x 64 into `workspace` (consumed by mi355_allreduce_argmax)
+extern "C" int mi355_argmax_candidates(const float* logits, int32_t B, int32_t V, int32_t ld, void* workspace,
+                                       size_t workspace_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(logits && workspace && B > 0 && V > 0 && ld >= V && ld % 4 == 0, "argmax: B=%d V=%d ld=%d", B, V, ld);
+    const int nparts = 64;
+    if (workspace_bytes < (size_t)B * nparts * 8) { mi355_set_error("argmax: workspace too small"); return MI355_ERR_WORKSPACE; }
+    float* cv = (float*)workspace; int* ci = (int*)(cv + (size_t)B * nparts);
+    hipLaunchKernelGGL(argmax_stage1, dim3(B, nparts), dim3(256), 0, (hipStream_t)stream, logits, V, ld, cv, ci);
+    MI355_CHECK_LAUNCH("argmax_stage1");
+    return MI355_OK;
+}
+
 extern "C" int mi355_argmax(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t* ids, void* workspace,
                             size_t workspace_bytes, mi355_stream_t stream) {
     return mi355_argmax_ex(logits, B, V, ld, ids, nullptr, workspace, workspace_bytes, stream);

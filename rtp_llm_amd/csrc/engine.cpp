@@ -37,6 +37,8 @@ struct mi355_decoder {
     // carved workspace
     void *resid, *xn, *q_buf, *attn_out, *act, *attn_ws, *argmax_ws;
     int32_t* oob_count; // tokens refused by the KV writer (stale position / block id)
+    mi355_allreduce_t* ar; // attached all-reduce context (tp_size > 1): the TP step runs entirely from C++
+    int    vocab_offset;
     float* partials;
     size_t attn_ws_bytes, argmax_ws_bytes, partials_bytes;
     int    B;
@@ -157,7 +159,7 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     d->cfg = *cfg; d->layers.assign(layers, layers + cfg->num_layers); d->model = *model; d->bufs = *bufs;
     carve_all(d, *cfg, bufs->workspace);
     d->xn = bufs->hidden; // the normed hidden state lives in the caller-visible buffer
-    d->B = 0; d->cap_stream = nullptr; d->prof_on = false; d->ev_used = 0;
+    d->B = 0; d->cap_stream = nullptr; d->prof_on = false; d->ev_used = 0; d->ar = nullptr; d->vocab_offset = 0;
     if (hipMemset(d->oob_count, 0, 256) != hipSuccess) { mi355_set_error("decoder_create: cannot clear the workspace"); delete d; return nullptr; }
     return d;
 }
@@ -176,9 +178,20 @@ extern "C" int mi355_decoder_begin(mi355_decoder_t* d, int32_t B, mi355_stream_t
     d->B = B;
     const auto& c = d->cfg;
     RUN(MI355_KC_OTHER, mi355_embedding(d->bufs.token_ids, B, d->model.embedding, c.hidden, d->model.vocab_full, d->resid, st));
-    if (c.tp_size == 1) {
+    if (c.tp_size == 1 || d->ar) {
         RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, d->layers[0].input_norm, c.rms_eps, B, c.hidden, d->xn, st));
     }
+    return MI355_OK;
+}
+
+extern "C" int mi355_decoder_attach_allreduce(mi355_decoder_t* d, mi355_allreduce_t* ar, int32_t vocab_offset) {
+    if (!d || !ar || d->cfg.tp_size <= 1 || vocab_offset < 0) {
+        mi355_set_error("decoder_attach_allreduce: needs a decoder created with tp_size > 1 and an opened context");
+        return MI355_ERR_ARG;
+    }
+    for (auto& kv : d->graphs) hipGraphExecDestroy(kv.second);   // graphs captured for the segmented path are stale now
+    d->graphs.clear();
+    d->ar = ar; d->vocab_offset = vocab_offset;
     return MI355_OK;
 }
 
@@ -186,7 +199,7 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
     if (!d || l < 0 || l >= d->cfg.num_layers || d->B <= 0) { mi355_set_error("decoder_layer_attn: layer=%d", l); return MI355_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     const auto& c = d->cfg; const auto& L = d->layers[l]; const int B = d->B;
-    if (c.tp_size > 1) {
+    if (c.tp_size > 1 && !d->ar) {
         if (l == 0) RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, L.input_norm, c.rms_eps, B, c.hidden, d->xn, st));
         else RUN(MI355_KC_NORM, mi355_add_rmsnorm(d->bufs.ar_buf, nullptr, 0, 0, nullptr, d->resid, d->resid, L.input_norm,
                                                    c.rms_eps, B, c.hidden, d->xn, st));
@@ -204,6 +217,9 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
     if (c.tp_size == 1) {
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid, L.post_norm,
                                              c.rms_eps, B, c.hidden, d->xn, st));
+    } else if (d->ar) { // split-K reduce + all-reduce + residual + post-attention norm in one launch
+        RUN(MI355_KC_COMM, mi355_allreduce_fused(d->ar, nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid,
+                                                 L.post_norm, c.rms_eps, B, c.hidden, d->xn, st));
     } else { // local split-K reduce -> fp16 tensor for the TP all-reduce
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.o.N_pad, nullptr, nullptr, d->bufs.ar_buf, nullptr,
                                              c.rms_eps, B, c.hidden, nullptr, st));
@@ -215,7 +231,7 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
     if (!d || l < 0 || l >= d->cfg.num_layers || d->B <= 0) { mi355_set_error("decoder_layer_mlp: layer=%d", l); return MI355_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     const auto& c = d->cfg; const auto& L = d->layers[l]; const int B = d->B;
-    if (c.tp_size > 1) {
+    if (c.tp_size > 1 && !d->ar) {
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(d->bufs.ar_buf, nullptr, 0, 0, nullptr, d->resid, d->resid, L.post_norm, c.rms_eps,
                                              B, c.hidden, d->xn, st));
     }
@@ -223,10 +239,13 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
                                                  d->partials_bytes, st));
     int ns = 0;
     RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->act, B, &L.down, d->partials, kMaxSplits, st));
+    const void* next_norm = (l + 1 < c.num_layers) ? d->layers[l + 1].input_norm : d->model.final_norm;
     if (c.tp_size == 1) {
-        const void* next_norm = (l + 1 < c.num_layers) ? d->layers[l + 1].input_norm : d->model.final_norm;
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
                                              c.rms_eps, B, c.hidden, d->xn, st));
+    } else if (d->ar) {
+        RUN(MI355_KC_COMM, mi355_allreduce_fused(d->ar, nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid,
+                                                 next_norm, c.rms_eps, B, c.hidden, d->xn, st));
     } else {
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.down.N_pad, nullptr, nullptr, d->bufs.ar_buf, nullptr,
                                              c.rms_eps, B, c.hidden, nullptr, st));
@@ -238,12 +257,15 @@ extern "C" int mi355_decoder_finish(mi355_decoder_t* d, int32_t sample, mi355_st
     if (!d || d->B <= 0) { mi355_set_error("decoder_finish: no step in flight"); return MI355_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     const auto& c = d->cfg; const int B = d->B;
-    if (c.tp_size > 1) {
+    if (c.tp_size > 1 && !d->ar) {
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(d->bufs.ar_buf, nullptr, 0, 0, nullptr, d->resid, d->resid, d->model.final_norm,
                                              c.rms_eps, B, c.hidden, d->xn, st));
     }
     RUN(MI355_KC_GEMM_LMHEAD, mi355_linear_direct(d->xn, B, &d->model.lm_head, nullptr, d->bufs.logits, MI355_EPI_OUT_F32, nullptr, 0, st));
-    if (sample) {
+    if (sample && d->ar) {   // vocab-split lm_head: (max, index) pairs cross the ranks, not the logits
+        RUN(MI355_KC_COMM, mi355_allreduce_argmax(d->ar, d->bufs.logits, B, c.vocab, c.vocab, d->vocab_offset, d->bufs.token_ids,
+                                                  d->bufs.positions, d->argmax_ws, d->argmax_ws_bytes, st));
+    } else if (sample) {
         RUN(MI355_KC_OTHER, mi355_argmax_ex(d->bufs.logits, B, c.vocab, c.vocab, d->bufs.token_ids, d->bufs.positions,
                                             d->argmax_ws, d->argmax_ws_bytes, st));
     }
@@ -251,7 +273,10 @@ extern "C" int mi355_decoder_finish(mi355_decoder_t* d, int32_t sample, mi355_st
 }
 
 extern "C" int mi355_decoder_step(mi355_decoder_t* d, int32_t B, mi355_stream_t stream) {
-    if (!d || d->cfg.tp_size != 1) { mi355_set_error("decoder_step: tp_size must be 1 (use the segment calls)"); return MI355_ERR_ARG; }
+    if (!d || (d->cfg.tp_size != 1 && !d->ar)) {
+        mi355_set_error("decoder_step: tp_size > 1 needs mi355_decoder_attach_allreduce (or the segment calls)");
+        return MI355_ERR_ARG;
+    }
     int rc = mi355_decoder_begin(d, B, stream);
     for (int l = 0; rc >= 0 && l < d->cfg.num_layers; ++l) {
         rc = mi355_decoder_layer_attn(d, l, stream);

@@ -1,6 +1,12 @@
 """TP collectives with the reference's call shape (rtp_llm/models_py/distributed/collective_torch.py:694-769):
-all_reduce(tensor, Group.TP) / all_gather(tensor, Group.TP).  Backend: torch.distributed — "nccl" is RCCL
-over xGMI on ROCm, "gloo" for the CPU tests.  One process per GPU."""
+all_reduce(tensor, Group.TP) / all_gather(tensor, Group.TP).  One process per GPU.
+
+Two transports, chosen like the reference does under graph capture (rocm_rccl.py:511-572: its custom one-shot kernel when
+the message fits the registered workspace, RCCL otherwise):
+  * ``CustomAllReduce`` -- the hand-written one-shot peer-read kernel of csrc/allreduce.hip over IPC-mapped buffers
+    (xGMI between GPUs): fp32 rank-order sums, bit-identical on every rank, graph-capturable, optionally fused with the
+    residual add + RMSNorm (and the split-K reduce) by the C++ step driver;
+  * torch.distributed -- "nccl" is RCCL on ROCm, "gloo" for the CPU tests -- for everything else."""
 import enum
 import os
 from typing import Optional
@@ -49,11 +55,84 @@ def tp_rank() -> int:
     return dist.get_rank(_tp_group)
 
 
+_custom_ar = None
+
+
+class CustomAllReduce:
+    """Host side of csrc/allreduce.hip (the role of TrtllmArFusionHandle + its Python wrapper, base/rocm/trt_allreduce.py:
+    51-230): create the context, exchange the IPC handle blobs through the (CPU-capable) process group, open the peers."""
+
+    def __init__(self, max_bytes: int, group=None, rank: Optional[int] = None, world: Optional[int] = None):
+        import ctypes as C
+        from . import _C
+        self._C, self.lib = _C, _C.lib()
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        n = self.lib.mi355_allreduce_handle_bytes()
+        blob = C.create_string_buffer(n)
+        self.handle = self.lib.mi355_allreduce_create(self.rank, self.world, int(max_bytes), blob)
+        if not self.handle:
+            raise _C.Mi355Error("allreduce_create failed: " + self.lib.mi355_last_error().decode())
+        blobs = [None] * self.world
+        dist.all_gather_object(blobs, blob.raw, group=group)           # host bytes: works over gloo and over nccl groups
+        self._all = C.create_string_buffer(b"".join(blobs), n * self.world)
+        _C.check(self.lib.mi355_allreduce_open(self.handle, self._all), "allreduce_open")
+        dist.barrier(group=group)                                     # every rank has mapped every peer before first use
+        self.max_bytes = int(max_bytes)
+
+    def _st(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def fits(self, t: torch.Tensor) -> bool:
+        return (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and t.dim() >= 1 and t.shape[-1] % 8 == 0
+                and t.shape[-1] <= 8192 and t.numel() * 2 <= self.max_bytes)
+
+    def all_reduce(self, t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = t if out is None else out
+        H = t.shape[-1]
+        self._C.check(self.lib.mi355_allreduce_sum(self.handle, t.data_ptr(), out.data_ptr(), t.numel() // H, H, self._st()), "allreduce_sum")
+        return out
+
+    def all_reduce_add_rmsnorm(self, t, residual, weight, eps):
+        """(normed, residual_out) = RMSResNorm(all_reduce(t), residual) in one launch (allreduce_fusion_kernel_1stage)."""
+        H = t.shape[-1]
+        y, res = torch.empty_like(t), torch.empty_like(t)
+        self._C.check(self.lib.mi355_allreduce_fused(self.handle, t.data_ptr(), None, 0, 0, None, residual.data_ptr(), res.data_ptr(),
+                                                     weight.data_ptr(), float(eps), t.numel() // H, H, y.data_ptr(), self._st()),
+                      "allreduce_fused")
+        return y, res
+
+    def argmax(self, logits_local: torch.Tensor, vocab_offset: int) -> torch.Tensor:
+        B, V = logits_local.shape
+        ids = torch.empty(B, dtype=torch.int32, device=logits_local.device)
+        ws = torch.empty(B * 64 * 8, dtype=torch.uint8, device=logits_local.device)
+        self._C.check(self.lib.mi355_allreduce_argmax(self.handle, logits_local.data_ptr(), B, V, V, int(vocab_offset), ids.data_ptr(),
+                                                      None, ws.data_ptr(), ws.numel(), self._st()), "allreduce_argmax")
+        return ids
+
+    def status(self) -> int:
+        """0 = healthy; != 0: a peer did not arrive within the kernel's spin bound (results invalid).  Synchronises."""
+        return int(self.lib.mi355_allreduce_status(self.handle, self._st()))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mi355_allreduce_destroy(self.handle)
+            self.handle = None
+
+
+def set_custom_all_reduce(ar: Optional[CustomAllReduce]) -> None:
+    """Route fitting TP all-reduces through the hand-written kernel (like the reference's capture path does)."""
+    global _custom_ar
+    _custom_ar = ar
+
+
 def all_reduce(tensor: torch.Tensor, group: Group = Group.TP, inplace: bool = True) -> torch.Tensor:
     """SUM over the TP ranks (C1/C2 of SURVEY 2.3: after O-proj and down-proj)."""
     if tp_size() == 1:
         return tensor
     t = tensor if inplace else tensor.clone()
+    if _custom_ar is not None and _custom_ar.fits(t):
+        return _custom_ar.all_reduce(t)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_tp_group)
     return t
 

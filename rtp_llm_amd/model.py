@@ -457,9 +457,15 @@ class DecoderEngine:
         _C.check(self.lib.mi355_decoder_replay(self.handle, B, nsteps, self._st()), "decoder_replay")
 
     def profile(self, B: int, nsteps: int):
-        ms, n = (C.c_float * 6)(), (C.c_int32 * 6)()
+        ms, n = (C.c_float * len(_C.KC_NAMES))(), (C.c_int32 * len(_C.KC_NAMES))()
         _C.check(self.lib.mi355_decoder_profile(self.handle, B, nsteps, ms, n, self._st()), "decoder_profile")
         return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(_C.KC_NAMES)}
+
+    def attach_allreduce(self, ar, vocab_offset: int):
+        """tp > 1: run the all-reduce points inside the C++ step (fused split-K reduce + all-reduce + residual + norm,
+        cross-rank greedy argmax): step() / capture() / replay() then drive the whole tensor-parallel step."""
+        _C.check(self.lib.mi355_decoder_attach_allreduce(self.handle, ar.handle, int(vocab_offset)), "decoder_attach_allreduce")
+        self._ar = ar
 
     # ---- tp > 1: the step cut at the all-reduce points (causal_attention.py:91-92, dense_mlp.py:104-105)
     def step_tp(self, B: int, sample: bool = True):
