@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q, inter):
+def _worker(rank, world, port, q, inter, nkv=4):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -35,7 +35,11 @@ def _worker(rank, world, port, q, inter):
         assert distributed.tp_size() == world and distributed.tp_rank() == rank
         # ---- one TP decoder layer: split weights per rank, all_reduce after O-proj and down-proj.  inter = 384 is not
         # a multiple of tp * 128: the split pads it to 512 with zero weights (the reference's align_size = tp * g)
-        cfg = model.ModelConfig("t", 1, 256, 8, 4, 64, inter, 64, max_pos=64)
+        # nkv = 1 < tp: the kv head is replicated on both ranks (get_sp_tensor, utils/model_weight.py:447-466)
+        cfg = model.ModelConfig("t", 1, 256, 8 if nkv == 4 else 4, nkv, 64 if nkv == 4 else 64, inter, 64, max_pos=64)
+        if nkv == 1:
+            cfg = model.ModelConfig("t", 1, 256, 4, 1, 64, inter, 64, max_pos=64)
+            assert cfg.per_rank(world).nkv == 1 and cfg.per_rank(world).nh == 2
         assert cfg.per_rank(world).inter == (256 if inter == 384 else inter // world)
         gen = torch.Generator().manual_seed(0)                      # same full weights on every rank
         L = model.synth_layer(cfg, "w4", "cpu", gen)
@@ -72,12 +76,12 @@ def _worker(rank, world, port, q, inter):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("inter", [512, 384])
-def test_tp2_gloo_layer_and_collectives(inter):
+@pytest.mark.parametrize("inter,nkv", [(512, 4), (384, 4), (512, 1)])
+def test_tp2_gloo_layer_and_collectives(inter, nkv):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, inter)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, inter, nkv)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=150) for _ in range(world)]
