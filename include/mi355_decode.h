@@ -196,6 +196,14 @@ int mi355_rope_kv_write(const void* qkv_f16, const float* partials, int32_t nspl
                         int32_t max_blocks_per_seq, int32_t T, int32_t nh,
                         const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count, mi355_stream_t stream);
 
+/* The same for q_len rows per sequence (speculative verify, chunked prefill): token t = row t % q_len of sequence t / q_len,
+ * block_table is [T / q_len][max_blocks_per_seq]; positions[t] < 0 marks a padding row (q produced, nothing stored). */
+int mi355_rope_kv_write_rows(const void* qkv_f16, const float* partials, int32_t nsplit, int32_t ld,
+                             const void* qkv_bias, const float* cos_sin, int32_t rope_dim, int32_t max_pos,
+                             const int32_t* positions, const int32_t* block_table,
+                             int32_t max_blocks_per_seq, int32_t T, int32_t q_len, int32_t nh,
+                             const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count, mi355_stream_t stream);
+
 /*
  * Paged decode attention (flash-decoding, split over the sequence) — replaces
  * AiterDecodeAttnOp*.forward / paged_attention_atrex
@@ -211,6 +219,20 @@ int mi355_paged_decode_attn(const void* q, const mi355_kv_layer_t* kv, const int
                             int32_t max_blocks_per_seq, const int32_t* seq_lens, int32_t B,
                             int32_t nh, float scale, int32_t max_seq_len, void* out,
                             void* workspace, size_t workspace_bytes, mi355_stream_t stream);
+
+/*
+ * q_len > 1 query rows per sequence against the paged cache, causal inside the page walk: row i of sequence b (index
+ * b * q_len + i into q / positions / out) attends the tokens 0 .. positions[b * q_len + i] of sequence b, which must be
+ * in the cache (mi355_rope_kv_write of the same rows runs first).  positions < 0 marks a padding row (output zeros).
+ * The KV of a sequence is streamed once per 2 * (16 / group) rows.  Serves the speculative target-verify step
+ * (`is_target_verify`, bindings/OpDefs.h:283: gamma + 1 rows per sequence) and chunked prefill over the paged cache
+ * (FusedRopeKVCacheOp.cc:216-461 + the paged prefill ops of factory/attention/rocm_impl/aiter.py:244-950).
+ * workspace: mi355_paged_attn_workspace_bytes(B * q_len, nh, hd, max_seq_len).
+ */
+int mi355_paged_attn_rows(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_table,
+                          int32_t max_blocks_per_seq, const int32_t* positions, int32_t B, int32_t q_len, int32_t nh,
+                          float scale, int32_t max_seq_len, void* out, void* workspace, size_t workspace_bytes,
+                          mi355_stream_t stream);
 
 /* Greedy fast path: ids[b] = argmax(logits[b, :]) on fp32 logits, lowest index on ties
  * (bindings/core/CudaSampleOp.cc:687-700).  workspace >= B * 64 * 8 bytes. */
@@ -350,6 +372,11 @@ void             mi355_decoder_destroy(mi355_decoder_t* d);
  *                      positions += 1
  * mi355_decoder_step = all of them (tp_size == 1 only). */
 int mi355_decoder_begin(mi355_decoder_t* d, int32_t B, mi355_stream_t stream);
+/* The same step over nseq sequences x q_len rows each (nseq * q_len <= max_batch): token_ids / positions hold
+ * nseq * q_len entries (row i of sequence b at b * q_len + i, positions ascending, < 0 = padding row), block_table one row
+ * per SEQUENCE.  Row i attends the cache up to its own position: the speculative target-verify step (is_target_verify,
+ * bindings/OpDefs.h:283).  Follow with the layer segments and mi355_decoder_finish as usual. */
+int mi355_decoder_begin_rows(mi355_decoder_t* d, int32_t nseq, int32_t q_len, mi355_stream_t stream);
 int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t layer, mi355_stream_t stream);
 int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t layer, mi355_stream_t stream);
 int mi355_decoder_finish(mi355_decoder_t* d, int32_t sample, mi355_stream_t stream);

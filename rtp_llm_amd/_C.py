@@ -65,8 +65,10 @@ SIGNATURES = {
     "mi355_silu_mul": (i32, [vp, i32, i32, vp, vp]),
     "mi355_embedding": (i32, [vp, i32, vp, i32, i32, vp, vp]),
     "mi355_rope_kv_write": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
+    "mi355_rope_kv_write_rows": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
     "mi355_paged_attn_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "mi355_paged_decode_attn": (i32, [vp, C.POINTER(KVLayer), vp, i32, vp, i32, i32, f32, i32, vp, vp, sz, vp]),
+    "mi355_paged_attn_rows": (i32, [vp, C.POINTER(KVLayer), vp, i32, vp, i32, i32, i32, f32, i32, vp, vp, sz, vp]),
     "mi355_argmax": (i32, [vp, i32, i32, i32, vp, vp, sz, vp]),
     "mi355_softmax_rows": (i32, [vp, i32, i32, i32, f32, vp, vp]),
     "mi355_sample_rows": (i32, [vp, i32, i32, i32, vp, vp, vp]),
@@ -84,6 +86,7 @@ SIGNATURES = {
     "mi355_decoder_create": (vp, [C.POINTER(ModelConfig), C.POINTER(LayerWeights), C.POINTER(ModelWeights), C.POINTER(StepBuffers)]),
     "mi355_decoder_destroy": (None, [vp]),
     "mi355_decoder_begin": (i32, [vp, i32, vp]),
+    "mi355_decoder_begin_rows": (i32, [vp, i32, i32, vp]),
     "mi355_decoder_layer_attn": (i32, [vp, i32, vp]),
     "mi355_decoder_layer_mlp": (i32, [vp, i32, vp]),
     "mi355_decoder_finish": (i32, [vp, i32, vp]),

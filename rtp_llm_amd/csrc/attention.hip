@@ -1,4 +1,6 @@
-// Paged flash-decoding attention (q_len = 1, GQA) with fp16 or INT8 KV-cache, gfx950.
+// Paged flash-decoding attention (GQA) with fp16 or INT8 KV-cache, gfx950: q_len = 1 (decode) and q_len > 1 rows per
+// sequence with the causal mask applied inside the page walk (speculative target-verify, `is_target_verify`
+// bindings/OpDefs.h:283, and chunked prefill over the paged cache, FusedRopeKVCacheOp.cc:216-461 / aiter.py:244-950).
 //
 // Replaces AiterDecodeAttnOp*.forward / paged_attention_atrex
 // (rtp_llm/models_py/modules/factory/attention/rocm_impl/aiter.py:1340-1561,
@@ -21,6 +23,9 @@
 // channel-major per block so the V^T fragment is one 16-byte load.
 // INT8: K/V bytes are widened in-register (v_perm + exact fp16 add), the per-token
 // scales are applied to S (K) and to P (V) in fp32.
+// Multi-row: the 16 MFMA columns of a tile hold (row, head) pairs -- R = 16 / G rows of one sequence x its G query heads --
+// and a block carries NT such tiles against the same K/V fragments, so a sequence's KV is streamed once per NT*R query rows
+// instead of once per row; column j masks tokens beyond ITS row's position (causality), nothing else changes.
 #include "common.h"
 #include "internal.h"
 
@@ -36,18 +41,34 @@ struct AttnParams {
     float*         tmp_out; // [B][nh][P][hd]
     float*         tmp_ml;  // [B][nh][P][2]
     int B, nh, nkv, G, page, max_blocks, P, PS, seq_add, max_seq, num_blocks;
+    int q_len, R, ntile;   // rows per sequence, rows per 16-column tile (16 / G), row tiles per sequence
     float scale_log2; // softmax scale * log2(e)
 };
 
 constexpr float NEG_BIG = -1e30f;
 
-template <int HD, bool INT8>
+template <int HD, bool INT8, int NT>
 __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
     constexpr int NSTEP = HD / 32; // QK k-steps
     constexpr int NDB   = HD / 16; // PV d-blocks
-    const int part = blockIdx.x, kh = blockIdx.y, b = blockIdx.z;
-    const int seq_len = min(max(p.seq_lens[b] + p.seq_add, 1), p.max_seq);   // clamped: block table / workspace stay in range
+    const int part = blockIdx.x, kh = blockIdx.y;
+    const int b = blockIdx.z / p.ntile, tile = blockIdx.z - b * p.ntile;
+    const int RT = NT * p.R;                       // query rows of this block
+    const int row0 = b * p.q_len + tile * RT;      // first row (index into q / positions / out)
+    const int nrows = min(RT, p.q_len - tile * RT);
+    // context of a row = its position + 1 (seq_add = 1: positions hold tokens already cached) or seq_lens[row] itself;
+    // a negative value marks a padding row.  The block walks up to the longest context of its rows.
+    int seq_len = 0;
+    for (int i = 0; i < nrows; ++i) seq_len = max(seq_len, min(p.seq_lens[row0 + i] + p.seq_add, p.max_seq));
     const int pstart = part * p.PS;
+    if (seq_len <= 0) {   // only padding rows here: their outputs are defined (zeros), nothing is read
+        if (part == 0)
+            for (int idx = threadIdx.x; idx < nrows * p.G * HD; idx += 256) {
+                const int rl = idx / (p.G * HD), rem = idx - rl * (p.G * HD);
+                p.out[((size_t)(row0 + rl) * p.nh + kh * p.G) * HD + rem] = (f16)0.f;
+            }
+        return;
+    }
     if (pstart >= seq_len) return;
     const int pend = min(seq_len, pstart + p.PS);
 
@@ -55,16 +76,22 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, w = lane >> 4;
 
-    // q fragments (B operand): head kh*G + j, zero for j >= G
-    f16x8 qf[NSTEP];
-    {
-        const f16* qrow = p.q + ((size_t)b * p.nh + kh * p.G + (j < p.G ? j : 0)) * HD;
+    // column j of tile c = (row c*R + j/G, head kh*G + j%G); q fragments (B operand), zero for unused columns
+    f16x8 qf[NT][NSTEP];
+    int   limit[NT];       // tokens [0, limit) are visible to this lane's column (causal mask); 0 = nothing
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const int rl = c * p.R + j / p.G, g = j - (j / p.G) * p.G;
+        const bool ok = j < p.R * p.G && rl < nrows;
+        const int row = row0 + (ok ? rl : 0);
+        limit[c] = ok ? min(max(p.seq_lens[row] + p.seq_add, 0), p.max_seq) : 0;
+        const f16* qrow = p.q + ((size_t)row * p.nh + kh * p.G + g) * HD;
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             const int d = INT8 ? (s >> 1) * 64 + w * 16 + (s & 1) * 8 : s * 32 + w * 8;
             f16x8 v = *reinterpret_cast<const f16x8*>(qrow + d);
-            if (j >= p.G) v = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            qf[s] = v;
+            if (!ok) v = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            qf[c][s] = v;
         }
     }
 
@@ -73,10 +100,14 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
     const char* kvb = (const char*)p.kv_base;
     constexpr int ES = INT8 ? 1 : 2;
 
-    f32x4 o[NDB];
+    f32x4 o[NT][NDB];
+    float m_run[NT], l_run[NT];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = NEG_BIG, l_run = 0.f;
+    for (int c = 0; c < NT; ++c) {
+        m_run[c] = NEG_BIG; l_run[c] = 0.f;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) o[c][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     // One 32-token group of K/V in registers (+ the per-token INT8 scales of the lane's own 8 tokens).
     struct Group {
@@ -125,55 +156,62 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
     };
     auto compute_group = [&](const Group& g, int tb) {
         const int vwin = tb + w * 8; // first token of this lane's S rows / P slots
-        // ---- S^T = K q^T
-        f32x4 sacc[2];
+        // ---- widen K once, S^T = K q^T for every column tile
+        f16x8 ka[2][NSTEP];
 #pragma unroll
-        for (int tau = 0; tau < 2; ++tau) {
-            sacc[tau] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int tau = 0; tau < 2; ++tau)
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) {
-                f16x8 a;
                 if (INT8) {
                     const u32x4 kk = g.kf[tau][s >> 1];
                     const uint32_t lo = kk[(s & 1) * 2] ^ 0x80808080u, hi = kk[(s & 1) * 2 + 1] ^ 0x80808080u;
                     const f16x2 zneg2 = {(f16)-1152.f, (f16)-1152.f};
-                    a = dequant_w8<false>(lo, hi, zneg2, zneg2);
+                    ka[tau][s] = dequant_w8<false>(lo, hi, zneg2, zneg2);
                 } else {
-                    a = __builtin_bit_cast(f16x8, g.kf[tau][s]);
+                    ka[tau][s] = __builtin_bit_cast(f16x8, g.kf[tau][s]);
                 }
-                sacc[tau] = mfma16x16x32(a, qf[s], sacc[tau]);
             }
-        }
-        // ---- scale, mask, online softmax (log2 domain)
-        float sv[8];
-        float mx = NEG_BIG;
+        f16x8 pf[NT];
+        float alpha[NT];
 #pragma unroll
-        for (int tau = 0; tau < 2; ++tau)
+        for (int c = 0; c < NT; ++c) {
+            f32x4 sacc[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = sacc[tau][r] * p.scale_log2;
-                if (INT8) v *= g.ksc[tau][r];
-                const int tok = vwin + tau * 4 + r;
-                v = tok < seq_len ? v : NEG_BIG;
-                sv[tau * 4 + r] = v;
-                mx = fmaxf(mx, v);
+            for (int tau = 0; tau < 2; ++tau) {
+                sacc[tau] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < NSTEP; ++s) sacc[tau] = mfma16x16x32(ka[tau][s], qf[c][s], sacc[tau]);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
-        f16x8 pf;
+            // ---- scale, causal mask, online softmax (log2 domain)
+            float sv[8];
+            float mx = NEG_BIG;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool valid = vwin + e < seq_len;
-            float pe = valid ? __builtin_amdgcn_exp2f(sv[e] - m_new) : 0.f;
-            psum += pe;
-            if (INT8) pe = valid ? pe * g.vsc[e >> 2][e & 3] : 0.f; // scale bytes past seq_len may be garbage
-            pf[e] = (f16)pe;
+            for (int tau = 0; tau < 2; ++tau)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = sacc[tau][r] * p.scale_log2;
+                    if (INT8) v *= g.ksc[tau][r];
+                    const int tok = vwin + tau * 4 + r;
+                    v = tok < limit[c] ? v : NEG_BIG;
+                    sv[tau * 4 + r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[c], mx);
+            alpha[c] = __builtin_amdgcn_exp2f(m_run[c] - m_new);
+            m_run[c] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool valid = vwin + e < limit[c];
+                float pe = valid ? __builtin_amdgcn_exp2f(sv[e] - m_new) : 0.f;
+                psum += pe;
+                if (INT8) pe = valid ? pe * g.vsc[e >> 2][e & 3] : 0.f; // scale bytes past the context may be garbage
+                pf[c][e] = (f16)pe;
+            }
+            l_run[c] = l_run[c] * alpha[c] + psum;
         }
-        l_run = l_run * alpha + psum;
         // ---- O^T = alpha * O^T + V^T P
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
@@ -184,12 +222,13 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
             } else {
                 a = __builtin_bit_cast(f16x8, g.vf16[db]);
             }
-            // tokens past seq_len carry p = 0 but V bytes there may be garbage (NaN/Inf): zero them
+            // tokens past the block's context carry p = 0 but V bytes there may be garbage (NaN/Inf): zero them
             if (vwin + 7 >= seq_len) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) if (vwin + e >= seq_len) a[e] = (f16)0.f;
             }
-            o[db] = mfma16x16x32(a, pf, o[db] * alpha);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) o[c][db] = mfma16x16x32(a, pf[c], o[c][db] * alpha[c]);
         }
     };
 
@@ -213,39 +252,47 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
         }
     }
 
-    // ---- merge the 4 waves through LDS.  o[db][r] is O^T[d = db*16 + w*4 + r][j].
-    l_run += __shfl_xor(l_run, 16);
-    l_run += __shfl_xor(l_run, 32);
+    // ---- merge the 4 waves through LDS, one column tile at a time.  o[c][db][r] is O^T[d = db*16 + w*4 + r][j].
     __shared__ float s_o[4][16][HD + 4];
     __shared__ float s_m[4][16], s_l[4][16];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db)
-        *reinterpret_cast<f32x4*>(&s_o[wave][j][db * 16 + w * 4]) = o[db];
-    if (w == 0) { s_m[wave][j] = m_run; s_l[wave][j] = l_run; }
-    __syncthreads();
-    // thread -> (head jj, 4 channels); 16 heads * HD/4 vectors
-    for (int idx = tid; idx < p.G * (HD / 4); idx += 256) {
-        const int jj = idx / (HD / 4), d0 = (idx - jj * (HD / 4)) * 4;
-        float mstar = fmaxf(fmaxf(s_m[0][jj], s_m[1][jj]), fmaxf(s_m[2][jj], s_m[3][jj]));
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        float l = 0.f;
+    for (int c = 0; c < NT; ++c) {
+        float lr = l_run[c];
+        lr += __shfl_xor(lr, 16);
+        lr += __shfl_xor(lr, 32);
+        if (c) __syncthreads();
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
-            const float f = __builtin_amdgcn_exp2f(s_m[ww][jj] - mstar);
-            acc += *reinterpret_cast<const f32x4*>(&s_o[ww][jj][d0]) * f;
-            l += s_l[ww][jj] * f;
-        }
-        const int h = kh * p.G + jj;
-        if (p.P == 1) {
-            const float inv = 1.f / l;
-            f16x4 ov;
+        for (int db = 0; db < NDB; ++db)
+            *reinterpret_cast<f32x4*>(&s_o[wave][j][db * 16 + w * 4]) = o[c][db];
+        if (w == 0) { s_m[wave][j] = m_run[c]; s_l[wave][j] = lr; }
+        __syncthreads();
+        // thread -> (column jj, 4 channels); 16 columns * HD/4 vectors
+        const int ncol = p.R * p.G;
+        for (int idx = tid; idx < ncol * (HD / 4); idx += 256) {
+            const int jj = idx / (HD / 4), d0 = (idx - jj * (HD / 4)) * 4;
+            const int rl = c * p.R + jj / p.G;
+            if (rl >= nrows) continue;
+            float mstar = fmaxf(fmaxf(s_m[0][jj], s_m[1][jj]), fmaxf(s_m[2][jj], s_m[3][jj]));
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            float l = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ov[r] = (f16)(acc[r] * inv);
-            *reinterpret_cast<f16x4*>(p.out + ((size_t)b * p.nh + h) * HD + d0) = ov;
-        } else {
-            const size_t slot = ((size_t)b * p.nh + h) * p.P + part;
-            *reinterpret_cast<f32x4*>(p.tmp_out + slot * HD + d0) = acc;
-            if (d0 == 0) { p.tmp_ml[slot * 2] = mstar; p.tmp_ml[slot * 2 + 1] = l; }
+            for (int ww = 0; ww < 4; ++ww) {
+                const float f = __builtin_amdgcn_exp2f(s_m[ww][jj] - mstar);
+                acc += *reinterpret_cast<const f32x4*>(&s_o[ww][jj][d0]) * f;
+                l += s_l[ww][jj] * f;
+            }
+            const int row = row0 + rl, h = kh * p.G + (jj - (jj / p.G) * p.G);
+            if (p.P == 1) {
+                const float inv = l > 0.f ? 1.f / l : 0.f;          // padding row / empty context: zeros, not NaN
+                f16x4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (f16)(acc[r] * inv);
+                *reinterpret_cast<f16x4*>(p.out + ((size_t)row * p.nh + h) * HD + d0) = ov;
+            } else {
+                const size_t slot = ((size_t)row * p.nh + h) * p.P + part;
+                *reinterpret_cast<f32x4*>(p.tmp_out + slot * HD + d0) = acc;
+                if (d0 == 0) { p.tmp_ml[slot * 2] = mstar; p.tmp_ml[slot * 2 + 1] = l; }
+            }
         }
     }
 }
@@ -254,10 +301,10 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
 template <int HD>
 __global__ __launch_bounds__(256) void attn_reduce_kernel(const AttnParams p) {
     const int lane = threadIdx.x & 63;
-    const int gid = blockIdx.x * 4 + (threadIdx.x >> 6); // (b, h)
-    if (gid >= p.B * p.nh) return;
-    const int b = gid / p.nh;
-    const int np = (min(max(p.seq_lens[b] + p.seq_add, 1), p.max_seq) + p.PS - 1) / p.PS;
+    const int gid = blockIdx.x * 4 + (threadIdx.x >> 6); // (row, h)
+    if (gid >= p.B * p.q_len * p.nh) return;
+    const int row = gid / p.nh;
+    const int np = (min(max(p.seq_lens[row] + p.seq_add, 0), p.max_seq) + p.PS - 1) / p.PS;   // partitions that saw this row
     const float* ml = p.tmp_ml + (size_t)gid * p.P * 2;
     float mstar = NEG_BIG;
     for (int i = 0; i < np; ++i) mstar = fmaxf(mstar, ml[i * 2]);
@@ -273,7 +320,7 @@ __global__ __launch_bounds__(256) void attn_reduce_kernel(const AttnParams p) {
 #pragma unroll
         for (int c = 0; c < CPL; ++c) acc[c] += src[c] * f;
     }
-    const float inv = 1.f / l;
+    const float inv = l > 0.f ? 1.f / l : 0.f;
     f16* dst = p.out + (size_t)gid * HD + lane * CPL;
 #pragma unroll
     for (int c = 0; c < CPL; ++c) dst[c] = (f16)(acc[c] * inv);
@@ -310,54 +357,77 @@ extern "C" size_t mi355_paged_attn_workspace_bytes(int32_t B, int32_t nh, int32_
     return (size_t)B * nh * P * (hd + 2) * sizeof(float);
 }
 
+namespace {
+int launch_attn(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_table, int32_t max_blocks_per_seq,
+                const int32_t* seq_lens, int32_t seq_lens_minus_one, int32_t B, int32_t q_len, int32_t nh, float scale,
+                int32_t max_seq_len, void* out, void* workspace, size_t workspace_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(q && kv && kv->kv_base && block_table && seq_lens && out, "paged_attn: null pointer");
+    MI355_CHECK_ARG(kv->hd == 64 || kv->hd == 128, "paged_attn: hd=%d (64 or 128)", kv->hd);
+    MI355_CHECK_ARG(kv->page >= 16 && kv->page % 8 == 0, "paged_attn: page=%d (>= 16, multiple of 8)", kv->page);
+    MI355_CHECK_ARG(B > 0 && q_len > 0 && nh > 0 && kv->nkv > 0 && nh % kv->nkv == 0 && nh / kv->nkv <= 16,
+                    "paged_attn: B=%d q_len=%d nh=%d nkv=%d (group <= 16)", B, q_len, nh, kv->nkv);
+    MI355_CHECK_ARG(kv->num_blocks > 0, "paged_attn: num_blocks=%d", kv->num_blocks);
+    MI355_CHECK_ARG(max_seq_len > 0 && (long)max_blocks_per_seq * kv->page >= max_seq_len,
+                    "paged_attn: max_seq_len=%d exceeds block table", max_seq_len);
+    const bool int8 = kv->kv_dtype == MI355_KV_INT8;
+    MI355_CHECK_ARG(!int8 || kv->scale_base, "paged_attn: int8 cache needs scale_base");
+    AttnParams p;
+    p.q = (const f16*)q; p.kv_base = kv->kv_base; p.scale_base = kv->scale_base; p.block_table = block_table;
+    p.seq_lens = seq_lens; p.out = (f16*)out; p.B = B; p.nh = nh; p.nkv = kv->nkv; p.G = nh / kv->nkv;
+    p.page = kv->page; p.max_blocks = max_blocks_per_seq; p.seq_add = seq_lens_minus_one ? 1 : 0;
+    p.max_seq = max_seq_len; p.num_blocks = kv->num_blocks;
+    p.q_len = q_len; p.R = 16 / p.G;
+    const int NT = q_len > p.R ? 2 : 1;                 // column tiles per block: 2 x R rows share one pass over the KV
+    p.ntile = cdiv(q_len, NT * p.R);
+    p.P = plan_partitions(B * p.ntile, kv->nkv, max_seq_len, &p.PS);
+    p.scale_log2 = scale * 1.4426950408889634f;
+    const size_t rows = (size_t)B * q_len;
+    const size_t need = p.P > 1 ? rows * nh * p.P * (kv->hd + 2) * sizeof(float) : 0;
+    if (need > workspace_bytes || (need && !workspace)) {
+        mi355_set_error("paged_attn: workspace %zu < %zu", workspace_bytes, need);
+        return MI355_ERR_WORKSPACE;
+    }
+    p.tmp_out = (float*)workspace;
+    p.tmp_ml  = p.tmp_out + rows * nh * p.P * kv->hd;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(p.P, kv->nkv, B * p.ntile);
+#define L_(HD_, I8_, NT_) hipLaunchKernelGGL((paged_attn_kernel<HD_, I8_, NT_>), grid, dim3(256), 0, st, p)
+#define L2_(HD_, I8_) do { if (NT == 1) L_(HD_, I8_, 1); else L_(HD_, I8_, 2); } while (0)
+    if (kv->hd == 128) { if (int8) L2_(128, true); else L2_(128, false); }
+    else               { if (int8) L2_(64, true);  else L2_(64, false); }
+#undef L2_
+#undef L_
+    MI355_CHECK_LAUNCH("paged_attn_kernel");
+    if (p.P > 1) {
+        const int nblk = cdiv((int)rows * nh, 4);
+        if (kv->hd == 128) hipLaunchKernelGGL(attn_reduce_kernel<128>, dim3(nblk), dim3(256), 0, st, p);
+        else               hipLaunchKernelGGL(attn_reduce_kernel<64>, dim3(nblk), dim3(256), 0, st, p);
+        MI355_CHECK_LAUNCH("attn_reduce_kernel");
+    }
+    return MI355_OK;
+}
+} // namespace
+
 extern "C" int mi355_paged_decode_attn(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_table,
                                        int32_t max_blocks_per_seq, const int32_t* seq_lens, int32_t B, int32_t nh,
                                        float scale, int32_t max_seq_len, void* out, void* workspace,
                                        size_t workspace_bytes, mi355_stream_t stream) {
-    return mi355_paged_decode_attn_ex(q, kv, block_table, max_blocks_per_seq, seq_lens, 0, B, nh, scale, max_seq_len, out,
-                                      workspace, workspace_bytes, stream);
+    return launch_attn(q, kv, block_table, max_blocks_per_seq, seq_lens, 0, B, 1, nh, scale, max_seq_len, out, workspace,
+                       workspace_bytes, stream);
 }
 
 extern "C" int mi355_paged_decode_attn_ex(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_table,
                                           int32_t max_blocks_per_seq, const int32_t* seq_lens, int32_t seq_lens_minus_one,
                                           int32_t B, int32_t nh, float scale, int32_t max_seq_len, void* out,
                                           void* workspace, size_t workspace_bytes, mi355_stream_t stream) {
-    MI355_CHECK_ARG(q && kv && kv->kv_base && block_table && seq_lens && out, "paged_decode_attn: null pointer");
-    MI355_CHECK_ARG(kv->hd == 64 || kv->hd == 128, "paged_decode_attn: hd=%d (64 or 128)", kv->hd);
-    MI355_CHECK_ARG(kv->page >= 16 && kv->page % 8 == 0, "paged_decode_attn: page=%d (>= 16, multiple of 8)", kv->page);
-    MI355_CHECK_ARG(B > 0 && nh > 0 && kv->nkv > 0 && nh % kv->nkv == 0 && nh / kv->nkv <= 16,
-                    "paged_decode_attn: nh=%d nkv=%d (group <= 16)", nh, kv->nkv);
-    MI355_CHECK_ARG(kv->num_blocks > 0, "paged_decode_attn: num_blocks=%d", kv->num_blocks);
-    MI355_CHECK_ARG(max_seq_len > 0 && (long)max_blocks_per_seq * kv->page >= max_seq_len,
-                    "paged_decode_attn: max_seq_len=%d exceeds block table", max_seq_len);
-    const bool int8 = kv->kv_dtype == MI355_KV_INT8;
-    MI355_CHECK_ARG(!int8 || kv->scale_base, "paged_decode_attn: int8 cache needs scale_base");
-    AttnParams p;
-    p.q = (const f16*)q; p.kv_base = kv->kv_base; p.scale_base = kv->scale_base; p.block_table = block_table;
-    p.seq_lens = seq_lens; p.out = (f16*)out; p.B = B; p.nh = nh; p.nkv = kv->nkv; p.G = nh / kv->nkv;
-    p.page = kv->page; p.max_blocks = max_blocks_per_seq; p.seq_add = seq_lens_minus_one ? 1 : 0;
-    p.max_seq = max_seq_len; p.num_blocks = kv->num_blocks;
-    p.P = plan_partitions(B, kv->nkv, max_seq_len, &p.PS);
-    p.scale_log2 = scale * 1.4426950408889634f;
-    const size_t need = p.P > 1 ? (size_t)B * nh * p.P * (kv->hd + 2) * sizeof(float) : 0;
-    if (need > workspace_bytes || (need && !workspace)) {
-        mi355_set_error("paged_decode_attn: workspace %zu < %zu", workspace_bytes, need);
-        return MI355_ERR_WORKSPACE;
-    }
-    p.tmp_out = (float*)workspace;
-    p.tmp_ml  = p.tmp_out + (size_t)B * nh * p.P * kv->hd;
-    hipStream_t st = (hipStream_t)stream;
-    dim3 grid(p.P, kv->nkv, B);
-#define L_(HD_, I8_) hipLaunchKernelGGL((paged_attn_kernel<HD_, I8_>), grid, dim3(256), 0, st, p)
-    if (kv->hd == 128) { if (int8) L_(128, true); else L_(128, false); }
-    else               { if (int8) L_(64, true);  else L_(64, false); }
-#undef L_
-    MI355_CHECK_LAUNCH("paged_attn_kernel");
-    if (p.P > 1) {
-        const int nblk = cdiv(B * nh, 4);
-        if (kv->hd == 128) hipLaunchKernelGGL(attn_reduce_kernel<128>, dim3(nblk), dim3(256), 0, st, p);
-        else               hipLaunchKernelGGL(attn_reduce_kernel<64>, dim3(nblk), dim3(256), 0, st, p);
-        MI355_CHECK_LAUNCH("attn_reduce_kernel");
-    }
-    return MI355_OK;
+    return launch_attn(q, kv, block_table, max_blocks_per_seq, seq_lens, seq_lens_minus_one, B, 1, nh, scale, max_seq_len, out,
+                       workspace, workspace_bytes, stream);
+}
+
+extern "C" int mi355_paged_attn_rows(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_table,
+                                     int32_t max_blocks_per_seq, const int32_t* positions, int32_t B, int32_t q_len, int32_t nh,
+                                     float scale, int32_t max_seq_len, void* out, void* workspace, size_t workspace_bytes,
+                                     mi355_stream_t stream) {
+    return launch_attn(q, kv, block_table, max_blocks_per_seq, positions, 1, B, q_len, nh, scale, max_seq_len, out, workspace,
+                       workspace_bytes, stream);
 }

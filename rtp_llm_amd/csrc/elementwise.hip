@@ -150,6 +150,18 @@ __global__ __launch_bounds__(256) void embedding_kernel(const int32_t* __restric
     *reinterpret_cast<f16x8*>(out + (size_t)t * H + c0) = *reinterpret_cast<const f16x8*>(table + (size_t)id * H + c0);
 }
 
+// ---------------------------------------------------------------- weight prefetch
+// Touch `bytes` of read-only data so that they sit in the Infinity Cache / L2 when the next GEMM asks for them: issued on a
+// side stream while a latency-bound all-reduce kernel (<= 64 blocks) occupies the main one (tensor-parallel step).
+__global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* __restrict__ p, size_t nvec, uint32_t* __restrict__ sink) {
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const u32x4 v = p[i];
+        acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+    }
+    if (acc == 0x9E3779B9u && sink) *sink = acc;   // practically never: keeps the loads alive without a store per thread
+}
+
 // ---------------------------------------------------------------- argmax
 // Stage 1: grid (B, 64): each block scans a contiguous 1/64 of the row.
 // Stage 2: one wave per row picks the best of the 64 candidates.
@@ -259,6 +271,15 @@ extern "C" int mi355_argmax_ex(const float* logits, int32_t B, int32_t V, int32_
     hipLaunchKernelGGL(argmax_stage1, dim3(B, nparts), dim3(256), 0, st, logits, V, ld, cv, ci);
     hipLaunchKernelGGL(argmax_stage2, dim3(B), dim3(64), 0, st, (const float*)cv, (const int*)ci, nparts, ids, positions);
     MI355_CHECK_LAUNCH("argmax");
+    return MI355_OK;
+}
+
+extern "C" int mi355_prefetch(const void* ptr, size_t bytes, void* sink, mi355_stream_t stream) {
+    if (!ptr || bytes < 16) return MI355_OK;
+    const size_t nvec = bytes / 16;
+    const int grid = (int)(nvec / 256 < 512 ? (nvec + 255) / 256 : 512);
+    hipLaunchKernelGGL(prefetch_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u32x4*)ptr, nvec, (uint32_t*)sink);
+    MI355_CHECK_LAUNCH("prefetch_kernel");
     return MI355_OK;
 }
 

@@ -39,9 +39,15 @@ struct mi355_decoder {
     int32_t* oob_count; // tokens refused by the KV writer (stale position / block id)
     mi355_allreduce_t* ar; // attached all-reduce context (tp_size > 1): the TP step runs entirely from C++
     int    vocab_offset;
+    // comm / weight-stream overlap: while the (latency-bound, <= 64 blocks) all-reduce kernel runs on the main stream, a
+    // side stream pulls the NEXT GEMM's weight shard into the Infinity Cache
+    hipStream_t side_stream;
+    hipEvent_t  ev_fork, ev_join;
+    bool        overlap;
     float* partials;
     size_t attn_ws_bytes, argmax_ws_bytes, partials_bytes;
-    int    B;
+    int    B;       // rows of the step in flight (= sequences * q_len)
+    int    q_len;   // rows per sequence: 1 = decode, > 1 = target-verify / prefill chunk (causal over the paged cache)
     // graphs
     hipStream_t                    cap_stream;
     std::map<int, hipGraphExec_t>  graphs;
@@ -159,7 +165,8 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     d->cfg = *cfg; d->layers.assign(layers, layers + cfg->num_layers); d->model = *model; d->bufs = *bufs;
     carve_all(d, *cfg, bufs->workspace);
     d->xn = bufs->hidden; // the normed hidden state lives in the caller-visible buffer
-    d->B = 0; d->cap_stream = nullptr; d->prof_on = false; d->ev_used = 0; d->ar = nullptr; d->vocab_offset = 0;
+    d->B = 0; d->q_len = 1; d->cap_stream = nullptr; d->prof_on = false; d->ev_used = 0; d->ar = nullptr; d->vocab_offset = 0;
+    d->side_stream = nullptr; d->ev_fork = d->ev_join = nullptr; d->overlap = false;
     if (hipMemset(d->oob_count, 0, 256) != hipSuccess) { mi355_set_error("decoder_create: cannot clear the workspace"); delete d; return nullptr; }
     return d;
 }
@@ -168,14 +175,25 @@ extern "C" void mi355_decoder_destroy(mi355_decoder_t* d) {
     if (!d) return;
     for (auto& kv : d->graphs) hipGraphExecDestroy(kv.second);
     if (d->cap_stream) hipStreamDestroy(d->cap_stream);
+    if (d->side_stream) hipStreamDestroy(d->side_stream);
+    if (d->ev_fork) hipEventDestroy(d->ev_fork);
+    if (d->ev_join) hipEventDestroy(d->ev_join);
     for (auto e : d->ev) hipEventDestroy(e);
     delete d;
 }
 
 extern "C" int mi355_decoder_begin(mi355_decoder_t* d, int32_t B, mi355_stream_t stream) {
-    if (!d || B <= 0 || B > d->cfg.max_batch) { mi355_set_error("decoder_begin: B=%d", B); return MI355_ERR_ARG; }
+    return mi355_decoder_begin_rows(d, B, 1, stream);
+}
+
+extern "C" int mi355_decoder_begin_rows(mi355_decoder_t* d, int32_t nseq, int32_t q_len, mi355_stream_t stream) {
+    const int B = nseq * q_len;
+    if (!d || nseq <= 0 || q_len <= 0 || B > d->cfg.max_batch) {
+        mi355_set_error("decoder_begin: %d sequences x %d rows exceed max_batch", nseq, q_len);
+        return MI355_ERR_ARG;
+    }
     hipStream_t st = (hipStream_t)stream;
-    d->B = B;
+    d->B = B; d->q_len = q_len;
     const auto& c = d->cfg;
     RUN(MI355_KC_OTHER, mi355_embedding(d->bufs.token_ids, B, d->model.embedding, c.hidden, d->model.vocab_full, d->resid, st));
     if (c.tp_size == 1 || d->ar) {
@@ -192,8 +210,40 @@ extern "C" int mi355_decoder_attach_allreduce(mi355_decoder_t* d, mi355_allreduc
     for (auto& kv : d->graphs) hipGraphExecDestroy(kv.second);   // graphs captured for the segmented path are stale now
     d->graphs.clear();
     d->ar = ar; d->vocab_offset = vocab_offset;
+    if (!d->side_stream) {
+        d->overlap = hipStreamCreateWithFlags(&d->side_stream, hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming) == hipSuccess;
+        (void)hipGetLastError();
+    }
     return MI355_OK;
 }
+
+namespace {
+// all-reduce on `st`, prefetch of the next GEMM's weights on the side stream, joined before the GEMM (fork / join are
+// plain event edges, so the pair is captured into the step graph like everything else)
+template <class F>
+int comm_with_prefetch(mi355_decoder* d, hipStream_t st, const mi355_weight_t* next_w, F&& comm) {
+    const bool ov = d->overlap && next_w && next_w->qweight;
+    if (ov) {
+        const size_t bytes = (size_t)next_w->K_pad * next_w->N_pad * next_w->wbits / 8;
+        if (hipEventRecord(d->ev_fork, st) != hipSuccess || hipStreamWaitEvent(d->side_stream, d->ev_fork, 0) != hipSuccess) {
+            mi355_set_error("decoder: fork to the side stream failed: %s", hipGetErrorString(hipGetLastError()));
+            return MI355_ERR_HIP;
+        }
+        // the last dword of the oob block is never read by anyone: a harmless sink
+        const int rc = mi355_prefetch(next_w->qweight, bytes < ((size_t)48 << 20) ? bytes : ((size_t)48 << 20), d->oob_count + 32, d->side_stream);
+        if (rc < 0) return rc;
+    }
+    const int rc = comm();
+    if (rc < 0) return rc;
+    if (ov && (hipEventRecord(d->ev_join, d->side_stream) != hipSuccess || hipStreamWaitEvent(st, d->ev_join, 0) != hipSuccess)) {
+        mi355_set_error("decoder: join of the side stream failed: %s", hipGetErrorString(hipGetLastError()));
+        return MI355_ERR_HIP;
+    }
+    return rc;
+}
+} // namespace
 
 extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_stream_t stream) {
     if (!d || l < 0 || l >= d->cfg.num_layers || d->B <= 0) { mi355_set_error("decoder_layer_attn: layer=%d", l); return MI355_ERR_ARG; }
@@ -207,19 +257,21 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
     int ns = 0;
     RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->xn, B, &L.qkv, d->partials, kMaxSplits, st));
     mi355_kv_layer_t kv = kv_of(d, l);
-    RUN(MI355_KC_ROPE_KV, mi355_rope_kv_write(nullptr, d->partials, ns, L.qkv.N_pad, L.qkv_bias, d->model.cos_sin, c.rope_dim,
-                                              c.max_pos, d->bufs.positions, d->bufs.block_table, c.max_blocks_per_seq, B, c.nh,
-                                              &kv, d->q_buf, d->oob_count, st));
-    RUN(MI355_KC_ATTN, mi355_paged_decode_attn_ex(d->q_buf, &kv, d->bufs.block_table, c.max_blocks_per_seq, d->bufs.positions,
-                                                  1, B, c.nh, 1.0f / sqrtf((float)c.hd), c.max_seq_len, d->attn_out,
-                                                  d->attn_ws, d->attn_ws_bytes, st));
+    RUN(MI355_KC_ROPE_KV, mi355_rope_kv_write_rows(nullptr, d->partials, ns, L.qkv.N_pad, L.qkv_bias, d->model.cos_sin, c.rope_dim,
+                                                   c.max_pos, d->bufs.positions, d->bufs.block_table, c.max_blocks_per_seq, B,
+                                                   d->q_len, c.nh, &kv, d->q_buf, d->oob_count, st));
+    // q_len > 1: rows of one sequence share a pass over its KV, causal mask inside the page walk (is_target_verify)
+    RUN(MI355_KC_ATTN, mi355_paged_attn_rows(d->q_buf, &kv, d->bufs.block_table, c.max_blocks_per_seq, d->bufs.positions,
+                                             B / d->q_len, d->q_len, c.nh, 1.0f / sqrtf((float)c.hd), c.max_seq_len, d->attn_out,
+                                             d->attn_ws, d->attn_ws_bytes, st));
     RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->attn_out, B, &L.o, d->partials, kMaxSplits, st));
     if (c.tp_size == 1) {
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid, L.post_norm,
                                              c.rms_eps, B, c.hidden, d->xn, st));
     } else if (d->ar) { // split-K reduce + all-reduce + residual + post-attention norm in one launch
-        RUN(MI355_KC_COMM, mi355_allreduce_fused(d->ar, nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid,
-                                                 L.post_norm, c.rms_eps, B, c.hidden, d->xn, st));
+        RUN(MI355_KC_COMM, comm_with_prefetch(d, st, &L.gate_up, [&]() {
+            return mi355_allreduce_fused(d->ar, nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid, L.post_norm,
+                                         c.rms_eps, B, c.hidden, d->xn, st); }));
     } else { // local split-K reduce -> fp16 tensor for the TP all-reduce
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.o.N_pad, nullptr, nullptr, d->bufs.ar_buf, nullptr,
                                              c.rms_eps, B, c.hidden, nullptr, st));
@@ -244,8 +296,10 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
                                              c.rms_eps, B, c.hidden, d->xn, st));
     } else if (d->ar) {
-        RUN(MI355_KC_COMM, mi355_allreduce_fused(d->ar, nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid,
-                                                 next_norm, c.rms_eps, B, c.hidden, d->xn, st));
+        const mi355_weight_t* next_w = (l + 1 < c.num_layers) ? &d->layers[l + 1].qkv : &d->model.lm_head;
+        RUN(MI355_KC_COMM, comm_with_prefetch(d, st, next_w, [&]() {
+            return mi355_allreduce_fused(d->ar, nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
+                                         c.rms_eps, B, c.hidden, d->xn, st); }));
     } else {
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.down.N_pad, nullptr, nullptr, d->bufs.ar_buf, nullptr,
                                              c.rms_eps, B, c.hidden, nullptr, st));

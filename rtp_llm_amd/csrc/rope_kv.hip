@@ -22,7 +22,7 @@ struct RopeParams {
     const float*   cos_sin;
     const int32_t* positions;
     const int32_t* block_table;
-    int            max_blocks, T, nh, nkv, hd, page, max_pos, num_blocks;
+    int            max_blocks, T, nh, nkv, hd, page, max_pos, num_blocks, q_len;
     int32_t*       oob_count;
     void*          kv_base;
     float*         scale_base;
@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const RopeParams p) 
     }
     // ---- K / V into the paged cache
     const int kh  = is_v ? h - p.nh - p.nkv : h - p.nh;
-    const int blk = p.block_table[(size_t)t * p.max_blocks + pos / p.page];
+    if (pos_in < 0) return;                                  // padding row of a multi-row step: nothing to store
+    const int blk = p.block_table[(size_t)(t / p.q_len) * p.max_blocks + pos / p.page];
     if (pos != pos_in || blk < 0 || blk >= p.num_blocks) {   // stale position / block id: never write somebody else's page
         if (h == p.nh && lane == 0 && p.oob_count) atomicAdd(p.oob_count, 1);
         return;
@@ -118,6 +119,16 @@ extern "C" int mi355_rope_kv_write(const void* qkv_f16, const float* partials, i
                                    const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq,
                                    int32_t T, int32_t nh, const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count,
                                    mi355_stream_t stream) {
+    return mi355_rope_kv_write_rows(qkv_f16, partials, nsplit, ld, qkv_bias, cos_sin, rope_dim, max_pos, positions, block_table,
+                                    max_blocks_per_seq, T, 1, nh, kv, q_out, oob_count, stream);
+}
+
+extern "C" int mi355_rope_kv_write_rows(const void* qkv_f16, const float* partials, int32_t nsplit, int32_t ld,
+                                        const void* qkv_bias, const float* cos_sin, int32_t rope_dim, int32_t max_pos,
+                                        const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq,
+                                        int32_t T, int32_t q_len, int32_t nh, const mi355_kv_layer_t* kv, void* q_out,
+                                        int32_t* oob_count, mi355_stream_t stream) {
+    MI355_CHECK_ARG(q_len >= 1 && T % q_len == 0, "rope_kv_write: T=%d must be a multiple of q_len=%d", T, q_len);
     MI355_CHECK_ARG((qkv_f16 != nullptr) != (partials != nullptr), "rope_kv_write: exactly one of qkv_f16 / partials");
     MI355_CHECK_ARG(kv && kv->kv_base && cos_sin && positions && block_table && q_out, "rope_kv_write: null pointer");
     MI355_CHECK_ARG(kv->hd == 64 || kv->hd == 128, "rope_kv_write: hd=%d (64 or 128)", kv->hd);
@@ -132,7 +143,7 @@ extern "C" int mi355_rope_kv_write(const void* qkv_f16, const float* partials, i
     p.qkv = (const f16*)qkv_f16; p.partials = partials; p.nsplit = nsplit; p.ld = ld; p.bias = (const f16*)qkv_bias;
     p.cos_sin = cos_sin; p.positions = positions; p.block_table = block_table; p.max_blocks = max_blocks_per_seq;
     p.T = T; p.nh = nh; p.nkv = kv->nkv; p.hd = kv->hd; p.page = kv->page; p.kv_base = kv->kv_base;
-    p.max_pos = max_pos; p.num_blocks = kv->num_blocks; p.oob_count = oob_count;
+    p.max_pos = max_pos; p.num_blocks = kv->num_blocks; p.oob_count = oob_count; p.q_len = q_len;
     p.scale_base = kv->scale_base; p.kv_int8 = kv->kv_dtype == MI355_KV_INT8; p.q_out = (f16*)q_out;
     hipLaunchKernelGGL(rope_kv_write_kernel, dim3(T, cdiv(nheads, 4)), dim3(256), 0, (hipStream_t)stream, p);
     MI355_CHECK_LAUNCH("rope_kv_write_kernel");

@@ -370,7 +370,7 @@ class DecoderEngine:
         self.token_ids[:B].copy_(torch.as_tensor(token_ids, dtype=torch.int32))
         self.positions[:B].copy_(torch.as_tensor(positions, dtype=torch.int32))
         bt = torch.as_tensor(block_table, dtype=torch.int32)
-        self.block_table[:B, : bt.shape[1]].copy_(bt)
+        self.block_table[:bt.shape[0], : bt.shape[1]].copy_(bt)   # one row per token (decode) or per sequence (q_len > 1)
 
     def _st(self) -> int:
         return torch.cuda.current_stream().cuda_stream
@@ -403,11 +403,12 @@ class DecoderEngine:
     def step(self, B: int):
         _C.check(self.lib.mi355_decoder_step(self.handle, B, self._st()), "decoder_step")
 
-    def forward(self, B: int):
+    def forward(self, B: int, q_len: int = 1):
         """The decode step without sampling: logits of the B rows stay in `self.logits`, token_ids / positions are not
-        advanced (speculative verify, scoring)."""
+        advanced (speculative verify, scoring).  q_len > 1: B = nseq * q_len rows, q_len consecutive rows per sequence,
+        block_table one row per sequence; the rows of a sequence share one pass over its KV (causal inside the kernel)."""
         st, h, lib = self._st(), self.handle, self.lib
-        _C.check(lib.mi355_decoder_begin(h, B, st), "decoder_begin")
+        _C.check(lib.mi355_decoder_begin_rows(h, B // q_len, q_len, st), "decoder_begin")
         for l in range(self.cfg.num_layers):
             _C.check(lib.mi355_decoder_layer_attn(h, l, st), "decoder_layer_attn")
             _C.check(lib.mi355_decoder_layer_mlp(h, l, st), "decoder_layer_mlp")

@@ -186,6 +186,35 @@ def rope_kv_write(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], cos_sin: 
     return q_out
 
 
+def rope_kv_write_rows(qkv: torch.Tensor, qkv_bias, cos_sin, positions, block_table, kv_base, scale_base, nh: int, nkv: int,
+                       hd: int, page: int, q_len: int, oob_count: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q_len rows per sequence: qkv [B*q_len, ...], positions [B*q_len] (< 0 = padding row), block_table [B, M]."""
+    _chk(qkv, torch.float16, "rope_kv_write_rows.qkv"); _chk(positions, torch.int32, "positions"); _chk(block_table, torch.int32, "block_table")
+    T = qkv.shape[0]
+    q_out = torch.empty(T, nh, hd, dtype=torch.float16, device=qkv.device)
+    kv = kv_struct(kv_base, scale_base, page, nkv, hd)
+    _C.check(_C.lib().mi355_rope_kv_write_rows(qkv.data_ptr(), None, 0, qkv.shape[1], _p(qkv_bias), cos_sin.data_ptr(), hd,
+                                               cos_sin.shape[0], positions.data_ptr(), block_table.data_ptr(), block_table.shape[1],
+                                               T, q_len, nh, C.byref(kv), q_out.data_ptr(), _p(oob_count), _stream()),
+             "rope_kv_write_rows")
+    return q_out
+
+
+def paged_attention_rows(q: torch.Tensor, kv_base, scale_base, block_table: torch.Tensor, positions: torch.Tensor, nkv: int,
+                         page: int, q_len: int, max_seq_len: int, scale: Optional[float] = None) -> torch.Tensor:
+    """q [B*q_len, nh, hd]; row i of sequence b attends tokens 0..positions[b*q_len+i] (causal over the paged cache)."""
+    _chk(q, torch.float16, "paged_attention_rows.q"); _chk(block_table, torch.int32, "block_table"); _chk(positions, torch.int32, "positions")
+    T, nh, hd = q.shape
+    kv = kv_struct(kv_base, scale_base, page, nkv, hd)
+    out = torch.empty(T, nh * hd, dtype=torch.float16, device=q.device)
+    need = _C.lib().mi355_paged_attn_workspace_bytes(T, nh, hd, max_seq_len)
+    ws = _workspace(need, q.device)
+    _C.check(_C.lib().mi355_paged_attn_rows(q.data_ptr(), C.byref(kv), block_table.data_ptr(), block_table.shape[1], positions.data_ptr(),
+                                            T // q_len, q_len, nh, scale if scale is not None else 1.0 / math.sqrt(hd), max_seq_len,
+                                            out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "paged_attn_rows")
+    return out
+
+
 def paged_decode_attention(q: torch.Tensor, kv_base: torch.Tensor, scale_base: Optional[torch.Tensor],
                            block_table: torch.Tensor, seq_lens: torch.Tensor, nkv: int, page: int,
                            max_seq_len: int, scale: Optional[float] = None) -> torch.Tensor:

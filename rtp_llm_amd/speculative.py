@@ -7,9 +7,10 @@ models_py/bindings/OpDefs.h:283) and chain rejection sampling keeps the longest 
 bonus token (cpp/normal_engine/speculative/SpeculativeSampler.cc:214, kernel
 bindings/rocm/speculative_sampling/sampling.cu:306).
 
-MI355X design: the verify step needs no new attention kernel.  A verify row (sequence b, draft position t) is a decode
-row with its own position ctx_b + t and sequence b's block table: `mi355_rope_kv_write` stores the K/V of all gamma+1
-tokens first, `mi355_paged_decode_attn` then gives row t a context of ctx_b + t + 1 tokens, which IS the causal mask.
+MI355X design: a verify row (sequence b, draft position t) is a query row with its own position ctx_b + t:
+`mi355_rope_kv_write_rows` stores the K/V of all gamma+1 tokens first, `mi355_paged_attn_rows` then lets row t see
+ctx_b + t + 1 tokens -- the causal mask lives inside the page walk, and the gamma+1 rows of a sequence ride in the MFMA
+column dimension next to its GQA heads, so the sequence's KV is streamed once, not gamma+1 times.
 The linears see M = B * (gamma + 1) rows (<= 64: the wide-batch GEMM shapes), so verifying 5 tokens costs about one
 decode step of a 5x larger batch.  Rejected tokens leave stale K/V beyond the accepted length; they are overwritten
 by the next step's tokens at the same positions.
@@ -111,11 +112,14 @@ class SpeculativeDecoder:
         dl = draft_ids.tolist()
         mark("draft_steps")
         # ---- target: gamma + 1 decode rows per sequence = causal verify over the paged cache
-        rows = []
+        toks, poss = [], []
         for b in range(B):
-            toks = [self.last[b]] + dl[b]
-            rows += [(b, toks[t], self.ctx[b] + t) for t in range(G + 1)]
-        self._forward(self.target, rows, self.tbt)
+            toks += [self.last[b]] + dl[b]
+            poss += [self.ctx[b] + t for t in range(G + 1)]
+        # gamma + 1 consecutive rows per sequence, one block-table row per sequence: the multi-row attention kernel walks each
+        # sequence's KV once for all of its rows (is_target_verify)
+        self.target.set_inputs(toks, poss, self.tbt[:B])
+        self.target.forward(B * (G + 1), q_len=G + 1)
         R = B * (G + 1)
         mark("target_verify")
         logits = self.target.logits[:R]

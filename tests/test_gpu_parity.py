@@ -456,3 +456,69 @@ def test_engine_graph_replay_equals_eager_full_width():
     for (t0, l0), (t1, l1) in zip(*res):
         assert torch.equal(t0, t1) and torch.equal(l0, l1)
     assert torch.equal(eng.positions[:B].cpu(), torch.full((B,), ctx + 3, dtype=torch.int32))
+
+
+# ------------------------------------------------------------------ multi-row (verify / prefill-chunk) attention
+@pytest.mark.parametrize("int8", [False, True])
+@pytest.mark.parametrize("nh,nkv,hd,page,q_len", [(28, 4, 128, 16, 5), (32, 8, 128, 16, 9), (14, 2, 64, 64, 3), (8, 1, 128, 16, 2), (16, 16, 128, 16, 33)])
+def test_paged_attention_rows_causal(int8, nh, nkv, hd, page, q_len):
+    """q_len rows per sequence over the paged cache, each row seeing tokens 0..its position (causal inside the page walk),
+    incl. a padding row (position -1) and a sequence whose rows start at position 0: every row equals the oracle's
+    single-row attention over its own prefix."""
+    base = [0, 7, 130, 1000]                                   # tokens cached before the step
+    B = len(base)
+    ctx = [b + q_len for b in base]
+    nblk = sum((c + page - 1) // page for c in ctx) + B * ((max(ctx) + page - 1) // page)
+    kv, sc, bt, nat = _fill_cache(B, ctx, nkv, hd, page, int8, nblk, 33)
+    q = torch.randn(B * q_len, nh, hd, generator=_gen(5)).half()
+    pos = torch.tensor([[b + i for i in range(q_len)] for b in base], dtype=torch.int32)
+    pos[1, q_len - 1] = -1                                     # padding row
+    out = ops.paged_attention_rows(q.to(DEV), kv, sc, bt.to(DEV), pos.reshape(-1).contiguous().to(DEV), nkv, page, q_len, max(ctx))
+    torch.cuda.synchronize()
+    for b in range(B):
+        K, V, ks, vs = nat[b]
+        for i in range(q_len):
+            n = int(pos[b, i]) + 1
+            got = out[b * q_len + i].cpu().float()
+            if n <= 0:
+                assert torch.equal(got, torch.zeros_like(got))
+                continue
+            ref = oracle.attention_decode(q[b * q_len + i], K[:n], V[:n], 1 / math.sqrt(hd), None if ks is None else ks[:n],
+                                          None if vs is None else vs[:n]).reshape(-1)
+            assert torch.allclose(got, ref.float(), **TOL), (b, i, n, float((got - ref.float()).abs().max()))
+    # q_len = 1 through the same entry == the decode entry, bit for bit
+    sl = torch.tensor(ctx, dtype=torch.int32)
+    q1 = q[:B].contiguous().to(DEV)
+    a = ops.paged_attention_rows(q1, kv, sc, bt.to(DEV), (sl - 1).to(DEV), nkv, page, 1, max(ctx))
+    assert torch.equal(a, ops.paged_decode_attention(q1, kv, sc, bt.to(DEV), sl.to(DEV), nkv, page, max(ctx)))
+
+
+def test_engine_multi_row_step_matches_oracle():
+    """The step driver in rows mode (target-verify shape): 3 sequences x 4 consecutive tokens in ONE step == the oracle fed
+    the same tokens one after the other."""
+    cfg = _tiny_cfg()
+    w = model.synth_model(cfg, "w4", "cpu", seed=19, zeros="centered")
+    nseq, q_len, page = 3, 4, 16
+    eng = model.DecoderEngine(cfg, model.weights_to(w, DEV), kv_int8=False, page=page, num_blocks=32, max_batch=16, max_seq_len=64, device=DEV)
+    odec = oracle.OracleDecoder({**cfg.__dict__}, _oracle_weights(w))
+    okv = oracle.OracleKV(cfg.num_layers, nseq, False)
+    bt = torch.arange(nseq * 4, dtype=torch.int32).reshape(nseq, 4)
+    g = _gen(23)
+    start = [0, 5, 17]
+    for b in range(nseq):                                     # earlier context, token by token on both sides
+        for p_ in range(start[b]):
+            t = torch.randint(0, cfg.vocab, (1,), generator=g, dtype=torch.int32)
+            odec.forward_tokens(t, torch.tensor([p_], dtype=torch.int32), okv, [b])
+            eng.set_inputs(t.tolist(), [p_], bt[b:b + 1])
+            eng.forward(1)
+    toks = torch.randint(0, cfg.vocab, (nseq, q_len), generator=g, dtype=torch.int32)
+    pos = torch.tensor([[s + i for i in range(q_len)] for s in start], dtype=torch.int32)
+    eng.set_inputs(toks.reshape(-1).tolist(), pos.reshape(-1).tolist(), bt)
+    eng.forward(nseq * q_len, q_len=q_len)
+    torch.cuda.synchronize()
+    got = eng.logits[: nseq * q_len].cpu().reshape(nseq, q_len, -1)
+    for b in range(nseq):
+        for i in range(q_len):
+            _, ref = odec.forward_tokens(toks[b, i:i + 1], pos[b, i:i + 1], okv, [b])
+            assert torch.allclose(got[b, i], ref[0], **TOL), (b, i, float((got[b, i] - ref[0]).abs().max()))
+    assert eng.oob_count() == 0
