@@ -110,7 +110,8 @@ size_t mi355_linear_workspace_bytes(int32_t M, const mi355_weight_t* w);
  * 16-bit impl: impl/rocm/f16_linear.py:100-112).  fp32 accumulation on MFMA
  * (v_mfma_f32_16x16x32_f16), output rounded once to fp16 (or fp32 with
  * MI355_EPI_OUT_F32, the lm_head contract of PyWrappedModel.cc:1039-1047).
- * M may be any positive value (processed in slabs of 64 rows).
+ * M may be any positive value: M <= 64 takes the HBM-bound decode kernels, M >= 128 (prefill chunks) the compute-shaped
+ * kernel that reads every weight once per 128 rows, anything between runs as 64-row slabs.
  */
 int mi355_linear_forward(const void* x, int32_t M, const mi355_weight_t* w, const void* bias,
                          void* y, int32_t epilogue, void* workspace, size_t workspace_bytes,

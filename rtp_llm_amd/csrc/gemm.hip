@@ -27,6 +27,7 @@ extern "C" int mi355_gemm_smallm(const void* gp, int wbits, int group_size, int 
                                  mi355_stream_t stream);
 extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int want_partial, int max_splits,
                                mi355_stream_t stream);
+extern "C" int mi355_gemm_prefill(const void* gp, int wbits, int group_size, mi355_stream_t stream);
 
 #ifdef MI355_TUNING
 int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -625,6 +626,12 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
     const int ldy  = (mode == MODE_SILU) ? w->N / 2 : w->N;
     const size_t ysz = (mode == MODE_F32) ? 4 : 2;
     hipStream_t st = (hipStream_t)stream;
+    if (M >= 128 && w->wbits != 16) {   // prefill-sized M: the compute-shaped kernel reads every weight once per 128 rows
+        GemmParams ps; fill_params(ps, x, M, w);
+        ps.mode = mode; ps.bias = (const f16*)bias; ps.y = y; ps.ldy = ldy;
+        const int rc = mi355_gemm_prefill(&ps, w->wbits, w->group_size, stream);
+        if (rc != MI355_ERR_UNSUPPORTED) return rc;
+    }
     for (int m0 = 0; m0 < M; m0 += 64) {
         const int Mc = (M - m0) > 64 ? 64 : (M - m0);
         GemmParams p; fill_params(p, (const f16*)x + (size_t)m0 * w->K, Mc, w);

@@ -522,3 +522,32 @@ def test_engine_multi_row_step_matches_oracle():
             _, ref = odec.forward_tokens(toks[b, i:i + 1], pos[b, i:i + 1], okv, [b])
             assert torch.allclose(got[b, i], ref[0], **TOL), (b, i, float((got[b, i] - ref[0]).abs().max()))
     assert eng.oob_count() == 0
+
+
+# ------------------------------------------------------------------ large-M (prefill) GEMM
+@pytest.mark.parametrize("kind,group", [("w4", 128), ("w4", 64), ("w4", 32), ("int8", 0), ("fp16", 0)])
+@pytest.mark.parametrize("M,K,N", [(128, 1024, 4608), (200, 3584, 512), (333, 9472, 896), (1000, 3584, 4608)])
+def test_linear_prefill_sized_batches(kind, group, M, K, N):
+    """M >= 128 takes the compute-shaped kernel (gemm_prefill.hip): ragged last row block, ragged last column block
+    (896 = 3.5 x 256), bias; fp16 weights keep the 64-row slab path."""
+    if group and K % group:
+        pytest.skip("group does not divide K")
+    c = _canon_cpu(K, N, kind, 7 + K + N, group or 128)
+    x = _x(M, K, M)
+    bias = (torch.randn(N, generator=_gen(3)) * 0.1).half()
+    ref = oracle.linear(x, _dense(c), bias)
+    y = ops.linear(x.to(DEV), c.pack().to(DEV), bias.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.allclose(y.cpu().float(), ref.float(), **TOL), float((y.cpu().float() - ref.float()).abs().max())
+    # rows of a big launch == the same rows through the 64-row decode kernels (independent rows, different kernels)
+    y64 = ops.linear(x[:64].contiguous().to(DEV), c.pack().to(DEV), bias.to(DEV))
+    assert torch.allclose(y[:64].float(), y64.float(), atol=4e-3, rtol=4e-3)
+
+
+def test_linear_prefill_silu_epilogue():
+    K, I, M = 1024, 1152, 300
+    c = _canon_cpu(K, 2 * I, "w4", 5)
+    x = _x(M, K, 1)
+    ref = oracle.silu_mul(oracle.linear(x, _dense(c)))
+    y = ops.linear(x.to(DEV), c.pack(gate_up=True).to(DEV), epilogue=_C.EPI_SILU_MUL)
+    assert y.shape == (M, I) and torch.allclose(y.cpu().float(), ref.float(), **TOL)
