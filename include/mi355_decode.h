@@ -383,6 +383,18 @@ int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t layer, mi355_stream_t st
 int mi355_decoder_finish(mi355_decoder_t* d, int32_t sample, mi355_stream_t stream);
 int mi355_decoder_step(mi355_decoder_t* d, int32_t B, mi355_stream_t stream);
 
+/* Prefill over the paged cache (reference: prefill half of FusedRopeKVCacheOp.cc:216-461 and the paged prefill
+ * ops of factory/attention/rocm_impl/aiter.py:244-950): one chunk of nseq sequences x q_len consecutive prompt tokens each
+ * (row i of sequence b at b * q_len + i; positions[...] = token position, < 0 = padding row of a ragged batch; block_table
+ * [nseq][max_blocks_per_seq]).  K/V of the chunk are stored, every row attends the cache up to its own position (earlier
+ * chunks of the prompt included), linears take the large-M kernel.  logit_rows [nseq] (may be NULL) selects one row per
+ * sequence whose fp32 logits [nseq][vocab] are written to logits_out (the last prompt token on the final chunk).
+ * All pointers are device pointers; nothing synchronises. */
+size_t mi355_decoder_prefill_workspace_bytes(mi355_decoder_t* d, int32_t max_tokens, int32_t max_seqs);
+int    mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_ids, const int32_t* positions, const int32_t* block_table,
+                             int32_t nseq, int32_t q_len, const int32_t* logit_rows, float* logits_out, void* workspace,
+                             size_t workspace_bytes, mi355_stream_t stream);
+
 /* hipGraph: capture one full step for batch B on an internal stream, then replay
  * `nsteps` times back-to-back on `stream` (greedy feedback stays on device). */
 /* Attach an opened all-reduce context (tp_size > 1): the two all-reduce points of every layer then run inside the step as

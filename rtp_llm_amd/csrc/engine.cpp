@@ -307,6 +307,93 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
     return MI355_OK;
 }
 
+// ------------------------------------------------------------------ prefill
+// One chunk of nseq x q_len prompt tokens through the same weights: large-M GEMMs (gemm_prefill.hip above 128 rows), the
+// rows-mode KV writer, causal multi-row attention over the paged cache (earlier chunks of the same prompt are already
+// there), fused residual + RMSNorm; logits only for the requested rows (the reference computes lm_head on the last token
+// of each sequence, PyWrappedModel.cc:1003-1047).
+namespace {
+struct PrefillBufs { void *resid, *xn, *qkv, *q, *attn, *act, *tmp, *gemm_ws, *attn_ws, *last_h; size_t gemm_ws_bytes, attn_ws_bytes; };
+
+size_t carve_prefill(const mi355_decoder* d, int T, int nseq, void* base, PrefillBufs* out) {
+    const mi355_model_config_t& c = d->cfg;
+    Carve cv{(char*)base, 0};
+    const size_t Ts = (size_t)T;
+    const int qdim = c.nh * c.hd, qkvdim = (c.nh + 2 * c.nkv) * c.hd;
+    PrefillBufs b;
+    b.resid = cv.take(Ts * c.hidden * 2); b.xn = cv.take(Ts * c.hidden * 2); b.qkv = cv.take(Ts * qkvdim * 2);
+    b.q = cv.take(Ts * qdim * 2); b.attn = cv.take(Ts * qdim * 2); b.act = cv.take(Ts * c.inter * 2); b.tmp = cv.take(Ts * c.hidden * 2);
+    b.last_h = cv.take((size_t)nseq * c.hidden * 2 * 2);
+    // 64-row slabs through the decode kernels (chunks below 128 rows) may split K into fp32 slabs: ask the planner
+    b.gemm_ws_bytes = 256;
+    for (const auto& L : d->layers)
+        for (const mi355_weight_t* w : {&L.qkv, &L.o, &L.gate_up, &L.down})
+            b.gemm_ws_bytes = std::max(b.gemm_ws_bytes, mi355_linear_workspace_bytes(64, w));
+    b.gemm_ws = cv.take(b.gemm_ws_bytes);
+    b.attn_ws_bytes = mi355_paged_attn_workspace_bytes(T, c.nh, c.hd, c.max_seq_len);
+    b.attn_ws = cv.take(b.attn_ws_bytes);
+    if (out) *out = b;
+    return cv.off;
+}
+} // namespace
+
+extern "C" size_t mi355_decoder_prefill_workspace_bytes(mi355_decoder_t* d, int32_t max_tokens, int32_t max_seqs) {
+    if (!d || max_tokens <= 0 || max_seqs <= 0) return 0;
+    return carve_prefill(d, max_tokens, max_seqs, nullptr, nullptr);
+}
+
+extern "C" int mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_ids, const int32_t* positions, const int32_t* block_table,
+                                     int32_t nseq, int32_t q_len, const int32_t* logit_rows, float* logits_out, void* workspace,
+                                     size_t workspace_bytes, mi355_stream_t stream) {
+    if (!d || !token_ids || !positions || !block_table || nseq <= 0 || q_len <= 0 || !workspace) {
+        mi355_set_error("decoder_prefill: bad arguments"); return MI355_ERR_ARG;
+    }
+    const auto& c = d->cfg;
+    const int T = nseq * q_len;
+    if (c.tp_size > 1 && !d->ar) { mi355_set_error("decoder_prefill: tp_size > 1 needs mi355_decoder_attach_allreduce"); return MI355_ERR_ARG; }
+    PrefillBufs b;
+    const size_t need = carve_prefill(d, T, nseq, workspace, &b);
+    if (need > workspace_bytes) { mi355_set_error("decoder_prefill: workspace %zu < %zu", workspace_bytes, need); return MI355_ERR_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    const float scale = 1.0f / sqrtf((float)c.hd);
+    RUN(MI355_KC_OTHER, mi355_embedding(token_ids, T, d->model.embedding, c.hidden, d->model.vocab_full, b.resid, st));
+    RUN(MI355_KC_NORM, mi355_rmsnorm(b.resid, d->layers[0].input_norm, c.rms_eps, T, c.hidden, b.xn, st));
+    for (int l = 0; l < c.num_layers; ++l) {
+        const auto& L = d->layers[l];
+        mi355_kv_layer_t kv = kv_of(d, l);
+        RUN(MI355_KC_GEMM_QUANT, mi355_linear_forward(b.xn, T, &L.qkv, L.qkv_bias, b.qkv, MI355_EPI_NONE, b.gemm_ws, b.gemm_ws_bytes, st));
+        RUN(MI355_KC_ROPE_KV, mi355_rope_kv_write_rows(b.qkv, nullptr, 0, L.qkv.N, nullptr, d->model.cos_sin, c.rope_dim, c.max_pos, positions,
+                                                       block_table, c.max_blocks_per_seq, T, q_len, c.nh, &kv, b.q, d->oob_count, st));
+        RUN(MI355_KC_ATTN, mi355_paged_attn_rows(b.q, &kv, block_table, c.max_blocks_per_seq, positions, nseq, q_len, c.nh, scale,
+                                                 c.max_seq_len, b.attn, b.attn_ws, b.attn_ws_bytes, st));
+        RUN(MI355_KC_GEMM_QUANT, mi355_linear_forward(b.attn, T, &L.o, nullptr, b.tmp, MI355_EPI_NONE, b.gemm_ws, b.gemm_ws_bytes, st));
+        if (c.tp_size == 1) {
+            RUN(MI355_KC_NORM, mi355_add_rmsnorm(b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, L.post_norm, c.rms_eps, T, c.hidden, b.xn, st));
+        } else {
+            RUN(MI355_KC_COMM, mi355_allreduce_fused(d->ar, b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, L.post_norm, c.rms_eps, T,
+                                                     c.hidden, b.xn, st));
+        }
+        RUN(MI355_KC_GEMM_QUANT, mi355_linear_forward(b.xn, T, &L.gate_up, nullptr, b.act, MI355_EPI_SILU_MUL, b.gemm_ws, b.gemm_ws_bytes, st));
+        RUN(MI355_KC_GEMM_QUANT, mi355_linear_forward(b.act, T, &L.down, nullptr, b.tmp, MI355_EPI_NONE, b.gemm_ws, b.gemm_ws_bytes, st));
+        const void* next_norm = (l + 1 < c.num_layers) ? d->layers[l + 1].input_norm : d->model.final_norm;
+        if (c.tp_size == 1) {
+            RUN(MI355_KC_NORM, mi355_add_rmsnorm(b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, next_norm, c.rms_eps, T, c.hidden, b.xn, st));
+        } else {
+            RUN(MI355_KC_COMM, mi355_allreduce_fused(d->ar, b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, next_norm, c.rms_eps, T,
+                                                     c.hidden, b.xn, st));
+        }
+    }
+    if (logit_rows && logits_out) {   // gather the requested rows of the final normed hidden state, then lm_head on nseq rows
+        RUN(MI355_KC_OTHER, mi355_embedding(logit_rows, nseq, b.xn, c.hidden, T, b.last_h, st));
+        for (int r0 = 0; r0 < nseq; r0 += 64) {
+            const int n = nseq - r0 < 64 ? nseq - r0 : 64;
+            RUN(MI355_KC_GEMM_LMHEAD, mi355_linear_direct((const char*)b.last_h + (size_t)r0 * c.hidden * 2, n, &d->model.lm_head, nullptr,
+                                                          logits_out + (size_t)r0 * c.vocab, MI355_EPI_OUT_F32, nullptr, 0, st));
+        }
+    }
+    return MI355_OK;
+}
+
 extern "C" int mi355_decoder_finish(mi355_decoder_t* d, int32_t sample, mi355_stream_t stream) {
     if (!d || d->B <= 0) { mi355_set_error("decoder_finish: no step in flight"); return MI355_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;

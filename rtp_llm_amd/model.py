@@ -414,13 +414,13 @@ class DecoderEngine:
             _C.check(lib.mi355_decoder_layer_mlp(h, l, st), "decoder_layer_mlp")
         _C.check(lib.mi355_decoder_finish(h, 0, st), "decoder_finish")
 
-    # ---- whole-request helpers (prompt ingestion rides on the decode path: no prefill kernels in this build)
+    # ---- whole-request helpers
     def ingest(self, prompts: List[List[int]], block_table) -> List[int]:
         """Write the K/V of every prompt token except the last into the paged cache and return the context lengths.
         A prompt token is a decode row with its own position and its sequence's block table, so up to `max_batch`
         tokens (of any mix of sequences) go through one step and causality holds by construction: row (b, p) attends to
         positions <= p of sequence b, all written by this or an earlier step (rope_kv_write precedes attention).
-        This is chunked prefill at decode-kernel efficiency (KV re-read per row) -- SURVEY 8f n4 is the real thing."""
+        Chunked prefill at decode-kernel efficiency (kept for tests and tiny prompts); `prefill` below is the real path."""
         bt = torch.as_tensor(block_table, dtype=torch.int32)
         self.check_room([len(pr) for pr in prompts], 0, bt, "ingest")
         rows = [(b, tok, pos) for b, pr in enumerate(prompts) for pos, tok in enumerate(pr[:-1])]
@@ -433,17 +433,63 @@ class DecoderEngine:
             self.forward(len(chunk))
         return [len(pr) - 1 for pr in prompts]
 
-    def generate(self, prompts: List[List[int]], block_table, max_new_tokens: int) -> List[List[int]]:
-        """Greedy generation for a batch of prompts (tp = 1): ingest, then graph-replayed decode steps."""
+    def prefill(self, prompts: List[List[int]], block_table, chunk: int = 512, start: Optional[List[int]] = None) -> torch.Tensor:
+        """Real prefill (csrc/engine.cpp mi355_decoder_prefill): the prompts go through the large-M GEMMs and the causal
+        multi-row attention in chunks of `chunk` tokens per sequence (ragged prompts are padded with position -1 rows).
+        `start[b]` tokens of sequence b are already cached.  Returns the fp32 logits [nseq, vocab] of every sequence's LAST
+        prompt token (its K/V is in the cache afterwards: decoding continues with the sampled token at position len)."""
+        nseq = len(prompts)
+        start = [0] * nseq if start is None else list(start)
+        bt = torch.as_tensor(block_table, dtype=torch.int32)
+        self.check_room([s + len(p) for s, p in zip(start, prompts)], 0, bt, "prefill")
+        dev, st = self.device, self._st()
+        btd = torch.zeros(nseq, self.max_blocks_per_seq, dtype=torch.int32, device=dev)
+        btd[:, : bt.shape[1]].copy_(bt)
+        longest = max(len(p) for p in prompts)
+        logits = torch.zeros(nseq, self.cfg.vocab, dtype=torch.float32, device=dev)
+        done = torch.zeros(nseq, dtype=torch.bool)
+        for c0 in range(0, longest, chunk):
+            q_len = min(chunk, longest - c0)
+            toks = torch.zeros(nseq, q_len, dtype=torch.int32)
+            pos = torch.full((nseq, q_len), -1, dtype=torch.int32)
+            last = torch.zeros(nseq, dtype=torch.int32)
+            need_logits = torch.zeros(nseq, dtype=torch.bool)
+            for b, p in enumerate(prompts):
+                n = max(0, min(q_len, len(p) - c0))
+                if n:
+                    toks[b, :n] = torch.tensor(p[c0:c0 + n], dtype=torch.int32)
+                    pos[b, :n] = torch.arange(start[b] + c0, start[b] + c0 + n, dtype=torch.int32)
+                    if c0 + n == len(p):
+                        last[b], need_logits[b] = b * q_len + n - 1, True
+            T = nseq * q_len
+            ws_bytes = self.lib.mi355_decoder_prefill_workspace_bytes(self.handle, T, nseq)
+            if getattr(self, "_prefill_ws", None) is None or self._prefill_ws.numel() < ws_bytes:
+                self._prefill_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            tmp_logits = torch.empty(nseq, self.cfg.vocab, dtype=torch.float32, device=dev) if bool(need_logits.any()) else None
+            td, pd, ld = toks.reshape(-1).to(dev), pos.reshape(-1).to(dev), last.to(dev)
+            _C.check(self.lib.mi355_decoder_prefill(self.handle, td.data_ptr(), pd.data_ptr(), btd.data_ptr(), nseq, q_len,
+                                                    ld.data_ptr() if tmp_logits is not None else None,
+                                                    tmp_logits.data_ptr() if tmp_logits is not None else None,
+                                                    self._prefill_ws.data_ptr(), self._prefill_ws.numel(), st), "decoder_prefill")
+            if tmp_logits is not None:
+                sel = need_logits.to(dev)
+                logits[sel] = tmp_logits[sel]
+            done |= need_logits
+        return logits
+
+    def generate(self, prompts: List[List[int]], block_table, max_new_tokens: int, prefill_chunk: int = 512) -> List[List[int]]:
+        """Greedy generation for a batch of prompts (tp = 1): real prefill of the prompts (large-M GEMMs, causal multi-row
+        attention), greedy first token from the prefill logits, then graph-replayed decode steps."""
         B = len(prompts)
         if B > self.max_batch or any(len(pr) < 1 for pr in prompts):
             raise _C.Mi355Error("generate: batch exceeds max_batch or empty prompt")
         self.check_room([len(pr) for pr in prompts], max_new_tokens - 1, block_table, "generate")
-        ctx = self.ingest(prompts, block_table)
-        self.set_inputs([pr[-1] for pr in prompts], ctx, block_table)
+        first = ops.argmax(self.prefill(prompts, block_table, chunk=prefill_chunk))
+        out = [first.clone()]
+        self.set_inputs([0] * B, [len(pr) for pr in prompts], block_table)
+        self.token_ids[:B].copy_(first)
         self.capture(B)
-        out = []
-        for _ in range(max_new_tokens):
+        for _ in range(max_new_tokens - 1):
             self.replay(B, 1)
             out.append(self.token_ids[:B].clone())
         toks = torch.stack(out, 1).cpu().tolist()

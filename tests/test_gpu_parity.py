@@ -551,3 +551,41 @@ def test_linear_prefill_silu_epilogue():
     ref = oracle.silu_mul(oracle.linear(x, _dense(c)))
     y = ops.linear(x.to(DEV), c.pack(gate_up=True).to(DEV), epilogue=_C.EPI_SILU_MUL)
     assert y.shape == (M, I) and torch.allclose(y.cpu().float(), ref.float(), **TOL)
+
+
+@pytest.mark.parametrize("kv_int8", [False, True])
+def test_prefill_ragged_prompts_multi_chunk_matches_oracle(kv_int8):
+    """Real prefill: three ragged prompts in chunks of 64 tokens per sequence (192 rows per chunk -> the large-M GEMM, the
+    rows-mode KV writer, causal multi-row attention over earlier chunks, padding rows), then the cache must be exactly what
+    token-by-token decoding needs: logits of the last prompt token and of three further greedy steps match the oracle."""
+    cfg = model.ModelConfig("tiny-prefill", 2, 512, 8, 2, 64, 1024, 2048, max_pos=512)
+    w = model.synth_model(cfg, "w4", "cpu", seed=29, zeros="centered")
+    lens, page = [150, 97, 201], 16
+    B = len(lens)
+    g = _gen(31)
+    prompts = [torch.randint(0, cfg.vocab, (n,), generator=g, dtype=torch.int32).tolist() for n in lens]
+    eng = model.DecoderEngine(cfg, model.weights_to(w, DEV), kv_int8=kv_int8, page=page, num_blocks=B * 16, max_batch=4, max_seq_len=256, device=DEV)
+    bt = torch.randperm(B * 16, generator=g).reshape(B, 16).to(torch.int32)
+    logits = eng.prefill(prompts, bt, chunk=64).cpu()
+    odec = oracle.OracleDecoder({**cfg.__dict__}, _oracle_weights(w))
+    okv = oracle.OracleKV(cfg.num_layers, B, kv_int8)
+    ref_last = []
+    for b, pr in enumerate(prompts):                          # the oracle eats the prompt token by token
+        for pos, tok in enumerate(pr):
+            _, lg = odec.forward_tokens(torch.tensor([tok], dtype=torch.int32), torch.tensor([pos], dtype=torch.int32), okv, [b])
+        ref_last.append(lg[0])
+    ref_last = torch.stack(ref_last)
+    tol = dict(atol=1.5e-2, rtol=1.5e-2) if kv_int8 else TOL
+    assert torch.allclose(logits, ref_last, **tol), float((logits - ref_last).abs().max())
+    # continue decoding from the prefilled cache
+    tok = oracle.greedy(ref_last)
+    eng.set_inputs(tok.tolist(), lens, bt)
+    for step in range(3):
+        pos = torch.tensor([n + step for n in lens], dtype=torch.int32)
+        _, ref = odec.forward_tokens(tok, pos, okv, list(range(B)))
+        eng.step(B)
+        torch.cuda.synchronize()
+        assert torch.allclose(eng.logits[:B].cpu(), ref, **tol), (step, float((eng.logits[:B].cpu() - ref).abs().max()))
+        tok = oracle.greedy(ref)
+        eng.token_ids[:B].copy_(tok)
+    assert eng.oob_count() == 0
