@@ -26,6 +26,8 @@
 // Multi-row: the 16 MFMA columns of a tile hold (row, head) pairs -- R = 16 / G rows of one sequence x its G query heads --
 // and a block carries NT such tiles against the same K/V fragments, so a sequence's KV is streamed once per NT*R query rows
 // instead of once per row; column j masks tokens beyond ITS row's position (causality), nothing else changes.
+#include <type_traits>
+
 #include "common.h"
 #include "internal.h"
 
@@ -47,8 +49,12 @@ struct AttnParams {
 
 constexpr float NEG_BIG = -1e30f;
 
-template <int HD, bool INT8, int NT>
-__global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
+// NW waves per block split the partition between them (each wave keeps two 32-token groups of K/V in flight).  NW = 8 for
+// the one-block-per-CU grids (B * nkv * P <= 256) was measured and lost: 34.2 vs 29.8 us at b = 64 / ctx 1024 fp16 KV and
+// 98 vs 89 us at ctx 4096 INT8 KV -- two waves per SIMD cap the kernel at 256 registers and it spills 12-21 of them.
+template <int HD, bool INT8, int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p) {
+    constexpr int NTHR = 64 * NW, GS = 32 * NW;    // threads; tokens one round of the block's waves covers
     constexpr int NSTEP = HD / 32; // QK k-steps
     constexpr int NDB   = HD / 16; // PV d-blocks
     const int part = blockIdx.x, kh = blockIdx.y;
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
     const int pstart = part * p.PS;
     if (seq_len <= 0) {   // only padding rows here: their outputs are defined (zeros), nothing is read
         if (part == 0)
-            for (int idx = threadIdx.x; idx < nrows * p.G * HD; idx += 256) {
+            for (int idx = threadIdx.x; idx < nrows * p.G * HD; idx += NTHR) {
                 const int rl = idx / (p.G * HD), rem = idx - rl * (p.G * HD);
                 p.out[((size_t)(row0 + rl) * p.nh + kh * p.G) * HD + rem] = (f16)0.f;
             }
@@ -154,7 +160,8 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
             g.vsc[0] = *reinterpret_cast<const f32x4*>(vs); g.vsc[1] = *reinterpret_cast<const f32x4*>(vs + 4);
         }
     };
-    auto compute_group = [&](const Group& g, int tb) {
+    auto compute_group = [&](const Group& g, int tb, auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;   // false: every token of the group is visible to every column
         const int vwin = tb + w * 8; // first token of this lane's S rows / P slots
         // ---- widen K once, S^T = K q^T for every column tile
         f16x8 ka[2][NSTEP];
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
                     float v = sacc[tau][r] * p.scale_log2;
                     if (INT8) v *= g.ksc[tau][r];
                     const int tok = vwin + tau * 4 + r;
-                    v = tok < limit[c] ? v : NEG_BIG;
+                    if (MASKED) v = tok < limit[c] ? v : NEG_BIG;
                     sv[tau * 4 + r] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
             float psum = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const bool valid = vwin + e < limit[c];
+                const bool valid = !MASKED || vwin + e < limit[c];
                 float pe = valid ? __builtin_amdgcn_exp2f(sv[e] - m_new) : 0.f;
                 psum += pe;
                 if (INT8) pe = valid ? pe * g.vsc[e >> 2][e & 3] : 0.f; // scale bytes past the context may be garbage
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
                 a = __builtin_bit_cast(f16x8, g.vf16[db]);
             }
             // tokens past the block's context carry p = 0 but V bytes there may be garbage (NaN/Inf): zero them
-            if (vwin + 7 >= seq_len) {
+            if (MASKED && vwin + 7 >= seq_len) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) if (vwin + e >= seq_len) a[e] = (f16)0.f;
             }
@@ -236,25 +243,36 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
     // with one long partition per (sequence, kv head) a SIMD holds a single wave, so the wave itself has to
     // keep >= 32 KB of K/V loads outstanding to cover HBM latency.
     {
+        // a group is fully visible when it ends at or before the shortest context of the block's columns: no masking code
+        int lim_min = limit[0];
+#pragma unroll
+        for (int c = 1; c < NT; ++c) lim_min = min(lim_min, limit[c]);
+        lim_min = min(lim_min, __shfl_xor(lim_min, 1)); lim_min = min(lim_min, __shfl_xor(lim_min, 2));
+        lim_min = min(lim_min, __shfl_xor(lim_min, 4)); lim_min = min(lim_min, __shfl_xor(lim_min, 8));
+        const int full_end = __builtin_amdgcn_readfirstlane(p.R * p.G == 16 && nrows == NT * p.R ? lim_min : (p.q_len == 1 ? seq_len : 0));
+        auto compute = [&](const Group& g, int tb) {
+            if (tb + 32 <= full_end) compute_group(g, tb, std::false_type{});
+            else compute_group(g, tb, std::true_type{});
+        };
         Group gA, gB;
         int tb = pstart + wave * 32;
         int kbA = 0, vbA = 0, kbB = 0, vbB = 0;
         if (tb < pend) { lookup(tb, kbA, vbA); load_group(gA, tb, kbA, vbA); }
-        if (tb + 128 < pend) lookup(tb + 128, kbB, vbB);
-        for (; tb < pend; tb += 256) {
-            const bool hasB = tb + 128 < pend;
-            if (hasB) load_group(gB, tb + 128, kbB, vbB);
-            if (tb + 256 < pend) lookup(tb + 256, kbA, vbA);
-            compute_group(gA, tb);
-            if (tb + 256 < pend) load_group(gA, tb + 256, kbA, vbA);
-            if (tb + 384 < pend) lookup(tb + 384, kbB, vbB);
-            if (hasB) compute_group(gB, tb + 128);
+        if (tb + GS < pend) lookup(tb + GS, kbB, vbB);
+        for (; tb < pend; tb += 2 * GS) {
+            const bool hasB = tb + GS < pend;
+            if (hasB) load_group(gB, tb + GS, kbB, vbB);
+            if (tb + 2 * GS < pend) lookup(tb + 2 * GS, kbA, vbA);
+            compute(gA, tb);
+            if (tb + 2 * GS < pend) load_group(gA, tb + 2 * GS, kbA, vbA);
+            if (tb + 3 * GS < pend) lookup(tb + 3 * GS, kbB, vbB);
+            if (hasB) compute(gB, tb + GS);
         }
     }
 
-    // ---- merge the 4 waves through LDS, one column tile at a time.  o[c][db][r] is O^T[d = db*16 + w*4 + r][j].
-    __shared__ float s_o[4][16][HD + 4];
-    __shared__ float s_m[4][16], s_l[4][16];
+    // ---- merge the NW waves through LDS, one column tile at a time.  o[c][db][r] is O^T[d = db*16 + w*4 + r][j].
+    __shared__ float s_o[NW][16][HD + 4];
+    __shared__ float s_m[NW][16], s_l[NW][16];
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
         float lr = l_run[c];
@@ -268,15 +286,17 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const AttnParams p) {
         __syncthreads();
         // thread -> (column jj, 4 channels); 16 columns * HD/4 vectors
         const int ncol = p.R * p.G;
-        for (int idx = tid; idx < ncol * (HD / 4); idx += 256) {
+        for (int idx = tid; idx < ncol * (HD / 4); idx += NTHR) {
             const int jj = idx / (HD / 4), d0 = (idx - jj * (HD / 4)) * 4;
             const int rl = c * p.R + jj / p.G;
             if (rl >= nrows) continue;
-            float mstar = fmaxf(fmaxf(s_m[0][jj], s_m[1][jj]), fmaxf(s_m[2][jj], s_m[3][jj]));
+            float mstar = s_m[0][jj];
+#pragma unroll
+            for (int ww = 1; ww < NW; ++ww) mstar = fmaxf(mstar, s_m[ww][jj]);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             float l = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) {
+            for (int ww = 0; ww < NW; ++ww) {
                 const float f = __builtin_amdgcn_exp2f(s_m[ww][jj] - mstar);
                 acc += *reinterpret_cast<const f32x4*>(&s_o[ww][jj][d0]) * f;
                 l += s_l[ww][jj] * f;
@@ -391,8 +411,8 @@ int launch_attn(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_
     p.tmp_ml  = p.tmp_out + rows * nh * p.P * kv->hd;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(p.P, kv->nkv, B * p.ntile);
-#define L_(HD_, I8_, NT_) hipLaunchKernelGGL((paged_attn_kernel<HD_, I8_, NT_>), grid, dim3(256), 0, st, p)
-#define L2_(HD_, I8_) do { if (NT == 1) L_(HD_, I8_, 1); else L_(HD_, I8_, 2); } while (0)
+#define L_(HD_, I8_, NT_, NW_) hipLaunchKernelGGL((paged_attn_kernel<HD_, I8_, NT_, NW_>), grid, dim3(64 * NW_), 0, st, p)
+#define L2_(HD_, I8_) do { if (NT == 1) L_(HD_, I8_, 1, 4); else L_(HD_, I8_, 2, 4); } while (0)
     if (kv->hd == 128) { if (int8) L2_(128, true); else L2_(128, false); }
     else               { if (int8) L2_(64, true);  else L2_(64, false); }
 #undef L2_

@@ -16,6 +16,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define MI355_WAVE 64
 
+// experiment switches exist only in the tuning build (see gemm.hip); TUNE(i) folds to 0 in the product library
+#ifdef MI355_TUNING
+extern int g_tune[8];
+#define TUNE(i) g_tune[i]
+#else
+#define TUNE(i) 0
+#endif
+
 // host-side error plumbing -------------------------------------------------
 void mi355_set_error(const char* fmt, ...);
 int  mi355_raise_dynamic_lds(const void* func, const char* name); // once per (kernel, device); error.cpp

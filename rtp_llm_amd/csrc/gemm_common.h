@@ -48,13 +48,6 @@
     "v_pk_mul_f16 " N2 ", " N2 ", %[sc]\n\t"                                \
     "v_pk_mul_f16 " N3 ", " N3 ", %[sc]"
 
-#ifdef MI355_TUNING
-extern int g_tune[8];
-#define TUNE(i) g_tune[i]
-#else
-#define TUNE(i) 0
-#endif
-
 namespace {
 
 struct GemmParams {

@@ -12,8 +12,12 @@ def main():
     ap.add_argument("--batch", type=int, default=64); ap.add_argument("--ctx", type=int, default=1024)
     ap.add_argument("--int8", action="store_true"); ap.add_argument("--ps", type=int, default=0)
     ap.add_argument("--page", type=int, default=16); ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--tune", default="", help="idx=val,... forwarded to mi355_debug_set")
     a = ap.parse_args()
     lib = _C.lib(); lib.mi355_debug_set_attn.argtypes = [C.c_int]; lib.mi355_debug_set_attn(a.ps)
+    lib.mi355_debug_set.argtypes = [C.c_int, C.c_int]
+    for kv_ in filter(None, a.tune.split(",")):
+        lib.mi355_debug_set(int(kv_.split("=")[0]), int(kv_.split("=")[1]))
     dev = "cuda:0"; nh, nkv, hd = 28, 4, 128
     B, ctx, page = a.batch, a.ctx, a.page
     mb = (ctx + page - 1) // page
