@@ -46,6 +46,9 @@ struct mi355_decoder {
     bool        overlap;
     float* partials;
     size_t attn_ws_bytes, argmax_ws_bytes, partials_bytes;
+    void*    wide_ws;        // max_batch > 64: buffers of the generic large-batch step (mi355_decoder_prefill with q_len = 1)
+    size_t   wide_ws_bytes;
+    int32_t* iota;           // [max_batch] 0, 1, 2, ...: "logits of every row"
     int    B;       // rows of the step in flight (= sequences * q_len)
     int    q_len;   // rows per sequence: 1 = decode, > 1 = target-verify / prefill chunk (causal over the paged cache)
     // graphs
@@ -70,9 +73,12 @@ struct Carve {
     }
 };
 
+struct PrefillBufs;
+size_t carve_prefill(const mi355_model_config_t& c, int T, int nseq, void* base, PrefillBufs* out);
+
 size_t carve_all(mi355_decoder* d, const mi355_model_config_t& c, void* base) {
     Carve cv{(char*)base, 0};
-    const size_t MB_ = (size_t)c.max_batch;
+    const size_t MB_ = (size_t)(c.max_batch < 64 ? c.max_batch : 64);   // the fused small-batch path handles <= 64 rows per step
     const int qdim = c.nh * c.hd, qkvdim = (c.nh + 2 * c.nkv) * c.hd;
     const int npad = (imax(qkvdim, c.hidden) + 15) & ~15;
     void* resid    = cv.take(MB_ * c.hidden * 2);
@@ -83,13 +89,16 @@ size_t carve_all(mi355_decoder* d, const mi355_model_config_t& c, void* base) {
     // split-K slabs: qkv / o / down use up to kMaxSplits of [max_batch, npad]; a K-split gate_up (TP shards) up to 4 of [max_batch, 2 inter]
     const size_t pbytes = std::max((size_t)kMaxSplits * MB_ * npad * 4, (size_t)4 * MB_ * ((2 * c.inter + 15) & ~15) * 4);
     void* partials = cv.take(pbytes);
-    const size_t aw = mi355_paged_attn_workspace_bytes(c.max_batch, c.nh, c.hd, c.max_seq_len);
+    const size_t aw = mi355_paged_attn_workspace_bytes((int)MB_, c.nh, c.hd, c.max_seq_len);
     void* attn_ws  = cv.take(aw);
-    const size_t gw = MB_ * 64 * 8;
+    const size_t gw = (size_t)c.max_batch * 64 * 8;
     void* argmax_ws = cv.take(gw);
     void* oob = cv.take(256);
+    const size_t wide_bytes = c.max_batch > 64 ? carve_prefill(c, c.max_batch, c.max_batch, nullptr, nullptr) : 0;
+    void* wide_ws = cv.take(wide_bytes);
+    void* iota = cv.take((size_t)c.max_batch * 4);
     if (d) {
-        d->oob_count = (int32_t*)oob;
+        d->oob_count = (int32_t*)oob; d->wide_ws = wide_ws; d->wide_ws_bytes = wide_bytes; d->iota = (int32_t*)iota;
         d->resid = resid; d->xn = xn; d->q_buf = q_buf; d->attn_out = attn_out; d->act = act;
         d->partials = (float*)partials; d->partials_bytes = pbytes; d->attn_ws = attn_ws; d->attn_ws_bytes = aw;
         d->argmax_ws = argmax_ws; d->argmax_ws_bytes = gw;
@@ -136,8 +145,8 @@ extern "C" size_t mi355_decoder_workspace_bytes(const mi355_model_config_t* cfg)
 extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg, const mi355_layer_weights_t* layers,
                                                  const mi355_model_weights_t* model, const mi355_step_buffers_t* bufs) {
     if (!cfg || !layers || !model || !bufs) { mi355_set_error("decoder_create: null argument"); return nullptr; }
-    if (cfg->num_layers <= 0 || cfg->max_batch <= 0 || cfg->max_batch > 64) {
-        mi355_set_error("decoder_create: num_layers=%d max_batch=%d (1..64)", cfg->num_layers, cfg->max_batch);
+    if (cfg->num_layers <= 0 || cfg->max_batch <= 0 || cfg->max_batch > 4096) {
+        mi355_set_error("decoder_create: num_layers=%d max_batch=%d (1..4096)", cfg->num_layers, cfg->max_batch);
         return nullptr;
     }
     if (cfg->nh % cfg->nkv != 0 || cfg->nh / cfg->nkv > 16 || (cfg->hd != 64 && cfg->hd != 128)) {
@@ -167,7 +176,12 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     d->xn = bufs->hidden; // the normed hidden state lives in the caller-visible buffer
     d->B = 0; d->q_len = 1; d->cap_stream = nullptr; d->prof_on = false; d->ev_used = 0; d->ar = nullptr; d->vocab_offset = 0;
     d->side_stream = nullptr; d->ev_fork = d->ev_join = nullptr; d->overlap = false;
-    if (hipMemset(d->oob_count, 0, 256) != hipSuccess) { mi355_set_error("decoder_create: cannot clear the workspace"); delete d; return nullptr; }
+    std::vector<int32_t> iota_h(cfg->max_batch);
+    for (int i = 0; i < cfg->max_batch; ++i) iota_h[i] = i;
+    if (hipMemset(d->oob_count, 0, 256) != hipSuccess ||
+        hipMemcpy(d->iota, iota_h.data(), iota_h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        mi355_set_error("decoder_create: cannot initialise the workspace"); delete d; return nullptr;
+    }
     return d;
 }
 
@@ -188,8 +202,9 @@ extern "C" int mi355_decoder_begin(mi355_decoder_t* d, int32_t B, mi355_stream_t
 
 extern "C" int mi355_decoder_begin_rows(mi355_decoder_t* d, int32_t nseq, int32_t q_len, mi355_stream_t stream) {
     const int B = nseq * q_len;
-    if (!d || nseq <= 0 || q_len <= 0 || B > d->cfg.max_batch) {
-        mi355_set_error("decoder_begin: %d sequences x %d rows exceed max_batch", nseq, q_len);
+    if (!d || nseq <= 0 || q_len <= 0 || B > d->cfg.max_batch || B > 64) {
+        mi355_set_error("decoder_begin: %d sequences x %d rows exceed max_batch or the 64-row limit of the segmented step "
+                        "(larger batches: mi355_decoder_step)", nseq, q_len);
         return MI355_ERR_ARG;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -315,8 +330,22 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
 namespace {
 struct PrefillBufs { void *resid, *xn, *qkv, *q, *attn, *act, *tmp, *gemm_ws, *attn_ws, *last_h; size_t gemm_ws_bytes, attn_ws_bytes; };
 
-size_t carve_prefill(const mi355_decoder* d, int T, int nseq, void* base, PrefillBufs* out) {
-    const mi355_model_config_t& c = d->cfg;
+// upper bound of the split-K slab workspace mi355_linear_forward may ask for on 64-row slabs of this model's linears
+size_t linear_ws_bound(const mi355_model_config_t& c) {
+    const int qkvdim = (c.nh + 2 * c.nkv) * c.hd;
+    const int shapes[4][2] = {{c.hidden, qkvdim}, {c.nh * c.hd, c.hidden}, {c.hidden, 2 * c.inter}, {c.inter, c.hidden}};
+    size_t need = 256;
+    for (const auto& sh : shapes)
+        for (int wbits : {4, 8, 16}) {
+            mi355_weight_t w;
+            w.qweight = &need; w.meta = &need; w.wbits = wbits; w.K = sh[0]; w.N = sh[1];
+            w.K_pad = (sh[0] + 127) & ~127; w.N_pad = (sh[1] + 15) & ~15; w.group_size = wbits == 4 ? 128 : 0;
+            need = std::max(need, mi355_linear_workspace_bytes(64, &w));
+        }
+    return need;
+}
+
+size_t carve_prefill(const mi355_model_config_t& c, int T, int nseq, void* base, PrefillBufs* out) {
     Carve cv{(char*)base, 0};
     const size_t Ts = (size_t)T;
     const int qdim = c.nh * c.hd, qkvdim = (c.nh + 2 * c.nkv) * c.hd;
@@ -325,10 +354,7 @@ size_t carve_prefill(const mi355_decoder* d, int T, int nseq, void* base, Prefil
     b.q = cv.take(Ts * qdim * 2); b.attn = cv.take(Ts * qdim * 2); b.act = cv.take(Ts * c.inter * 2); b.tmp = cv.take(Ts * c.hidden * 2);
     b.last_h = cv.take((size_t)nseq * c.hidden * 2 * 2);
     // 64-row slabs through the decode kernels (chunks below 128 rows) may split K into fp32 slabs: ask the planner
-    b.gemm_ws_bytes = 256;
-    for (const auto& L : d->layers)
-        for (const mi355_weight_t* w : {&L.qkv, &L.o, &L.gate_up, &L.down})
-            b.gemm_ws_bytes = std::max(b.gemm_ws_bytes, mi355_linear_workspace_bytes(64, w));
+    b.gemm_ws_bytes = linear_ws_bound(c);
     b.gemm_ws = cv.take(b.gemm_ws_bytes);
     b.attn_ws_bytes = mi355_paged_attn_workspace_bytes(T, c.nh, c.hd, c.max_seq_len);
     b.attn_ws = cv.take(b.attn_ws_bytes);
@@ -339,7 +365,7 @@ size_t carve_prefill(const mi355_decoder* d, int T, int nseq, void* base, Prefil
 
 extern "C" size_t mi355_decoder_prefill_workspace_bytes(mi355_decoder_t* d, int32_t max_tokens, int32_t max_seqs) {
     if (!d || max_tokens <= 0 || max_seqs <= 0) return 0;
-    return carve_prefill(d, max_tokens, max_seqs, nullptr, nullptr);
+    return carve_prefill(d->cfg, max_tokens, max_seqs, nullptr, nullptr);
 }
 
 extern "C" int mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_ids, const int32_t* positions, const int32_t* block_table,
@@ -352,7 +378,7 @@ extern "C" int mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_id
     const int T = nseq * q_len;
     if (c.tp_size > 1 && !d->ar) { mi355_set_error("decoder_prefill: tp_size > 1 needs mi355_decoder_attach_allreduce"); return MI355_ERR_ARG; }
     PrefillBufs b;
-    const size_t need = carve_prefill(d, T, nseq, workspace, &b);
+    const size_t need = carve_prefill(c, T, nseq, workspace, &b);
     if (need > workspace_bytes) { mi355_set_error("decoder_prefill: workspace %zu < %zu", workspace_bytes, need); return MI355_ERR_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     const float scale = 1.0f / sqrtf((float)c.hd);
@@ -417,6 +443,22 @@ extern "C" int mi355_decoder_step(mi355_decoder_t* d, int32_t B, mi355_stream_t 
     if (!d || (d->cfg.tp_size != 1 && !d->ar)) {
         mi355_set_error("decoder_step: tp_size > 1 needs mi355_decoder_attach_allreduce (or the segment calls)");
         return MI355_ERR_ARG;
+    }
+    if (B > 64) {   // large batch: the generic path (large-M GEMMs, fp16 intermediates), one row per sequence
+        if (B > d->cfg.max_batch) { mi355_set_error("decoder_step: B=%d > max_batch", B); return MI355_ERR_ARG; }
+        hipStream_t st = (hipStream_t)stream;
+        const auto& c = d->cfg;
+        int rc = mi355_decoder_prefill(d, d->bufs.token_ids, d->bufs.positions, d->bufs.block_table, B, 1, d->iota, d->bufs.logits,
+                                       d->wide_ws, d->wide_ws_bytes, stream);
+        if (rc < 0) return rc;
+        if (d->ar) {
+            RUN(MI355_KC_COMM, mi355_allreduce_argmax(d->ar, d->bufs.logits, B, c.vocab, c.vocab, d->vocab_offset, d->bufs.token_ids,
+                                                      d->bufs.positions, d->argmax_ws, d->argmax_ws_bytes, st));
+        } else {
+            RUN(MI355_KC_OTHER, mi355_argmax_ex(d->bufs.logits, B, c.vocab, c.vocab, d->bufs.token_ids, d->bufs.positions, d->argmax_ws,
+                                                d->argmax_ws_bytes, st));
+        }
+        return MI355_OK;
     }
     int rc = mi355_decoder_begin(d, B, stream);
     for (int l = 0; rc >= 0 && l < d->cfg.num_layers; ++l) {

@@ -491,6 +491,10 @@ int launch_gemm_t(const GemmParams& p, int cfg, hipStream_t st) {
 int launch_gemm(const GemmParams& p, int wbits, int group_size, int cfg, hipStream_t st) {
     if (wbits == 16) return launch_gemm_t<16, 0, 2, 2, 2>(p, cfg, st);
     if (wbits == 4) {
+#ifdef MI355_TUNING
+        if (group_size == 128 && TUNE(3) == 1) return launch_gemm_t<4, 4, 8, 4, 4>(p, cfg, st);     // ring depth experiment
+        if (group_size == 128 && TUNE(3) == 2) return launch_gemm_t<4, 4, 12, 4, 4>(p, cfg, st);
+#endif
         if (group_size == 128) return launch_gemm_t<4, 4, 4, 4, 4>(p, cfg, st);
         if (group_size == 64) return launch_gemm_t<4, 2, 4, 4, 4>(p, cfg, st);
         if (group_size == 32) return launch_gemm_t<4, 1, 4, 4, 4>(p, cfg, st);

@@ -200,9 +200,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_smallm_kernel(const SmallMParams
     }
 }
 
-template <int WBITS, int GS>
+template <int WBITS, int GS, int D = 4>
 int launch_t(const SmallMParams& sp, size_t lds, hipStream_t st) {
-    constexpr int NW = 16, D = 4;
+    constexpr int NW = 16;
     auto k = gemm_smallm_kernel<WBITS, GS, D, NW>;
     if (int e = raise_dynamic_lds((const void*)k, "gemm_smallm")) return e; // allow > 64 KiB of dynamic LDS
     hipLaunchKernelGGL(k, dim3(sp.GT, sp.g.nsplit), dim3(64 * NW), lds, st, sp);
@@ -246,6 +246,9 @@ extern "C" int mi355_gemm_smallm(const void* gp, int wbits, int group_size, int 
     if (lds > 150 * 1024) return MI355_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     int rc = MI355_ERR_UNSUPPORTED;
+#ifdef MI355_TUNING
+    if (wbits == 4 && group_size == 128 && TUNE(3) == 1) return (rc = launch_t<4, 4, 8>(sp, lds, st)) < 0 ? rc : g.nsplit;
+#endif
     if (wbits == 4) rc = group_size == 128 ? launch_t<4, 4>(sp, lds, st) : group_size == 64 ? launch_t<4, 2>(sp, lds, st) : launch_t<4, 1>(sp, lds, st);
     else            rc = group_size == 0 ? launch_t<8, 0>(sp, lds, st) : launch_t<8, 4>(sp, lds, st);
     return rc < 0 ? rc : g.nsplit;

@@ -589,3 +589,32 @@ def test_prefill_ragged_prompts_multi_chunk_matches_oracle(kv_int8):
         tok = oracle.greedy(ref)
         eng.token_ids[:B].copy_(tok)
     assert eng.oob_count() == 0
+
+
+def test_engine_large_batch_step_matches_oracle():
+    """B > 64: the step driver takes its generic large-batch path (large-M GEMMs, one row per sequence), captured and
+    replayed as a hipGraph like the small-batch step; logits and greedy feedback vs the oracle."""
+    cfg = _tiny_cfg()
+    w = model.synth_model(cfg, "w4", "cpu", seed=41, zeros="centered")
+    B, page = 150, 16
+    eng = model.DecoderEngine(cfg, model.weights_to(w, DEV), kv_int8=False, page=page, num_blocks=B * 2, max_batch=160, max_seq_len=32, device=DEV)
+    odec = oracle.OracleDecoder({**cfg.__dict__}, _oracle_weights(w))
+    okv = oracle.OracleKV(cfg.num_layers, B, False)
+    bt = torch.randperm(B * 2, generator=_gen(1)).reshape(B, 2).to(torch.int32)
+    tok = torch.randint(0, cfg.vocab, (B,), generator=_gen(2), dtype=torch.int32)
+    eng.set_inputs(tok.tolist(), [0] * B, bt)
+    eng.capture(B)
+    for step in range(3):
+        pos = torch.full((B,), step, dtype=torch.int32)
+        _, ref = odec.forward_tokens(tok, pos, okv, list(range(B)))
+        eng.replay(B, 1)
+        torch.cuda.synchronize()
+        got = eng.logits[:B].cpu()
+        assert torch.allclose(got, ref, **TOL), (step, float((got - ref).abs().max()))
+        nxt = oracle.greedy(ref)
+        top2 = ref.topk(2, -1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-2
+        assert torch.equal(eng.token_ids[:B].cpu()[safe], nxt[safe]) and torch.equal(eng.positions[:B].cpu(), pos + 1)
+        tok = nxt
+        eng.token_ids[:B].copy_(tok)
+    assert eng.oob_count() == 0

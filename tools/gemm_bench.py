@@ -28,10 +28,14 @@ def main():
     ap.add_argument("--partial", type=int, default=0, help="1: qkv/o/down through mi355_linear_partial (split-K slabs, as the engine)")
     ap.add_argument("--nowide", type=int, default=0, help="1: disable the register-resident wide-M kernel")
     ap.add_argument("--nosmall", type=int, default=0, help="1: disable the persistent small-M kernel")
+    ap.add_argument("--tune", default="", help="idx=val,... extra mi355_debug_set switches")
+    ap.add_argument("--copies", type=int, default=0, help="weight copies rotated (0: enough to defeat the 256 MiB Infinity Cache; 1: cache-resident)")
     a = ap.parse_args()
     lib = _C.lib()
     lib.mi355_debug_set.argtypes = [C.c_int, C.c_int]
     lib.mi355_debug_set(0, a.var); lib.mi355_debug_set(1, a.nsplit); lib.mi355_debug_set(2, a.nbw); lib.mi355_debug_set(4, a.nosmall); lib.mi355_debug_set(5, a.nowide)
+    for kv_ in filter(None, a.tune.split(",")):
+        lib.mi355_debug_set(int(kv_.split("=")[0]), int(kv_.split("=")[1]))
     dev = "cuda:0"
     gen = torch.Generator(device=dev).manual_seed(0)
     for kind in a.kinds.split(","):
@@ -39,7 +43,7 @@ def main():
             K, N = SHAPES[name]
             k = "fp16" if name == "lm_head" else kind
             base = model.synth_linear(K, N, k, dev, gen).pack(gate_up=(name == "gate_up" or name.startswith("gu_")))
-            ncopy = max(2, int(600e6 // base.nbytes) + 1)
+            ncopy = a.copies if a.copies > 0 else max(2, int(600e6 // base.nbytes) + 1)
             copies = [base] + [type(base)(base.qweight.clone(), None if base.meta is None else base.meta.clone(), base.wbits,
                                           base.K, base.N, base.K_pad, base.N_pad, base.group_size) for _ in range(ncopy - 1)]
             for M in [int(m) for m in a.ms.split(",")]:
@@ -54,7 +58,7 @@ def main():
                     ns = run(0)
                     assert ns > 0, _C.last_error() if hasattr(_C, "last_error") else ns
                 else:
-                    outs = [ops.linear(x, c, None, epi) for c in copies[:2]]
+                    outs = [ops.linear(x, c, None, epi) for c in copies[:1]]
                     run = lambda i: ops.linear(x, copies[i % ncopy], None, epi, out=outs[0])
                 torch.cuda.synchronize()
                 st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
