@@ -160,10 +160,8 @@ def main():
     cfg_full = model.MODELS[mname]
     if args.layers:
         cfg_full = model.ModelConfig(**{**cfg_full.__dict__, "num_layers": args.layers})
-    total_steps = args.steps + args.warmup + 8
-    max_seq_len = ctx + total_steps + 64
-    blocks_per_seq = (max_seq_len + page - 1) // page
-    num_blocks = B * blocks_per_seq
+    total_steps = args.steps + args.warmup + 8 + 40
+    cfg_full0, kind0, kv_int8_0, B0, ctx0, page0 = cfg_full, kind, kv_int8, B, ctx, page
 
     # ---- control plane for N > 1: gloo (CPU tensors) for the barrier and the max-over-ranks; RCCL only carries the
     # data-path collectives of the TP layout below, so the headline does not hang on it
@@ -183,9 +181,14 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return float(t.item())
 
-    def build_engine(tp, tp_rank, replica):
+    def build_engine(tp, tp_rank, replica, spec=None):
         """Synthetic weights generated per rank directly at per-rank shapes (the TP split of random tensors is random
-        tensors; norms / embedding use the same seed on every rank)."""
+        tensors; norms / embedding use the same seed on every rank).  spec = (cfg_full, kind, kv_int8, B, ctx, page)
+        overrides the command-line workload (the extra driver-timed workloads of the default run)."""
+        cfg_full, kind, kv_int8, B, ctx, page = spec or (cfg_full0, kind0, kv_int8_0, B0, ctx0, page0)
+        max_seq_len = ctx + total_steps + 64
+        blocks_per_seq = (max_seq_len + page - 1) // page
+        num_blocks = B * blocks_per_seq
         cfg = cfg_full.per_rank(tp)
         if args.shard_of > 1 and world == 1:
             cfg = cfg_full.per_rank(args.shard_of)
@@ -276,15 +279,17 @@ def main():
         alg_bytes_launch = (bps["linears"] + act_bytes) / n_launch_step
         avg_ms = gq["ms"] / max(1, gq["launches"])
         ach = alg_bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        try:  # HBM read + write bytes per launch from the committed PMC passes of this workload (profiles/README.md)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(args.workload)
+        traffic, traffic_src = None, None
+        try:  # HBM read + write bytes per launch of THESE launches (the engine's four linears per layer), from the committed
+            # rocprofv3 --pmc passes over `bench.py --no-graph` (tools/engine_traffic.sh -> profiles/r02_traffic.json); PMC
+            # collection needs its own profiled runs, so it cannot happen inside this timed invocation: the value is static
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json"))).get(args.workload)
             if tj and tj.get("batch") == B:
-                traffic = int(tj["gemm_quant_bytes_per_launch"])
+                traffic, traffic_src = int(tj["gemm_quant_bytes_per_launch"]), tj.get("source")
         except Exception:  # noqa: BLE001
             traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": "gemm_wq_kernel / gemm_wide_kernel (the four quantised linears of a layer: qkv, o, gate_up, down)", "achieved": round(ach, 1),
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_ms * 1e3, 3),
                            "launches_timed": gq["launches"]}
         total_b = sum(bps.values())
@@ -304,6 +309,27 @@ def main():
                 sweep.append({"batch": b, "tokens_per_s": round(b / ms * 1e3, 1), "ms_per_step": round(ms, 4),
                               "hbm_frac": round(sum(bb.values()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
             out["sweep"] = sweep
+        # ---- the other single-GPU BASELINE configs, timed in this same (driver-run) invocation: configs[2] = W4 + INT8 KV,
+        # b=64, ctx 4096; configs[1] = W8A16 (load-time autoquant), b=16, ctx 1024
+        if args.workload == "qwen2-7b-w4a16" and not args.no_sweep and not args.no_graph and not args.batch and not args.ctx and not args.layers:
+            others = {}
+            del eng
+            for name in ("qwen2-7b-w4a16-kv8", "qwen2-7b-w8a16"):
+                torch.cuda.empty_cache()
+                mn, kd, k8, b2, c2, pg = WORKLOADS[name]
+                cfg2, eng2, reset2 = build_engine(1, 0, 0, (model.MODELS[mn], kd, k8, b2, c2, pg))
+                eng2.capture(b2)
+                reset2(); eng2.replay(b2, 4); torch.cuda.synchronize()
+                n2 = min(args.steps, 32)
+                t0 = time.perf_counter(); eng2.replay(b2, n2); torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / n2 * 1e3
+                bb = bytes_per_step(cfg2, eng2, b2, c2, k8)
+                others[name] = {"batch": b2, "seq_len": c2, "weights": kd, "kv": "int8" if k8 else "fp16", "steps": n2,
+                                "tokens_per_s": round(b2 / ms * 1e3, 1), "ms_per_step": round(ms, 4),
+                                "bytes_per_step": int(sum(bb.values())),
+                                "hbm_frac": round(sum(bb.values()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                del eng2
+            out["other_workloads"] = others
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg_full, kind, kv_int8, B, ctx)
     # ---- N > 1: the metric's multi-GPU layout is tensor parallelism with TP degree = GPU count: Megatron split,
