@@ -52,7 +52,7 @@ constexpr float NEG_BIG = -1e30f;
 // NW waves per block split the partition between them (each wave keeps two 32-token groups of K/V in flight).  NW = 8 for
 // the one-block-per-CU grids (B * nkv * P <= 256) was measured and lost: 34.2 vs 29.8 us at b = 64 / ctx 1024 fp16 KV and
 // 98 vs 89 us at ctx 4096 INT8 KV -- two waves per SIMD cap the kernel at 256 registers and it spills 12-21 of them.
-template <int HD, bool INT8, int NT, int NW>
+template <int HD, bool INT8, int NT, int NW, int NG>
 __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p) {
     constexpr int NTHR = 64 * NW, GS = 32 * NW;    // threads; tokens one round of the block's waves covers
     constexpr int NSTEP = HD / 32; // QK k-steps
@@ -180,6 +180,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             }
         f16x8 pf[NT];
         float alpha[NT];
+        bool rescale = false;
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
             f32x4 sacc[2];
@@ -205,8 +206,14 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[c], mx);
-            alpha[c] = __builtin_amdgcn_exp2f(m_run[c] - m_new);
+            // Deferred rescale: the running max is only advanced (and O / l rescaled) when some column's max grew by more than
+            // 2^kDefer; until then p = exp2(s - m_run) may exceed 1 by that factor, harmless in fp16 / fp32.  In steady state
+            // the per-group multiply of the 32 O accumulators (and their AGPR round trip) disappears.
+            constexpr float kDefer = 6.f;
+            const bool grow = __builtin_amdgcn_ballot_w64(mx > m_run[c] + kDefer) != 0;   // wave-uniform
+            const float m_new = grow ? fmaxf(m_run[c], mx) : m_run[c];
+            alpha[c] = grow ? __builtin_amdgcn_exp2f(m_run[c] - m_new) : 1.f;
+            rescale |= grow;
             m_run[c] = m_new;
             float psum = 0.f;
 #pragma unroll
@@ -219,7 +226,13 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             }
             l_run[c] = l_run[c] * alpha[c] + psum;
         }
-        // ---- O^T = alpha * O^T + V^T P
+        if (rescale) {
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) o[c][db] *= alpha[c];
+        }
+        // ---- O^T += V^T P
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
             f16x8 a;
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
                 for (int e = 0; e < 8; ++e) if (vwin + e >= seq_len) a[e] = (f16)0.f;
             }
 #pragma unroll
-            for (int c = 0; c < NT; ++c) o[c][db] = mfma16x16x32(a, pf[c], o[c][db] * alpha[c]);
+            for (int c = 0; c < NT; ++c) o[c][db] = mfma16x16x32(a, pf[c], o[c][db]);
         }
     };
 
@@ -254,19 +267,39 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             if (tb + 32 <= full_end) compute_group(g, tb, std::false_type{});
             else compute_group(g, tb, std::true_type{});
         };
-        Group gA, gB;
+        // NG groups of K/V in flight per wave, the load of group n + NG - 1 issued BEFORE the wait for group n: a SIMD holds a
+        // single wave here (one long partition per (sequence, kv head)), so the wave itself has to cover the HBM latency --
+        // with a period of ~L / (NG - 1) per group instead of L (measured L ~ 3.5 us under load at b = 64).
+        // (separate named groups, not an array: an indexed array of these structs ends up in scratch memory)
+        Group g0, g1, g2;
+        int k0 = 0, v0 = 0, k1 = 0, v1 = 0, k2 = 0, v2 = 0;
         int tb = pstart + wave * 32;
-        int kbA = 0, vbA = 0, kbB = 0, vbB = 0;
-        if (tb < pend) { lookup(tb, kbA, vbA); load_group(gA, tb, kbA, vbA); }
-        if (tb + GS < pend) lookup(tb + GS, kbB, vbB);
-        for (; tb < pend; tb += 2 * GS) {
-            const bool hasB = tb + GS < pend;
-            if (hasB) load_group(gB, tb + GS, kbB, vbB);
-            if (tb + 2 * GS < pend) lookup(tb + 2 * GS, kbA, vbA);
-            compute(gA, tb);
-            if (tb + 2 * GS < pend) load_group(gA, tb + 2 * GS, kbA, vbA);
-            if (tb + 3 * GS < pend) lookup(tb + 3 * GS, kbB, vbB);
-            if (hasB) compute(gB, tb + GS);
+        if constexpr (NG == 2) {
+            if (tb < pend) { lookup(tb, k0, v0); load_group(g0, tb, k0, v0); }
+            if (tb + GS < pend) lookup(tb + GS, k1, v1);
+            for (; tb < pend; tb += 2 * GS) {
+                if (tb + GS < pend) load_group(g1, tb + GS, k1, v1);
+                if (tb + 2 * GS < pend) lookup(tb + 2 * GS, k0, v0);
+                compute(g0, tb);
+                if (tb + 2 * GS < pend) load_group(g0, tb + 2 * GS, k0, v0);
+                if (tb + 3 * GS < pend) lookup(tb + 3 * GS, k1, v1);
+                if (tb + GS < pend) compute(g1, tb + GS);
+            }
+        } else {
+            if (tb < pend) { lookup(tb, k0, v0); load_group(g0, tb, k0, v0); }
+            if (tb + GS < pend) { lookup(tb + GS, k1, v1); load_group(g1, tb + GS, k1, v1); }
+            if (tb + 2 * GS < pend) lookup(tb + 2 * GS, k2, v2);
+            for (; tb < pend; tb += 3 * GS) {
+                if (tb + 2 * GS < pend) load_group(g2, tb + 2 * GS, k2, v2);
+                if (tb + 3 * GS < pend) lookup(tb + 3 * GS, k0, v0);
+                compute(g0, tb);
+                if (tb + 3 * GS < pend) load_group(g0, tb + 3 * GS, k0, v0);
+                if (tb + 4 * GS < pend) lookup(tb + 4 * GS, k1, v1);
+                if (tb + GS < pend) compute(g1, tb + GS);
+                if (tb + 4 * GS < pend) load_group(g1, tb + 4 * GS, k1, v1);
+                if (tb + 5 * GS < pend) lookup(tb + 5 * GS, k2, v2);
+                if (tb + 2 * GS < pend) compute(g2, tb + 2 * GS);
+            }
         }
     }
 
@@ -411,8 +444,12 @@ int launch_attn(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_
     p.tmp_ml  = p.tmp_out + rows * nh * p.P * kv->hd;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(p.P, kv->nkv, B * p.ntile);
-#define L_(HD_, I8_, NT_, NW_) hipLaunchKernelGGL((paged_attn_kernel<HD_, I8_, NT_, NW_>), grid, dim3(64 * NW_), 0, st, p)
-#define L2_(HD_, I8_) do { if (NT == 1) L_(HD_, I8_, 1, 4); else L_(HD_, I8_, 2, 4); } while (0)
+#define L_(HD_, I8_, NT_, NW_, NG_) hipLaunchKernelGGL((paged_attn_kernel<HD_, I8_, NT_, NW_, NG_>), grid, dim3(64 * NW_), 0, st, p)
+#ifdef MI355_TUNING
+#define L2_(HD_, I8_) do { if (NT == 1) { if (TUNE(6) == 3) L_(HD_, I8_, 1, 4, 3); else L_(HD_, I8_, 1, 4, 2); } else L_(HD_, I8_, 2, 4, 2); } while (0)
+#else
+#define L2_(HD_, I8_) do { if (NT == 1) L_(HD_, I8_, 1, 4, 2); else L_(HD_, I8_, 2, 4, 2); } while (0)
+#endif
     if (kv->hd == 128) { if (int8) L2_(128, true); else L2_(128, false); }
     else               { if (int8) L2_(64, true);  else L2_(64, false); }
 #undef L2_

@@ -4,6 +4,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <type_traits>
 #include "../../include/mi355_decode.h"
 
 typedef _Float16 f16;
@@ -102,3 +103,12 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// compile-time loop: the body sees its index as a constant expression (std::integral_constant)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}

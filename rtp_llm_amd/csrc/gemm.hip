@@ -688,7 +688,7 @@ extern "C" int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_
     GemmParams p; fill_params(p, x, M, w);
     p.mode = mode; p.bias = (const f16*)bias; p.y = y;
     p.ldy = (mode == MODE_SILU) ? w->N / 2 : w->N;
-    if (M <= 8 && w->wbits != 16 && TUNE(4) == 2) {
+    if (M <= 8 && w->wbits != 16 && (TUNE(4) == 2 || TUNE(7) == 1)) {
         const int rc = mi355_gemm_smallm(&p, w->wbits, w->group_size, 0, 1, stream);
         if (rc >= 0) return MI355_OK;
         if (rc != MI355_ERR_UNSUPPORTED) return rc;

@@ -30,15 +30,6 @@
 
 namespace {
 
-// compile-time loop: the body sees its index as a constant expression (sched_group_barrier needs literal arguments)
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
 struct WideParams {
     GemmParams g;
     int G; // tile groups (grid.x)

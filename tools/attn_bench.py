@@ -12,6 +12,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64); ap.add_argument("--ctx", type=int, default=1024)
     ap.add_argument("--int8", action="store_true"); ap.add_argument("--ps", type=int, default=0)
     ap.add_argument("--page", type=int, default=16); ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--seq-bt", type=int, default=0, help="1: identity block table (contiguous pages) instead of a random permutation")
     ap.add_argument("--tune", default="", help="idx=val,... forwarded to mi355_debug_set")
     a = ap.parse_args()
     lib = _C.lib(); lib.mi355_debug_set_attn.argtypes = [C.c_int]; lib.mi355_debug_set_attn(a.ps)
@@ -33,7 +34,7 @@ def main():
         else:
             kv.copy_(torch.randn(kv.shape, device=dev, generator=g, dtype=torch.float16))
         caches.append((kv, sc))
-    bt = torch.randperm(nblk, generator=torch.Generator().manual_seed(1)).reshape(B, mb).to(torch.int32).to(dev)
+    bt = (torch.arange(nblk) if a.seq_bt else torch.randperm(nblk, generator=torch.Generator().manual_seed(1))).reshape(B, mb).to(torch.int32).to(dev)
     sl = torch.full((B,), ctx, dtype=torch.int32, device=dev)
     q = torch.randn(B, nh, hd, device=dev, generator=g, dtype=torch.float16)
     for kv, sc in caches[:2]:

@@ -5,14 +5,15 @@ FETCH_SIZE / WRITE_SIZE count KiB; on gfx950 a wide coalesced read stream is tal
 usage: engine_traffic.py <fetch_dir> <write_dir>"""
 import collections, csv, glob, json, os, sys
 
-CLASSES = [("gemm_wide_kernel", "gemm_quant"), ("gemm_wq_kernelILi4", "gemm_quant"), ("gemm_wq_kernelILi8", "gemm_quant"),
-           ("gemm_smallm", "gemm_quant"), ("gemm_wq_kernelILi16", "gemm_lmhead"), ("paged_attn", "attn"), ("attn_reduce", "attn"),
-           ("rope_kv", "rope_kv"), ("add_rmsnorm", "norm"), ("reduce_epilogue", "gemm_quant_reduce")]
+import re
+CLASSES = [(r"gemm_wide_kernel", "gemm_quant"), (r"gemm_wq_kernel(ILi|<)(4|8)[E,]", "gemm_quant"), (r"gemm_smallm", "gemm_quant"),
+           (r"gemm_prefill", "gemm_quant"), (r"gemm_wq_kernel(ILi|<)16[E,]", "gemm_lmhead"), (r"paged_attn|attn_reduce", "attn"),
+           (r"rope_kv", "rope_kv"), (r"add_rmsnorm", "norm"), (r"reduce_epilogue", "gemm_quant_reduce")]
 
 
 def klass(name):
-    for sub, c in CLASSES:
-        if sub in name:
+    for pat, c in CLASSES:
+        if re.search(pat, name):
             return c
     return None
 
