@@ -197,6 +197,22 @@ int mi355_rope_kv_write(const void* qkv_f16, const float* partials, int32_t nspl
                         int32_t max_blocks_per_seq, int32_t T, int32_t nh,
                         const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count, mi355_stream_t stream);
 
+/* Fused fast paths of the decode step (gemm_fullk.hip): one launch, no split-K workspace.  Both return
+ * MI355_ERR_UNSUPPORTED (nothing launched) for shapes / formats they do not take -- W4 group-wise weights with K a
+ * multiple of 128 and M <= 64 are taken; the caller then composes mi355_linear_forward + the separate op.
+ *
+ * mi355_linear_residual: residual_out = residual_in + fp16(x W + bias)   (may alias residual_in)
+ *   replaces o_proj / down_proj followed by the residual add of the reference decoder layer
+ *   (rtp_llm/models_py/model_desc/qwen3.py:63-77: hidden_states = residual + hidden_states, twice per layer).
+ * mi355_qkv_rope_kv_write: QKV projection + bias + NeoX RoPE + Q extract + fp16 paged KV write in one launch
+ *   replaces LinearBase.forward (linear_base.py:75-85) followed by FusedRopeKVCacheDecodeOp::forward
+ *   (FusedRopeKVCacheOp.cc:519-646); arguments as mi355_rope_kv_write_rows, x = the normed hidden rows. */
+int mi355_linear_residual(const void* x, int32_t M, const mi355_weight_t* w, const void* bias, const void* residual_in,
+                          void* residual_out, mi355_stream_t stream);
+int mi355_qkv_rope_kv_write(const void* x, int32_t M, const mi355_weight_t* wqkv, const void* qkv_bias, const float* cos_sin,
+                            int32_t rope_dim, int32_t max_pos, const int32_t* positions, const int32_t* block_table,
+                            int32_t max_blocks_per_seq, int32_t q_len, int32_t nh, const mi355_kv_layer_t* kv, void* q_out,
+                            int32_t* oob_count, mi355_stream_t stream);
 /* The same for q_len rows per sequence (speculative verify, chunked prefill): token t = row t % q_len of sequence t / q_len,
  * block_table is [T / q_len][max_blocks_per_seq]; positions[t] < 0 marks a padding row (q produced, nothing stored). */
 int mi355_rope_kv_write_rows(const void* qkv_f16, const float* partials, int32_t nsplit, int32_t ld,

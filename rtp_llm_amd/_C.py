@@ -66,6 +66,8 @@ SIGNATURES = {
     "mi355_embedding": (i32, [vp, i32, vp, i32, i32, vp, vp]),
     "mi355_rope_kv_write": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
     "mi355_rope_kv_write_rows": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
+    "mi355_linear_residual": (i32, [vp, i32, C.POINTER(Weight), vp, vp, vp, vp]),
+    "mi355_qkv_rope_kv_write": (i32, [vp, i32, C.POINTER(Weight), vp, vp, i32, i32, vp, vp, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
     "mi355_paged_attn_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "mi355_paged_decode_attn": (i32, [vp, C.POINTER(KVLayer), vp, i32, vp, i32, i32, f32, i32, vp, vp, sz, vp]),
     "mi355_paged_attn_rows": (i32, [vp, C.POINTER(KVLayer), vp, i32, vp, i32, i32, i32, f32, i32, vp, vp, sz, vp]),

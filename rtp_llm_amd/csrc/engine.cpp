@@ -51,6 +51,13 @@ struct mi355_decoder {
     int32_t* iota;           // [max_batch] 0, 1, 2, ...: "logits of every row"
     int    B;       // rows of the step in flight (= sequences * q_len)
     int    q_len;   // rows per sequence: 1 = decode, > 1 = target-verify / prefill chunk (causal over the paged cache)
+    // fused full-K launches (gemm_fullk.hip), decided once from the weight formats: QKV + bias + RoPE + KV write in one
+    // launch (fp16 cache), O / down projection + residual add without split-K slabs (tp = 1: under TP the partial sums
+    // of the row-parallel linears meet in the all-reduce first).  Only up to fuse_rows rows: every block reads ALL
+    // activation rows of its K range from L2, which is free at a few rows and 2x slower than the staged split-K kernels
+    // at 64 (measured M = 64: qkv+rope 20.8 vs 9.0 + 4.9 us, o 18.6 vs 9.7 + slab fold; M = 1: 6.8 vs 7.3 + 3.1 us)
+    bool   fuse_qkv, fuse_o, fuse_down;
+    int    fuse_rows;
     // graphs
     hipStream_t                    cap_stream;
     std::map<int, hipGraphExec_t>  graphs;
@@ -176,6 +183,14 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     d->xn = bufs->hidden; // the normed hidden state lives in the caller-visible buffer
     d->B = 0; d->q_len = 1; d->cap_stream = nullptr; d->prof_on = false; d->ev_used = 0; d->ar = nullptr; d->vocab_offset = 0;
     d->side_stream = nullptr; d->ev_fork = d->ev_join = nullptr; d->overlap = false;
+    d->fuse_qkv = cfg->kv_dtype == MI355_KV_FP16 && cfg->rope_dim == cfg->hd;
+    d->fuse_o = d->fuse_down = cfg->tp_size == 1;
+    d->fuse_rows = 8;
+    for (const auto& L : d->layers) {
+        d->fuse_qkv = d->fuse_qkv && mi355_fullk_weight_ok(&L.qkv);
+        d->fuse_o = d->fuse_o && mi355_fullk_weight_ok(&L.o);
+        d->fuse_down = d->fuse_down && mi355_fullk_weight_ok(&L.down);
+    }
     std::vector<int32_t> iota_h(cfg->max_batch);
     for (int i = 0; i < cfg->max_batch; ++i) iota_h[i] = i;
     if (hipMemset(d->oob_count, 0, 256) != hipSuccess ||
@@ -270,15 +285,26 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
                                                    c.rms_eps, B, c.hidden, d->xn, st));
     }
     int ns = 0;
-    RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->xn, B, &L.qkv, d->partials, kMaxSplits, st));
     mi355_kv_layer_t kv = kv_of(d, l);
-    RUN(MI355_KC_ROPE_KV, mi355_rope_kv_write_rows(nullptr, d->partials, ns, L.qkv.N_pad, L.qkv_bias, d->model.cos_sin, c.rope_dim,
-                                                   c.max_pos, d->bufs.positions, d->bufs.block_table, c.max_blocks_per_seq, B,
-                                                   d->q_len, c.nh, &kv, d->q_buf, d->oob_count, st));
+    if (d->fuse_qkv && B <= d->fuse_rows) {
+        RUN(MI355_KC_GEMM_QUANT, mi355_qkv_rope_kv_write(d->xn, B, &L.qkv, L.qkv_bias, d->model.cos_sin, c.rope_dim, c.max_pos,
+                                                         d->bufs.positions, d->bufs.block_table, c.max_blocks_per_seq, d->q_len,
+                                                         c.nh, &kv, d->q_buf, d->oob_count, st));
+    } else {
+        RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->xn, B, &L.qkv, d->partials, kMaxSplits, st));
+        RUN(MI355_KC_ROPE_KV, mi355_rope_kv_write_rows(nullptr, d->partials, ns, L.qkv.N_pad, L.qkv_bias, d->model.cos_sin, c.rope_dim,
+                                                       c.max_pos, d->bufs.positions, d->bufs.block_table, c.max_blocks_per_seq, B,
+                                                       d->q_len, c.nh, &kv, d->q_buf, d->oob_count, st));
+    }
     // q_len > 1: rows of one sequence share a pass over its KV, causal mask inside the page walk (is_target_verify)
     RUN(MI355_KC_ATTN, mi355_paged_attn_rows(d->q_buf, &kv, d->bufs.block_table, c.max_blocks_per_seq, d->bufs.positions,
                                              B / d->q_len, d->q_len, c.nh, 1.0f / sqrtf((float)c.hd), c.max_seq_len, d->attn_out,
                                              d->attn_ws, d->attn_ws_bytes, st));
+    if (d->fuse_o && B <= d->fuse_rows) {     // h += fp16(attn W_o) in the GEMM's epilogue, then the plain norm: no slabs
+        RUN(MI355_KC_GEMM_QUANT, mi355_linear_residual(d->attn_out, B, &L.o, nullptr, d->resid, d->resid, st));
+        RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, L.post_norm, c.rms_eps, B, c.hidden, d->xn, st));
+        return MI355_OK;
+    }
     RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->attn_out, B, &L.o, d->partials, kMaxSplits, st));
     if (c.tp_size == 1) {
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid, L.post_norm,
@@ -305,8 +331,13 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
     RUN(MI355_KC_GEMM_QUANT, mi355_linear_direct(d->xn, B, &L.gate_up, nullptr, d->act, MI355_EPI_SILU_MUL, d->partials,
                                                  d->partials_bytes, st));
     int ns = 0;
-    RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->act, B, &L.down, d->partials, kMaxSplits, st));
     const void* next_norm = (l + 1 < c.num_layers) ? d->layers[l + 1].input_norm : d->model.final_norm;
+    if (d->fuse_down && B <= d->fuse_rows) {
+        RUN(MI355_KC_GEMM_QUANT, mi355_linear_residual(d->act, B, &L.down, nullptr, d->resid, d->resid, st));
+        RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, next_norm, c.rms_eps, B, c.hidden, d->xn, st));
+        return MI355_OK;
+    }
+    RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->act, B, &L.down, d->partials, kMaxSplits, st));
     if (c.tp_size == 1) {
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
                                              c.rms_eps, B, c.hidden, d->xn, st));

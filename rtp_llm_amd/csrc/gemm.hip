@@ -28,6 +28,16 @@ extern "C" int mi355_gemm_smallm(const void* gp, int wbits, int group_size, int 
 extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int want_partial, int max_splits,
                                mi355_stream_t stream);
 extern "C" int mi355_gemm_prefill(const void* gp, int wbits, int group_size, mi355_stream_t stream);
+#ifdef MI355_TUNING   // producer / consumer experiment (gemm_pc.hip), tuning build only: switch 5 = 3 routes M > 32 W4 shapes to it
+extern "C" int mi355_gemm_pc(const void* gp, int wbits, int group_size, int want_partial, int max_splits, mi355_stream_t stream);
+#endif
+extern "C" int mi355_gemm_fullk(const void* gp, int wbits, int group_size, mi355_stream_t stream);
+extern "C" int mi355_gemm_fullk_residual(const void* gp, int wbits, int group_size, const void* residual_in, void* residual_out,
+                                         mi355_stream_t stream);
+extern "C" int mi355_gemm_fullk_rope(const void* gp, int wbits, int group_size, const float* cos_sin, int32_t max_pos,
+                                     const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq,
+                                     int32_t q_len, int32_t nh, const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count,
+                                     mi355_stream_t stream);
 
 #ifdef MI355_TUNING
 int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -611,7 +621,13 @@ extern "C" int mi355_linear_partial(const void* x, int32_t M, const mi355_weight
         const int rc = mi355_gemm_smallm(&p, w->wbits, w->group_size, 1, max_splits, stream);
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
-    if (M > 16 && w->wbits != 16 && !TUNE(5)) { // register-resident activations, K split over the waves (gemm_wide.hip)
+#ifdef MI355_TUNING
+    if (M > 32 && w->wbits == 4 && TUNE(5) == 3) {
+        const int rc = mi355_gemm_pc(&p, w->wbits, w->group_size, 1, max_splits, stream);
+        if (rc != MI355_ERR_UNSUPPORTED) return rc;
+    }
+#endif
+    if (M > 16 && w->wbits != 16 && TUNE(5) != 1) { // register-resident activations, K split over the waves (gemm_wide.hip)
         const int rc = mi355_gemm_wide(&p, w->wbits, w->group_size, 1, max_splits, stream);
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
@@ -647,10 +663,14 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
             if (rc >= 0) continue;
             if (rc != MI355_ERR_UNSUPPORTED) return rc;
         }
-        if (Mc > 16 && w->wbits != 16 && !(epilogue & MI355_HINT_STAGED) && !TUNE(5)) {
+        if (Mc > 16 && w->wbits != 16 && !(epilogue & MI355_HINT_STAGED) && TUNE(5) != 1) {
             GemmParams ps; fill_params(ps, (const f16*)x + (size_t)m0 * w->K, Mc, w);
             ps.mode = mode; ps.bias = (const f16*)bias; ps.y = (char*)y + (size_t)m0 * ldy * ysz; ps.ldy = ldy;
-            const int rc = mi355_gemm_wide(&ps, w->wbits, w->group_size, 0, 1, stream);
+            int rc = MI355_ERR_UNSUPPORTED;
+#ifdef MI355_TUNING
+            if (Mc > 32 && w->wbits == 4 && TUNE(5) == 3) rc = mi355_gemm_pc(&ps, w->wbits, w->group_size, 0, 1, stream);
+#endif
+            if (rc == MI355_ERR_UNSUPPORTED) rc = mi355_gemm_wide(&ps, w->wbits, w->group_size, 0, 1, stream);
             if (rc >= 0) continue;
             if (rc != MI355_ERR_UNSUPPORTED) return rc;
         }
@@ -693,8 +713,12 @@ extern "C" int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_
         if (rc >= 0) return MI355_OK;
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
-    if (M > 16 && w->wbits != 16 && !(epilogue & MI355_HINT_STAGED) && !TUNE(5)) {
-        const int rc = mi355_gemm_wide(&p, w->wbits, w->group_size, 0, 1, stream);
+    if (M > 16 && w->wbits != 16 && !(epilogue & MI355_HINT_STAGED) && TUNE(5) != 1) {
+        int rc = MI355_ERR_UNSUPPORTED;
+#ifdef MI355_TUNING
+        if (M > 32 && w->wbits == 4 && TUNE(5) == 3) rc = mi355_gemm_pc(&p, w->wbits, w->group_size, 0, 1, stream);
+#endif
+        if (rc == MI355_ERR_UNSUPPORTED) rc = mi355_gemm_wide(&p, w->wbits, w->group_size, 0, 1, stream);
         if (rc >= 0) return MI355_OK;
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
@@ -715,4 +739,36 @@ extern "C" int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_
                        g.nsplit, M, w->N, w->N_pad, (const f16*)bias, y, (mode == MODE_SILU) ? w->N / 2 : w->N, mode);
     MI355_CHECK_LAUNCH("reduce_epilogue_kernel");
     return MI355_OK;
+}
+
+// ------------------------------------------------------------------ full-K kernels with fused consumers (gemm_fullk.hip)
+extern "C" int mi355_fullk_weight_ok(const mi355_weight_t* w) {
+    return w && w->qweight && w->meta && w->wbits == 4 && (w->group_size == 128 || w->group_size == 64 || w->group_size == 32) &&
+           w->K % 128 == 0 && w->K_pad == w->K && w->K_pad / 128 >= 4 && w->N % 16 == 0;
+}
+
+extern "C" int mi355_linear_residual(const void* x, int32_t M, const mi355_weight_t* w, const void* bias, const void* residual_in,
+                                     void* residual_out, mi355_stream_t stream) {
+    if (int e = check_weight(w)) return e;
+    MI355_CHECK_ARG(x && residual_in && residual_out && M > 0, "linear_residual: bad args (M=%d)", M);
+    if (M > 64 || !mi355_fullk_weight_ok(w)) return MI355_ERR_UNSUPPORTED;
+    GemmParams p; fill_params(p, x, M, w);
+    p.mode = MODE_F16; p.bias = (const f16*)bias; p.ldy = w->N;
+    return mi355_gemm_fullk_residual(&p, w->wbits, w->group_size, residual_in, residual_out, stream);
+}
+
+extern "C" int mi355_qkv_rope_kv_write(const void* x, int32_t M, const mi355_weight_t* wqkv, const void* qkv_bias,
+                                       const float* cos_sin, int32_t rope_dim, int32_t max_pos, const int32_t* positions,
+                                       const int32_t* block_table, int32_t max_blocks_per_seq, int32_t q_len, int32_t nh,
+                                       const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count, mi355_stream_t stream) {
+    if (int e = check_weight(wqkv)) return e;
+    MI355_CHECK_ARG(x && M > 0 && q_len >= 1 && M % q_len == 0, "qkv_rope_kv_write: M=%d q_len=%d", M, q_len);
+    MI355_CHECK_ARG(kv && kv->kv_base && cos_sin && positions && block_table && q_out, "qkv_rope_kv_write: null pointer");
+    MI355_CHECK_ARG(kv->page > 0 && nh > 0 && kv->nkv > 0 && max_pos > 0 && max_blocks_per_seq > 0 && kv->num_blocks > 0,
+                    "qkv_rope_kv_write: bad dims");
+    if (M > 64 || !mi355_fullk_weight_ok(wqkv) || rope_dim != kv->hd) return MI355_ERR_UNSUPPORTED;
+    GemmParams p; fill_params(p, x, M, wqkv);
+    p.mode = MODE_F16; p.bias = (const f16*)qkv_bias; p.ldy = wqkv->N;
+    return mi355_gemm_fullk_rope(&p, wqkv->wbits, wqkv->group_size, cos_sin, max_pos, positions, block_table, max_blocks_per_seq,
+                                 q_len, nh, kv, q_out, oob_count, stream);
 }

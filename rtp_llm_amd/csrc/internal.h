@@ -15,6 +15,7 @@ int mi355_paged_decode_attn_ex(const void* q, const mi355_kv_layer_t* kv, const 
                                int32_t max_blocks_per_seq, const int32_t* seq_lens, int32_t seq_lens_minus_one, int32_t B,
                                int32_t nh, float scale, int32_t max_seq_len, void* out, void* workspace,
                                size_t workspace_bytes, mi355_stream_t stream);
+int mi355_fullk_weight_ok(const mi355_weight_t* w);
 int mi355_prefetch(const void* ptr, size_t bytes, void* sink, mi355_stream_t stream);
 int mi355_argmax_candidates(const float* logits, int32_t B, int32_t V, int32_t ld, void* workspace, size_t workspace_bytes,
                             mi355_stream_t stream);

@@ -76,6 +76,45 @@ def linear(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None
     return out
 
 
+ERR_UNSUPPORTED = -3
+
+
+def linear_residual(x: torch.Tensor, w: PackedWeight, residual: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                    out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """residual + fp16(x @ W + bias) in one launch (gemm_fullk.hip); None when the shape is not taken by the fused kernel
+    (the caller composes linear + add).  `out` may alias `residual`."""
+    _chk(x, torch.float16, "linear_residual.x"); _chk(residual, torch.float16, "linear_residual.residual")
+    M = x.numel() // w.K
+    if x.shape[-1] != w.K or residual.shape[-1] != w.N or residual.numel() != M * w.N:
+        raise _C.Mi355Error(f"linear_residual: x {tuple(x.shape)} / residual {tuple(residual.shape)} against K={w.K} N={w.N}")
+    if out is None:
+        out = torch.empty_like(residual)
+    ws_struct = weight_struct(w)
+    rc = _C.lib().mi355_linear_residual(x.data_ptr(), M, C.byref(ws_struct), _p(bias), residual.data_ptr(), out.data_ptr(), _stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    _C.check(rc, "linear_residual")
+    return out
+
+
+def qkv_rope_kv_write(x: torch.Tensor, wqkv: PackedWeight, qkv_bias, cos_sin, positions, block_table, kv_base, scale_base,
+                      nh: int, nkv: int, hd: int, page: int, q_len: int = 1, oob_count: Optional[torch.Tensor] = None):
+    """QKV projection + bias + RoPE + Q extract + fp16 paged KV write in one launch; None when not taken (INT8 cache,
+    non-W4 weights): compose linear + rope_kv_write_rows then."""
+    _chk(x, torch.float16, "qkv_rope_kv_write.x"); _chk(positions, torch.int32, "positions"); _chk(block_table, torch.int32, "block_table")
+    T = x.numel() // wqkv.K
+    q_out = torch.empty(T, nh, hd, dtype=torch.float16, device=x.device)
+    kv = kv_struct(kv_base, scale_base, page, nkv, hd)
+    ws_struct = weight_struct(wqkv)
+    rc = _C.lib().mi355_qkv_rope_kv_write(x.data_ptr(), T, C.byref(ws_struct), _p(qkv_bias), cos_sin.data_ptr(), hd, cos_sin.shape[0],
+                                          positions.data_ptr(), block_table.data_ptr(), block_table.shape[1], q_len, nh, C.byref(kv),
+                                          q_out.data_ptr(), _p(oob_count), _stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    _C.check(rc, "qkv_rope_kv_write")
+    return q_out
+
+
 # ------------------------------------------------------------------ norms / elementwise
 def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
     _chk(x, torch.float16, "rmsnorm.x"); _chk(weight, torch.float16, "rmsnorm.weight")

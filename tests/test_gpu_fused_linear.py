@@ -1,0 +1,127 @@
+"""GPU parity of the full-K fused launches (gemm_fullk.hip) against the CPU oracle:
+
+  * mi355_linear_residual  = oracle.linear (fp16 output tensor) + fp16 residual add, at the Qwen2-7B o / down shapes and a
+    ragged toy shape, for the batch heights where the kernel shape changes (M = 1, 5, 16, 17, 32, 33, 48, 64);
+  * mi355_qkv_rope_kv_write = oracle.linear + oracle.apply_rope + the paged-cache writer, at the Qwen2-7B qkv shape
+    (28 + 2 x 4 heads of 128) and a head_dim 64 toy shape, single- and multi-row steps, stale positions included;
+  * both agree with the composed launches they replace (same tolerance), and refuse (None) what they do not take.
+"""
+import pytest
+import torch
+
+from oracle import oracle
+from rtp_llm_amd import _C, kvcache, model, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = dict(atol=1e-2, rtol=1e-2)
+MS = (1, 5, 16, 17, 32, 33, 48, 64)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_native():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    _C.lib()
+
+
+def _w4(K, N, seed, group_size=128):
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    c_dev = model.synth_linear(K, N, "w4", DEV, gen, group_size=group_size, zeros="centered")
+    c = model.weights_to({"w": c_dev}, "cpu")["w"]
+    return c_dev.pack(), oracle.dequant_groupwise(c.q, c.z_eff, c.scales, c.group_size)
+
+
+@pytest.mark.parametrize("K,N,gs", [(3584, 3584, 128), (18944, 3584, 128), (512, 272, 128), (1024, 256, 64), (512, 128, 32)],
+                         ids=["o", "down", "ragged-n", "g64", "g32"])
+def test_linear_residual_vs_oracle(K, N, gs):
+    packed, W = _w4(K, N, K + N, gs)
+    x = (torch.randn(64, K, generator=torch.Generator().manual_seed(3)) * 0.5).half()
+    res = (torch.randn(64, N, generator=torch.Generator().manual_seed(5)) * 2.0).half()
+    bias = (torch.randn(N, generator=torch.Generator().manual_seed(4)) * 0.1).half()
+    y = oracle.linear(x, W, bias)                                   # fp16 tensor, as the reference's linear returns it
+    ref = (y.float() + res.float()).half()
+    xd, rd, bd = x.to(DEV), res.to(DEV), bias.to(DEV)
+    for M in MS:
+        out = ops.linear_residual(xd[:M].contiguous(), packed, rd[:M].contiguous(), bd)
+        assert out is not None, "W4 group-wise, K % 128 == 0: the fused kernel must take it"
+        torch.cuda.synchronize()
+        err = (out.cpu().float() - ref[:M].float()).abs().max()
+        assert torch.allclose(out.cpu().float(), ref[:M].float(), **TOL), f"M={M}: max err {err}"
+        comp = (ops.linear(xd[:M].contiguous(), packed, bd).float() + rd[:M].float()).half()      # the two launches it replaces
+        assert torch.allclose(out.float(), comp.float(), **TOL)
+    # in place on the residual stream, as the step driver calls it
+    r2 = rd[:16].clone()
+    ops.linear_residual(xd[:16].contiguous(), packed, r2, bd, out=r2)
+    assert torch.equal(r2, ops.linear_residual(xd[:16].contiguous(), packed, rd[:16].contiguous(), bd))
+
+
+def test_linear_residual_refuses_other_formats():
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.zeros(4, 512, dtype=torch.float16, device=DEV); r = torch.zeros(4, 256, dtype=torch.float16, device=DEV)
+    for kind in ("int8", "fp16"):
+        p = model.synth_linear(512, 256, kind, DEV, gen).pack()
+        assert ops.linear_residual(x, p, r) is None
+    p = model.synth_linear(512, 256, "w4", DEV, gen).pack()
+    assert ops.linear_residual(torch.zeros(65, 512, dtype=torch.float16, device=DEV), p, torch.zeros(65, 256, dtype=torch.float16, device=DEV)) is None
+    with pytest.raises(_C.Mi355Error):
+        ops.linear_residual(x, p, torch.zeros(4, 128, dtype=torch.float16, device=DEV))
+
+
+@pytest.mark.parametrize("nh,nkv,hd,hidden,page,q_len", [(28, 4, 128, 3584, 16, 1), (28, 4, 128, 3584, 16, 4), (4, 2, 64, 512, 8, 1), (8, 1, 128, 1024, 16, 2)],
+                         ids=["qwen2-7b", "qwen2-7b-rows4", "hd64", "mqa-rows2"])
+def test_qkv_rope_kv_write_vs_oracle(nh, nkv, hd, hidden, page, q_len):
+    N = (nh + 2 * nkv) * hd
+    packed, W = _w4(hidden, N, hidden + N)
+    max_blocks, nblk = 8, 512
+    cfg = model.ModelConfig("t", 1, hidden, nh, nkv, hd, 64, 128, max_pos=max_blocks * page)
+    cs = oracle.rope_cos_sin(hd, cfg.rope_theta, cfg.max_pos)
+    bias = (torch.randn(N, generator=torch.Generator().manual_seed(4)) * 0.1).half()
+    for T in (q_len, 5 * q_len, 16 * q_len, (64 // q_len) * q_len):
+        nseq = T // q_len
+        g = torch.Generator().manual_seed(T)
+        x = (torch.randn(T, hidden, generator=g) * 0.5).half()
+        start = torch.randint(0, max_blocks * page - q_len, (nseq,), generator=g)
+        pos = (start[:, None] + torch.arange(q_len)[None, :]).reshape(-1).to(torch.int32)
+        bt = torch.randperm(nblk, generator=g)[: nseq * max_blocks].reshape(nseq, max_blocks).to(torch.int32)
+        kv, sc = kvcache.alloc_layer_cache(nblk, nkv, page, hd, False, DEV)
+        q = ops.qkv_rope_kv_write(x.to(DEV), packed, bias.to(DEV), cs.to(DEV), pos.to(DEV), bt.to(DEV), kv, sc, nh, nkv, hd, page, q_len)
+        assert q is not None
+        torch.cuda.synchronize()
+        qkv = oracle.linear(x, W, bias)
+        qh = qkv[:, : nh * hd].reshape(T, nh, hd)
+        kh = qkv[:, nh * hd: (nh + nkv) * hd].reshape(T, nkv, hd)
+        vh = qkv[:, (nh + nkv) * hd:].reshape(T, nkv, hd)
+        q_ref, k_ref = oracle.apply_rope(qh, pos, cs), oracle.apply_rope(kh, pos, cs)
+        assert torch.allclose(q.cpu().float(), q_ref.float(), **TOL), f"T={T}: q max err {(q.cpu().float() - q_ref.float()).abs().max()}"
+        for t in range(T):
+            K, V, _, _ = kvcache.read_tokens(kv, sc, bt[t // q_len], int(pos[t]) + 1)
+            assert torch.allclose(K[-1].cpu().float(), k_ref[t].float(), **TOL)
+            assert torch.allclose(V[-1].cpu().float(), vh[t].float(), **TOL)
+        # the composed launches it replaces: same numbers within the same tolerance, same cache image
+        kv2, sc2 = kvcache.alloc_layer_cache(nblk, nkv, page, hd, False, DEV)
+        y = ops.linear(x.to(DEV), packed, None)
+        q2 = ops.rope_kv_write_rows(y, bias.to(DEV), cs.to(DEV), pos.to(DEV), bt.to(DEV), kv2, sc2, nh, nkv, hd, page, q_len)
+        assert torch.allclose(q.float(), q2.float(), **TOL) and torch.allclose(kv.float(), kv2.float(), **TOL)
+
+
+def test_qkv_rope_kv_write_stale_rows_and_int8_refusal():
+    nh, nkv, hd, hidden, page = 4, 2, 64, 512, 8
+    N = (nh + 2 * nkv) * hd
+    packed, _ = _w4(hidden, N, 9)
+    max_blocks, nblk = 4, 32
+    cfg = model.ModelConfig("t", 1, hidden, nh, nkv, hd, 64, 128, max_pos=max_blocks * page)
+    cs = oracle.rope_cos_sin(hd, cfg.rope_theta, cfg.max_pos).to(DEV)
+    x = (torch.randn(4, hidden, generator=torch.Generator().manual_seed(1)) * 0.5).half().to(DEV)
+    pos = torch.tensor([3, -1, max_blocks * page + 7, 5], dtype=torch.int32, device=DEV)      # ok, padding row, past the table, ok
+    bt = torch.arange(4 * max_blocks, dtype=torch.int32, device=DEV).reshape(4, max_blocks)
+    bt[3, 0] = nblk + 5                                                                      # stale block id
+    kv, sc = kvcache.alloc_layer_cache(nblk, nkv, page, hd, False, DEV)
+    oob = torch.zeros(1, dtype=torch.int32, device=DEV)
+    before = kv.clone()
+    q = ops.qkv_rope_kv_write(x, packed, None, cs, pos, bt, kv, sc, nh, nkv, hd, page, 1, oob)
+    torch.cuda.synchronize()
+    assert q is not None and int(oob.item()) == 2            # rows 2 and 3 refused, row 1 is padding (not an error)
+    changed = (kv != before).reshape(nblk, -1).any(dim=1).nonzero().flatten().tolist()
+    assert changed == [0]                                     # only row 0's page was written
+    kv8, sc8 = kvcache.alloc_layer_cache(nblk, nkv, page, hd, True, DEV)
+    assert ops.qkv_rope_kv_write(x, packed, None, cs, pos, bt, kv8, sc8, nh, nkv, hd, page, 1) is None

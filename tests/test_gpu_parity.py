@@ -357,9 +357,11 @@ def test_engine_wide_hidden_mid_batch_matches_oracle():
 
 def test_module_graph_matches_engine():
     """The reference-shaped Python module graph (LinearFactory / FMHA impl / RMSNorm modules) and the C++ step
-    driver run the same kernels: hidden states agree to fp16 rounding of the fused epilogues."""
+    driver compute the same layer: the driver's small-batch step fuses QKV+RoPE+KV-write and the residual adds into
+    full-K launches (gemm_fullk.hip), the module graph composes the separate ops -- different fp32 summation orders, same
+    numbers to the tolerance both hold against the oracle (well-conditioned weights, see synth_linear)."""
     cfg = _tiny_cfg()
-    w = model.synth_model(cfg, "w4", DEV, seed=5)
+    w = model.synth_model(cfg, "w4", DEV, seed=5, zeros="centered")
     B, page = 2, 16
     eng = model.DecoderEngine(cfg, w, kv_int8=False, page=page, num_blocks=32, max_batch=2, max_seq_len=64, device=DEV)
     pym = model.Qwen2DecoderModel(cfg, w, page, 64)
