@@ -646,7 +646,10 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
     const int ldy  = (mode == MODE_SILU) ? w->N / 2 : w->N;
     const size_t ysz = (mode == MODE_F32) ? 4 : 2;
     hipStream_t st = (hipStream_t)stream;
-    if (M >= 128 && w->wbits != 16) {   // prefill-sized M: the compute-shaped kernel reads every weight once per 128 rows
+    // prefill-sized M: the compute-shaped kernel reads every weight once per 128 rows.  Its grid is (N / 256) x (M / 128)
+    // blocks without a K split: narrow outputs at moderate M (down_proj, N = 3584: 14 blocks per 128 rows) would leave
+    // most CUs idle (measured M = 128: 246 us vs 2 x 21 us as 64-row slabs), so those stay on the decode kernels
+    if (M >= 128 && w->wbits != 16 && cdiv(w->N_pad / 16, 16) * cdiv(M, 128) >= 128) {
         GemmParams ps; fill_params(ps, x, M, w);
         ps.mode = mode; ps.bias = (const f16*)bias; ps.y = y; ps.ldy = ldy;
         const int rc = mi355_gemm_prefill(&ps, w->wbits, w->group_size, stream);
