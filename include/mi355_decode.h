@@ -197,22 +197,40 @@ int mi355_rope_kv_write(const void* qkv_f16, const float* partials, int32_t nspl
                         int32_t max_blocks_per_seq, int32_t T, int32_t nh,
                         const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count, mi355_stream_t stream);
 
-/* Fused fast paths of the decode step (gemm_fullk.hip): one launch, no split-K workspace.  Both return
+/* Fused fast paths of the decode step (gemm_fullk.hip): one launch, no split-K workspace.  All return
  * MI355_ERR_UNSUPPORTED (nothing launched) for shapes / formats they do not take -- W4 group-wise weights with K a
- * multiple of 128 and M <= 64 are taken; the caller then composes mi355_linear_forward + the separate op.
+ * multiple of 128 and M <= 64 are taken (with a fused norm: M <= 16); the caller then composes mi355_linear_forward +
+ * the separate op.
  *
- * mi355_linear_residual: residual_out = residual_in + fp16(x W + bias)   (may alias residual_in)
+ * mi355_fused_norm_t: RMSNorm applied to the GEMM's input on the fly, x_n = weight * fp16(h * rs) (the arithmetic of
+ *   mi355_add_rmsnorm; reference modules/base/common/norm.py:83-92), with rs = rsqrt(sum_k h^2 / K + eps) rebuilt from
+ *   per-tile partial sums: tile_sumsq[row * ld + t] = sum over the 16 columns of tile t of h[row]^2, tiles = K / 16 (a
+ *   multiple of 4), ld >= tiles and a multiple of 4, 16-byte aligned -- what
+ *   mi355_linear_residual leaves behind for the rows it produces.  The norm launch between two GEMMs disappears.
+ * mi355_linear_residual: residual_out = residual_in + fp16(x W + bias)   (may alias residual_in); tile_sumsq_out
+ *   (nullable) receives the per-tile sums of residual_out^2, [M][tile_sumsq_ld >= N / 16].
  *   replaces o_proj / down_proj followed by the residual add of the reference decoder layer
  *   (rtp_llm/models_py/model_desc/qwen3.py:63-77: hidden_states = residual + hidden_states, twice per layer).
- * mi355_qkv_rope_kv_write: QKV projection + bias + NeoX RoPE + Q extract + fp16 paged KV write in one launch
+ * mi355_norm_linear: y = epilogue(RMSNorm(h) W + bias): post-attention norm + gate_up + SiLU-gate in one launch
+ *   (qwen3.py:74-76 + modules/hybrid/dense_mlp.py:95-106); epilogue as mi355_linear_forward.
+ * mi355_qkv_rope_kv_write: [RMSNorm +] QKV projection + bias + NeoX RoPE + Q extract + fp16 paged KV write in one launch
  *   replaces LinearBase.forward (linear_base.py:75-85) followed by FusedRopeKVCacheDecodeOp::forward
- *   (FusedRopeKVCacheOp.cc:519-646); arguments as mi355_rope_kv_write_rows, x = the normed hidden rows. */
+ *   (FusedRopeKVCacheOp.cc:519-646); arguments as mi355_rope_kv_write_rows; norm == NULL: x holds the normed rows. */
+typedef struct {
+    const float* tile_sumsq; /* [rows][ld] fp32 */
+    int32_t      tiles, ld;
+    const void*  weight;     /* fp16 [K] */
+    float        eps;
+} mi355_fused_norm_t;
+
 int mi355_linear_residual(const void* x, int32_t M, const mi355_weight_t* w, const void* bias, const void* residual_in,
-                          void* residual_out, mi355_stream_t stream);
-int mi355_qkv_rope_kv_write(const void* x, int32_t M, const mi355_weight_t* wqkv, const void* qkv_bias, const float* cos_sin,
-                            int32_t rope_dim, int32_t max_pos, const int32_t* positions, const int32_t* block_table,
-                            int32_t max_blocks_per_seq, int32_t q_len, int32_t nh, const mi355_kv_layer_t* kv, void* q_out,
-                            int32_t* oob_count, mi355_stream_t stream);
+                          void* residual_out, float* tile_sumsq_out, int32_t tile_sumsq_ld, mi355_stream_t stream);
+int mi355_norm_linear(const void* h, int32_t M, const mi355_fused_norm_t* norm, const mi355_weight_t* w, const void* bias,
+                      void* y, int32_t epilogue, mi355_stream_t stream);
+int mi355_qkv_rope_kv_write(const void* x, int32_t M, const mi355_weight_t* wqkv, const void* qkv_bias,
+                            const mi355_fused_norm_t* norm, const float* cos_sin, int32_t rope_dim, int32_t max_pos,
+                            const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq, int32_t q_len,
+                            int32_t nh, const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count, mi355_stream_t stream);
 /* The same for q_len rows per sequence (speculative verify, chunked prefill): token t = row t % q_len of sequence t / q_len,
  * block_table is [T / q_len][max_blocks_per_seq]; positions[t] < 0 marks a padding row (q produced, nothing stored). */
 int mi355_rope_kv_write_rows(const void* qkv_f16, const float* partials, int32_t nsplit, int32_t ld,

@@ -33,6 +33,10 @@ class KVLayer(C.Structure):  # mi355_kv_layer_t
                 ("nkv", i32), ("hd", i32), ("num_blocks", i32)]
 
 
+class FusedNorm(C.Structure):  # mi355_fused_norm_t
+    _fields_ = [("tile_sumsq", vp), ("tiles", i32), ("ld", i32), ("weight", vp), ("eps", f32)]
+
+
 class ModelConfig(C.Structure):  # mi355_model_config_t
     _fields_ = [(n, i32) for n in ("num_layers", "hidden", "nh", "nkv", "hd", "inter", "vocab", "rope_dim", "max_pos")] + \
                [("rms_eps", f32)] + \
@@ -66,8 +70,9 @@ SIGNATURES = {
     "mi355_embedding": (i32, [vp, i32, vp, i32, i32, vp, vp]),
     "mi355_rope_kv_write": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
     "mi355_rope_kv_write_rows": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
-    "mi355_linear_residual": (i32, [vp, i32, C.POINTER(Weight), vp, vp, vp, vp]),
-    "mi355_qkv_rope_kv_write": (i32, [vp, i32, C.POINTER(Weight), vp, vp, i32, i32, vp, vp, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
+    "mi355_linear_residual": (i32, [vp, i32, C.POINTER(Weight), vp, vp, vp, vp, i32, vp]),
+    "mi355_norm_linear": (i32, [vp, i32, C.POINTER(FusedNorm), C.POINTER(Weight), vp, vp, i32, vp]),
+    "mi355_qkv_rope_kv_write": (i32, [vp, i32, C.POINTER(Weight), vp, C.POINTER(FusedNorm), vp, i32, i32, vp, vp, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
     "mi355_paged_attn_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "mi355_paged_decode_attn": (i32, [vp, C.POINTER(KVLayer), vp, i32, vp, i32, i32, f32, i32, vp, vp, sz, vp]),
     "mi355_paged_attn_rows": (i32, [vp, C.POINTER(KVLayer), vp, i32, vp, i32, i32, i32, f32, i32, vp, vp, sz, vp]),

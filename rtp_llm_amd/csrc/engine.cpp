@@ -56,8 +56,9 @@ struct mi355_decoder {
     // of the row-parallel linears meet in the all-reduce first).  Only up to fuse_rows rows: every block reads ALL
     // activation rows of its K range from L2, which is free at a few rows and 2x slower than the staged split-K kernels
     // at 64 (measured M = 64: qkv+rope 20.8 vs 9.0 + 4.9 us, o 18.6 vs 9.7 + slab fold; M = 1: 6.8 vs 7.3 + 3.1 us)
-    bool   fuse_qkv, fuse_o, fuse_down;
+    bool   fuse_qkv, fuse_o, fuse_down, fuse_norm;
     int    fuse_rows;
+    float* ssq;      // [16 rows][hidden / 16]: the producer GEMM's per-tile sums of h^2, consumed by the next GEMM's on-the-fly RMSNorm
     // graphs
     hipStream_t                    cap_stream;
     std::map<int, hipGraphExec_t>  graphs;
@@ -101,10 +102,12 @@ size_t carve_all(mi355_decoder* d, const mi355_model_config_t& c, void* base) {
     const size_t gw = (size_t)c.max_batch * 64 * 8;
     void* argmax_ws = cv.take(gw);
     void* oob = cv.take(256);
+    void* ssq = cv.take((size_t)16 * ((c.hidden / 16 + 3) & ~3) * 4);   // per-tile sums of squares of the residual rows (fused norm, <= 16 rows)
     const size_t wide_bytes = c.max_batch > 64 ? carve_prefill(c, c.max_batch, c.max_batch, nullptr, nullptr) : 0;
     void* wide_ws = cv.take(wide_bytes);
     void* iota = cv.take((size_t)c.max_batch * 4);
     if (d) {
+        d->ssq = (float*)ssq;
         d->oob_count = (int32_t*)oob; d->wide_ws = wide_ws; d->wide_ws_bytes = wide_bytes; d->iota = (int32_t*)iota;
         d->resid = resid; d->xn = xn; d->q_buf = q_buf; d->attn_out = attn_out; d->act = act;
         d->partials = (float*)partials; d->partials_bytes = pbytes; d->attn_ws = attn_ws; d->attn_ws_bytes = aw;
@@ -191,6 +194,10 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
         d->fuse_o = d->fuse_o && mi355_fullk_weight_ok(&L.o);
         d->fuse_down = d->fuse_down && mi355_fullk_weight_ok(&L.down);
     }
+    // the norm launches disappear as well when every GEMM of the small-batch layer is a full-K launch: O / down leave the
+    // per-tile sums of squares of the new residual rows, QKV / gate_up rebuild 1 / rms from them and normalise on load
+    d->fuse_norm = d->fuse_qkv && d->fuse_o && d->fuse_down && cfg->hidden % 64 == 0;
+    for (const auto& L : d->layers) d->fuse_norm = d->fuse_norm && mi355_fullk_weight_ok(&L.gate_up) && L.gate_up.group_size == 128;
     std::vector<int32_t> iota_h(cfg->max_batch);
     for (int i = 0; i < cfg->max_batch; ++i) iota_h[i] = i;
     if (hipMemset(d->oob_count, 0, 256) != hipSuccess ||
@@ -286,10 +293,16 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
     }
     int ns = 0;
     mi355_kv_layer_t kv = kv_of(d, l);
-    if (d->fuse_qkv && B <= d->fuse_rows) {
-        RUN(MI355_KC_GEMM_QUANT, mi355_qkv_rope_kv_write(d->xn, B, &L.qkv, L.qkv_bias, d->model.cos_sin, c.rope_dim, c.max_pos,
-                                                         d->bufs.positions, d->bufs.block_table, c.max_blocks_per_seq, d->q_len,
-                                                         c.nh, &kv, d->q_buf, d->oob_count, st));
+    const bool small = B <= d->fuse_rows;
+    const bool normed = small && d->fuse_norm;            // no norm launches in this step: see fuse_norm
+    if (d->fuse_qkv && small) {
+        // layer 0 reads the rows mi355_decoder_begin normed; later layers normalise the residual rows on load
+        const mi355_fused_norm_t fn = {d->ssq, c.hidden / 16, (c.hidden / 16 + 3) & ~3, L.input_norm, c.rms_eps};
+        const bool on_load = normed && l > 0;
+        RUN(MI355_KC_GEMM_QUANT, mi355_qkv_rope_kv_write(on_load ? d->resid : d->xn, B, &L.qkv, L.qkv_bias, on_load ? &fn : nullptr,
+                                                         d->model.cos_sin, c.rope_dim, c.max_pos, d->bufs.positions,
+                                                         d->bufs.block_table, c.max_blocks_per_seq, d->q_len, c.nh, &kv, d->q_buf,
+                                                         d->oob_count, st));
     } else {
         RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->xn, B, &L.qkv, d->partials, kMaxSplits, st));
         RUN(MI355_KC_ROPE_KV, mi355_rope_kv_write_rows(nullptr, d->partials, ns, L.qkv.N_pad, L.qkv_bias, d->model.cos_sin, c.rope_dim,
@@ -300,9 +313,9 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
     RUN(MI355_KC_ATTN, mi355_paged_attn_rows(d->q_buf, &kv, d->bufs.block_table, c.max_blocks_per_seq, d->bufs.positions,
                                              B / d->q_len, d->q_len, c.nh, 1.0f / sqrtf((float)c.hd), c.max_seq_len, d->attn_out,
                                              d->attn_ws, d->attn_ws_bytes, st));
-    if (d->fuse_o && B <= d->fuse_rows) {     // h += fp16(attn W_o) in the GEMM's epilogue, then the plain norm: no slabs
-        RUN(MI355_KC_GEMM_QUANT, mi355_linear_residual(d->attn_out, B, &L.o, nullptr, d->resid, d->resid, st));
-        RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, L.post_norm, c.rms_eps, B, c.hidden, d->xn, st));
+    if (d->fuse_o && small) {     // h += fp16(attn W_o) in the GEMM's epilogue: no slabs; the norm moves into gate_up (or stays a launch)
+        RUN(MI355_KC_GEMM_QUANT, mi355_linear_residual(d->attn_out, B, &L.o, nullptr, d->resid, d->resid, normed ? d->ssq : nullptr, (c.hidden / 16 + 3) & ~3, st));
+        if (!normed) RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, L.post_norm, c.rms_eps, B, c.hidden, d->xn, st));
         return MI355_OK;
     }
     RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->attn_out, B, &L.o, d->partials, kMaxSplits, st));
@@ -328,13 +341,21 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(d->bufs.ar_buf, nullptr, 0, 0, nullptr, d->resid, d->resid, L.post_norm, c.rms_eps,
                                              B, c.hidden, d->xn, st));
     }
-    RUN(MI355_KC_GEMM_QUANT, mi355_linear_direct(d->xn, B, &L.gate_up, nullptr, d->act, MI355_EPI_SILU_MUL, d->partials,
-                                                 d->partials_bytes, st));
+    const bool small = B <= d->fuse_rows;
+    const bool normed = small && d->fuse_norm && d->fuse_o;
+    if (normed) {   // post-attention RMSNorm on load + gate_up + SiLU-gate in one launch
+        const mi355_fused_norm_t fn = {d->ssq, c.hidden / 16, (c.hidden / 16 + 3) & ~3, L.post_norm, c.rms_eps};
+        RUN(MI355_KC_GEMM_QUANT, mi355_norm_linear(d->resid, B, &fn, &L.gate_up, nullptr, d->act, MI355_EPI_SILU_MUL, st));
+    } else {
+        RUN(MI355_KC_GEMM_QUANT, mi355_linear_direct(d->xn, B, &L.gate_up, nullptr, d->act, MI355_EPI_SILU_MUL, d->partials,
+                                                     d->partials_bytes, st));
+    }
     int ns = 0;
     const void* next_norm = (l + 1 < c.num_layers) ? d->layers[l + 1].input_norm : d->model.final_norm;
-    if (d->fuse_down && B <= d->fuse_rows) {
-        RUN(MI355_KC_GEMM_QUANT, mi355_linear_residual(d->act, B, &L.down, nullptr, d->resid, d->resid, st));
-        RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, next_norm, c.rms_eps, B, c.hidden, d->xn, st));
+    if (d->fuse_down && small) {
+        const bool last = l + 1 == c.num_layers;          // the final norm feeds lm_head: that one stays a launch
+        RUN(MI355_KC_GEMM_QUANT, mi355_linear_residual(d->act, B, &L.down, nullptr, d->resid, d->resid, (normed && !last) ? d->ssq : nullptr, (c.hidden / 16 + 3) & ~3, st));
+        if (!normed || last) RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, next_norm, c.rms_eps, B, c.hidden, d->xn, st));
         return MI355_OK;
     }
     RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->act, B, &L.down, d->partials, kMaxSplits, st));

@@ -31,10 +31,10 @@ extern "C" int mi355_gemm_prefill(const void* gp, int wbits, int group_size, mi3
 #ifdef MI355_TUNING   // producer / consumer experiment (gemm_pc.hip), tuning build only: switch 5 = 3 routes M > 32 W4 shapes to it
 extern "C" int mi355_gemm_pc(const void* gp, int wbits, int group_size, int want_partial, int max_splits, mi355_stream_t stream);
 #endif
-extern "C" int mi355_gemm_fullk(const void* gp, int wbits, int group_size, mi355_stream_t stream);
+extern "C" int mi355_gemm_fullk(const void* gp, int wbits, int group_size, const void* norm, mi355_stream_t stream);
 extern "C" int mi355_gemm_fullk_residual(const void* gp, int wbits, int group_size, const void* residual_in, void* residual_out,
-                                         mi355_stream_t stream);
-extern "C" int mi355_gemm_fullk_rope(const void* gp, int wbits, int group_size, const float* cos_sin, int32_t max_pos,
+                                         float* ssq_out, int ssq_ld, mi355_stream_t stream);
+extern "C" int mi355_gemm_fullk_rope(const void* gp, int wbits, int group_size, const void* norm, const float* cos_sin, int32_t max_pos,
                                      const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq,
                                      int32_t q_len, int32_t nh, const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count,
                                      mi355_stream_t stream);
@@ -751,27 +751,48 @@ extern "C" int mi355_fullk_weight_ok(const mi355_weight_t* w) {
 }
 
 extern "C" int mi355_linear_residual(const void* x, int32_t M, const mi355_weight_t* w, const void* bias, const void* residual_in,
-                                     void* residual_out, mi355_stream_t stream) {
+                                     void* residual_out, float* tile_sumsq_out, int32_t tile_sumsq_ld, mi355_stream_t stream) {
     if (int e = check_weight(w)) return e;
     MI355_CHECK_ARG(x && residual_in && residual_out && M > 0, "linear_residual: bad args (M=%d)", M);
+    MI355_CHECK_ARG(!tile_sumsq_out || (tile_sumsq_ld >= w->N / 16 && tile_sumsq_ld % 4 == 0), "linear_residual: tile_sumsq_ld=%d (>= N/16 = %d, multiple of 4)", tile_sumsq_ld, w->N / 16);
     if (M > 64 || !mi355_fullk_weight_ok(w)) return MI355_ERR_UNSUPPORTED;
     GemmParams p; fill_params(p, x, M, w);
     p.mode = MODE_F16; p.bias = (const f16*)bias; p.ldy = w->N;
-    return mi355_gemm_fullk_residual(&p, w->wbits, w->group_size, residual_in, residual_out, stream);
+    return mi355_gemm_fullk_residual(&p, w->wbits, w->group_size, residual_in, residual_out, tile_sumsq_out, tile_sumsq_ld, stream);
+}
+
+static int check_fused_norm(const mi355_fused_norm_t* n, int M, int K, const char* what) {
+    MI355_CHECK_ARG(n->tile_sumsq && n->weight && n->tiles == K / 16 && n->tiles % 4 == 0 && n->ld >= n->tiles && n->ld % 4 == 0 && n->eps > 0.f,
+                    "%s: fused norm needs tile_sumsq [M = %d][ld >= K/16 = %d, multiple of 4], weight and eps (got tiles=%d ld=%d)", what, M, K / 16, n->tiles, n->ld);
+    return MI355_OK;
+}
+
+extern "C" int mi355_norm_linear(const void* h, int32_t M, const mi355_fused_norm_t* norm, const mi355_weight_t* w, const void* bias,
+                                 void* y, int32_t epilogue, mi355_stream_t stream) {
+    if (int e = check_weight(w)) return e;
+    MI355_CHECK_ARG(h && y && norm && M > 0, "norm_linear: bad args (M=%d)", M);
+    if (int e = check_fused_norm(norm, M, w->K, "norm_linear")) return e;
+    if (M > 16 || !mi355_fullk_weight_ok(w)) return MI355_ERR_UNSUPPORTED;
+    GemmParams p; fill_params(p, h, M, w);
+    p.mode = (epilogue & MI355_EPI_OUT_F32) ? MODE_F32 : (epilogue & MI355_EPI_SILU_MUL) ? MODE_SILU : MODE_F16;
+    p.bias = (const f16*)bias; p.y = y; p.ldy = (p.mode == MODE_SILU) ? w->N / 2 : w->N;
+    return mi355_gemm_fullk(&p, w->wbits, w->group_size, norm, stream);
 }
 
 extern "C" int mi355_qkv_rope_kv_write(const void* x, int32_t M, const mi355_weight_t* wqkv, const void* qkv_bias,
-                                       const float* cos_sin, int32_t rope_dim, int32_t max_pos, const int32_t* positions,
-                                       const int32_t* block_table, int32_t max_blocks_per_seq, int32_t q_len, int32_t nh,
-                                       const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count, mi355_stream_t stream) {
+                                       const mi355_fused_norm_t* norm, const float* cos_sin, int32_t rope_dim, int32_t max_pos,
+                                       const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq,
+                                       int32_t q_len, int32_t nh, const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count,
+                                       mi355_stream_t stream) {
     if (int e = check_weight(wqkv)) return e;
     MI355_CHECK_ARG(x && M > 0 && q_len >= 1 && M % q_len == 0, "qkv_rope_kv_write: M=%d q_len=%d", M, q_len);
     MI355_CHECK_ARG(kv && kv->kv_base && cos_sin && positions && block_table && q_out, "qkv_rope_kv_write: null pointer");
     MI355_CHECK_ARG(kv->page > 0 && nh > 0 && kv->nkv > 0 && max_pos > 0 && max_blocks_per_seq > 0 && kv->num_blocks > 0,
                     "qkv_rope_kv_write: bad dims");
-    if (M > 64 || !mi355_fullk_weight_ok(wqkv) || rope_dim != kv->hd) return MI355_ERR_UNSUPPORTED;
+    if (norm) if (int e = check_fused_norm(norm, M, wqkv->K, "qkv_rope_kv_write")) return e;
+    if (M > (norm ? 16 : 64) || !mi355_fullk_weight_ok(wqkv) || rope_dim != kv->hd) return MI355_ERR_UNSUPPORTED;
     GemmParams p; fill_params(p, x, M, wqkv);
     p.mode = MODE_F16; p.bias = (const f16*)qkv_bias; p.ldy = wqkv->N;
-    return mi355_gemm_fullk_rope(&p, wqkv->wbits, wqkv->group_size, cos_sin, max_pos, positions, block_table, max_blocks_per_seq,
+    return mi355_gemm_fullk_rope(&p, wqkv->wbits, wqkv->group_size, norm, cos_sin, max_pos, positions, block_table, max_blocks_per_seq,
                                  q_len, nh, kv, q_out, oob_count, stream);
 }

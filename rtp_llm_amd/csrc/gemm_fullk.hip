@@ -35,14 +35,22 @@ struct FullKParams {
     const f16* res_in;
     f16*       res_out;
     RopeEpi    r;
+    // NORM: x is the un-normed residual row h; the kernel applies RMSNorm on the fly, x_n = gamma * fp16(h * rs), with
+    // rs = rsqrt(sum_k h^2 / K + eps) rebuilt from the per-tile partial sums the producing launch left in ssq_in
+    const float* ssq_in;     // [rows][ssq_ld], ssq_ld >= ssq_tiles: sum over the 16 columns of tile t of h[row]^2
+    int          ssq_tiles, ssq_ld;
+    const f16*   gamma;
+    float        eps;
+    int          dbg;        // tuning build only: 1 = widen without zero / scale (timing experiment, wrong numbers)
+    float*       ssq_out;    // FK_RESID: the same partial sums of the rows this launch produces ([M][ssq_ld]), or null
 };
 enum { FK_PLAIN = 0, FK_RESID = 1, FK_ROPE = 2 };
 
-template <int GS, int MB, int TPB, int EPI>
+template <int GS, int MB, int TPB, int EPI, bool NORM>
 __global__ __launch_bounds__(MB >= 3 ? (TPB >= 2 ? 512 : 768) : 1024) void gemm_fullk_kernel(const FullKParams fp) {
     constexpr int NSUB = 4 / GS, SPG = 4 / NSUB;     // GS: 4 -> g128, 2 -> g64, 1 -> g32
     constexpr int WD = 2;                            // weight ring, chunks
-    constexpr int HD = (MB >= 3 && TPB < 2) ? 2 : 4;  // activation ring, half chunks (2 k-steps x MB row blocks each); by register budget
+    constexpr int HD = ((MB >= 3 && TPB < 2) || (MB == 2 && TPB >= 2) || NORM || TPB >= 4) ? 2 : 4;   // activation ring, half chunks (2 k-steps x MB row blocks each); by register budget
     constexpr uint32_t FLAGS = 0x00020000u, OOBX = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* red = reinterpret_cast<f32x4*>(smem);     // [NW][TPB * MB][64]
@@ -84,7 +92,12 @@ __global__ __launch_bounds__(MB >= 3 ? (TPB >= 2 ? 512 : 768) : 1024) void gemm_
     int nhc = 2 * n_ch;                              // half chunks of this wave; a VGPR so that the range select below is a
     asm volatile("" : "+v"(nhc));                    // v_cndmask, not a branch around the loads (which would drain vmcnt)
 
+    float rs[MB];
+    __amdgpu_buffer_rsrc_t rg = rx;
+    if constexpr (NORM) rg = __builtin_amdgcn_make_buffer_rsrc((void*)fp.gamma, 0, p.K * 2, FLAGS);
     const uint32_t lane16 = lane * 16u, jj4 = jj * 4u;
+    const uint32_t gv = (uint32_t)((c0 * 128 + q * 8) * 2);
+    u32x4    gr[NORM ? HD : 1][2];                   // gamma of the half chunk's two k-steps (k = the fragment's 8 columns)
     u32x4    wr[WD][TPB];
     uint32_t mr[WD][TPB][NSUB];
     u32x4    xr[HD][MB][2];
@@ -107,10 +120,27 @@ __global__ __launch_bounds__(MB >= 3 ? (TPB >= 2 ? 512 : 768) : 1024) void gemm_
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) xr[d][mb][ss] = bload128<0>(rx, hc < nhc ? xv[mb] : OOBX, (uint32_t)hc * 128u + ss * 64u);
+        if constexpr (NORM) {
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) gr[d][ss] = bload128<0>(rg, hc < nhc ? gv : OOBX, (uint32_t)hc * 128u + ss * 64u);
+        }
+    };
+    auto normed = [&](const u32x4& hraw, const u32x4& graw, float r) -> f16x8 {   // gamma * fp16(h * rs): add_rmsnorm_kernel's arithmetic
+        const f16x8 h = __builtin_bit_cast(f16x8, hraw), g = __builtin_bit_cast(f16x8, graw);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = g[e] * (f16)((float)h[e] * r);
+        return o;
     };
     const W4Consts w4c = w4_consts();
     const f16x2 c960 = {(f16)960.f, (f16)960.f};
     auto half_chunk = [&](int d, int xb, int hf) {   // k-steps 2 hf, 2 hf + 1 of ring chunk d against activation buffer xb
+        if constexpr (NORM) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) xr[xb][mb][ss] = __builtin_bit_cast(u32x4, normed(xr[xb][mb][ss], gr[xb][ss], rs[mb]));
+        }
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             const int s = 2 * hf + ss;
@@ -118,7 +148,11 @@ __global__ __launch_bounds__(MB >= 3 ? (TPB >= 2 ? 512 : 768) : 1024) void gemm_
             for (int t = 0; t < TPB; ++t) {
                 const uint32_t m = mr[d][t][s / SPG];
                 const f16x2 zn = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u)), sc = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
+#ifdef MI355_TUNING
+                const f16x8 a = fp.dbg == 1 ? widen_w4(wr[d][t][s], w4c) : dequant_w4_vc(wr[d][t][s], zn, zn + c960, sc, w4c);
+#else
                 const f16x8 a = dequant_w4_vc(wr[d][t][s], zn, zn + c960, sc, w4c);
+#endif
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) acc[t][mb] = mfma16x16x32(a, __builtin_bit_cast(f16x8, xr[xb][mb][ss]), acc[t][mb]);
             }
@@ -165,6 +199,22 @@ __global__ __launch_bounds__(MB >= 3 ? (TPB >= 2 ? 512 : 768) : 1024) void gemm_
     for (int d = 0; d < HD; ++d) load_x(d, d);
 #pragma unroll
     for (int d = 0; d < WD; ++d) load_w(d, d);
+    // NORM: 1 / rms of the rows from the producer's per-tile partial sums -- wave w adds up row w (one 16-byte load per lane,
+    // one round trip under the weight loads just issued), the block meets once, every lane picks up its rows
+    if constexpr (NORM) {
+        float* rs_sh = reinterpret_cast<float*>(smem + (size_t)NW * TPB * MB * 1024);
+        const int nv = fp.ssq_tiles >> 2;
+        for (int r = wave; r < p.M; r += NW) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(fp.ssq_in + (size_t)r * fp.ssq_ld);
+            float a = 0.f;
+            for (int v = lane; v < nv; v += 64) { const f32x4 t = src[v]; a += (t[0] + t[1]) + (t[2] + t[3]); }
+            a = wave_sum(a);
+            if (lane == 0) rs_sh[r] = rsqrtf(a / (float)p.K + fp.eps);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) rs[mb] = (mb * 16 + jj < p.M) ? rs_sh[mb * 16 + jj] : 0.f;
+    }
     // rounds of WD chunks = 2 WD half chunks, no guards inside (slots past the end multiply zero activations)
     for (int i = 0; i < n_ch; i += WD) {
 #pragma unroll
@@ -210,6 +260,13 @@ __global__ __launch_bounds__(MB >= 3 ? (TPB >= 2 ? 512 : 768) : 1024) void gemm_
                 o[r] = (f16)(y + (float)rin[r]);
             }
             *reinterpret_cast<f16x4*>(fp.res_out + (size_t)m * p.N + n0) = o;
+            if (fp.ssq_out) {                         // this tile's share of sum h'^2 of the row, for the consumer's RMSNorm
+                float a = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a += (float)o[r] * (float)o[r];
+                a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+                if (q == 0) fp.ssq_out[(size_t)m * fp.ssq_ld + tile[t]] = a;
+            }
         }
     } else {
         // tile pair of one head: this lane holds dims d0..d0+3 (v[0]) and d0+half..+3 (v[1]) of row m = token m
@@ -268,10 +325,10 @@ __global__ __launch_bounds__(MB >= 3 ? (TPB >= 2 ? 512 : 768) : 1024) void gemm_
     }
 }
 
-template <int GS, int MB, int TPB, int EPI>
+template <int GS, int MB, int TPB, int EPI, bool NORM>
 int launch_fullk_t(const FullKParams& fp, int blocks, int NW, hipStream_t st) {
-    auto k = gemm_fullk_kernel<GS, MB, TPB, EPI>;
-    const size_t lds = (size_t)NW * TPB * MB * 1024;
+    auto k = gemm_fullk_kernel<GS, MB, TPB, EPI, NORM>;
+    const size_t lds = (size_t)NW * TPB * MB * 1024 + (NORM ? 256 : 0);
     if (lds > 64 * 1024)
         if (int e = raise_dynamic_lds((const void*)k, "gemm_fullk")) return e;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * NW), lds, st, fp);
@@ -279,18 +336,23 @@ int launch_fullk_t(const FullKParams& fp, int blocks, int NW, hipStream_t st) {
     return MI355_OK;
 }
 
-template <int TPB, int EPI>
-int launch_fullk(const FullKParams& fp, int group_size, int blocks, hipStream_t st) {
+// waves per block = K slices, bounded by the register budget of the shape and by `wave_cap` (callers that want several
+// blocks per CU: 32 wave slots)
+template <int TPB, int EPI, bool NORM>
+int launch_fullk(const FullKParams& fp, int group_size, int blocks, hipStream_t st, int wave_cap = 16) {
     const GemmParams& g = fp.g;
     const int MB = g.M <= 16 ? 1 : (g.M <= 32 ? 2 : 4);
-    const int maxw = MB >= 3 ? (TPB >= 2 ? 8 : 12) : 16;   // waves per block = K slices, bounded by the register budget of the shape
+    if (NORM && MB > 1) return MI355_ERR_UNSUPPORTED;       // the on-the-fly norm is instantiated for <= 16 rows (latency regime)
+    int maxw = MB >= 3 ? (TPB >= 2 ? 8 : 12) : 16;
+    if (maxw > wave_cap) maxw = wave_cap;
     const int cpw = cdiv(g.KC, maxw), NW = cdiv(g.KC, cpw);
     if (NW < MB) return MI355_ERR_UNSUPPORTED;
-#define FK_(GS_)                                                                 \
-    switch (MB) {                                                                \
-    case 1: return launch_fullk_t<GS_, 1, TPB, EPI>(fp, blocks, NW, st);         \
-    case 2: return launch_fullk_t<GS_, 2, TPB, EPI>(fp, blocks, NW, st);         \
-    default: return launch_fullk_t<GS_, 4, TPB, EPI>(fp, blocks, NW, st);        \
+#define FK_(GS_)                                                                                   \
+    if constexpr (NORM || TPB >= 4) { if (MB > 1) return MI355_ERR_UNSUPPORTED; return launch_fullk_t<GS_, 1, TPB, EPI, NORM>(fp, blocks, NW, st); } \
+    else switch (MB) {                                                                             \
+    case 1: return launch_fullk_t<GS_, 1, TPB, EPI, false>(fp, blocks, NW, st);                    \
+    case 2: return launch_fullk_t<GS_, 2, TPB, EPI, false>(fp, blocks, NW, st);                    \
+    default: return launch_fullk_t<GS_, 4, TPB, EPI, false>(fp, blocks, NW, st);                   \
     }
     if (group_size == 128) { FK_(4) }
     if (group_size == 64) { FK_(2) }
@@ -307,26 +369,40 @@ bool fullk_shape_ok(const GemmParams& g, int wbits, int group_size) {
 
 } // namespace
 
-// y = xW (+ bias) with the epilogue of p.mode (fp16 / fp32 / SiLU-mul), one launch, no workspace.
-extern "C" int mi355_gemm_fullk(const void* gp, int wbits, int group_size, mi355_stream_t stream) {
+static void set_norm(FullKParams& fp, const mi355_fused_norm_t* n) {
+    fp.dbg = TUNE(6);
+    fp.ssq_in = n->tile_sumsq; fp.ssq_tiles = n->tiles; fp.ssq_ld = n->ld; fp.gamma = (const f16*)n->weight; fp.eps = n->eps;
+}
+
+// y = [RMSNorm](x) W (+ bias) with the epilogue of p.mode (fp16 / fp32 / SiLU-mul), one launch, no workspace.
+// norm != null: x is the un-normed row, see FullKParams.  Wide outputs at a few rows (gate_up) take five tiles per block and
+// two blocks per CU so that one wave of blocks covers the matrix.
+extern "C" int mi355_gemm_fullk(const void* gp, int wbits, int group_size, const void* norm, mi355_stream_t stream) {
     FullKParams fp{};
     fp.g = *reinterpret_cast<const GemmParams*>(gp);
     if (!fullk_shape_ok(fp.g, wbits, group_size) || fp.g.mode == MODE_PARTIAL) return MI355_ERR_UNSUPPORTED;
-    return launch_fullk<1, FK_PLAIN>(fp, group_size, fp.g.NT, (hipStream_t)stream);
+    const bool wide = fp.g.NT >= 1024 && fp.g.M <= 16 && group_size == 128;     // 5 tiles per block, 8 waves: two blocks per CU, one wave of blocks for gate_up
+    if (norm) {
+        set_norm(fp, (const mi355_fused_norm_t*)norm);
+        return wide ? launch_fullk<5, FK_PLAIN, true>(fp, group_size, cdiv(fp.g.NT, 5), (hipStream_t)stream, 8)
+                    : launch_fullk<1, FK_PLAIN, true>(fp, group_size, fp.g.NT, (hipStream_t)stream);
+    }
+    return wide ? launch_fullk<5, FK_PLAIN, false>(fp, group_size, cdiv(fp.g.NT, 5), (hipStream_t)stream, 8)
+                : launch_fullk<1, FK_PLAIN, false>(fp, group_size, fp.g.NT, (hipStream_t)stream);
 }
 
-// residual_out = residual_in + fp16(xW + bias)
+// residual_out = residual_in + fp16(xW + bias); ssq_out (optional): per-tile sums of residual_out^2, [M][ssq_ld >= N / 16]
 extern "C" int mi355_gemm_fullk_residual(const void* gp, int wbits, int group_size, const void* residual_in, void* residual_out,
-                                         mi355_stream_t stream) {
+                                         float* ssq_out, int ssq_ld, mi355_stream_t stream) {
     FullKParams fp{};
     fp.g = *reinterpret_cast<const GemmParams*>(gp);
     if (!fullk_shape_ok(fp.g, wbits, group_size) || fp.g.N % 4 != 0) return MI355_ERR_UNSUPPORTED;
-    fp.res_in = (const f16*)residual_in; fp.res_out = (f16*)residual_out;
-    return launch_fullk<1, FK_RESID>(fp, group_size, fp.g.NT, (hipStream_t)stream);
+    fp.res_in = (const f16*)residual_in; fp.res_out = (f16*)residual_out; fp.ssq_out = ssq_out; fp.ssq_ld = ssq_ld;
+    return launch_fullk<1, FK_RESID, false>(fp, group_size, fp.g.NT, (hipStream_t)stream);
 }
 
-// QKV projection + bias + RoPE + Q extract + fp16 paged KV write (rows = tokens)
-extern "C" int mi355_gemm_fullk_rope(const void* gp, int wbits, int group_size, const float* cos_sin, int32_t max_pos,
+// QKV projection (+ on-the-fly RMSNorm of its input) + bias + RoPE + Q extract + fp16 paged KV write (rows = tokens)
+extern "C" int mi355_gemm_fullk_rope(const void* gp, int wbits, int group_size, const void* norm, const float* cos_sin, int32_t max_pos,
                                      const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq,
                                      int32_t q_len, int32_t nh, const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count,
                                      mi355_stream_t stream) {
@@ -340,5 +416,9 @@ extern "C" int mi355_gemm_fullk_rope(const void* gp, int wbits, int group_size, 
     r.cos_sin = cos_sin; r.positions = positions; r.block_table = block_table; r.max_blocks = max_blocks_per_seq;
     r.nh = nh; r.nkv = kv->nkv; r.hd = kv->hd; r.page = kv->page; r.max_pos = max_pos; r.num_blocks = kv->num_blocks;
     r.q_len = q_len; r.oob_count = oob_count; r.kv_base = kv->kv_base; r.q_out = (f16*)q_out;
-    return launch_fullk<2, FK_ROPE>(fp, group_size, nheads * (kv->hd / 32), (hipStream_t)stream);
+    if (norm) {
+        set_norm(fp, (const mi355_fused_norm_t*)norm);
+        return launch_fullk<2, FK_ROPE, true>(fp, group_size, nheads * (kv->hd / 32), (hipStream_t)stream);
+    }
+    return launch_fullk<2, FK_ROPE, false>(fp, group_size, nheads * (kv->hd / 32), (hipStream_t)stream);
 }

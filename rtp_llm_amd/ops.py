@@ -79,36 +79,70 @@ def linear(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None
 ERR_UNSUPPORTED = -3
 
 
+def _fused_norm(norm, M: int, K: int):
+    """(tile_sumsq [rows >= M, ld >= K/16] fp32, weight [K] fp16, eps) -> mi355_fused_norm_t (kept alive by the caller's tuple)."""
+    if norm is None:
+        return None
+    tile_sumsq, weight, eps = norm
+    _chk(tile_sumsq, torch.float32, "fused norm tile_sumsq"); _chk(weight, torch.float16, "fused norm weight")
+    if tile_sumsq.dim() != 2 or tile_sumsq.shape[0] < M or tile_sumsq.shape[1] < K // 16 or weight.numel() != K:
+        raise _C.Mi355Error(f"fused norm: tile_sumsq {tuple(tile_sumsq.shape)} / weight {weight.numel()} against K={K} M={M}")
+    return _C.FusedNorm(tile_sumsq.data_ptr(), K // 16, tile_sumsq.shape[1], weight.data_ptr(), float(eps))
+
+
 def linear_residual(x: torch.Tensor, w: PackedWeight, residual: torch.Tensor, bias: Optional[torch.Tensor] = None,
-                    out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                    out: Optional[torch.Tensor] = None, tile_sumsq: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """residual + fp16(x @ W + bias) in one launch (gemm_fullk.hip); None when the shape is not taken by the fused kernel
-    (the caller composes linear + add).  `out` may alias `residual`."""
+    (the caller composes linear + add).  `out` may alias `residual`.  tile_sumsq ([rows >= M, ld >= N/16] fp32) receives the per-tile
+    sums of squares of the produced rows -- the input of a consumer's fused RMSNorm."""
     _chk(x, torch.float16, "linear_residual.x"); _chk(residual, torch.float16, "linear_residual.residual")
     M = x.numel() // w.K
     if x.shape[-1] != w.K or residual.shape[-1] != w.N or residual.numel() != M * w.N:
         raise _C.Mi355Error(f"linear_residual: x {tuple(x.shape)} / residual {tuple(residual.shape)} against K={w.K} N={w.N}")
+    if tile_sumsq is not None:
+        _chk(tile_sumsq, torch.float32, "linear_residual.tile_sumsq")
+        if tile_sumsq.dim() != 2 or tile_sumsq.shape[0] < M or tile_sumsq.shape[1] < w.N // 16:
+            raise _C.Mi355Error(f"linear_residual: tile_sumsq {tuple(tile_sumsq.shape)} must be [>= {M}, >= N/16 = {w.N // 16}]")
     if out is None:
         out = torch.empty_like(residual)
     ws_struct = weight_struct(w)
-    rc = _C.lib().mi355_linear_residual(x.data_ptr(), M, C.byref(ws_struct), _p(bias), residual.data_ptr(), out.data_ptr(), _stream())
+    rc = _C.lib().mi355_linear_residual(x.data_ptr(), M, C.byref(ws_struct), _p(bias), residual.data_ptr(), out.data_ptr(),
+                                        _p(tile_sumsq), 0 if tile_sumsq is None else tile_sumsq.shape[1], _stream())
     if rc == ERR_UNSUPPORTED:
         return None
     _C.check(rc, "linear_residual")
     return out
 
 
+def norm_linear(h: torch.Tensor, norm, w: PackedWeight, bias: Optional[torch.Tensor] = None, epilogue: int = _C.EPI_NONE):
+    """epilogue(RMSNorm(h) @ W + bias) in one launch; norm = (tile_sumsq, weight, eps) as left by linear_residual.  None when
+    not taken (more than 16 rows, non-W4 weights)."""
+    _chk(h, torch.float16, "norm_linear.h")
+    M = h.numel() // w.K
+    fn = _fused_norm(norm, M, w.K)
+    n_out = w.N // 2 if epilogue & _C.EPI_SILU_MUL else w.N
+    out = torch.empty(*h.shape[:-1], n_out, dtype=torch.float32 if epilogue & _C.EPI_OUT_F32 else torch.float16, device=h.device)
+    ws_struct = weight_struct(w)
+    rc = _C.lib().mi355_norm_linear(h.data_ptr(), M, C.byref(fn), C.byref(ws_struct), _p(bias), out.data_ptr(), epilogue, _stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    _C.check(rc, "norm_linear")
+    return out
+
+
 def qkv_rope_kv_write(x: torch.Tensor, wqkv: PackedWeight, qkv_bias, cos_sin, positions, block_table, kv_base, scale_base,
-                      nh: int, nkv: int, hd: int, page: int, q_len: int = 1, oob_count: Optional[torch.Tensor] = None):
-    """QKV projection + bias + RoPE + Q extract + fp16 paged KV write in one launch; None when not taken (INT8 cache,
-    non-W4 weights): compose linear + rope_kv_write_rows then."""
+                      nh: int, nkv: int, hd: int, page: int, q_len: int = 1, oob_count: Optional[torch.Tensor] = None, norm=None):
+    """[RMSNorm +] QKV projection + bias + RoPE + Q extract + fp16 paged KV write in one launch; None when not taken (INT8
+    cache, non-W4 weights): compose linear + rope_kv_write_rows then.  norm = (tile_sumsq, weight, eps): x is un-normed."""
     _chk(x, torch.float16, "qkv_rope_kv_write.x"); _chk(positions, torch.int32, "positions"); _chk(block_table, torch.int32, "block_table")
     T = x.numel() // wqkv.K
     q_out = torch.empty(T, nh, hd, dtype=torch.float16, device=x.device)
     kv = kv_struct(kv_base, scale_base, page, nkv, hd)
     ws_struct = weight_struct(wqkv)
-    rc = _C.lib().mi355_qkv_rope_kv_write(x.data_ptr(), T, C.byref(ws_struct), _p(qkv_bias), cos_sin.data_ptr(), hd, cos_sin.shape[0],
-                                          positions.data_ptr(), block_table.data_ptr(), block_table.shape[1], q_len, nh, C.byref(kv),
-                                          q_out.data_ptr(), _p(oob_count), _stream())
+    fn = _fused_norm(norm, T, wqkv.K)
+    rc = _C.lib().mi355_qkv_rope_kv_write(x.data_ptr(), T, C.byref(ws_struct), _p(qkv_bias), None if fn is None else C.byref(fn),
+                                          cos_sin.data_ptr(), hd, cos_sin.shape[0], positions.data_ptr(), block_table.data_ptr(),
+                                          block_table.shape[1], q_len, nh, C.byref(kv), q_out.data_ptr(), _p(oob_count), _stream())
     if rc == ERR_UNSUPPORTED:
         return None
     _C.check(rc, "qkv_rope_kv_write")

@@ -125,3 +125,57 @@ def test_qkv_rope_kv_write_stale_rows_and_int8_refusal():
     assert changed == [0]                                     # only row 0's page was written
     kv8, sc8 = kvcache.alloc_layer_cache(nblk, nkv, page, hd, True, DEV)
     assert ops.qkv_rope_kv_write(x, packed, None, cs, pos, bt, kv8, sc8, nh, nkv, hd, page, 1) is None
+
+
+@pytest.mark.parametrize("M", [1, 3, 8, 16])
+def test_fused_norm_chain_vs_oracle(M):
+    """o_proj + residual (leaving per-tile sums of squares) -> RMSNorm on load + gate_up + SiLU-gate, and -> RMSNorm on load +
+    QKV + RoPE + KV write: the launches of a small-batch layer without norm kernels, against oracle.rmsnorm + oracle.linear."""
+    cfg = model.QWEN2_7B
+    H, I, nh, nkv, hd, page = cfg.hidden, 9472, cfg.nh, cfg.nkv, cfg.hd, 16      # 2 I / 16 = 1184 tiles: the 5-tiles-per-block shape, ragged last block
+    wo, Wo = _w4(H, H, 1)
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    cg = model.synth_linear(H, 2 * I, "w4", DEV, gen, zeros="centered")
+    wg = cg.pack(gate_up=True)
+    cgc = model.weights_to({"w": cg}, "cpu")["w"]
+    Wg = oracle.dequant_groupwise(cgc.q, cgc.z_eff, cgc.scales, cgc.group_size)
+    wq, Wq = _w4(H, (nh + 2 * nkv) * hd, 3)
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, H, generator=g) * 0.5).half()
+    res = (torch.randn(M, H, generator=g) * 3.0).half()
+    gamma = (1.0 + 0.2 * torch.randn(H, generator=g)).half()
+    eps = 1e-6
+    # ---- producer
+    ssq = torch.zeros(16, H // 16, dtype=torch.float32, device=DEV)
+    h = ops.linear_residual(x.to(DEV), wo, res.to(DEV), tile_sumsq=ssq)
+    torch.cuda.synchronize()
+    h_ref = (oracle.linear(x, Wo, None).float() + res.float()).half()
+    assert torch.allclose(h.cpu().float(), h_ref.float(), **TOL)
+    assert torch.allclose(ssq[:M].sum(1).cpu(), (h.cpu().float() ** 2).sum(1), rtol=1e-5)      # exact partial sums of what was stored
+    # ---- consumers: normalise the rows the producer stored
+    xn_ref = oracle.rmsnorm(h.cpu(), gamma, eps)
+    norm = (ssq, gamma.to(DEV), eps)
+    act = ops.norm_linear(h, norm, wg, None, _C.EPI_SILU_MUL)
+    assert act is not None
+    act_ref = oracle.silu_mul(oracle.linear(xn_ref, Wg, None))
+    assert torch.allclose(act.cpu().float(), act_ref.float(), **TOL), (act.cpu().float() - act_ref.float()).abs().max()
+    max_blocks, nblk = 8, 128
+    c2 = model.ModelConfig("t", 1, H, nh, nkv, hd, 64, 128, max_pos=max_blocks * page)
+    cs = oracle.rope_cos_sin(hd, c2.rope_theta, c2.max_pos)
+    pos = torch.randint(0, max_blocks * page, (M,), generator=g).to(torch.int32)
+    bt = torch.randperm(nblk, generator=g)[: M * max_blocks].reshape(M, max_blocks).to(torch.int32)
+    bias = (torch.randn((nh + 2 * nkv) * hd, generator=g) * 0.1).half()
+    kv, sc = kvcache.alloc_layer_cache(nblk, nkv, page, hd, False, DEV)
+    q = ops.qkv_rope_kv_write(h, wq, bias.to(DEV), cs.to(DEV), pos.to(DEV), bt.to(DEV), kv, sc, nh, nkv, hd, page, 1, None, norm)
+    assert q is not None
+    torch.cuda.synchronize()
+    qkv = oracle.linear(xn_ref, Wq, bias)
+    q_ref = oracle.apply_rope(qkv[:, : nh * hd].reshape(M, nh, hd), pos, cs)
+    k_ref = oracle.apply_rope(qkv[:, nh * hd: (nh + nkv) * hd].reshape(M, nkv, hd), pos, cs)
+    assert torch.allclose(q.cpu().float(), q_ref.float(), **TOL)
+    for t in range(M):
+        K, V, _, _ = kvcache.read_tokens(kv, sc, bt[t], int(pos[t]) + 1)
+        assert torch.allclose(K[-1].cpu().float(), k_ref[t].float(), **TOL)
+    # more than 16 rows: not taken with a fused norm
+    ssq2 = torch.zeros(32, H // 16, dtype=torch.float32, device=DEV)
+    assert ops.norm_linear(torch.zeros(17, H, dtype=torch.float16, device=DEV), (ssq2, gamma.to(DEV), eps), wg) is None
