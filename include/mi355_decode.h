@@ -185,7 +185,8 @@ typedef struct {
  * Token t is written at position positions[t] of sequence t (decode: one token
  * per sequence) through block_table[t][pos / page].
  * INT8 cache: scale = max|x| / 127 per (token, kv head) fp32, q = rne_sat(x / scale)
- * (rounding of rocm_utils/_cast_to_int8.h:5-24).
+ * (rounding of rocm_utils/_cast_to_int8.h:5-24); the byte stored is q + 128 (offset-binary, private to this writer and
+ * mi355_paged_*attn: the pool owner never interprets cache bytes).
  * Range checks (device side; the reference's kernel has none): a token whose position is outside
  * [0, min(max_pos, max_blocks_per_seq * page)) or whose block id is outside [0, kv->num_blocks) is NOT written to the
  * cache (its q row is still produced, rotated with the clamped position) and *oob_count (dev, may be NULL) is

@@ -52,6 +52,19 @@ constexpr float NEG_BIG = -1e30f;
 // NW waves per block split the partition between them (each wave keeps two 32-token groups of K/V in flight).  NW = 8 for
 // the one-block-per-CU grids (B * nkv * P <= 256) was measured and lost: 34.2 vs 29.8 us at b = 64 / ctx 1024 fp16 KV and
 // 98 vs 89 us at ctx 4096 INT8 KV -- two waves per SIMD cap the kernel at 256 registers and it spills 12-21 of them.
+// 8 cache bytes (code + 128) -> 8 fp16 holding 1152 + k (offset-binary byte under the exponent of 1024: exact).  The bias is NOT
+// subtracted per element: it rides through the MFMA and leaves as one term per output, 1152 * sum_d q (scores) or
+// 1152 * sum_tok p (values) -- 4 VALU per 8 bytes instead of 10, on a path that is VALU-issue bound.
+__device__ __forceinline__ f16x8 widen_kv8(uint32_t lo, uint32_t hi) {
+    const uint32_t C = 0x64646464u;   // the cache holds code + 128 (rope_kv.hip): no sign fix-up here
+    u32x4 r;
+    r[0] = __builtin_amdgcn_perm(C, lo, 0x04010400u);
+    r[1] = __builtin_amdgcn_perm(C, lo, 0x04030402u);
+    r[2] = __builtin_amdgcn_perm(C, hi, 0x04010400u);
+    r[3] = __builtin_amdgcn_perm(C, hi, 0x04030402u);
+    return __builtin_bit_cast(f16x8, r);
+}
+
 template <int HD, bool INT8, int NT, int NW, int NG>
 __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p) {
     constexpr int NTHR = 64 * NW, GS = 32 * NW;    // threads; tokens one round of the block's waves covers
@@ -101,6 +114,24 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
         }
     }
 
+    // INT8: 1152 * sum_d q of the lane's column (fp32; the S tile of a lane is one column), see widen_kv8
+    float kq[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        kq[c] = 0.f;
+        if (INT8) {
+            const f16x2 ones = {(f16)1.f, (f16)1.f};
+            float qs = 0.f;
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                const u32x4 v = __builtin_bit_cast(u32x4, qf[c][s]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qs = __builtin_amdgcn_fdot2(as_h2(v[e]), ones, qs, false);
+            }
+            qs += __shfl_xor(qs, 16); qs += __shfl_xor(qs, 32);
+            kq[c] = 1152.f * qs;
+        }
+    }
     const int32_t* bt = p.block_table + (size_t)b * p.max_blocks;
     const size_t head_elems = (size_t)p.page * HD;
     const char* kvb = (const char*)p.kv_base;
@@ -108,9 +139,10 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
 
     f32x4 o[NT][NDB];
     float m_run[NT], l_run[NT];
+    float l16_run[NT];     // INT8: running sum of the fp16-rounded, V-scaled probabilities the PV MFMA actually consumed
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
-        m_run[c] = NEG_BIG; l_run[c] = 0.f;
+        m_run[c] = NEG_BIG; l_run[c] = 0.f; l16_run[c] = 0.f;
 #pragma unroll
         for (int db = 0; db < NDB; ++db) o[c][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -171,9 +203,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             for (int s = 0; s < NSTEP; ++s) {
                 if (INT8) {
                     const u32x4 kk = g.kf[tau][s >> 1];
-                    const uint32_t lo = kk[(s & 1) * 2] ^ 0x80808080u, hi = kk[(s & 1) * 2 + 1] ^ 0x80808080u;
-                    const f16x2 zneg2 = {(f16)-1152.f, (f16)-1152.f};
-                    ka[tau][s] = dequant_w8<false>(lo, hi, zneg2, zneg2);
+                    ka[tau][s] = widen_kv8(kk[(s & 1) * 2], kk[(s & 1) * 2 + 1]);
                 } else {
                     ka[tau][s] = __builtin_bit_cast(f16x8, g.kf[tau][s]);
                 }
@@ -197,7 +227,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             for (int tau = 0; tau < 2; ++tau)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = sacc[tau][r] * p.scale_log2;
+                    float v = (INT8 ? sacc[tau][r] - kq[c] : sacc[tau][r]) * p.scale_log2;
                     if (INT8) v *= g.ksc[tau][r];
                     const int tok = vwin + tau * 4 + r;
                     if (MASKED) v = tok < limit[c] ? v : NEG_BIG;
@@ -225,6 +255,14 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
                 pf[c][e] = (f16)pe;
             }
             l_run[c] = l_run[c] * alpha[c] + psum;
+            if (INT8) {
+                const f16x2 ones = {(f16)1.f, (f16)1.f};
+                const u32x4 pv = __builtin_bit_cast(u32x4, pf[c]);
+                float s16 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s16 = __builtin_amdgcn_fdot2(as_h2(pv[e]), ones, s16, false);
+                l16_run[c] = l16_run[c] * alpha[c] + s16;
+            }
         }
         if (rescale) {
 #pragma unroll
@@ -237,8 +275,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
         for (int db = 0; db < NDB; ++db) {
             f16x8 a;
             if (INT8) {
-                const f16x2 zneg2 = {(f16)-1152.f, (f16)-1152.f};
-                a = dequant_w8<false>(g.vf8[db][0] ^ 0x80808080u, g.vf8[db][1] ^ 0x80808080u, zneg2, zneg2);
+                a = widen_kv8(g.vf8[db][0], g.vf8[db][1]);
             } else {
                 a = __builtin_bit_cast(f16x8, g.vf16[db]);
             }
@@ -305,7 +342,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
 
     // ---- merge the NW waves through LDS, one column tile at a time.  o[c][db][r] is O^T[d = db*16 + w*4 + r][j].
     __shared__ float s_o[NW][16][HD + 4];
-    __shared__ float s_m[NW][16], s_l[NW][16];
+    __shared__ float s_m[NW][16], s_l[NW][16], s_b[NW][16];   // s_b: INT8 bias term 1152 * sum p16 of the wave's tokens
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
         float lr = l_run[c];
@@ -315,7 +352,9 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
             *reinterpret_cast<f32x4*>(&s_o[wave][j][db * 16 + w * 4]) = o[c][db];
-        if (w == 0) { s_m[wave][j] = m_run[c]; s_l[wave][j] = lr; }
+        float l16 = l16_run[c];
+        if (INT8) { l16 += __shfl_xor(l16, 16); l16 += __shfl_xor(l16, 32); }
+        if (w == 0) { s_m[wave][j] = m_run[c]; s_l[wave][j] = lr; s_b[wave][j] = 1152.f * l16; }
         __syncthreads();
         // thread -> (column jj, 4 channels); 16 columns * HD/4 vectors
         const int ncol = p.R * p.G;
@@ -331,7 +370,9 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
 #pragma unroll
             for (int ww = 0; ww < NW; ++ww) {
                 const float f = __builtin_amdgcn_exp2f(s_m[ww][jj] - mstar);
-                acc += *reinterpret_cast<const f32x4*>(&s_o[ww][jj][d0]) * f;
+                f32x4 ow = *reinterpret_cast<const f32x4*>(&s_o[ww][jj][d0]);
+                if (INT8) ow -= s_b[ww][jj];
+                acc += ow * f;
                 l += s_l[ww][jj] * f;
             }
             const int row = row0 + rl, h = kh * p.G + (jj - (jj / p.G) * p.G);

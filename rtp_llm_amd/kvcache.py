@@ -8,6 +8,10 @@ Inside a block the layout is MI355-native (we own the writer and every reader):
 
     K block: [nkv][page][hd]     V block: [nkv][hd][page]
 
+8-bit caches hold the codes offset-binary (code + 128, i.e. the int8 with its top bit flipped): the attention kernel widens
+bytes by placing them under an fp16 exponent, which wants unsigned bytes.  write_tokens / read_tokens take and return the
+signed codes.
+
 The hot-path writer is the HIP kernel behind ``ops.rope_kv_write``; the functions here
 are the slow-path equivalents used to import a prefilled cache (the prefill path itself
 is out of scope this round) and by the tests to read the cache back.
@@ -22,6 +26,11 @@ def alloc_layer_cache(num_blocks: int, nkv: int, page: int, hd: int, int8: bool,
     kv = torch.zeros(num_blocks, 2, nkv, page, hd, dtype=dt, device=device)
     sc = torch.ones(num_blocks, 2, nkv, page, dtype=torch.float32, device=device) if int8 else None
     return kv, sc
+
+
+def _flip(x: torch.Tensor) -> torch.Tensor:
+    """signed code <-> stored byte (top bit flipped)."""
+    return torch.bitwise_xor(x, torch.tensor(-128, dtype=torch.int8, device=x.device))
 
 
 def _views(kv_base: torch.Tensor):
@@ -43,8 +52,11 @@ def write_tokens(kv_base: torch.Tensor, scale_base: Optional[torch.Tensor], bloc
     blk = block_table_row.to(kv_base.device).long()[pos // page]
     off = pos % page
     kview, vview = _views(kv_base)
-    kview[blk, :, off, :] = K.to(kv_base.device)
-    vview[blk, :, :, off] = V.to(kv_base.device)
+    K, V = K.to(kv_base.device), V.to(kv_base.device)
+    if kv_base.dtype == torch.int8:
+        K, V = _flip(K), _flip(V)
+    kview[blk, :, off, :] = K
+    vview[blk, :, :, off] = V
     if scale_base is not None:
         scale_base[blk, 0, :, off] = k_scale.to(kv_base.device)
         scale_base[blk, 1, :, off] = v_scale.to(kv_base.device)
@@ -60,4 +72,4 @@ def read_tokens(kv_base: torch.Tensor, scale_base: Optional[torch.Tensor], block
     K, V = kview[blk, :, off, :], vview[blk, :, :, off]
     if scale_base is None:
         return K, V, None, None
-    return K, V, scale_base[blk, 0, :, off], scale_base[blk, 1, :, off]
+    return _flip(K), _flip(V), scale_base[blk, 0, :, off], scale_base[blk, 1, :, off]

@@ -127,10 +127,11 @@ def test_kvcache_layout_roundtrip_cpu():
     kvcache.write_tokens(kv, sc, bt, 0, K, V, ks, vs)
     K2, V2, ks2, vs2 = kvcache.read_tokens(kv, sc, bt, 40)
     assert torch.equal(K2, K) and torch.equal(V2, V) and torch.equal(ks2, ks) and torch.equal(vs2, vs)
-    # native intra-block layout: K block [nkv][page][hd], V block [nkv][hd][page]
-    assert kv[5, 0].reshape(2, 16, 64)[1, 3, 10] == K[3, 1, 10]
-    assert kv[5, 1].reshape(2, 64, 16)[1, 10, 3] == V[3, 1, 10]
-    assert kv[2, 1].reshape(2, 64, 16)[0, 7, 4] == V[16 + 4, 0, 7]
+    # native intra-block layout: K block [nkv][page][hd], V block [nkv][hd][page]; 8-bit codes stored with the top bit flipped
+    flip = lambda x: int(x) ^ -128
+    assert kv[5, 0].reshape(2, 16, 64)[1, 3, 10] == flip(K[3, 1, 10])
+    assert kv[5, 1].reshape(2, 64, 16)[1, 10, 3] == flip(V[3, 1, 10])
+    assert kv[2, 1].reshape(2, 64, 16)[0, 7, 4] == flip(V[16 + 4, 0, 7])
 
 
 def test_kv_head_replication_when_tp_exceeds_kv_heads():
