@@ -199,8 +199,8 @@ int mi355_rope_kv_write(const void* qkv_f16, const float* partials, int32_t nspl
                         const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count, mi355_stream_t stream);
 
 /* Fused fast paths of the decode step (gemm_fullk.hip): one launch, no split-K workspace.  All return
- * MI355_ERR_UNSUPPORTED (nothing launched) for shapes / formats they do not take -- W4 group-wise weights with K a
- * multiple of 128 and M <= 64 are taken (with a fused norm: M <= 16); the caller then composes mi355_linear_forward +
+ * MI355_ERR_UNSUPPORTED (nothing launched) for shapes / formats they do not take -- W4 group-wise and fp16 weights with
+ * K a multiple of 128 and M <= 64 are taken (with a fused norm: M <= 16); the caller then composes mi355_linear_forward +
  * the separate op.
  *
  * mi355_fused_norm_t: RMSNorm applied to the GEMM's input on the fly, x_n = weight * fp16(h * rs) (the arithmetic of

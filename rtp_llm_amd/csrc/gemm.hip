@@ -746,8 +746,8 @@ extern "C" int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_
 
 // ------------------------------------------------------------------ full-K kernels with fused consumers (gemm_fullk.hip)
 extern "C" int mi355_fullk_weight_ok(const mi355_weight_t* w) {
-    return w && w->qweight && w->meta && w->wbits == 4 && (w->group_size == 128 || w->group_size == 64 || w->group_size == 32) &&
-           w->K % 128 == 0 && w->K_pad == w->K && w->K_pad / 128 >= 4 && w->N % 16 == 0;
+    const bool fmt = w && w->qweight && ((w->wbits == 4 && w->meta && (w->group_size == 128 || w->group_size == 64 || w->group_size == 32)) || w->wbits == 16);
+    return fmt && w->K % 128 == 0 && w->K_pad == w->K && w->K_pad / 128 >= 4 && w->N % 16 == 0;
 }
 
 extern "C" int mi355_linear_residual(const void* x, int32_t M, const mi355_weight_t* w, const void* bias, const void* residual_in,

@@ -41,16 +41,17 @@ struct FullKParams {
     int          ssq_tiles, ssq_ld;
     const f16*   gamma;
     float        eps;
-    int          dbg;        // tuning build only: 1 = widen without zero / scale (timing experiment, wrong numbers)
     float*       ssq_out;    // FK_RESID: the same partial sums of the rows this launch produces ([M][ssq_ld]), or null
 };
 enum { FK_PLAIN = 0, FK_RESID = 1, FK_ROPE = 2 };
 
 template <int GS, int MB, int TPB, int EPI, bool NORM>
 __global__ __launch_bounds__(MB >= 3 ? (TPB >= 2 ? 512 : 768) : 1024) void gemm_fullk_kernel(const FullKParams fp) {
-    constexpr int NSUB = 4 / GS, SPG = 4 / NSUB;     // GS: 4 -> g128, 2 -> g64, 1 -> g32
-    constexpr int WD = 2;                            // weight ring, chunks
-    constexpr int HD = ((MB >= 3 && TPB < 2) || (MB == 2 && TPB >= 2) || NORM || TPB >= 4) ? 2 : 4;   // activation ring, half chunks (2 k-steps x MB row blocks each); by register budget
+    constexpr bool W16 = GS == 0;                    // GS: 4 -> W4 g128, 2 -> g64, 1 -> g32, 0 -> fp16 weights (no meta, 4 wave-loads per chunk)
+    constexpr int LPC = W16 ? 4 : 1;
+    constexpr int NSUB = W16 ? 1 : 4 / (W16 ? 1 : GS), SPG = 4 / NSUB;
+    constexpr int WD = (GS == 0 && TPB >= 2) ? 1 : 2; // weight ring, chunks (fp16 tiles are 4x the registers)
+    constexpr int HD = ((MB >= 3 && TPB < 2) || (MB == 2 && TPB >= 2) || NORM || TPB >= 4 || WD == 1) ? 2 : 4;   // activation ring, half chunks (2 k-steps x MB row blocks each); by register budget
     constexpr uint32_t FLAGS = 0x00020000u, OOBX = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* red = reinterpret_cast<f32x4*>(smem);     // [NW][TPB * MB][64]
@@ -78,10 +79,10 @@ __global__ __launch_bounds__(MB >= 3 ? (TPB >= 2 ? 512 : 768) : 1024) void gemm_
 #pragma unroll
     for (int t = 0; t < TPB; ++t) {
         const bool ok = tile[t] < p.NT;
-        const char* wb = (const char*)p.qw + ((size_t)tile[t] * p.KC + c0) * 1024;
-        rw[t] = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, ok ? n_ch * 1024 : 0, FLAGS);
+        const char* wb = (const char*)p.qw + ((size_t)tile[t] * p.KC + c0) * (LPC * 1024);
+        rw[t] = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, ok ? n_ch * LPC * 1024 : 0, FLAGS);
         const char* mb = (const char*)p.meta + ((size_t)c0 * NSUB * p.N_pad + tile[t] * 16) * 4;
-        rm[t] = __builtin_amdgcn_make_buffer_rsrc((void*)mb, 0, (ok && n_ch > 0) ? ((n_ch * NSUB - 1) * p.N_pad + 16) * 4 : 0, FLAGS);
+        rm[t] = __builtin_amdgcn_make_buffer_rsrc((void*)(W16 ? (const char*)p.qw : mb), 0, (ok && n_ch > 0 && !W16) ? ((n_ch * NSUB - 1) * p.N_pad + 16) * 4 : 0, FLAGS);
     }
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, FLAGS);
 
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(MB >= 3 ? (TPB >= 2 ? 512 : 768) : 1024) void gemm_
     const uint32_t lane16 = lane * 16u, jj4 = jj * 4u;
     const uint32_t gv = (uint32_t)((c0 * 128 + q * 8) * 2);
     u32x4    gr[NORM ? HD : 1][2];                   // gamma of the half chunk's two k-steps (k = the fragment's 8 columns)
-    u32x4    wr[WD][TPB];
+    u32x4    wr[WD][TPB][LPC];
     uint32_t mr[WD][TPB][NSUB];
     u32x4    xr[HD][MB][2];
     f32x4    acc[TPB][MB];
@@ -109,10 +110,13 @@ __global__ __launch_bounds__(MB >= 3 ? (TPB >= 2 ? 512 : 768) : 1024) void gemm_
     auto load_w = [&](int d, int i) {                // past the wave's range: out of the descriptor, returns 0, no traffic
 #pragma unroll
         for (int t = 0; t < TPB; ++t) {
-            wr[d][t] = bload128<2 /*nt*/>(rw[t], lane16, (uint32_t)i * 1024u);
 #pragma unroll
-            for (int gi = 0; gi < NSUB; ++gi)
-                mr[d][t][gi] = __builtin_amdgcn_raw_buffer_load_b32(rm[t], jj4, (uint32_t)(i * NSUB + gi) * (uint32_t)p.N_pad * 4u, 0);
+            for (int lp = 0; lp < LPC; ++lp) wr[d][t][lp] = bload128<2 /*nt*/>(rw[t], lane16, (uint32_t)(i * LPC + lp) * 1024u);
+            if constexpr (!W16) {
+#pragma unroll
+                for (int gi = 0; gi < NSUB; ++gi)
+                    mr[d][t][gi] = __builtin_amdgcn_raw_buffer_load_b32(rm[t], jj4, (uint32_t)(i * NSUB + gi) * (uint32_t)p.N_pad * 4u, 0);
+            }
         }
     };
     auto load_x = [&](int d, int hc) {               // past the range the next wave's slice would be read: force zeros
@@ -146,13 +150,14 @@ __global__ __launch_bounds__(MB >= 3 ? (TPB >= 2 ? 512 : 768) : 1024) void gemm_
             const int s = 2 * hf + ss;
 #pragma unroll
             for (int t = 0; t < TPB; ++t) {
-                const uint32_t m = mr[d][t][s / SPG];
-                const f16x2 zn = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u)), sc = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
-#ifdef MI355_TUNING
-                const f16x8 a = fp.dbg == 1 ? widen_w4(wr[d][t][s], w4c) : dequant_w4_vc(wr[d][t][s], zn, zn + c960, sc, w4c);
-#else
-                const f16x8 a = dequant_w4_vc(wr[d][t][s], zn, zn + c960, sc, w4c);
-#endif
+                f16x8 a;
+                if constexpr (W16) {
+                    a = __builtin_bit_cast(f16x8, wr[d][t][s]);
+                } else {
+                    const uint32_t m = mr[d][t][s / SPG];
+                    const f16x2 zn = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u)), sc = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
+                    a = dequant_w4_vc(wr[d][t][0][s], zn, zn + c960, sc, w4c);
+                }
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) acc[t][mb] = mfma16x16x32(a, __builtin_bit_cast(f16x8, xr[xb][mb][ss]), acc[t][mb]);
             }
@@ -355,22 +360,25 @@ int launch_fullk(const FullKParams& fp, int group_size, int blocks, hipStream_t 
     default: return launch_fullk_t<GS_, 4, TPB, EPI, false>(fp, blocks, NW, st);                   \
     }
     if (group_size == 128) { FK_(4) }
-    if (group_size == 64) { FK_(2) }
-    if (group_size == 32) { FK_(1) }
+    if constexpr (TPB < 4) {     // the wide few-row shape exists for g128 only
+        if (group_size == 64) { FK_(2) }
+        if (group_size == 32) { FK_(1) }
+        if (group_size == 0) { FK_(0) }
+    }
 #undef FK_
     return MI355_ERR_UNSUPPORTED;
 }
 
-// shapes this kernel takes: W4 group-wise, whole chunks, x image below the OOB offset
-bool fullk_shape_ok(const GemmParams& g, int wbits, int group_size) {
-    return wbits == 4 && (group_size == 128 || group_size == 64 || group_size == 32) && g.M >= 1 && g.M <= 64 && g.K % 128 == 0 &&
+// shapes this kernel takes: W4 group-wise or fp16 weights, whole chunks, x image below the OOB offset
+bool fullk_shape_ok(const GemmParams& g, int wbits, int& group_size) {
+    if (wbits == 16) group_size = 0;                 // fp16 weights: the GS = 0 instances
+    return ((wbits == 4 && (group_size == 128 || group_size == 64 || group_size == 32)) || wbits == 16) && g.M >= 1 && g.M <= 64 && g.K % 128 == 0 &&
            g.K == g.KC * 128 && (uint64_t)g.M * g.K * 2 < 0x7FFFFFF0ull && g.KC >= 4;
 }
 
 } // namespace
 
 static void set_norm(FullKParams& fp, const mi355_fused_norm_t* n) {
-    fp.dbg = TUNE(6);
     fp.ssq_in = n->tile_sumsq; fp.ssq_tiles = n->tiles; fp.ssq_ld = n->ld; fp.gamma = (const f16*)n->weight; fp.eps = n->eps;
 }
 

@@ -25,14 +25,18 @@ def _require_native():
 
 
 def _w4(K, N, seed, group_size=128):
+    """(packed weight, dense fp32 reference); group_size 0 = fp16 weights (the draft models of speculative decoding)."""
     gen = torch.Generator(device=DEV).manual_seed(seed)
+    if group_size == 0:
+        c_dev = model.synth_linear(K, N, "fp16", DEV, gen)
+        return c_dev.pack(), c_dev.w.float().cpu()
     c_dev = model.synth_linear(K, N, "w4", DEV, gen, group_size=group_size, zeros="centered")
     c = model.weights_to({"w": c_dev}, "cpu")["w"]
     return c_dev.pack(), oracle.dequant_groupwise(c.q, c.z_eff, c.scales, c.group_size)
 
 
-@pytest.mark.parametrize("K,N,gs", [(3584, 3584, 128), (18944, 3584, 128), (512, 272, 128), (1024, 256, 64), (512, 128, 32)],
-                         ids=["o", "down", "ragged-n", "g64", "g32"])
+@pytest.mark.parametrize("K,N,gs", [(3584, 3584, 128), (18944, 3584, 128), (512, 272, 128), (1024, 256, 64), (512, 128, 32), (896, 896, 0), (4864, 896, 0)],
+                         ids=["o", "down", "ragged-n", "g64", "g32", "fp16-o-0.5b", "fp16-down-0.5b"])
 def test_linear_residual_vs_oracle(K, N, gs):
     packed, W = _w4(K, N, K + N, gs)
     x = (torch.randn(64, K, generator=torch.Generator().manual_seed(3)) * 0.5).half()
@@ -43,7 +47,7 @@ def test_linear_residual_vs_oracle(K, N, gs):
     xd, rd, bd = x.to(DEV), res.to(DEV), bias.to(DEV)
     for M in MS:
         out = ops.linear_residual(xd[:M].contiguous(), packed, rd[:M].contiguous(), bd)
-        assert out is not None, "W4 group-wise, K % 128 == 0: the fused kernel must take it"
+        assert out is not None, "W4 group-wise / fp16, K % 128 == 0: the fused kernel must take it"
         torch.cuda.synchronize()
         err = (out.cpu().float() - ref[:M].float()).abs().max()
         assert torch.allclose(out.cpu().float(), ref[:M].float(), **TOL), f"M={M}: max err {err}"
@@ -58,20 +62,20 @@ def test_linear_residual_vs_oracle(K, N, gs):
 def test_linear_residual_refuses_other_formats():
     gen = torch.Generator(device=DEV).manual_seed(1)
     x = torch.zeros(4, 512, dtype=torch.float16, device=DEV); r = torch.zeros(4, 256, dtype=torch.float16, device=DEV)
-    for kind in ("int8", "fp16"):
-        p = model.synth_linear(512, 256, kind, DEV, gen).pack()
-        assert ops.linear_residual(x, p, r) is None
+    p = model.synth_linear(512, 256, "int8", DEV, gen).pack()
+    assert ops.linear_residual(x, p, r) is None
     p = model.synth_linear(512, 256, "w4", DEV, gen).pack()
     assert ops.linear_residual(torch.zeros(65, 512, dtype=torch.float16, device=DEV), p, torch.zeros(65, 256, dtype=torch.float16, device=DEV)) is None
     with pytest.raises(_C.Mi355Error):
         ops.linear_residual(x, p, torch.zeros(4, 128, dtype=torch.float16, device=DEV))
 
 
-@pytest.mark.parametrize("nh,nkv,hd,hidden,page,q_len", [(28, 4, 128, 3584, 16, 1), (28, 4, 128, 3584, 16, 4), (4, 2, 64, 512, 8, 1), (8, 1, 128, 1024, 16, 2)],
-                         ids=["qwen2-7b", "qwen2-7b-rows4", "hd64", "mqa-rows2"])
-def test_qkv_rope_kv_write_vs_oracle(nh, nkv, hd, hidden, page, q_len):
+@pytest.mark.parametrize("nh,nkv,hd,hidden,page,q_len,gs", [(28, 4, 128, 3584, 16, 1, 128), (28, 4, 128, 3584, 16, 4, 128), (4, 2, 64, 512, 8, 1, 128),
+                                                            (8, 1, 128, 1024, 16, 2, 128), (14, 2, 64, 896, 16, 1, 0)],
+                         ids=["qwen2-7b", "qwen2-7b-rows4", "hd64", "mqa-rows2", "fp16-qwen2-0.5b"])
+def test_qkv_rope_kv_write_vs_oracle(nh, nkv, hd, hidden, page, q_len, gs):
     N = (nh + 2 * nkv) * hd
-    packed, W = _w4(hidden, N, hidden + N)
+    packed, W = _w4(hidden, N, hidden + N, gs)
     max_blocks, nblk = 8, 512
     cfg = model.ModelConfig("t", 1, hidden, nh, nkv, hd, 64, 128, max_pos=max_blocks * page)
     cs = oracle.rope_cos_sin(hd, cfg.rope_theta, cfg.max_pos)
