@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--workload", default="qwen2-7b-w4a16", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--ctx", type=int, default=None)
+    ap.add_argument("--page", type=int, default=None, help="KV block size in tokens (default: the workload's)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then labelled invalid)")
     ap.add_argument("--shard-of", type=int, default=0, help="debug only: run ONE rank's shard of a tp=N layout without the collectives "
                     "(per-rank kernel shapes on a 1-GPU box; result is labelled invalid)")
@@ -156,6 +157,7 @@ def main():
         _C.lib().mi355_debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
 
     mname, kind, kv_int8, dB, dctx, page = WORKLOADS[args.workload]
+    page = args.page or page
     B, ctx = args.batch or dB, args.ctx or dctx
     cfg_full = model.MODELS[mname]
     if args.layers:
