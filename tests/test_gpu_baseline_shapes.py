@@ -6,6 +6,7 @@
       - W4 g128, B = 64, ctx 1024, fp16 KV        (the configuration BASELINE.json's metric is quoted on)
       - W4 g128, B = 64, ctx 4096, INT8 KV        (configs[2])
       - W8 per-channel, B = 16, ctx 1024, fp16 KV (configs[1])
+      - W4 g128, B = 1 and B = 8, ctx 1024        (the small-batch step: full-K launches, RMSNorm on load, 6 launches per layer)
     logits within 1e-2 (north_star's tolerance), greedy ids identical wherever the oracle's top-2 margin exceeds it.
 
 The oracle computes M = 64 rows once per weight and every smaller M is checked against its leading rows (rows of a GEMM
@@ -103,8 +104,10 @@ def _oracle_weights(w):
                         **{k: _dense(L[k]) for k in ("qkv", "o", "gate_up", "down")}} for L in w["layers"]]}
 
 
-@pytest.mark.parametrize("kind,kv_int8,B,ctx", [("w4", False, 64, 1024), ("w4", True, 64, 4096), ("int8", False, 16, 1024)],
-                         ids=["w4-b64-ctx1024-kvf16", "w4-b64-ctx4096-kvint8", "w8-b16-ctx1024-kvf16"])
+@pytest.mark.parametrize("kind,kv_int8,B,ctx", [("w4", False, 64, 1024), ("w4", True, 64, 4096), ("int8", False, 16, 1024),
+                                                ("w4", False, 1, 1024), ("w4", False, 8, 1024)],
+                         ids=["w4-b64-ctx1024-kvf16", "w4-b64-ctx4096-kvint8", "w8-b16-ctx1024-kvf16",
+                              "w4-b1-fused-small-batch-step", "w4-b8-fused-small-batch-step"])
 def test_engine_full_width_step_vs_oracle(kind, kv_int8, B, ctx):
     cfg = model.ModelConfig("qwen2-7b-2l", 2, 3584, 28, 4, 128, 18944, 152064, max_pos=ctx + 16)
     w_dev = model.synth_model(cfg, kind, DEV, seed=21, zeros="centered")   # see synth_linear: realistic zero points
@@ -143,7 +146,7 @@ def test_engine_full_width_step_vs_oracle(kind, kv_int8, B, ctx):
         ref_next = oracle.greedy(ref_logits)
         top2 = ref_logits.topk(2, dim=-1).values
         safe = (top2[:, 0] - top2[:, 1]) > 1e-2
-        assert int(safe.sum()) >= B // 2
+        assert int(safe.sum()) >= (B + 1) // 2
         assert torch.equal(eng.token_ids[:B].cpu()[safe], ref_next[safe])
         tok = ref_next
         eng.token_ids[:B].copy_(tok)
