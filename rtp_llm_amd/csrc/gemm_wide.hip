@@ -316,8 +316,9 @@ extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int wa
     GemmParams g = *reinterpret_cast<const GemmParams*>(gp);
     constexpr int T = 5, TB = 2 * T, CUS = 256;     // tiles per wave / per block
     if (g.M <= 16 || g.M > 64) return MI355_ERR_UNSUPPORTED;
-    if (!(wbits == 4 && (group_size == 128 || group_size == 64 || group_size == 32))) return MI355_ERR_UNSUPPORTED;
-    if (g.K % 128 != 0 || g.qw_bytes > 0x40000000u || g.meta_bytes > 0x40000000u) return MI355_ERR_UNSUPPORTED;
+    const bool w8 = wbits == 8 && group_size == 0;    // per-channel int8 (W8A16): compiler-scheduled unit, scale applied at the merge
+    if (!w8 && !(wbits == 4 && (group_size == 128 || group_size == 64 || group_size == 32))) return MI355_ERR_UNSUPPORTED;
+    if (g.K % 128 != 0 || g.qw_bytes > 0x40000000u || (!w8 && g.meta_bytes > 0x40000000u)) return MI355_ERR_UNSUPPORTED;
     WideParams wp;
     int G = (g.NT + TB - 1) / TB;                   // fewest groups with <= TB tiles each
     int nsplit = 1;
@@ -340,7 +341,8 @@ extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int wa
     int rc;
     hipStream_t st = (hipStream_t)stream;
     const bool mb2 = g.M <= 32;
-    if (group_size == 64)      rc = mb2 ? launch_wide_t<4, 2, 2, T>(wp, st) : launch_wide_t<4, 4, 2, T>(wp, st);
+    if (w8)                    rc = mb2 ? launch_wide_t<8, 2, 0, T>(wp, st) : launch_wide_t<8, 4, 0, T>(wp, st);
+    else if (group_size == 64) rc = mb2 ? launch_wide_t<4, 2, 2, T>(wp, st) : launch_wide_t<4, 4, 2, T>(wp, st);
     else if (group_size == 32) rc = mb2 ? launch_wide_t<4, 2, 1, T>(wp, st) : launch_wide_t<4, 4, 1, T>(wp, st);
     else if (mb2 && (WIDE_DBG & 7) == 0) rc = launch_wide_t<4, 2, 4, T>(wp, st);
     else
