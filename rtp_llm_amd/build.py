@@ -20,8 +20,8 @@ LIB = os.path.join(LIBDIR, "libmi355_decode.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 SOURCES = ["gemm.hip", "gemm_smallm.hip", "gemm_wide.hip", "gemm_fullk.hip", "gemm_prefill.hip", "attention.hip", "rope_kv.hip", "elementwise.hip", "sampling.hip", "allreduce.hip", "engine.cpp", "error.cpp"]
-TUNING_ONLY = ["gemm_pc.hip"]   # experiments kept for tools/ (producer / consumer waves: measured slower than gemm_wide)
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "internal.h"), os.path.join(INCLUDE, "mi355_decode.h")]
+TUNING_ONLY = ["gemm_pc.hip", "gemm_wide1.hip"]   # experiments kept for tools/ (producer / consumer waves; one wave per SIMD: measured behind gemm_wide)
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "gemm_wide1_phases.inc"), os.path.join(CSRC, "internal.h"), os.path.join(INCLUDE, "mi355_decode.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"

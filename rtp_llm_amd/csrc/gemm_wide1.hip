@@ -1,7 +1,3 @@
-// EXPERIMENT, not built: hipcc (ROCm 7.2) allocates this kernel with 194 VGPRs + 256 AGPRs, 76 spills to scratch and 467
-// v_accvgpr copies -- copies of ring registers whose asm-issued loads are still in flight would be silently wrong, so it was
-// never run.  Kept as the written-down design (operation stream, vmcnt distances) for an all-assembly main loop.
-//
 // Weight-only W4 g128 GEMM for 32 < M <= 64 rows and wide N (gate_up), gfx950: ONE wave per SIMD, everything in registers.
 //
 // Same contract and weight image as gemm_wide.hip.  What bounds that kernel at 64 rows (profiles/r02_pmc_gemm_wide_m64.txt: a
@@ -15,7 +11,10 @@
 //     OTHER of two register sets -- one in VGPRs, one in AGPRs (an MFMA takes its B operand from either file), so there is no
 //     copy, no LDS traffic and NO barrier anywhere in the main loop (a K slice has a single wave);
 //   * every load is issued from inline asm and waited for with a hand-counted vmcnt (hipcc does not count asm loads, and its
-//     own counts for loop-carried rings come out short): operations per phase and the distances are spelled out below;
+//     own counts for loop-carried rings come out short), and every register that a load may have in flight sits in a FIXED
+//     physical register (left to itself hipcc spills 76 registers of this kernel and inserts 467 v_accvgpr copies -- a copy of
+//     a register whose load has not landed is silently wrong): constraint strings must be literals, so the operation stream is
+//     generated (tools/gen_wide1.py -> gemm_wide1_phases.inc); operations per phase and the distances are spelled out below;
 //   * the (4 MFMA + 13 VALU) unit is the fixed hand-ordered stream of gemm_wide.hip (WIDE_UNIT_W4); with one wave per SIMD
 //     it runs at 52 instead of 43 ns (tools/probe/unit_rate.hip) -- the price of the registers.
 #include "gemm_common.h"
@@ -27,26 +26,6 @@ struct Wide1Params {
     GemmParams g;
     int G; // tile groups (grid.x)
 };
-
-// the unit with its B fragments in VGPRs (BC = "v") or AGPRs (BC = "a"); AIN/N0..N3 alternate between the two fixed tuples
-#define W1_UNIT(EVEN, BC)                                                                                                   \
-    do {                                                                                                                    \
-        if constexpr (EVEN) {                                                                                               \
-            asm volatile(WIDE_UNIT_W4("v[100:103]", "v104", "v105", "v106", "v107")                                         \
-                         : [t] "=&v"(tmp), "=&{v[104:107]}"(aO), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1]),                \
-                           [c2] "+a"(acc[t][2]), [c3] "+a"(acc[t][3])                                                       \
-                         : "{v[100:103]}"(aE), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),           \
-                           [e1] "v"(w4c.e1), [zn] "v"(zn), [znb] "v"(znb), [sc] "v"(scl), [b0] BC(bc[0][s]),                \
-                           [b1] BC(bc[1][s]), [b2] BC(bc[2][s]), [b3] BC(bc[3][s]));                                        \
-        } else {                                                                                                            \
-            asm volatile(WIDE_UNIT_W4("v[104:107]", "v100", "v101", "v102", "v103")                                         \
-                         : [t] "=&v"(tmp), "=&{v[100:103]}"(aE), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1]),                \
-                           [c2] "+a"(acc[t][2]), [c3] "+a"(acc[t][3])                                                       \
-                         : "{v[104:107]}"(aO), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),           \
-                           [e1] "v"(w4c.e1), [zn] "v"(zn), [znb] "v"(znb), [sc] "v"(scl), [b0] BC(bc[0][s]),                \
-                           [b1] BC(bc[1][s]), [b2] BC(bc[2][s]), [b3] BC(bc[3][s]));                                        \
-        }                                                                                                                   \
-    } while (0)
 
 template <int T>
 __global__ __launch_bounds__(256) void gemm_wide1_kernel(const Wide1Params wp) {
@@ -108,77 +87,31 @@ __global__ __launch_bounds__(256) void gemm_wide1_kernel(const Wide1Params wp) {
         scl = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
         znb = zn + c960;
     };
-    auto ld_tile = [&](u32x4& w, uint32_t& m, int t, uint32_t ws, uint32_t ms) {
-        const uint32_t so = toff[t] + ws, mv = mvoff + t * 64u;
-        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen nt\n\tbuffer_load_dword %1, %5, %6, %7 offen"
-                     : "=&v"(w), "=&v"(m) : "v"(lane16), "s"(rw), "s"(so), "v"(mv), "s"(rm), "s"(ms) : "memory");
-    };
-    auto ld_xv = [&](u32x4& d, int j, uint32_t xs) {        // fragment j = 4 mb + s of a chunk
-        const uint32_t so = xs + (uint32_t)(j / 4) * xrow + (uint32_t)(j % 4) * 64u;
-        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(d) : "v"(xvoff), "s"(rx), "s"(so) : "memory");
-    };
-    auto ld_xa = [&](u32x4& d, int j, uint32_t xs) {
-        const uint32_t so = xs + (uint32_t)(j / 4) * xrow + (uint32_t)(j % 4) * 64u;
-        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&a"(d) : "v"(xvoff), "s"(rx), "s"(so) : "memory");
-    };
-    // one phase's operation stream without the arithmetic (the two pseudo-phases of the prologue): R = ring slot refilled,
-    // fragments into the VGPR set (XA = false) or the AGPR set
-    auto issue_phase = [&](auto rc, auto xac, uint32_t xs, uint32_t ws, uint32_t ms) {
-        constexpr int R = decltype(rc)::value;
-        constexpr bool XA = decltype(xac)::value;
-        static_for<0, NU>([&](auto uc) {
-            constexpr int u = decltype(uc)::value;
-            if constexpr (u < XF) { if constexpr (XA) ld_xa(ba[u / 4][u % 4], u, xs); else ld_xv(bv[u / 4][u % 4], u, xs); }
-            if constexpr (u % 4 == 3) ld_tile(wr[R][u / 4], mr[R][u / 4], u / 4, ws, ms);
-        });
-    };
-    auto wait_tile = [&](u32x4& w, uint32_t& m, auto nc) {
-        asm volatile("s_waitcnt vmcnt(%c2)" : "+v"(w), "+v"(m) : "i"(decltype(nc)::value) : "memory");
-    };
-
-    // ---- prologue = phases -2 and -1 without arithmetic: (no fragments, tiles of chunk 0) then (fragments of chunk 0, tiles of chunk 1)
-    issue_phase(std::integral_constant<int, 0>{}, std::true_type{}, INVX, w_soff(cw0, ncw > 0), m_soff(cw0, ncw > 0));
-    issue_phase(std::integral_constant<int, 1>{}, std::false_type{}, x_soff(cw0, ncw > 0), w_soff(cw0 + 1, ncw > 1), m_soff(cw0 + 1, ncw > 1));
-    wait_tile(wr[0][0], mr[0][0], std::integral_constant<int, WT0>{});
+    uint32_t wn, tmp;
+    u32x4 aE, aO;
+    // ---- prologue (generated: fixed register map, see tools/gen_wide1.py)
+    {
+        const uint32_t ws_a = w_soff(cw0, ncw > 0), ms_a = m_soff(cw0, ncw > 0);
+        const uint32_t xs_b = x_soff(cw0, ncw > 0), ws_b = w_soff(cw0 + 1, ncw > 1), ms_b = m_soff(cw0 + 1, ncw > 1);
+#define W1_PROLOGUE
+#include "gemm_wide1_phases.inc"
+#undef W1_PROLOGUE
+    }
     meta_of(mr[0][0]);
-    u32x4 aE = __builtin_bit_cast(u32x4, dequant_w4_vc(wr[0][0][0], zn, znb, scl, w4c)), aO = aE;
-
-    // ---- phase k: chunk k from ring slot R = k & 1 and fragment set R; loads fragments of chunk k + 1 and tiles of chunk k + 2
-    auto phase = [&](auto rc, int k) {
-        constexpr int R = decltype(rc)::value;
-        const uint32_t xs = x_soff(cw0 + k + 1, k + 1 < ncw), ws = w_soff(cw0 + k + 2, k + 2 < ncw), ms = m_soff(cw0 + k + 2, k + 2 < ncw);
-        // this chunk's fragments were loaded during the previous phase
-        if constexpr (R == 0) {
-            asm volatile("s_waitcnt vmcnt(%c8)"
-                         : "+v"(bv[0][0]), "+v"(bv[0][1]), "+v"(bv[0][2]), "+v"(bv[0][3]), "+v"(bv[1][0]), "+v"(bv[1][1]), "+v"(bv[1][2]), "+v"(bv[1][3])
-                         : "i"(WX) : "memory");
-            asm volatile("" : "+v"(bv[2][0]), "+v"(bv[2][1]), "+v"(bv[2][2]), "+v"(bv[2][3]), "+v"(bv[3][0]), "+v"(bv[3][1]), "+v"(bv[3][2]), "+v"(bv[3][3]) :: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(%c8)"
-                         : "+a"(ba[0][0]), "+a"(ba[0][1]), "+a"(ba[0][2]), "+a"(ba[0][3]), "+a"(ba[1][0]), "+a"(ba[1][1]), "+a"(ba[1][2]), "+a"(ba[1][3])
-                         : "i"(WX) : "memory");
-            asm volatile("" : "+a"(ba[2][0]), "+a"(ba[2][1]), "+a"(ba[2][2]), "+a"(ba[2][3]), "+a"(ba[3][0]), "+a"(ba[3][1]), "+a"(ba[3][2]), "+a"(ba[3][3]) :: "memory");
-        }
-        static_for<0, NU>([&](auto uc) {
-            constexpr int u = decltype(uc)::value;
-            constexpr int t = u / 4, s = u % 4;
-            if constexpr (u < XF) { if constexpr (R == 0) ld_xa(ba[u / 4][u % 4], u, xs); else ld_xv(bv[u / 4][u % 4], u, xs); }
-            if constexpr (s == 3) ld_tile(wr[R][t], mr[R][t], t, ws, ms);
-            constexpr int un = (u + 1) % NU, tn = un / 4, sn = un % 4, rn = (u + 1 == NU) ? (R ^ 1) : R;
-            if constexpr (sn == 0) {
-                wait_tile(wr[rn][tn], mr[rn][tn], std::integral_constant<int, (u + 1 == NU) ? WT0 : WT(tn)>{});
-                meta_of(mr[rn][tn]);
-            }
-            const uint32_t wn = wr[rn][tn][sn];
-            uint32_t tmp;
-            if constexpr (R == 0) { auto& bc = bv; W1_UNIT(u % 2 == 0, "v"); }
-            else                  { auto& bc = ba; W1_UNIT(u % 2 == 0, "a"); }
-            __builtin_amdgcn_sched_barrier(0);   // fence per unit: the order written IS the schedule
-        });
-    };
+    aE = __builtin_bit_cast(u32x4, dequant_w4_vc(wr[0][0][0], zn, znb, scl, w4c)); aO = aE;
     for (int k = 0; k < per; k += 2) {
-        phase(std::integral_constant<int, 0>{}, k);
-        if (k + 1 < per) phase(std::integral_constant<int, 1>{}, k + 1);
+        {
+            const uint32_t xs = x_soff(cw0 + k + 1, k + 1 < ncw), ws = w_soff(cw0 + k + 2, k + 2 < ncw), ms = m_soff(cw0 + k + 2, k + 2 < ncw);
+#define W1_PHASE0
+#include "gemm_wide1_phases.inc"
+#undef W1_PHASE0
+        }
+        if (k + 1 < per) {
+            const uint32_t xs = x_soff(cw0 + k + 2, k + 2 < ncw), ws = w_soff(cw0 + k + 3, k + 3 < ncw), ms = m_soff(cw0 + k + 3, k + 3 < ncw);
+#define W1_PHASE1
+#include "gemm_wide1_phases.inc"
+#undef W1_PHASE1
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15" ::: "memory");   // stragglers past the end; the last MFMAs' results are read by compiler code below
 
