@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 trace() { # tag, bench args...
   tag=$1; shift
-  rocprofv3 --kernel-trace --stats -d $O/trace_$tag -o run -- python $R/bench.py "$@" > $O/bench_under_rocprof_$tag.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_$tag -o run -- python $R/bench.py "$@" > $O/bench_under_rocprof_$tag.log 2>&1
   tail -1 $O/bench_under_rocprof_$tag.log > $O/bench_under_rocprof_$tag.json
   python $R/tools/rocpd_summary.py $(ls $O/trace_$tag/*.db $O/trace_$tag/*/*.db 2>/dev/null | head -1) --by-grid > $O/kernel_stats_$tag.txt
   rm -rf $O/trace_$tag
@@ -15,7 +15,7 @@ trace b64 --steps 8 --warmup 2 --no-cpu-baseline --no-sweep
 trace b1 --steps 8 --warmup 2 --no-cpu-baseline --no-sweep --batch 1
 pmc() { # tag, counters, cmd...
   tag=$1; ctr=$2; shift; shift
-  ( cd $R && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_$tag -o run -- "$@" > $O/pmc_$tag.log 2>&1 )
+  ( cd $R && timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_$tag -o run -- "$@" > $O/pmc_$tag.log 2>&1 )
   python $R/tools/pmc_sum.py $O/pmc_$tag gemm > $O/pmc_$tag.txt
   rm -rf $O/pmc_$tag
 }

@@ -6,7 +6,7 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND:-r02}; mkdir -p $O
 export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  ( cd $R && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_engine_$ctr -o run -- \
+  ( cd $R && timeout 240 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_engine_$ctr -o run -- \
       python bench.py --no-graph --steps 3 --warmup 1 --no-cpu-baseline --no-sweep > $O/pmc_engine_$ctr.log 2>&1 )
 done
 python $R/tools/engine_traffic.py $O/pmc_engine_FETCH_SIZE $O/pmc_engine_WRITE_SIZE > $O/pmc_engine_traffic.txt

@@ -6,7 +6,7 @@ for cfg in "fp16 --ctx 1024" "int8 --ctx 4096 --int8"; do
   i=0
   for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS"; do
     i=$((i+1))
-    ( cd $R && rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/${tag}_$i -o run -- python tools/attn_bench.py $args --iters 6 > $O/${tag}_$i.log 2>&1 )
+    ( cd $R && timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/${tag}_$i -o run -- python tools/attn_bench.py $args --iters 6 > $O/${tag}_$i.log 2>&1 )
     python - "$O/${tag}_$i" "$tag" <<'PY'
 import csv, glob, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Kernel-trace durations of a gemm_bench run (host-loop timing floors at ~33 us per ctypes call).  usage: ktime.sh tag <gemm_bench args>
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ktime/$1; shift; mkdir -p $O; export TMPDIR=/tmp
-( cd $R && MI355_TUNING_LIB=1 rocprofv3 --kernel-trace --output-format csv -d $O -o run -- python tools/gemm_bench.py "$@" > $O/log.txt 2>&1 )
+( cd $R && MI355_TUNING_LIB=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O -o run -- python tools/gemm_bench.py "$@" > $O/log.txt 2>&1 )
 python - "$O" <<'PY'
 import csv, glob, sys, collections
 d = collections.defaultdict(list)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Kernel-trace durations of any command, grouped by (kernel, grid).  usage: ktrace.sh tag <command...>
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ktrace/$1; shift; mkdir -p $O; export TMPDIR=/tmp
-( cd $R && rocprofv3 --kernel-trace --output-format csv -d $O -o run -- "$@" > $O/log.txt 2>&1 )
+( cd $R && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O -o run -- "$@" > $O/log.txt 2>&1 )
 python - "$O" <<'PY'
 import csv, glob, sys, collections
 d = collections.OrderedDict()

@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND:-r02}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 tag=$1; shift
-rocprofv3 --kernel-trace --stats -d $O/trace_$tag -o run -- python $R/bench.py "$@" > $O/bench_under_rocprof_$tag.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_$tag -o run -- python $R/bench.py "$@" > $O/bench_under_rocprof_$tag.log 2>&1
 grep "^{\"metric\"" $O/bench_under_rocprof_$tag.log | tail -1 > $O/bench_under_rocprof_$tag.json
 python $R/tools/rocpd_summary.py $(ls $O/trace_$tag/*.db $O/trace_$tag/*/*.db 2>/dev/null | head -1) --by-grid > $O/kernel_stats_$tag.txt
 rm -rf $O/trace_$tag
