@@ -1,4 +1,4 @@
-// Weight-only W4 GEMM with the WHOLE reduction inside one block ("full K"), gfx950: no split-K slabs, no reduce launch,
+// Weight-only W4 (and fp16-weight) GEMM with the WHOLE reduction inside one block ("full K"), gfx950: no split-K slabs, no reduce launch,
 // the consumer's elementwise work fused into the epilogue.
 //
 // The decode step is a chain of short dependent launches; each one pays a launch + ramp + drain of ~5 us around

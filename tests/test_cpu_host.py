@@ -180,3 +180,30 @@ def test_native_registration_shim_exports_the_reference_hook():
     assert callable(ops.Mi355AttnParams.update_kv_cache_offset) and callable(ops.Mi355AttnParams.prepare_in_place)
     with pytest.raises(RuntimeError):                     # TORCH_CHECK -> RuntimeError, and no CPU path
         ops.rmsnorm(torch.zeros(2, 8).half(), torch.zeros(2, 8).half(), torch.ones(8).half(), 1e-6)
+
+
+def test_fused_ops_refuse_cpu_tensors_and_bad_shapes():
+    """The fused small-batch entry points are product path: no CPU fallback -- a CPU tensor is an error, not a slow path."""
+    import pytest
+    from rtp_llm_amd import _C, ops
+    x = torch.zeros(2, 512, dtype=torch.float16)
+    class _W:   # never reaches the library: the tensor checks come first
+        K, N = 512, 256
+    with pytest.raises(_C.Mi355Error):
+        ops.linear_residual(x, _W(), torch.zeros(2, 256, dtype=torch.float16))
+    with pytest.raises(_C.Mi355Error):
+        ops.norm_linear(x, (torch.zeros(2, 32), torch.ones(512, dtype=torch.float16), 1e-6), _W())
+    with pytest.raises(_C.Mi355Error):
+        ops.qkv_rope_kv_write(x, _W(), None, torch.zeros(8, 32, 2), torch.zeros(2, dtype=torch.int32), torch.zeros(2, 4, dtype=torch.int32),
+                              torch.zeros(1), None, 2, 1, 64, 16)
+
+
+def test_generated_wide1_phases_are_current():
+    """gemm_wide1_phases.inc is generated (fixed register map, tools/gen_wide1.py): the checked-in file must be what the generator
+    writes, or the ISA audit (tools/audit_wide1.py) no longer describes the kernel that is built."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "rtp_llm_amd", "csrc", "gemm_wide1_phases.inc")
+    before = open(inc).read()
+    subprocess.run([sys.executable, os.path.join(root, "tools", "gen_wide1.py")], check=True, capture_output=True)
+    assert open(inc).read() == before
