@@ -294,6 +294,26 @@ int mi355_softmax_rows(const float* logits, int32_t rows, int32_t V, int32_t ld,
  * gives the target model's own sampled token per verify row (target_token_ids of mi355_rejection_sample). */
 int mi355_sample_rows(const float* probs, int32_t rows, int32_t V, int32_t ld, const float* uniform_samples, int32_t* ids,
                       mi355_stream_t stream);
+/* The non-greedy branch of the sampler (sampleGreedy, bindings/core/CudaSampleOp.cc:619-800), on fp32 logit rows.
+ * mi355_apply_penalties: in place, one launch (+ one memset node):
+ *   temperature [B] or NULL: logit *= 1 / (T + 1e-6)          (batchApplyTemperaturePenalty, sampling_penalty_kernels.cu:26-54;
+ *                the caller passes NULL when every T == 1, as CudaSampleOp.cc:633-645 skips the launch)
+ *   repetition / presence / frequency [B] or NULL, output_ids [step][batch_size] int32 (the transposed token history),
+ *   input_lengths [B] or NULL, max_input_length, step: argument for argument invokeBatchApplyRepetitionPenalty
+ *   (sampling_penalty_kernels.cu:129-213): every id seen in the history (padding [input_length, max_input_length) skipped)
+ *   is penalised once: logit = logit < 0 ? logit * rep : logit / rep; logit -= presence; logit -= frequency * count.
+ *   penalty_ws: [B][V] int32 scratch (zeroed here).
+ * mi355_top_k_top_p_sample (CudaSampleOp.cc:748-786): per row of probabilities, drop what is below the top_k-th largest value
+ *   (top_k <= 0 or >= V: keep all; ties with the k-th value stay), drop an entry when the mass before it in descending order
+ *   (equal values in index order) exceeds top_p (|top_p| < 1e-7 reads as 1), renormalise by max(sum, 1e-10) into probs_out (optional, may alias probs) and draw
+ *   ids[r] by inverse CDF in index order with uniform_samples[r] (the reference calls torch.multinomial: same distribution).
+ *   top_k / top_p may be NULL (no filter of that kind). */
+int mi355_apply_penalties(float* logits, int32_t batch_size, int32_t V, int32_t ld, const float* temperature,
+                          const float* repetition_penalty, const float* presence_penalty, const float* frequency_penalty,
+                          const int32_t* output_ids, const int32_t* input_lengths, int32_t max_input_length, int32_t step,
+                          int32_t* penalty_ws, mi355_stream_t stream);
+int mi355_top_k_top_p_sample(const float* probs, int32_t rows, int32_t V, int32_t ld, const int32_t* top_k, const float* top_p,
+                             const float* uniform_samples, int32_t* ids, float* probs_out, int32_t ld_out, mi355_stream_t stream);
 int mi355_rejection_sample(const float* draft_probs, const int32_t* draft_token_ids, const float* uniform_samples,
                            const float* target_probs, const int32_t* target_token_ids, int32_t target_token_stride,
                            int32_t* output_token_ids, int32_t* output_accepted_token_num, const uint8_t* do_sample,

@@ -283,3 +283,67 @@ def sample_rows(probs, uniform):
 def softmax_rows(logits: torch.Tensor, temperature: float = 1.0) -> torch.Tensor:
     """softmax(logits / T) per row in fp32 (the distribution handed to rejection sampling)."""
     return torch.softmax(logits.float() / temperature, dim=-1)
+
+
+def apply_penalties(logits, temperature=None, repetition_penalty=None, presence_penalty=None, frequency_penalty=None,
+                    output_ids=None, input_lengths=None, max_input_length=0, step=0):
+    """fp32, returns a new tensor.  Temperature as batchApplyTemperaturePenalty
+    (bindings/common/kernels/sampling_penalty_kernels.cu:26-54): logit * (1 / (T + 1e-6)); then batchApplyPenaltyLongSeq
+    (:129-180): ids counted over output_ids[0:step, row] (positions [input_length, max_input_length) skipped, ids outside the
+    vocabulary skipped), each seen id penalised once with its count."""
+    import numpy as np
+    x = (logits.detach().cpu().numpy() if isinstance(logits, torch.Tensor) else np.asarray(logits)).astype(np.float32, copy=True)
+    B, V = x.shape
+    if temperature is not None:
+        t = np.asarray(temperature, dtype=np.float32)
+        inv = (np.float32(1.0) / (t + np.float32(1e-6))).astype(np.float32)
+        x = (x * inv[:, None]).astype(np.float32)
+    if repetition_penalty is not None or presence_penalty is not None or frequency_penalty is not None:
+        ids = np.asarray(output_ids)
+        for b in range(B):
+            n_in = int(input_lengths[b]) if input_lengths is not None else max_input_length
+            count = np.zeros(V, dtype=np.int64)
+            for index in range(step):
+                if n_in <= index < max_input_length:
+                    continue
+                tok = int(ids[index, b])
+                if 0 <= tok < V:
+                    count[tok] += 1
+            seen = count > 0
+            row = x[b]
+            if repetition_penalty is not None:
+                r = np.float32(repetition_penalty[b])
+                row[seen] = np.where(row[seen] < 0, row[seen] * r, row[seen] / r).astype(np.float32)
+            if presence_penalty is not None:
+                row[seen] = (row[seen] - np.float32(presence_penalty[b])).astype(np.float32)
+            if frequency_penalty is not None:
+                row[seen] = (row[seen] - (np.float32(frequency_penalty[b]) * count[seen].astype(np.float32)).astype(np.float32)).astype(np.float32)
+    return torch.from_numpy(x)
+
+
+def top_k_top_p_filter(probs, top_k, top_p):
+    """The filter of the sampler's ROCm branch, statement for statement in torch (bindings/core/CudaSampleOp.cc:748-781):
+    per row topk(k) -> entries below the k-th value zeroed; sort descending, cumsum, entries whose preceding mass exceeds p
+    zeroed, scattered back; renormalised by clamp_min(sum, 1e-10).  Equal values are taken in index order (stable sort): the order
+    the reference's known answers imply (CudaSamplerTest.cc:659-719 accepts token 1 of the tied {1, 2, 6}, not 2 or 6)."""
+    out = probs.clone().float()
+    B, V = out.shape
+    for b in range(B):
+        k = int(top_k[b]) if top_k is not None else 0
+        k = V if k <= 0 else k
+        if k < V:
+            row = out[b]
+            vals, _ = row.topk(k)
+            row.masked_fill_(row < vals[-1], 0.0)
+    for b in range(B):
+        p = float(top_p[b]) if top_p is not None else 1.0
+        if abs(p) < 1e-7:
+            p = 1.0
+        if abs(p - 1.0) >= 1e-7:
+            row = out[b]
+            sp, si = row.sort(dim=0, descending=True, stable=True)
+            cs = sp.cumsum(0)
+            sp = sp.masked_fill(cs - sp > p, 0.0)
+            row.scatter_(0, si, sp)
+    sums = out.sum(-1, keepdim=True)
+    return out / sums.clamp_min(1e-10)

@@ -1,4 +1,6 @@
-// Speculative-decoding verify step: row softmax and chain rejection sampling, gfx950.
+// Sampler kernels on fp32 logit rows, gfx950: the speculative-decoding verify step (row softmax, chain rejection sampling) and
+// the non-greedy branch of the sampler (temperature + repetition / presence / frequency penalties, top-k / top-p filter,
+// inverse-CDF draw: bindings/core/CudaSampleOp.cc:632-786, common/kernels/sampling_penalty_kernels.cu:26-180).
 //
 // Replaces rejection_sampling_kernel / invokeRejectionSampling
 // (rtp_llm/models_py/bindings/rocm/speculative_sampling/sampling.cu:306-530, called from
@@ -33,9 +35,9 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
 // Inverse-CDF draw from the unnormalised non-negative weights f(0..V-1): the first index j with f(j) > 0 whose inclusive
 // prefix sum, taken in index order, exceeds u01 * sum (V - 1 when rounding leaves none: sampling.cu:418).  Thread tx owns
 // the contiguous segment [lo, hi), so the block-level prefix over threads is the prefix over indices.  Result in *s_found
-// (valid for every thread after the call).
+// (valid for every thread after the call); returns sum.
 template <class F>
-__device__ __forceinline__ void block_draw(F&& f, int V, float u01, float* s_red, float* s_scan, int* s_found) {
+__device__ __forceinline__ float block_draw(F&& f, int V, float u01, float* s_red, float* s_scan, int* s_found) {
     const int tx = threadIdx.x;
     const int seg = (V + kThreads - 1) / kThreads;
     const int lo = min(V, tx * seg), hi = min(V, lo + seg);
@@ -65,6 +67,7 @@ __device__ __forceinline__ void block_draw(F&& f, int V, float u01, float* s_red
         *s_found = found;
     }
     __syncthreads();
+    return total;
 }
 
 struct RejectParams {
@@ -169,6 +172,172 @@ __global__ __launch_bounds__(kThreads) void sample_rows_kernel(const float* __re
     if (threadIdx.x == 0) ids[blockIdx.x] = s_found;
 }
 
+
+// (a, b) summed over the block in a fixed order (wave butterfly, then 16 partials added by every thread): deterministic.
+__device__ __forceinline__ void block_sum2(float& a, float& b, float (*s_pair)[2]) {
+    a = wave_sum(a); b = wave_sum(b);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_pair[wave][0] = a; s_pair[wave][1] = b; }
+    __syncthreads();
+    float ta = 0.f, tb = 0.f;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) { ta += s_pair[w][0]; tb += s_pair[w][1]; }
+    __syncthreads();
+    a = ta; b = tb;
+}
+
+// Temperature, then repetition / presence / frequency penalties, in place on fp32 logits: one block per row.
+//   batchApplyTemperaturePenalty (sampling_penalty_kernels.cu:26-54): logit *= 1 / (T[row] + 1e-6)
+//   batchApplyPenaltyLongSeq (:129-180): every vocabulary id seen among output_ids[0 .. step)[row] (padding positions
+//   [input_length, max_input_length) skipped, ids outside [0, V) skipped) is penalised ONCE:
+//   logit = logit < 0 ? logit * rep : logit / rep;  logit -= presence;  logit -= frequency * count.
+struct PenaltyParams {
+    float*         logits;
+    int            V, ld;
+    const float   *temperature, *repetition, *presence, *frequency;
+    const int32_t* output_ids;     // [step][batch]
+    const int32_t* input_lengths;  // [batch] or null
+    int            batch, max_input_length, step;
+    int32_t*       counts;         // [batch][V], zero on entry
+};
+
+__global__ __launch_bounds__(kThreads) void penalties_kernel(const PenaltyParams p) {
+    const int row = blockIdx.x, tx = threadIdx.x;
+    float* x = p.logits + (size_t)row * p.ld;
+    const bool pen = p.output_ids != nullptr;
+    int32_t* cnt = pen ? p.counts + (size_t)row * p.V : nullptr;
+    if (pen) {
+        const int input_length = p.input_lengths ? p.input_lengths[row] : p.max_input_length;
+        for (int index = tx; index < p.step; index += kThreads) {
+            if (index >= input_length && index < p.max_input_length) continue;
+            const int tok = p.output_ids[(size_t)index * p.batch + row];
+            if (tok >= p.V || tok < 0) continue;
+            atomicAdd(&cnt[tok], 1);
+        }
+        __syncthreads();
+    }
+    const float inv_t = p.temperature ? 1.0f / (p.temperature[row] + 1e-6f) : 1.0f;
+    const float rep = p.repetition ? p.repetition[row] : 1.0f, pres = p.presence ? p.presence[row] : 0.0f,
+                freq = p.frequency ? p.frequency[row] : 0.0f;
+    for (int j = tx; j < p.V; j += kThreads) {
+        // the counts were written by atomics of other lanes of this block: read them past the CU's vector cache
+        const int c = pen ? __hip_atomic_load(&cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        if (!p.temperature && c == 0) continue;
+        float logit = x[j];
+        if (p.temperature) logit *= inv_t;
+        if (c > 0) {
+            if (p.repetition) logit = logit < 0.0f ? logit * rep : logit / rep;
+            if (p.presence) logit -= pres;
+            if (p.frequency) logit -= freq * (float)c;
+        }
+        x[j] = logit;
+    }
+}
+
+// Top-k / top-p filter and draw on probability rows (CudaSampleOp.cc:748-786), one block per row:
+//   k = top_k[row] (<= 0 or >= V: no filter): entries below the k-th largest value are dropped (ties with it stay, :755-760);
+//   p = top_p[row] (|p| < 1e-7 reads as 1; |p - 1| < 1e-7: no filter): in descending order (equal values in index order) an
+//       entry is dropped when the mass before it exceeds p (:768-775).  Only the smallest surviving value v can lose part of
+//       its equals: with S = mass of all strictly larger entries, its j-th occurrence stays while S + j v <= p;
+//   the survivors are renormalised by max(sum, 1e-10) (probs_out, optional) and one index is drawn by inverse CDF in index order
+//   with uniform[row] (torch.multinomial in the reference: same distribution, explicit randomness).
+// No sort: both thresholds are built bit by bit from the top of the fp32 pattern (non-negative floats order like their bits), one
+// pass over the row and one fixed-order block reduction per bit.
+struct TopKPParams {
+    const float*   probs;
+    int            V, ld;
+    const int32_t* top_k;
+    const float*   top_p;
+    const float*   uniform;
+    int32_t*       ids;
+    float*         probs_out;
+    int            ld_out;
+};
+
+__global__ __launch_bounds__(kThreads) void top_k_top_p_sample_kernel(const TopKPParams p) {
+    __shared__ float s_red[kThreads / 64];
+    __shared__ float s_pair[kThreads / 64][2];
+    __shared__ float s_scan[kThreads];
+    __shared__ int   s_found;
+    const int row = blockIdx.x, tx = threadIdx.x, V = p.V;
+    const float* q = p.probs + (size_t)row * p.ld;
+    auto pos = [](float v) { return v > 0.f ? v : 0.f; };   // +0 for -0, negatives and NaN: the bit pattern is the order
+    int k = p.top_k ? p.top_k[row] : 0;
+    const bool use_k = k > 0 && k < V;
+    float tp = p.top_p ? p.top_p[row] : 1.0f;
+    if (fabsf(tp) < 1e-7f) tp = 1.0f;
+    bool use_p = fabsf(tp - 1.0f) >= 1e-7f;
+    uint32_t tk = 0, tq = 0;   // tk: largest t with #(bits >= t) >= k;  tq: largest t with mass(bits > t) > p
+    if (use_p) {               // nothing to drop when even the mass above 0 fits
+        float m = 0.f, z = 0.f;
+        for (int j = tx; j < V; j += kThreads) m += pos(q[j]);
+        block_sum2(m, z, s_pair);
+        use_p = m > tp;
+    }
+    if (use_k || use_p) {
+        for (int bit = 30; bit >= 0; --bit) {
+            const uint32_t ck = tk | (1u << bit), cq = tq | (1u << bit);
+            float cnt = 0.f, mass = 0.f;
+            for (int j = tx; j < V; j += kThreads) {
+                const float v = pos(q[j]);
+                const uint32_t b = __float_as_uint(v);
+                cnt += (b >= ck) ? 1.f : 0.f;
+                mass += (b > cq) ? v : 0.f;
+            }
+            block_sum2(cnt, mass, s_pair);
+            if (use_k && cnt >= (float)k) tk = ck;
+            if (use_p && mass > tp) tq = cq;
+        }
+    }
+    // top-p boundary value vb = tq + 1 (an entry's value: the mass above a threshold only changes at entries).  Its equals are
+    // ranked in index order over the contiguous segments block_draw uses; `cut` = first index of this thread's segment from
+    // which they are dropped.
+    const uint32_t kb = use_k ? tk : 0u, vbits = use_p ? tq + 1u : 0u;
+    const int seg = (V + kThreads - 1) / kThreads;
+    const int lo = min(V, tx * seg), hi = min(V, lo + seg);
+    int cut = hi;
+    if (use_p) {
+        float sb = 0.f, ties = 0.f;
+        for (int j = lo; j < hi; ++j) {
+            const float v = pos(q[j]);
+            const uint32_t b = __float_as_uint(v);
+            sb += (b > vbits) ? v : 0.f;
+            ties += (b == vbits) ? 1.f : 0.f;
+        }
+        const float mine = ties;
+        float z = 0.f;
+        block_sum2(sb, z, s_pair);
+        s_scan[tx] = mine;                       // inclusive scan of the tie counts over threads (exact: counts < 2^24)
+        __syncthreads();
+        for (int off = 1; off < kThreads; off <<= 1) {
+            const float add = (tx >= off) ? s_scan[tx - off] : 0.f;
+            __syncthreads();
+            s_scan[tx] += add;
+            __syncthreads();
+        }
+        float rank = s_scan[tx] - mine;
+        __syncthreads();
+        const float vb = __uint_as_float(vbits);
+        for (int j = lo; j < hi; ++j) {
+            if (__float_as_uint(pos(q[j])) != vbits) continue;
+            if (sb + rank * vb > tp) { cut = j; break; }
+            rank += 1.f;
+        }
+    }
+    auto kept = [&](int j) {      // j inside this thread's segment
+        const float v = pos(q[j]);
+        const uint32_t b = __float_as_uint(v);
+        return (b >= kb && (b > vbits || (b == vbits && j < cut))) ? v : 0.f;
+    };
+    const float total = block_draw(kept, V, p.uniform[row], s_red, s_scan, &s_found);
+    if (tx == 0) p.ids[row] = s_found;
+    if (p.probs_out) {
+        const float den = fmaxf(total, 1e-10f);
+        float* y = p.probs_out + (size_t)row * p.ld_out;
+        for (int j = lo; j < hi; ++j) y[j] = kept(j) / den;
+    }
+}
+
 } // namespace
 
 extern "C" int mi355_sample_rows(const float* probs, int32_t rows, int32_t V, int32_t ld, const float* uniform_samples,
@@ -205,5 +374,41 @@ extern "C" int mi355_rejection_sample(const float* draft_probs, const int32_t* d
                    draft_probs_point_mass ? 1 : 0};
     hipLaunchKernelGGL(rejection_sample_kernel, dim3(batch_size), dim3(kThreads), 0, (hipStream_t)stream, p);
     MI355_CHECK_LAUNCH("rejection_sample_kernel");
+    return MI355_OK;
+}
+
+extern "C" int mi355_apply_penalties(float* logits, int32_t batch_size, int32_t V, int32_t ld, const float* temperature,
+                                     const float* repetition_penalty, const float* presence_penalty, const float* frequency_penalty,
+                                     const int32_t* output_ids, const int32_t* input_lengths, int32_t max_input_length,
+                                     int32_t step, int32_t* penalty_ws, mi355_stream_t stream) {
+    if (batch_size == 0) return MI355_OK;
+    MI355_CHECK_ARG(logits && batch_size > 0 && V > 0 && ld >= V, "apply_penalties: bad args");
+    const bool pen = repetition_penalty || presence_penalty || frequency_penalty;
+    MI355_CHECK_ARG(!pen || (output_ids && penalty_ws && step >= 0 && max_input_length >= 0),
+                    "apply_penalties: penalties need output_ids [step][batch] and a [batch][V] int32 workspace");
+    if (!pen && !temperature) return MI355_OK;
+    if (pen) {
+        if (hipMemsetAsync(penalty_ws, 0, (size_t)batch_size * V * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) {
+            (void)hipGetLastError();
+            mi355_set_error("apply_penalties: hipMemsetAsync failed");
+            return MI355_ERR_HIP;
+        }
+    }
+    PenaltyParams p{logits, V, ld, temperature, repetition_penalty, presence_penalty, frequency_penalty,
+                    pen ? output_ids : nullptr, input_lengths, batch_size, max_input_length, step, penalty_ws};
+    hipLaunchKernelGGL(penalties_kernel, dim3(batch_size), dim3(kThreads), 0, (hipStream_t)stream, p);
+    MI355_CHECK_LAUNCH("penalties_kernel");
+    return MI355_OK;
+}
+
+extern "C" int mi355_top_k_top_p_sample(const float* probs, int32_t rows, int32_t V, int32_t ld, const int32_t* top_k,
+                                        const float* top_p, const float* uniform_samples, int32_t* ids, float* probs_out,
+                                        int32_t ld_out, mi355_stream_t stream) {
+    if (rows == 0) return MI355_OK;
+    MI355_CHECK_ARG(probs && uniform_samples && ids && rows > 0 && V > 0 && ld >= V, "top_k_top_p_sample: bad args");
+    MI355_CHECK_ARG(!probs_out || ld_out >= V, "top_k_top_p_sample: ld_out %d < V %d", ld_out, V);
+    TopKPParams p{probs, V, ld, top_k, top_p, uniform_samples, ids, probs_out, ld_out};
+    hipLaunchKernelGGL(top_k_top_p_sample_kernel, dim3(rows), dim3(kThreads), 0, (hipStream_t)stream, p);
+    MI355_CHECK_LAUNCH("top_k_top_p_sample_kernel");
     return MI355_OK;
 }

@@ -187,9 +187,15 @@ def embedding(ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
 def argmax(logits: torch.Tensor) -> torch.Tensor:
     _chk(logits, torch.float32, "argmax.logits")
     B, V = logits.shape
+    ld = V
+    if V % 4:            # the kernel reads 16-byte vectors: rows of an odd vocabulary go through a row-padded copy
+        ld = (V + 3) // 4 * 4
+        padded = torch.empty(B, ld, dtype=torch.float32, device=logits.device)
+        padded[:, :V] = logits
+        logits = padded
     ids = torch.empty(B, dtype=torch.int32, device=logits.device)
     ws = _workspace(B * 64 * 8, logits.device)
-    _C.check(_C.lib().mi355_argmax(logits.data_ptr(), B, V, V, ids.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "argmax")
+    _C.check(_C.lib().mi355_argmax(logits.data_ptr(), B, V, ld, ids.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "argmax")
     return ids
 
 
@@ -211,6 +217,61 @@ def sample_rows(probs: torch.Tensor, uniform: torch.Tensor) -> torch.Tensor:
     ids = torch.empty(R, dtype=torch.int32, device=probs.device)
     _C.check(_C.lib().mi355_sample_rows(probs.data_ptr(), R, V, V, uniform.data_ptr(), ids.data_ptr(), _stream()), "sample_rows")
     return ids
+
+
+def apply_penalties(logits: torch.Tensor, temperature: Optional[torch.Tensor] = None, repetition_penalty: Optional[torch.Tensor] = None,
+                    presence_penalty: Optional[torch.Tensor] = None, frequency_penalty: Optional[torch.Tensor] = None,
+                    output_ids: Optional[torch.Tensor] = None, input_lengths: Optional[torch.Tensor] = None,
+                    max_input_length: int = 0, step: int = 0) -> torch.Tensor:
+    """In place on fp32 logits [B, V]: temperature (logit / (T + 1e-6)), then repetition / presence / frequency penalties over
+    the token history output_ids [step, B] int32 (bindings/common/kernels/sampling_penalty_kernels.cu:26-54,129-213)."""
+    _chk(logits, torch.float32, "apply_penalties.logits")
+    B, V = logits.shape
+    dev = logits.device
+
+    def vec(t, dt, name):
+        if t is None:
+            return None
+        t = t.to(device=dev, dtype=dt).contiguous()
+        if t.numel() != B:
+            raise _C.Mi355Error(f"apply_penalties: {name} needs one value per row")
+        return t
+    temp, rep = vec(temperature, torch.float32, "temperature"), vec(repetition_penalty, torch.float32, "repetition_penalty")
+    pres, freq = vec(presence_penalty, torch.float32, "presence_penalty"), vec(frequency_penalty, torch.float32, "frequency_penalty")
+    lens = vec(input_lengths, torch.int32, "input_lengths")
+    ws = None
+    if rep is not None or pres is not None or freq is not None:
+        if output_ids is None:
+            raise _C.Mi355Error("apply_penalties: penalties need the token history output_ids [step, B]")
+        _chk(output_ids, torch.int32, "apply_penalties.output_ids")
+        if output_ids.dim() != 2 or output_ids.shape[1] != B or output_ids.shape[0] < step:
+            raise _C.Mi355Error("apply_penalties: output_ids must be [>= step, B]")
+        ws = torch.empty(B, V, dtype=torch.int32, device=dev)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    _C.check(_C.lib().mi355_apply_penalties(logits.data_ptr(), B, V, V, ptr(temp), ptr(rep), ptr(pres), ptr(freq), ptr(output_ids),
+                                            ptr(lens), int(max_input_length), int(step), ptr(ws), _stream()), "apply_penalties")
+    return logits
+
+
+def top_k_top_p_sample(probs: torch.Tensor, top_k: Optional[torch.Tensor], top_p: Optional[torch.Tensor], uniform: torch.Tensor,
+                       return_probs: bool = False):
+    """Per row of fp32 probabilities: top-k then top-p filter, renormalise, draw by inverse CDF with uniform[r]
+    (bindings/core/CudaSampleOp.cc:748-786).  -> ids [R] int32 (, renormalised filtered probs [R, V])."""
+    _chk(probs, torch.float32, "top_k_top_p_sample.probs"); _chk(uniform, torch.float32, "top_k_top_p_sample.uniform")
+    R, V = probs.shape
+    dev = probs.device
+    if uniform.numel() != R:
+        raise _C.Mi355Error("top_k_top_p_sample: one uniform per row")
+    k = top_k.to(device=dev, dtype=torch.int32).contiguous() if top_k is not None else None
+    p = top_p.to(device=dev, dtype=torch.float32).contiguous() if top_p is not None else None
+    if (k is not None and k.numel() != R) or (p is not None and p.numel() != R):
+        raise _C.Mi355Error("top_k_top_p_sample: one top_k / top_p per row")
+    ids = torch.empty(R, dtype=torch.int32, device=dev)
+    out = torch.empty_like(probs) if return_probs else None
+    _C.check(_C.lib().mi355_top_k_top_p_sample(probs.data_ptr(), R, V, V, k.data_ptr() if k is not None else None,
+                                               p.data_ptr() if p is not None else None, uniform.data_ptr(), ids.data_ptr(),
+                                               out.data_ptr() if out is not None else None, V, _stream()), "top_k_top_p_sample")
+    return (ids, out) if return_probs else ids
 
 
 def rejection_sample(draft_token_ids: torch.Tensor, target_token_ids: torch.Tensor, target_probs: torch.Tensor,
