@@ -396,8 +396,18 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        # the line is out: a rank that lost its peers (a TP-leg failure on one rank only) must not sit in the collective's
+        # own timeout
+        import threading
+        bye = threading.Timer(60.0, lambda: os._exit(0))
+        bye.daemon = True
+        bye.start()
+        try:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        except Exception as e:  # noqa: BLE001
+            log(f"[rank {rank}] shutdown barrier: {type(e).__name__}: {e}")
+        bye.cancel()
 
 
 if __name__ == "__main__":
