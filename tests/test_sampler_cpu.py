@@ -47,3 +47,80 @@ def test_oracle_filter_definitions():
     assert torch.allclose(f, torch.tensor([[0, 0.4, 0.25, 0, 0]]) / 0.65)
     f = oracle.top_k_top_p_filter(p, torch.tensor([0]), torch.tensor([0.0]))      # 0 reads as 1
     assert torch.allclose(f, p)
+
+
+class _OracleOps:
+    """Stand-in for rtp_llm_amd.ops inside THIS test only: the host flow of sampler.sample_greedy is plain Python and is checked
+    here without a GPU by letting the oracle play the kernels (and by recording which kernels the flow asked for)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def apply_penalties(self, logits, **kw):
+        self.calls.append("apply_penalties:" + ",".join(sorted(k for k, v in kw.items() if v is not None and k.endswith(("temperature", "penalty")))))
+        logits.copy_(oracle.apply_penalties(logits, **kw))
+        return logits
+
+    def argmax(self, x):
+        self.calls.append("argmax")
+        return x.argmax(-1).int()
+
+    def softmax_rows(self, x, temperature=1.0):
+        self.calls.append("softmax_rows")
+        return oracle.softmax_rows(x, temperature)
+
+    def top_k_top_p_sample(self, probs, top_k, top_p, uniform, return_probs=False):
+        self.calls.append("top_k_top_p_sample")
+        f = oracle.top_k_top_p_filter(probs, top_k, top_p)
+        ids = oracle.sample_rows(f, uniform)
+        return (ids, f) if return_probs else ids
+
+
+@pytest.mark.parametrize("name", sorted(sv.CASES))
+def test_sample_greedy_host_flow(name, monkeypatch):
+    """Order of operations and host-side shortcuts of sampleGreedy (CudaSampleOp.cc:633-700,739-786)."""
+    from rtp_llm_amd import sampler
+    fake = _OracleOps()
+    monkeypatch.setattr(sampler, "ops", fake)
+    c = sv.case(name)
+    u = torch.full((4,), 0.37)
+    p = sampler.GreedyParams(logits=c["logits"].clone(), input_lengths=c["input_lengths"], sequence_lengths=c["sequence_lengths"],
+                             token_ids=c["token_ids"].clone(), step=c["step"], top_k=c["top_k"], top_p=c["top_p"].clone(),
+                             temperature=c["temperature"], uniform=u)
+    ids = sampler.sample_greedy(p)
+    want, _ = sv.oracle_sample_greedy(oracle, c, u)
+    assert torch.equal(ids, want.int()) and torch.equal(p.token_ids[:, c["step"]], ids)
+    if name == "top_k_1":      # temperature, then arg-max of the logits: no softmax
+        assert fake.calls == ["apply_penalties:temperature", "argmax"]
+    else:
+        assert fake.calls == ["apply_penalties:temperature", "softmax_rows", "top_k_top_p_sample"]
+    assert torch.equal(c["top_p"], sv.case(name)["top_p"])          # the caller's top_p is not edited in place
+
+
+def test_sample_greedy_host_flow_penalties_and_probabilities(monkeypatch):
+    from rtp_llm_amd import sampler
+    fake = _OracleOps()
+    monkeypatch.setattr(sampler, "ops", fake)
+    c = sv.PENALTY
+    probs = torch.zeros(4, 10)
+    p = sampler.GreedyParams(logits=c["logits"].clone(), input_lengths=c["input_lengths"], sequence_lengths=c["sequence_lengths"],
+                             token_ids=c["token_ids"].clone(), step=c["step"], top_k=c["top_k"], top_p=c["top_p"], temperature=c["temperature"],
+                             repetition_penalty=c["repetition_penalty"], presence_penalty=c["presence_penalty"],
+                             frequency_penalty=c["frequency_penalty"], output_all_probs=probs, uniform=torch.full((4,), 0.5))
+    sampler.sample_greedy(p)
+    # every T == 1: no temperature launch; penalties in one call; the probabilities the reference's test expects
+    assert fake.calls == ["apply_penalties:frequency_penalty,presence_penalty,repetition_penalty", "softmax_rows", "top_k_top_p_sample"]
+    assert torch.allclose(probs, c["expected_probs"], atol=c["atol"], rtol=0)
+    # default penalties: the launch is skipped altogether
+    fake.calls.clear()
+    p2 = sampler.GreedyParams(logits=c["logits"].clone(), input_lengths=c["input_lengths"], sequence_lengths=c["sequence_lengths"],
+                              token_ids=c["token_ids"].clone(), step=c["step"], top_k=torch.ones(4, dtype=torch.int32), top_p=c["top_p"],
+                              temperature=c["temperature"], repetition_penalty=torch.ones(4), presence_penalty=torch.zeros(4),
+                              frequency_penalty=torch.zeros(4))
+    sampler.sample_greedy(p2)
+    assert fake.calls == ["argmax"]
+    with pytest.raises(ValueError):
+        sampler.sample_greedy(sampler.GreedyParams(logits=c["logits"].clone(), input_lengths=c["input_lengths"],
+                                                   sequence_lengths=c["sequence_lengths"], token_ids=c["token_ids"].clone(), step=c["step"],
+                                                   top_k=c["top_k"], top_p=c["top_p"], temperature=c["temperature"],
+                                                   repetition_penalty=torch.ones(4)))
