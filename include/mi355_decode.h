@@ -341,6 +341,11 @@ int                mi355_allreduce_open(mi355_allreduce_t* ar, const void* all_h
 void               mi355_allreduce_destroy(mi355_allreduce_t* ar);
 int                mi355_allreduce_status(mi355_allreduce_t* ar, mi355_stream_t stream); /* synchronises; 0 = healthy */
 
+/* out[T, n * world] = the ranks' [T, n] column slices side by side, out[t][r n + j] = x_r[t][j]: the all-gather of the
+ * reference's hidden-split embedding (modules/base/common/embedding.py:50-58: all_gather, then reshape(tp, m, n).transpose(0, 1)
+ * .reshape(m, -1)).  Same transport, same graph-capture rules as the all-reduce; T * n * world * 2 <= max_bytes; out != x. */
+int mi355_allgather_hidden(mi355_allreduce_t* ar, const void* x_f16, void* out_f16, int32_t T, int32_t n, mi355_stream_t stream);
+
 /* out[T,H] = sum over ranks of x[T,H] (fp16).  out may alias x. */
 int mi355_allreduce_sum(mi355_allreduce_t* ar, const void* x_f16, void* out_f16, int32_t T, int32_t H, mi355_stream_t stream);
 
@@ -457,6 +462,10 @@ int    mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_ids, const
  * mi355_allreduce_argmax, so mi355_decoder_step / _capture / _replay drive the whole tensor-parallel step from C++ with
  * no host round trip per layer.  vocab_offset: first vocabulary column of this rank's lm_head slice. */
 int mi355_decoder_attach_allreduce(mi355_decoder_t* d, mi355_allreduce_t* ar, int32_t vocab_offset);
+/* on != 0: the embedding table given at creation holds only this rank's hidden / tp_size columns ([vocab][hidden / tp], the
+ * reference's hidden-split embedding weight, modules/base/common/embedding.py:22-59); every step then looks its slice up and
+ * all-gathers the hidden dimension (mi355_allgather_hidden) instead of reading a replicated table.  After attach_allreduce. */
+int mi355_decoder_set_embedding_split(mi355_decoder_t* d, int32_t on);
 
 int mi355_decoder_capture(mi355_decoder_t* d, int32_t B);
 int mi355_decoder_replay(mi355_decoder_t* d, int32_t B, int32_t nsteps, mi355_stream_t stream);

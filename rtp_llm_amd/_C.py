@@ -91,6 +91,8 @@ SIGNATURES = {
     "mi355_allreduce_fused": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, vp]),
     "mi355_allreduce_argmax": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "mi355_decoder_attach_allreduce": (i32, [vp, vp, i32]),
+    "mi355_decoder_set_embedding_split": (i32, [vp, i32]),
+    "mi355_allgather_hidden": (i32, [vp, vp, vp, i32, i32, vp]),
     "mi355_decoder_workspace_bytes": (sz, [C.POINTER(ModelConfig)]),
     "mi355_decoder_create": (vp, [C.POINTER(ModelConfig), C.POINTER(LayerWeights), C.POINTER(ModelWeights), C.POINTER(StepBuffers)]),
     "mi355_decoder_destroy": (None, [vp]),

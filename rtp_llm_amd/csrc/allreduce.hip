@@ -215,6 +215,42 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
     if (tid == 0) ar.epoch[b] = epoch;
 }
 
+// All-gather along the hidden dimension over the same transport: every rank publishes its [T][n] column slice, then copies
+// the N slices side by side -- out[t][r n + j] = slice_r[t][j], the result of the reference's hidden-split embedding
+// (all_gather + reshape(tp, m, n).transpose(0, 1).reshape(m, -1), modules/base/common/embedding.py:50-58).  Rows keep the
+// FULL row stride n * world inside the registered buffer, so a row has the same owner block as under the all-reduce (the
+// one-owner rule above) and both kinds of call may alternate freely.
+struct GatherParams {
+    ArDev      ar;
+    const f16* x;      // [T][n]
+    f16*       out;    // [T][n * world]
+    int        T, n;
+};
+
+__global__ __launch_bounds__(256) void allgather_hidden_kernel(const GatherParams p) {
+    const ArDev& ar = p.ar;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int H = p.n * ar.world, nv = p.n >> 3;
+    const uint32_t epoch = ar.epoch[b] + 1;
+    const size_t par = (epoch & 1) * ar.parity_elems;
+    for (int row = b; row < p.T; row += gridDim.x)
+        for (int vi = tid; vi < nv; vi += 256)
+            *reinterpret_cast<f16x8*>(ar.my_data + par + (size_t)row * H + vi * 8) = *reinterpret_cast<const f16x8*>(p.x + (size_t)row * p.n + vi * 8);
+    peer_barrier(ar, b, epoch);
+#pragma unroll
+    for (int r = 0; r < kMaxWorld; ++r) {
+        if (r >= ar.world) break;
+        __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)ar.peer_data[r], 0, ar.data_bytes, 0x00020000u);
+        for (int row = b; row < p.T; row += gridDim.x)
+            for (int vi = tid; vi < nv; vi += 256) {
+                const u32x4 v = load_sys(rp, (uint32_t)((par + (size_t)row * H + vi * 8) * 2));
+                *reinterpret_cast<u32x4*>(p.out + (size_t)row * H + (size_t)r * p.n + vi * 8) = v;
+            }
+    }
+    __syncthreads();
+    if (tid == 0) ar.epoch[b] = epoch;
+}
+
 // Greedy argmax across a vocab-split lm_head: every rank publishes (best local logit, global index) per row, then picks
 // the overall best -- highest value, lowest global index on ties (torch.argmax semantics on the gathered row).
 struct ArgmaxParams {
@@ -425,6 +461,22 @@ extern "C" int mi355_allreduce_fused(mi355_allreduce_t* a, const void* x_f16, co
 extern "C" int mi355_allreduce_sum(mi355_allreduce_t* a, const void* x_f16, void* out_f16, int32_t T, int32_t H,
                                    mi355_stream_t stream) {
     return mi355_allreduce_fused(a, x_f16, nullptr, 0, 0, nullptr, nullptr, out_f16, nullptr, 0.f, T, H, nullptr, stream);
+}
+
+extern "C" int mi355_allgather_hidden(mi355_allreduce_t* a, const void* x_f16, void* out_f16, int32_t T, int32_t n,
+                                      mi355_stream_t stream) {
+    MI355_CHECK_ARG(a && a->ready, "allgather: context not opened (mi355_allreduce_open)");
+    MI355_CHECK_ARG(x_f16 && out_f16 && x_f16 != out_f16, "allgather: null or aliased tensors");
+    MI355_CHECK_ARG(T > 0 && n > 0 && n % 8 == 0, "allgather: T=%d n=%d (n %% 8 == 0)", T, n);
+    const size_t bytes = (size_t)T * n * a->world * 2;
+    MI355_CHECK_ARG(bytes <= a->max_bytes, "allgather: gathered tensor %zu bytes > registered %zu", bytes, a->max_bytes);
+    GatherParams p;
+    p.ar = dev_view(a);
+    p.x = (const f16*)x_f16; p.out = (f16*)out_f16; p.T = T; p.n = n;
+    const int grid = T < kMaxBlocks ? T : kMaxBlocks;
+    hipLaunchKernelGGL(allgather_hidden_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    MI355_CHECK_LAUNCH("allgather_hidden_kernel");
+    return MI355_OK;
 }
 
 extern "C" int mi355_allreduce_argmax(mi355_allreduce_t* a, const float* logits, int32_t B, int32_t V_local, int32_t ld,

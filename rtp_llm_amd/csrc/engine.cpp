@@ -42,6 +42,7 @@ struct mi355_decoder {
     int32_t* oob_count; // tokens refused by the KV writer (stale position / block id)
     mi355_allreduce_t* ar; // attached all-reduce context (tp_size > 1): the TP step runs entirely from C++
     int    vocab_offset;
+    bool   embed_split;   // the embedding table holds this rank's hidden / tp columns: lookup + all-gather (embedding.py:50-58)
     // comm / weight-stream overlap: while the (latency-bound, <= 64 blocks) all-reduce kernel runs on the main stream, a
     // side stream pulls the NEXT GEMM's weight shard into the Infinity Cache
     hipStream_t side_stream;
@@ -238,7 +239,13 @@ extern "C" int mi355_decoder_begin_rows(mi355_decoder_t* d, int32_t nseq, int32_
     hipStream_t st = (hipStream_t)stream;
     d->B = B; d->q_len = q_len;
     const auto& c = d->cfg;
-    RUN(MI355_KC_OTHER, mi355_embedding(d->bufs.token_ids, B, d->model.embedding, c.hidden, d->model.vocab_full, d->resid, st));
+    if (d->embed_split) {   // hidden-split table: this rank's columns, then the ranks' slices side by side
+        const int n = c.hidden / c.tp_size;
+        RUN(MI355_KC_OTHER, mi355_embedding(d->bufs.token_ids, B, d->model.embedding, n, d->model.vocab_full, d->act, st));
+        RUN(MI355_KC_COMM, mi355_allgather_hidden(d->ar, d->act, d->resid, B, n, st));
+    } else {
+        RUN(MI355_KC_OTHER, mi355_embedding(d->bufs.token_ids, B, d->model.embedding, c.hidden, d->model.vocab_full, d->resid, st));
+    }
     if (c.tp_size == 1 || d->ar) {
         RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, d->layers[0].input_norm, c.rms_eps, B, c.hidden, d->xn, st));
     }
@@ -259,6 +266,17 @@ extern "C" int mi355_decoder_attach_allreduce(mi355_decoder_t* d, mi355_allreduc
                      hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming) == hipSuccess;
         (void)hipGetLastError();
     }
+    return MI355_OK;
+}
+
+extern "C" int mi355_decoder_set_embedding_split(mi355_decoder_t* d, int32_t on) {
+    if (!d || (on && (!d->ar || d->cfg.tp_size <= 1 || d->cfg.hidden % (8 * d->cfg.tp_size) != 0))) {
+        mi355_set_error("decoder_set_embedding_split: needs an attached all-reduce context and hidden %% (8 tp) == 0");
+        return MI355_ERR_ARG;
+    }
+    for (auto& kv : d->graphs) hipGraphExecDestroy(kv.second);   // captured steps bake the embedding path in
+    d->graphs.clear();
+    d->embed_split = on != 0;
     return MI355_OK;
 }
 
@@ -440,7 +458,13 @@ extern "C" int mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_id
     if (need > workspace_bytes) { mi355_set_error("decoder_prefill: workspace %zu < %zu", workspace_bytes, need); return MI355_ERR_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     const float scale = 1.0f / sqrtf((float)c.hd);
-    RUN(MI355_KC_OTHER, mi355_embedding(token_ids, T, d->model.embedding, c.hidden, d->model.vocab_full, b.resid, st));
+    if (d->embed_split) {
+        const int n = c.hidden / c.tp_size;
+        RUN(MI355_KC_OTHER, mi355_embedding(token_ids, T, d->model.embedding, n, d->model.vocab_full, b.tmp, st));
+        RUN(MI355_KC_COMM, mi355_allgather_hidden(d->ar, b.tmp, b.resid, T, n, st));
+    } else {
+        RUN(MI355_KC_OTHER, mi355_embedding(token_ids, T, d->model.embedding, c.hidden, d->model.vocab_full, b.resid, st));
+    }
     RUN(MI355_KC_NORM, mi355_rmsnorm(b.resid, d->layers[0].input_norm, c.rms_eps, T, c.hidden, b.xn, st));
     for (int l = 0; l < c.num_layers; ++l) {
         const auto& L = d->layers[l];

@@ -102,6 +102,14 @@ class CustomAllReduce:
                       "allreduce_fused")
         return y, res
 
+    def all_gather_hidden(self, t: torch.Tensor) -> torch.Tensor:
+        """[T, n] column slice per rank -> [T, n * world], slices side by side in rank order (the all_gather + transpose of the
+        reference's hidden-split embedding, modules/base/common/embedding.py:50-58)."""
+        T, n = t.shape
+        out = torch.empty(T, n * self.world, dtype=torch.float16, device=t.device)
+        self._C.check(self.lib.mi355_allgather_hidden(self.handle, t.data_ptr(), out.data_ptr(), T, n, self._st()), "allgather_hidden")
+        return out
+
     def argmax(self, logits_local: torch.Tensor, vocab_offset: int) -> torch.Tensor:
         B, V = logits_local.shape
         ids = torch.empty(B, dtype=torch.int32, device=logits_local.device)

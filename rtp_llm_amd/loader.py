@@ -106,9 +106,12 @@ def _linear_quant(sh: _Shards, prefix: str, method: str, group_size: int) -> Can
 
 
 def load_hf_checkpoint(path: str, quantization: Optional[str] = None, tp: int = 1, rank: int = 0,
-                       max_layers: Optional[int] = None) -> Tuple[ModelConfig, Dict]:
+                       max_layers: Optional[int] = None, split_embedding: bool = False) -> Tuple[ModelConfig, Dict]:
     """Read an HF Qwen2/Llama checkpoint (fp16, GPTQ-4bit or AWQ-4bit) into the canonical weight dict of
-    rtp_llm_amd.model (per-rank tensors when tp > 1).  quantization="int8" autoquantises fp16 linears at load time."""
+    rtp_llm_amd.model (per-rank tensors when tp > 1).  quantization="int8" autoquantises fp16 linears at load time.
+    split_embedding (tp > 1): the embedding table comes back as this rank's [vocab, hidden / tp] column slice, the reference's TP
+    layout (utils/model_weight.py:1490 sp_neg1) -- pair it with DecoderEngine.set_embedding_split(); default: replicated table
+    (no collective in the lookup)."""
     cfg_json = json.load(open(os.path.join(path, "config.json")))
     mc, qc = config_from_hf(cfg_json, os.path.basename(os.path.normpath(path)))
     if qc["method"] not in ("none", "gptq", "awq") or (qc["method"] != "none" and qc["bits"] != 4):
@@ -159,6 +162,9 @@ def load_hf_checkpoint(path: str, quantization: Optional[str] = None, tp: int = 
             raise ValueError(f"lm_head rows {V} not divisible by tp={tp}")
         head = head[rank * (V // tp):(rank + 1) * (V // tp)]
     mc = ModelConfig(**{**mc.__dict__, "num_layers": L, "qkv_bias": has_bias, "vocab": V})
+    if split_embedding and tp > 1:
+        from .model import split_embedding_tp
+        emb = split_embedding_tp(emb, tp, rank)
     weights = {"layers": layers, "embedding": emb, "final_norm": _f16(sh.get(pre + "norm.weight"), "norm"),
                "lm_head": CanonLinear("fp16", head.shape[1], head.shape[0], w=head.t().contiguous())}
     return (mc.per_rank(tp) if tp > 1 else mc), weights

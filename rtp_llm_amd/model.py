@@ -204,6 +204,16 @@ def weights_to(w: Dict, device) -> Dict:
     return mv(w)
 
 
+def split_embedding_tp(embedding: torch.Tensor, tp: int, rank: int) -> torch.Tensor:
+    """This rank's hidden-dimension slice [vocab, hidden / tp] of the embedding table -- the TP layout of the reference's
+    embedding weight (utils/model_weight.py:257-263 sp_neg1, :1490; consumed by modules/base/common/embedding.py:22-59)."""
+    H = embedding.shape[1]
+    if H % (8 * tp):
+        raise ValueError(f"hidden {H} does not split into {tp} slices of whole 16-byte vectors")
+    n = H // tp
+    return embedding[:, rank * n:(rank + 1) * n].contiguous()
+
+
 def split_layer_tp(layer: Dict, cfg: ModelConfig, tp: int, rank: int) -> Dict:
     """Megatron TP split of one layer (table utils/model_weight.py:1517-1563): column-parallel QKV
     (q heads / tp, k and v heads / tp) and gate/up, row-parallel O and down; norms replicated;
@@ -513,6 +523,13 @@ class DecoderEngine:
         cross-rank greedy argmax): step() / capture() / replay() then drive the whole tensor-parallel step."""
         _C.check(self.lib.mi355_decoder_attach_allreduce(self.handle, ar.handle, int(vocab_offset)), "decoder_attach_allreduce")
         self._ar = ar
+
+    def set_embedding_split(self, on: bool = True):
+        """The embedding tensor of this engine is the rank's [vocab, hidden / tp] column slice (split_embedding_tp): look it up and
+        all-gather the hidden dimension every step (modules/base/common/embedding.py:50-58).  After attach_allreduce."""
+        if on and self.embedding.shape[1] * self.tp_size != self.cfg.hidden:
+            raise ValueError(f"embedding slice is {tuple(self.embedding.shape)}, expected [vocab, {self.cfg.hidden // self.tp_size}]")
+        _C.check(self.lib.mi355_decoder_set_embedding_split(self.handle, 1 if on else 0), "decoder_set_embedding_split")
 
     # ---- tp > 1: the step cut at the all-reduce points (causal_attention.py:91-92, dense_mlp.py:104-105)
     def step_tp(self, B: int, sample: bool = True):

@@ -81,6 +81,35 @@ def _worker(rank, world, port, q, mode):
             s1 = (parts[0].float() + parts[1].float()).half()
             s2 = (s1.float() + s1.float()).half()
             assert torch.equal(out.cpu(), s2)
+            # all-gather of the hidden dimension (hidden-split embedding): slices side by side in rank order, interleaved with
+            # all-reduces of other shapes on the same buffers, eager and replayed
+            for it, (T, n) in enumerate([(1, 1792), (5, 448), (64, 1792), (300, 4096), (7, 8), (64, 1792)]):
+                xs_ = (torch.randn(T, n, generator=g)).half()
+                got = ar.all_gather_hidden(xs_.to(dev))
+                if it % 2:
+                    ar.all_reduce(torch.ones(3, 3584, dtype=torch.float16, device=dev))
+                torch.cuda.synchronize()
+                ref = torch.cat(_gather_cpu(xs_, world), dim=1)
+                assert torch.equal(got.cpu(), ref), (it, T, n)
+            xg = (torch.randn(16, 1792, generator=g)).half().to(dev)
+            og, osum = torch.empty(16, 3584, dtype=torch.float16, device=dev), torch.empty(16, 3584, dtype=torch.float16, device=dev)
+            torch.cuda.synchronize(); dist.barrier()
+            st2 = torch.cuda.Stream()
+            with torch.cuda.stream(st2):
+                lib, hd = ar.lib, ar.handle
+                run = lambda: (_C.check(lib.mi355_allgather_hidden(hd, xg.data_ptr(), og.data_ptr(), 16, 1792, st2.cuda_stream), "allgather"),
+                               _C.check(lib.mi355_allreduce_sum(hd, og.data_ptr(), osum.data_ptr(), 16, 3584, st2.cuda_stream), "allreduce"))
+                run(); torch.cuda.synchronize()
+                gr2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr2, stream=st2):
+                    run()
+                for rep in range(4):
+                    gr2.replay()
+                torch.cuda.synchronize()
+            refg = torch.cat(_gather_cpu(xg.cpu(), world), dim=1)
+            assert torch.equal(og.cpu(), refg) and torch.equal(osum.cpu(), (refg.float() + refg.float()).half())
+            with pytest.raises(_C.Mi355Error):
+                ar.all_gather_hidden(torch.zeros(4, 12, dtype=torch.float16, device=dev))       # not whole 16-byte vectors
             # cross-rank greedy argmax incl. a tie across the rank boundary (lowest global index wins)
             V = 5000
             lg = torch.randn(9, V, generator=g)
@@ -127,6 +156,26 @@ def _worker(rank, world, port, q, mode):
                 tok = oracle.greedy(ref)
                 eng.token_ids[:B].copy_(tok)
             assert ar.status() == 0 and eng.oob_count() == 0
+            # hidden-split embedding (the reference's TP layout of the table): lookup of this rank's columns + all-gather inside
+            # the captured step == the replicated table, bit for bit
+            shard2 = {**shard, "embedding": model.split_embedding_tp(w["embedding"], world, rank)}
+            eng2 = model.DecoderEngine(cfg.per_rank(world), model.weights_to(shard2, dev), kv_int8=False, page=page, num_blocks=B * 2,
+                                       max_batch=B, max_seq_len=32, device=dev, tp_size=world, vocab_full=V)
+            eng2.attach_allreduce(ar, rank * (V // world))
+            eng2.set_embedding_split(True)
+            eng3 = model.DecoderEngine(cfg.per_rank(world), model.weights_to(shard, dev), kv_int8=False, page=page, num_blocks=B * 2,
+                                       max_batch=B, max_seq_len=32, device=dev, tp_size=world, vocab_full=V)
+            eng3.attach_allreduce(ar, rank * (V // world))
+            tok0 = torch.randint(0, V, (B,), generator=torch.Generator().manual_seed(4), dtype=torch.int32)
+            for e in (eng2, eng3):
+                e.set_inputs(tok0.tolist(), [0] * B, bt)
+            dist.barrier()
+            eng2.capture(B); eng3.capture(B)
+            for step in range(4):
+                eng2.replay(B, 1); eng3.replay(B, 1)
+                torch.cuda.synchronize()
+                assert torch.equal(eng2.logits[:B], eng3.logits[:B]) and torch.equal(eng2.token_ids[:B], eng3.token_ids[:B]), step
+            assert ar.status() == 0
         elif mode == "timeout":
             x = torch.ones(4, 3584, dtype=torch.float16, device=dev)
             ar.all_reduce(x.clone()); torch.cuda.synchronize(); dist.barrier()

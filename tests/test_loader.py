@@ -53,6 +53,11 @@ def test_load_int8_autoquant_and_tp_split(tmp_path):
         Lr = wr["layers"][1]
         assert Lr["qkv"].N == (4 + 2 * 2) * 64 and Lr["o"].K == 256 and Lr["down"].K == 256 and Lr["gate_up"].N == 512
         assert Lr["down"].scales.shape == (2, 256) and wr["lm_head"].N == 256
+        # the reference's TP layout of the embedding table (hidden split, utils/model_weight.py:1490): the rank's columns of the same table
+        _, ws = loader.load_hf_checkpoint(str(d2), tp=2, rank=r, split_embedding=True)
+        H = wr["embedding"].shape[1]
+        assert ws["embedding"].shape == (wr["embedding"].shape[0], H // 2) and ws["embedding"].is_contiguous()
+        assert torch.equal(ws["embedding"], wr["embedding"][:, r * (H // 2):(r + 1) * (H // 2)])
 
 
 def test_act_order_checkpoint_is_rejected(tmp_path):
