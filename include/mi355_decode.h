@@ -328,6 +328,9 @@ int mi355_rejection_sample(const float* draft_probs, const int32_t* draft_token_
  * fills an opaque handle blob), the host gathers the `world` blobs in rank order by any means (torch.distributed
  * all_gather_object, as base/rocm/trt_allreduce.py:51-230 does) and every rank opens them.  Numerics: fp32 sum of the
  * fp16 copies in rank order 0..N-1, one rounding -- bit-identical on every rank (trtllm_allreduce_fusion.cu:228-246).
+ * Tensors of more than 64 rows (prefill chunks) on more than two ranks take the two-shot form inside the same call: rank r
+ * reduces rows r, r + N, ... and every rank fetches each row once from its owner -- 2 (N - 1) / N instead of (N - 1) element
+ * reads per element over the links, bit-identical results (trtllm_allreduce_fusion.cu:606-692).
  * All calls only enqueue one kernel: graph-capturable; epochs advance on the device.  A peer that never arrives makes the
  * kernel give up after ~2 s and sets a status word (mi355_allreduce_status != 0) instead of hanging the GPU.
  * ---------------------------------------------------------------------- */

@@ -33,8 +33,9 @@ namespace {
 
 constexpr int kMaxWorld  = 8;
 constexpr int kMaxBlocks = 256;            // flag rows; grid of an all-reduce launch <= kMaxBlocks
-constexpr int kFlagRow   = 16;             // dwords per block row (8 used): one 64-byte line per block
+constexpr int kFlagRow   = 16;             // dwords per block row: slots 0..7 first barrier, 8..15 second barrier (two-shot); one 64-byte line per block
 constexpr unsigned long long kSpinTicks = 200000000ull;   // 2 s of the 100 MHz wall clock
+constexpr int kOneShotRows = 64;          // tensors with more rows take the two-shot form (world > 2)
 constexpr size_t kAuxBytes = 32768;        // per parity, after the tensor region: 8-byte records of the argmax exchange.
 // Every location of a registered buffer has ONE owner block for all time (tensor row r and record r belong to block
 // r % kMaxBlocks whatever T is), and a block alternates parities with its own epoch: a location is rewritten two of its
@@ -49,6 +50,7 @@ struct ArDev {                             // device-visible part of the context
     int32_t*        status;                // != 0: a spin timed out (results invalid)
     size_t          parity_elems;          // elements between the two parities
     size_t          aux_elems;             // element offset of the record region inside a parity
+    size_t          res_elems;             // element offset of the result region inside a parity (two-shot: rows this rank reduced)
     uint32_t        data_bytes;            // bytes of one peer buffer (both parities): buffer range of the remote loads
     int             rank, world;
 };
@@ -73,13 +75,14 @@ __device__ __forceinline__ u32x4 load_sys(__amdgpu_buffer_rsrc_t r, uint32_t off
 }
 
 // Raise this block's flag at every peer, then wait for every peer's flag of the same epoch.  Executed by the whole block.
-__device__ __forceinline__ void peer_barrier(const ArDev& ar, int b, uint32_t epoch) {
+// slot0: 0 = the call's first barrier, 8 = the second barrier of a two-shot call (its own flag slots, same epoch value).
+__device__ __forceinline__ void peer_barrier(const ArDev& ar, int b, uint32_t epoch, int slot0 = 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: this block's published rows first
     __syncthreads();
     const int t = threadIdx.x;
     if (t < ar.world) {
-        __hip_atomic_store(ar.peer_flags[t] + b * kFlagRow + ar.rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const uint32_t* mine = ar.peer_flags[ar.rank] + b * kFlagRow + t;
+        __hip_atomic_store(ar.peer_flags[t] + b * kFlagRow + slot0 + ar.rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t* mine = ar.peer_flags[ar.rank] + b * kFlagRow + slot0 + t;
         const unsigned long long t0 = wall_clock64();
         // monotonic epochs: a peer may already be one call ahead (its next call's flag), never behind once it arrived
         while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
@@ -91,7 +94,12 @@ __device__ __forceinline__ void peer_barrier(const ArDev& ar, int b, uint32_t ep
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
-template <int VPT>
+// TWO = false: one-shot (every rank reads every peer's copy of every row: (N - 1) T H elements over its links -- cheapest for
+// the <= 64 rows of a decode step).  TWO = true: two-shot for larger tensors (prefill chunks): rank r reduces the rows
+// r, r + N, ... (rank-ordered fp32 sum of the N copies, one rounding -- the same numbers as the one-shot), publishes them in
+// its result region, and after a second flag barrier every rank fetches each row ONCE from its owner: 2 (N - 1) / N T H
+// elements per rank instead of (N - 1) T H (trtllm_allreduce_fusion.cu:606-692 is the reference's two-shot form).
+template <int VPT, bool TWO>
 __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams p) {
     constexpr int NTH = 512;
     const ArDev& ar = p.ar;
@@ -149,6 +157,35 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
 #pragma unroll
     for (int r = 0; r < kMaxWorld; ++r)
         rp[r] = __builtin_amdgcn_make_buffer_rsrc((void*)ar.peer_data[r < ar.world ? r : 0], 0, ar.data_bytes, 0x00020000u);
+    if constexpr (TWO) {
+        for (int row = b; row < p.T; row += gridDim.x) {
+            if (row % ar.world != ar.rank) continue;                        // rows this rank reduces
+#pragma unroll
+            for (int t = 0; t < VPT; ++t) {
+                const int vi = tid + t * NTH;
+                if (vi >= nvec) continue;
+                const uint32_t off = (uint32_t)((par + (size_t)row * p.H + vi * 8) * 2);
+                u32x4 in[kMaxWorld];
+#pragma unroll
+                for (int r = 0; r < kMaxWorld; ++r)
+                    if (r < ar.world) in[r] = load_sys(rp[r], off);
+                float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < kMaxWorld; ++r) {
+                    if (r < ar.world) {
+                        const f16x8 h = __builtin_bit_cast(f16x8, in[r]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a[e] += (float)h[e];
+                    }
+                }
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)a[e];
+                *reinterpret_cast<f16x8*>(ar.my_data + par + ar.res_elems + (size_t)row * p.H + vi * 8) = o;
+            }
+        }
+        peer_barrier(ar, b, epoch, 8);
+    }
     __shared__ float red[NTH / 64];
     for (int row = b; row < p.T; row += gridDim.x) {
         float v[VPT][8];
@@ -161,20 +198,34 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
             const int c0 = vi * 8;
             const uint32_t off = (uint32_t)((par + (size_t)row * p.H + c0) * 2);
             u32x4 in[kMaxWorld];
+            if constexpr (TWO) {                                            // the row as its owner reduced it
+                const int owner = row % ar.world;
+                const uint32_t roff = (uint32_t)((par + ar.res_elems + (size_t)row * p.H + c0) * 2);
 #pragma unroll
-            for (int r = 0; r < kMaxWorld; ++r)
-                if (r < ar.world) in[r] = load_sys(rp[r], off);            // all peers in flight together
+                for (int r = 0; r < kMaxWorld; ++r)
+                    if (r == owner) in[0] = load_sys(rp[r], roff);
+            } else {
+#pragma unroll
+                for (int r = 0; r < kMaxWorld; ++r)
+                    if (r < ar.world) in[r] = load_sys(rp[r], off);        // all peers in flight together
+            }
             f16x8 rin = {0, 0, 0, 0, 0, 0, 0, 0};
             if (p.res_in) rin = *reinterpret_cast<const f16x8*>(p.res_in + (size_t)row * p.H + c0);
             win[t] = (p.y && p.weight) ? *reinterpret_cast<const f16x8*>(p.weight + c0) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[t][e] = 0.f;
+            if constexpr (TWO) {
+                const f16x8 h = __builtin_bit_cast(f16x8, in[0]);
 #pragma unroll
-            for (int r = 0; r < kMaxWorld; ++r) {                           // rank order 0..N-1 on every rank
-                if (r < ar.world) {
-                    const f16x8 h = __builtin_bit_cast(f16x8, in[r]);
+                for (int e = 0; e < 8; ++e) v[t][e] = (float)h[e];
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[t][e] += (float)h[e];
+                for (int r = 0; r < kMaxWorld; ++r) {                       // rank order 0..N-1 on every rank
+                    if (r < ar.world) {
+                        const f16x8 h = __builtin_bit_cast(f16x8, in[r]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[t][e] += (float)h[e];
+                    }
                 }
             }
 #pragma unroll
@@ -308,7 +359,7 @@ __global__ __launch_bounds__(64) void allreduce_argmax_kernel(const ArgmaxParams
 struct mi355_allreduce {
     int     rank, world;
     size_t  max_bytes;                 // largest message (one parity)
-    void*   data;                      // 2 x max_bytes, IPC-exported
+    void*   data;                      // 2 parities x (tensor max_bytes | records | results max_bytes), IPC-exported
     void*   flags;                     // kMaxBlocks x kFlagRow dwords, IPC-exported
     void*   peer_data[kMaxWorld];
     void*   peer_flags[kMaxWorld];
@@ -353,9 +404,10 @@ ArDev dev_view(const mi355_allreduce* a) {
         d.peer_flags[r] = (uint32_t*)a->peer_flags[r < a->world ? r : 0];
     }
     d.epoch = a->epoch; d.status = a->status;
-    d.parity_elems = (a->max_bytes + kAuxBytes) / 2;
+    d.parity_elems = (2 * a->max_bytes + kAuxBytes) / 2;
     d.aux_elems = a->max_bytes / 2;
-    d.data_bytes = (uint32_t)(2 * (a->max_bytes + kAuxBytes));
+    d.res_elems = (a->max_bytes + kAuxBytes) / 2;
+    d.data_bytes = (uint32_t)(2 * (2 * a->max_bytes + kAuxBytes));
     d.rank = a->rank; d.world = a->world;
     return d;
 }
@@ -366,7 +418,7 @@ extern "C" size_t mi355_allreduce_handle_bytes(void) { return sizeof(HandleBlob)
 
 extern "C" mi355_allreduce_t* mi355_allreduce_create(int32_t rank, int32_t world, size_t max_bytes, void* handle_out) {
     if (rank < 0 || world < 1 || world > kMaxWorld || rank >= world || !handle_out || max_bytes == 0 ||
-        2 * (max_bytes + kAuxBytes) >= 0xFFFFFF00ull) {
+        2 * (2 * max_bytes + kAuxBytes) >= 0xFFFFFF00ull) {
         mi355_set_error("allreduce_create: rank=%d world=%d (1..%d) max_bytes=%zu", rank, world, kMaxWorld, max_bytes);
         return nullptr;
     }
@@ -377,7 +429,7 @@ extern "C" mi355_allreduce_t* mi355_allreduce_create(int32_t rank, int32_t world
     for (int r = 0; r < kMaxWorld; ++r) { a->peer_data[r] = a->peer_flags[r] = nullptr; a->opened[r] = false; }
     HandleBlob hb;
     memset(&hb, 0, sizeof(hb));
-    a->data  = alloc_shared(2 * (a->max_bytes + kAuxBytes), &hb.data);
+    a->data  = alloc_shared(2 * (2 * a->max_bytes + kAuxBytes), &hb.data);   // per parity: tensor | records | two-shot results
     a->flags = alloc_shared((size_t)kMaxBlocks * kFlagRow * 4, &hb.flags);
     a->epoch = nullptr; a->status = nullptr;
     if (!a->data || !a->flags || hipMalloc((void**)&a->epoch, kMaxBlocks * 4 + 256) != hipSuccess ||
@@ -452,8 +504,11 @@ extern "C" int mi355_allreduce_fused(mi355_allreduce_t* a, const void* x_f16, co
     p.eps = eps; p.T = T; p.H = H;
     const int grid = T < kMaxBlocks ? T : kMaxBlocks;
     hipStream_t st = (hipStream_t)stream;
-    if (H / 8 <= 512) hipLaunchKernelGGL(allreduce_fused_kernel<1>, dim3(grid), dim3(512), 0, st, p);
-    else              hipLaunchKernelGGL(allreduce_fused_kernel<2>, dim3(grid), dim3(512), 0, st, p);
+    const bool two = T > kOneShotRows && a->world > 2;   // (N - 1) vs 2 (N - 1) / N reads per element: equal at N = 2
+    if (H / 8 <= 512) { if (two) hipLaunchKernelGGL((allreduce_fused_kernel<1, true>), dim3(grid), dim3(512), 0, st, p);
+                        else     hipLaunchKernelGGL((allreduce_fused_kernel<1, false>), dim3(grid), dim3(512), 0, st, p); }
+    else              { if (two) hipLaunchKernelGGL((allreduce_fused_kernel<2, true>), dim3(grid), dim3(512), 0, st, p);
+                        else     hipLaunchKernelGGL((allreduce_fused_kernel<2, false>), dim3(grid), dim3(512), 0, st, p); }
     MI355_CHECK_LAUNCH("allreduce_fused_kernel");
     return MI355_OK;
 }

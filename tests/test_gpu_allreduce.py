@@ -176,6 +176,52 @@ def _worker(rank, world, port, q, mode):
                 torch.cuda.synchronize()
                 assert torch.equal(eng2.logits[:B], eng3.logits[:B]) and torch.equal(eng2.token_ids[:B], eng3.token_ids[:B]), step
             assert ar.status() == 0
+        elif mode == "twoshot":
+            # world = 3 on one GPU: tensors of more than 64 rows take the two-shot form (rank r reduces rows r, r + 3, ...; second
+            # flag barrier; every row fetched once from its owner) -- same numbers as the one-shot: fp32 sum in rank order, one rounding
+            for it, (T, H) in enumerate([(65, 3584), (100, 8192), (5, 3584), (130, 896), (100, 8192), (64, 3584), (67, 3584)]):
+                x = (torch.randn(T, H, generator=g) * 2).half()
+                got = ar.all_reduce(x.to(dev).clone())
+                torch.cuda.synchronize()
+                parts = _gather_cpu(x, world)
+                acc = torch.zeros(T, H)
+                for p in parts:
+                    acc = acc + p.float()
+                assert torch.equal(got.cpu(), acc.half()), (it, T, H)
+                both = _gather_cpu(got.cpu(), world)
+                assert all(torch.equal(both[0], o) for o in both[1:])
+            T, H = 100, 3584                                          # fused epilogue on the two-shot path == unfused composition
+            x, res = (torch.randn(T, H, generator=g)).half().to(dev), torch.randn(T, H, generator=torch.Generator().manual_seed(7)).half().to(dev)
+            w = (1 + 0.1 * torch.randn(H, generator=torch.Generator().manual_seed(8))).half().to(dev)
+            y, r_out = ar.all_reduce_add_rmsnorm(x, res, w, 1e-6)
+            s = ar.all_reduce(x.clone())
+            y2, r2 = ops.add_rmsnorm(s, res, w, 1e-6)
+            assert torch.equal(y, y2) and torch.equal(r_out, r2)
+            xs_ = (torch.randn(70, 1200, generator=g)).half()         # and the all-gather with three slices
+            got = ar.all_gather_hidden(xs_.to(dev))
+            torch.cuda.synchronize()
+            assert torch.equal(got.cpu(), torch.cat(_gather_cpu(xs_, world), dim=1))
+            # replayed: two-shot then one-shot on the same buffers
+            xa, oa, ob = (torch.randn(80, 3584, generator=g)).half().to(dev), torch.empty(80, 3584, dtype=torch.float16, device=dev), torch.empty(8, 3584, dtype=torch.float16, device=dev)
+            torch.cuda.synchronize(); dist.barrier()
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                ar.all_reduce(xa, oa); ar.all_reduce(oa[:8].contiguous(), ob)
+                torch.cuda.synchronize()
+                xb = oa[:8].contiguous()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=st):
+                    ar.all_reduce(xa, oa)
+                    ar.all_reduce(xb, ob)
+                for rep in range(4):
+                    gr.replay()
+                torch.cuda.synchronize()
+            parts = _gather_cpu(xa.cpu(), world)
+            s1 = (parts[0].float() + parts[1].float() + parts[2].float()).half()
+            assert torch.equal(oa.cpu(), s1)
+            s8 = s1[:8].float()
+            assert torch.equal(ob.cpu(), (s8 + s8 + s8).half())
+            assert ar.status() == 0
         elif mode == "timeout":
             x = torch.ones(4, 3584, dtype=torch.float16, device=dev)
             ar.all_reduce(x.clone()); torch.cuda.synchronize(); dist.barrier()
@@ -200,10 +246,10 @@ def _worker(rank, world, port, q, mode):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("mode", ["kernels", "engine", "timeout"])
-def test_custom_allreduce_two_processes_one_gpu(mode):
+@pytest.mark.parametrize("mode,world", [("kernels", 2), ("engine", 2), ("timeout", 2), ("twoshot", 3)])
+def test_custom_allreduce_processes_on_one_gpu(mode, world):
     assert torch.cuda.is_available()
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
@@ -212,4 +258,4 @@ def test_custom_allreduce_two_processes_one_gpu(mode):
     res = [q.get(timeout=240) for _ in range(world)]
     for p in procs:
         p.join(30)
-    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
