@@ -312,6 +312,12 @@ int mi355_apply_penalties(float* logits, int32_t batch_size, int32_t V, int32_t 
                           const float* repetition_penalty, const float* presence_penalty, const float* frequency_penalty,
                           const int32_t* output_ids, const int32_t* input_lengths, int32_t max_input_length, int32_t step,
                           int32_t* penalty_ws, mi355_stream_t stream);
+/* no_repeat_ngram_size (invokeBanRepeatNgram, bindings/common/kernels/banRepeatNgram.cu:30-170, as called for greedy rows from
+ * CudaSampleOp.cc:242-283): token_ids [batch][token_ld] int32 (row b = the tokens of sequence b so far), sequence_last_index [batch]
+ * (index of the last valid token: the kernel's N = index + 1), no_repeat_ngram_size [batch] (0 = off).  Every earlier occurrence of
+ * the sequence's last n - 1 tokens bans the token that followed it: logits[b][that token] = -inf. */
+int mi355_ban_repeat_ngram(float* logits, int32_t batch_size, int32_t V, int32_t ld, const int32_t* token_ids, int32_t token_ld,
+                           const int32_t* sequence_last_index, const int32_t* no_repeat_ngram_size, mi355_stream_t stream);
 int mi355_top_k_top_p_sample(const float* probs, int32_t rows, int32_t V, int32_t ld, const int32_t* top_k, const float* top_p,
                              const float* uniform_samples, int32_t* ids, float* probs_out, int32_t ld_out, mi355_stream_t stream);
 int mi355_rejection_sample(const float* draft_probs, const int32_t* draft_token_ids, const float* uniform_samples,

@@ -347,3 +347,20 @@ def top_k_top_p_filter(probs, top_k, top_p):
             row.scatter_(0, si, sp)
     sums = out.sum(-1, keepdim=True)
     return out / sums.clamp_min(1e-10)
+
+
+def ban_repeat_ngram(logits, token_ids, sequence_last_index, no_repeat_ngram_size):
+    """fp32, returns a new tensor.  ban_repeat_ngram for beam_width = 1 (bindings/common/kernels/banRepeatNgram.cu:60-136): with
+    N = last_index + 1 tokens and n = ngram size (0, or N < n: nothing), every i <= N - n with tokens[i : i + n - 1] equal to the
+    last n - 1 tokens bans tokens[i + n - 1]."""
+    out = logits.clone().float()
+    for b in range(token_ids.shape[0]):
+        n, N = int(no_repeat_ngram_size[b]), int(sequence_last_index[b]) + 1
+        if n == 0 or N < n:
+            continue
+        t = [int(v) for v in token_ids[b][:N]]
+        last = t[N - n + 1:N]
+        for i in range(N - n + 1):
+            if t[i:i + n - 1] == last:
+                out[b, t[i + n - 1]] = float("-inf")
+    return out

@@ -80,6 +80,7 @@ SIGNATURES = {
     "mi355_softmax_rows": (i32, [vp, i32, i32, i32, f32, vp, vp]),
     "mi355_sample_rows": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "mi355_apply_penalties": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    "mi355_ban_repeat_ngram": (i32, [vp, i32, i32, i32, vp, i32, vp, vp, vp]),
     "mi355_top_k_top_p_sample": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
     "mi355_rejection_sample": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mi355_allreduce_handle_bytes": (sz, []),

@@ -338,6 +338,30 @@ __global__ __launch_bounds__(kThreads) void top_k_top_p_sample_kernel(const TopK
     }
 }
 
+
+// no_repeat_ngram_size: ban_repeat_ngram (bindings/common/kernels/banRepeatNgram.cu:30-136, greedy case beam_width = 1; called from
+// CudaSampleOp.cc:242-283).  With N = last_index[row] + 1 tokens so far and n = ngram[row]: every position i <= N - n whose n - 1
+// tokens equal the last n - 1 tokens of the sequence bans the token that followed it there (logit = -inf), so that no n-gram of
+// the sequence can be produced a second time.  n == 0 or N < n: nothing.  One block per row; the history is read from global
+// memory (N n int32 reads per row: nothing next to the vocabulary row the sampler touches anyway).
+__global__ __launch_bounds__(256) void ban_repeat_ngram_kernel(float* __restrict__ logits, int V, int ld, const int32_t* __restrict__ token_ids,
+                                                               int token_ld, const int32_t* __restrict__ last_index,
+                                                               const int32_t* __restrict__ ngram) {
+    const int row = blockIdx.x;
+    const int n = ngram[row], N = last_index[row] + 1;
+    if (n <= 0 || N < n || N > token_ld) return;
+    const int32_t* tok = token_ids + (size_t)row * token_ld;
+    const int32_t* last = tok + (N - n + 1);                // the n - 1 most recent tokens
+    for (int i = threadIdx.x; i <= N - n; i += 256) {
+        bool match = true;
+        for (int k = 0; k < n - 1; ++k)
+            if (tok[i + k] != last[k]) { match = false; break; }
+        if (!match) continue;
+        const int banned = tok[i + n - 1];
+        if (banned >= 0 && banned < V) logits[(size_t)row * ld + banned] = -INFINITY;
+    }
+}
+
 } // namespace
 
 extern "C" int mi355_sample_rows(const float* probs, int32_t rows, int32_t V, int32_t ld, const float* uniform_samples,
@@ -410,5 +434,17 @@ extern "C" int mi355_top_k_top_p_sample(const float* probs, int32_t rows, int32_
     TopKPParams p{probs, V, ld, top_k, top_p, uniform_samples, ids, probs_out, ld_out};
     hipLaunchKernelGGL(top_k_top_p_sample_kernel, dim3(rows), dim3(kThreads), 0, (hipStream_t)stream, p);
     MI355_CHECK_LAUNCH("top_k_top_p_sample_kernel");
+    return MI355_OK;
+}
+
+extern "C" int mi355_ban_repeat_ngram(float* logits, int32_t batch_size, int32_t V, int32_t ld, const int32_t* token_ids,
+                                      int32_t token_ld, const int32_t* sequence_last_index, const int32_t* no_repeat_ngram_size,
+                                      mi355_stream_t stream) {
+    if (batch_size == 0) return MI355_OK;
+    MI355_CHECK_ARG(logits && token_ids && sequence_last_index && no_repeat_ngram_size && batch_size > 0 && V > 0 && ld >= V && token_ld > 0,
+                    "ban_repeat_ngram: bad args");
+    hipLaunchKernelGGL(ban_repeat_ngram_kernel, dim3(batch_size), dim3(256), 0, (hipStream_t)stream, logits, V, ld, token_ids, token_ld,
+                       sequence_last_index, no_repeat_ngram_size);
+    MI355_CHECK_LAUNCH("ban_repeat_ngram_kernel");
     return MI355_OK;
 }

@@ -253,6 +253,22 @@ def apply_penalties(logits: torch.Tensor, temperature: Optional[torch.Tensor] = 
     return logits
 
 
+def ban_repeat_ngram(logits: torch.Tensor, token_ids: torch.Tensor, sequence_last_index: torch.Tensor,
+                     no_repeat_ngram_size: torch.Tensor) -> torch.Tensor:
+    """In place on fp32 logits [B', V] (the first B rows are touched): token_ids [B, L] int32, sequence_last_index [B],
+    no_repeat_ngram_size [B] (bindings/common/kernels/banRepeatNgram.cu:30-136)."""
+    _chk(logits, torch.float32, "ban_repeat_ngram.logits"); _chk(token_ids, torch.int32, "ban_repeat_ngram.token_ids")
+    dev = logits.device
+    B, L = token_ids.shape
+    last = sequence_last_index.to(device=dev, dtype=torch.int32).contiguous()
+    ng = no_repeat_ngram_size.to(device=dev, dtype=torch.int32).contiguous()
+    if last.numel() != B or ng.numel() != B or B > logits.shape[0]:
+        raise _C.Mi355Error("ban_repeat_ngram: one last index / n-gram size per history row, at most one row per logit row")
+    _C.check(_C.lib().mi355_ban_repeat_ngram(logits.data_ptr(), B, logits.shape[1], logits.shape[1], token_ids.data_ptr(), L,
+                                             last.data_ptr(), ng.data_ptr(), _stream()), "ban_repeat_ngram")
+    return logits
+
+
 def top_k_top_p_sample(probs: torch.Tensor, top_k: Optional[torch.Tensor], top_p: Optional[torch.Tensor], uniform: torch.Tensor,
                        return_probs: bool = False):
     """Per row of fp32 probabilities: top-k then top-p filter, renormalise, draw by inverse CDF with uniform[r]

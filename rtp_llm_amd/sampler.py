@@ -4,6 +4,7 @@ and the same host-side shortcuts:
 
   1. temperature, only when some row has T != 1                          (:633-645)
   2. repetition / presence / frequency penalties, only when some row is off-default   (:648-685)
+  2b. no_repeat_ngram_size, only when some decoder row has one                          (:242-283)
   3. every top_k == 1 and no probabilities wanted: arg-max of the logits (:688-700)
   4. softmax in place, top_p == 0 reads as 1                             (:703-736)
   5. every top_k == 1: arg-max of the probabilities; otherwise top-k / top-p filter, renormalise, draw   (:739-786)
@@ -11,7 +12,7 @@ and the same host-side shortcuts:
 
 Randomness is explicit: where the reference consumes `generator` inside torch.multinomial, the caller passes one uniform in
 [0, 1) per row (`uniform`), so a run is reproducible and checkable against the oracle.  `cum_log_probs` / `output_log_probs`
-and `no_repeat_ngram_size` are not on this path (the reference's ROCm branch does not update them per token either)."""
+are not on this path (the reference's ROCm branch does not update them per token either)."""
 from dataclasses import dataclass
 from typing import Optional
 
@@ -33,6 +34,7 @@ class GreedyParams:
     repetition_penalty: Optional[torch.Tensor] = None
     presence_penalty: Optional[torch.Tensor] = None
     frequency_penalty: Optional[torch.Tensor] = None
+    no_repeat_ngram_size: Optional[torch.Tensor] = None   # [decoder_batch_size] int32, 0 = off
     output_all_probs: Optional[torch.Tensor] = None     # [batch_size, vocab_size] fp32 GPU: receives the probabilities
     return_original_all_probs: bool = False
     uniform: Optional[torch.Tensor] = None              # [batch_size] fp32 in [0, 1): the draw (see the module docstring)
@@ -67,6 +69,14 @@ def sample_greedy(params: GreedyParams) -> torch.Tensor:
                 lengths[:nd] = _host(params.sequence_lengths, torch.int32)
             ops.apply_penalties(logits, repetition_penalty=rep, presence_penalty=pres, frequency_penalty=freq, output_ids=transposed,
                                 input_lengths=lengths, max_input_length=step + 1, step=step + 1)
+
+    if params.no_repeat_ngram_size is not None and params.sequence_lengths.numel() > 0:
+        ngram = _host(params.no_repeat_ngram_size, torch.int32)
+        nd = params.sequence_lengths.numel()
+        if bool((ngram[:nd] != 0).any()):
+            # the kernel takes the index of the last valid token and adds one itself (CudaSampleOp.cc:262-265)
+            tokens = params.token_ids.to(device=dev, dtype=torch.int32).contiguous()
+            ops.ban_repeat_ngram(logits, tokens[:nd], _host(params.sequence_lengths, torch.int32) - 1, ngram[:nd])
 
     top_k = _host(params.top_k, torch.int32)
     all_greedy = bool((top_k == 1).all())

@@ -43,6 +43,16 @@ PENALTY = dict(
     atol=1e-3)
 
 
+# CudaSamplerTest.cc:842-903 (testBanRepeatNGram): token histories [4, 9], index of the last token per row, n-gram sizes, the one
+# token each row must lose
+NGRAM = dict(
+    logits=torch.tensor([0.1, 0.1, 0.1, 0.1, 0.2, 0.3, 0.1, 0.1, 0.1, 0.1] * 4).reshape(4, 10),
+    token_ids=torch.tensor([0, 2, 3, 4, 5, 0, 0, 2, 0, 1, 2, 3, 3, 3, 1, 2, 3, 0, 1, 2, 1, 2, 1, 2, 1, 2, 0, 9, 8, 6, 9, 8, 0, 0, 0, 0],
+                           dtype=torch.int32).reshape(4, 9),
+    sequence_last_index=torch.tensor([7, 7, 7, 4], dtype=torch.int32), no_repeat_ngram_size=torch.tensor([3, 4, 5, 2], dtype=torch.int32),
+    banned=[3, 3, 1, 6])
+
+
 def oracle_sample_greedy(oracle, c, uniform):
     """The sampler flow (CudaSampleOp.cc:619-800) composed from the oracle's pieces.  -> (ids, probabilities after filter)."""
     step = c["step"]

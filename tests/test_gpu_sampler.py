@@ -158,3 +158,39 @@ def test_sampler_refuses_missing_uniform_and_cpu_logits():
     p.logits = p.logits.cpu()
     with pytest.raises(_C.Mi355Error):
         sampler.sample_greedy(p)
+
+
+def test_ban_repeat_ngram_reproduces_reference_known_answer_and_oracle():
+    """CudaSamplerTest.cc:842-903, then random histories (short vocabularies make repeats frequent) against the oracle, bit for bit."""
+    c = sv.NGRAM
+    got = ops.ban_repeat_ngram(c["logits"].clone().to(DEV), c["token_ids"].to(DEV), c["sequence_last_index"], c["no_repeat_ngram_size"]).cpu()
+    for r in range(4):
+        assert torch.nonzero(got[r] == float("-inf")).flatten().tolist() == [c["banned"][r]]
+    assert torch.equal(got, oracle.ban_repeat_ngram(c["logits"], c["token_ids"], c["sequence_last_index"], c["no_repeat_ngram_size"]))
+    g = torch.Generator().manual_seed(12)
+    B, V, L = 9, 37, 700
+    x = torch.randn(B + 2, V, generator=g)                                  # two extra rows (context rows): untouched
+    tok = torch.randint(-1, 6, (B, L), generator=g, dtype=torch.int32)      # ids in [-1, 5]: many repeats, a few invalid ids
+    last = torch.randint(0, L, (B,), generator=g, dtype=torch.int32)
+    last[0], last[1] = L - 1, 0
+    ng = torch.tensor([2, 3, 0, 1, 4, 2, 7, 3, 700], dtype=torch.int32)
+    got = ops.ban_repeat_ngram(x.clone().to(DEV), tok.to(DEV), last, ng).cpu()
+    # the oracle indexes the logits with the banned id: feed it only the rows' valid ids (an invalid id is skipped by the kernel)
+    exp = x.clone()
+    for b in range(B):
+        n, N = int(ng[b]), int(last[b]) + 1
+        if n == 0 or N < n:
+            continue
+        t = tok[b, :N].tolist()
+        for i in range(N - n + 1):
+            if t[i:i + n - 1] == t[N - n + 1:N] and 0 <= t[i + n - 1] < V:
+                exp[b, t[i + n - 1]] = float("-inf")
+    assert torch.equal(got, exp)
+    # through the sampler flow: greedy rows with a 2-gram ban never repeat a bigram
+    p = sampler.GreedyParams(logits=c["logits"].clone().to(DEV), input_lengths=torch.full((4,), -1, dtype=torch.int32),
+                             sequence_lengths=c["sequence_last_index"] + 1, token_ids=c["token_ids"].clone(), step=8,
+                             top_k=torch.ones(4, dtype=torch.int32), top_p=torch.ones(4), temperature=torch.ones(4),
+                             no_repeat_ngram_size=c["no_repeat_ngram_size"])
+    ids = sampler.sample_greedy(p).cpu()
+    masked = oracle.ban_repeat_ngram(c["logits"], c["token_ids"], c["sequence_last_index"], c["no_repeat_ngram_size"])
+    assert torch.equal(ids, masked.argmax(-1).int())

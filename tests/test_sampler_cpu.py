@@ -124,3 +124,17 @@ def test_sample_greedy_host_flow_penalties_and_probabilities(monkeypatch):
                                                    sequence_lengths=c["sequence_lengths"], token_ids=c["token_ids"].clone(), step=c["step"],
                                                    top_k=c["top_k"], top_p=c["top_p"], temperature=c["temperature"],
                                                    repetition_penalty=torch.ones(4)))
+
+
+def test_oracle_ban_repeat_ngram_reproduces_reference_known_answer():
+    c = sv.NGRAM
+    out = oracle.ban_repeat_ngram(c["logits"], c["token_ids"], c["sequence_last_index"], c["no_repeat_ngram_size"])
+    for r in range(4):
+        for j in range(10):
+            assert (out[r, j] == float("-inf")) == (j == c["banned"][r]), (r, j)
+            assert j == c["banned"][r] or out[r, j] == c["logits"][r, j]
+    # n = 0 and sequences shorter than n: untouched; n = 1 bans every token seen so far
+    out = oracle.ban_repeat_ngram(c["logits"], c["token_ids"], torch.tensor([7, 1, 7, 4]), torch.tensor([0, 4, 1, 1]))
+    assert torch.equal(out[:2], c["logits"][:2])
+    assert sorted(torch.nonzero(out[2] == float("-inf")).flatten().tolist()) == [1, 2]
+    assert sorted(torch.nonzero(out[3] == float("-inf")).flatten().tolist()) == [6, 8, 9]
