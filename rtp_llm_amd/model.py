@@ -507,6 +507,56 @@ class DecoderEngine:
             raise _C.Mi355Error("generate: the KV writer dropped out-of-range tokens (corrupt block table?)")
         return toks
 
+    def generate_sampled(self, prompts: List[List[int]], block_table, max_new_tokens: int, *, top_k=0, top_p=1.0, temperature=1.0,
+                         repetition_penalty=None, presence_penalty=None, frequency_penalty=None, no_repeat_ngram_size=None,
+                         seed: int = 0, prefill_chunk: int = 512) -> List[List[int]]:
+        """Generation through the sampler's non-greedy branch (tp = 1): prefill, then per token one step without sampling
+        (logits only) and `sampler.sample_greedy` over them -- temperature, repetition / presence / frequency penalties over the
+        tokens so far, no-repeat n-gram ban, top-k / top-p filter, draw.  Scalars or one value per sequence; the uniforms of the draw
+        come from `seed` (one per sequence and token), so a run is reproducible.  top_k = 1 is greedy decoding (== generate())."""
+        from . import sampler
+        B = len(prompts)
+        if B > self.max_batch or any(len(pr) < 1 for pr in prompts):
+            raise _C.Mi355Error("generate_sampled: batch exceeds max_batch or empty prompt")
+        self.check_room([len(pr) for pr in prompts], max_new_tokens - 1, block_table, "generate_sampled")
+        vec = lambda v, dt: None if v is None else (torch.as_tensor(v, dtype=dt).reshape(-1).expand(B).contiguous() if torch.as_tensor(v).numel() == 1
+                                                    else torch.as_tensor(v, dtype=dt).reshape(B))
+        k, p_, t = vec(top_k, torch.int32), vec(top_p, torch.float32), vec(temperature, torch.float32)
+        pen = repetition_penalty is not None or presence_penalty is not None or frequency_penalty is not None
+        rep = vec(1.0 if repetition_penalty is None else repetition_penalty, torch.float32) if pen else None
+        pres = vec(0.0 if presence_penalty is None else presence_penalty, torch.float32) if pen else None
+        freq = vec(0.0 if frequency_penalty is None else frequency_penalty, torch.float32) if pen else None
+        ngram = vec(no_repeat_ngram_size, torch.int32)
+        lens = torch.tensor([len(pr) for pr in prompts], dtype=torch.int32)
+        cols = int(lens.max()) + max_new_tokens + 1
+        hist = torch.zeros(B, cols, dtype=torch.int32)            # row b: its prompt, then its generated tokens, compact
+        for b, pr in enumerate(prompts):
+            hist[b, : len(pr)] = torch.tensor(pr, dtype=torch.int32)
+        seq = lens.clone()                                        # valid tokens per row
+        u = torch.rand(max_new_tokens, B, generator=torch.Generator().manual_seed(seed))
+        logits = self.prefill(prompts, block_table, chunk=prefill_chunk)
+        self.set_inputs([0] * B, lens.tolist(), block_table)
+        out = []
+        for i in range(max_new_tokens):
+            step = int(seq.max())                                 # column that receives the new token (CudaSampleOp.cc:797-799)
+            params = sampler.GreedyParams(logits=logits, input_lengths=lens, sequence_lengths=seq, token_ids=hist[:, : step + 1].contiguous(),
+                                          step=step, top_k=k, top_p=p_, temperature=t, repetition_penalty=rep, presence_penalty=pres,
+                                          frequency_penalty=freq, no_repeat_ngram_size=ngram, uniform=u[i])
+            ids = sampler.sample_greedy(params)
+            idc = ids.cpu()
+            hist[torch.arange(B), seq.long()] = idc
+            seq += 1
+            out.append(idc)
+            if i + 1 == max_new_tokens:
+                break
+            self.token_ids[:B].copy_(ids)
+            self.forward(B)                                       # logits of the next token; positions advance here, not in the step
+            self.positions[:B] += 1
+            logits = self.logits[:B]
+        if self.oob_count():
+            raise _C.Mi355Error("generate_sampled: the KV writer dropped out-of-range tokens (corrupt block table?)")
+        return torch.stack(out, 1).tolist()
+
     def capture(self, B: int):
         _C.check(self.lib.mi355_decoder_capture(self.handle, B), "decoder_capture")
 

@@ -194,3 +194,28 @@ def test_ban_repeat_ngram_reproduces_reference_known_answer_and_oracle():
     ids = sampler.sample_greedy(p).cpu()
     masked = oracle.ban_repeat_ngram(c["logits"], c["token_ids"], c["sequence_last_index"], c["no_repeat_ngram_size"])
     assert torch.equal(ids, masked.argmax(-1).int())
+
+
+def test_generate_sampled_end_to_end():
+    """Engine + sampler: top_k = 1 and a one-token nucleus reproduce greedy generation token for token; a seeded sampled run is
+    reproducible; a 2-gram ban leaves no repeated bigram; a presence penalty of 1e4 never emits a token twice."""
+    from rtp_llm_amd import model
+    cfg = model.ModelConfig("tiny-sampler", 2, 512, 8, 2, 64, 1024, 2048, max_pos=512)
+    w = model.synth_model(cfg, "w4", DEV, seed=3)
+    mk = lambda: model.DecoderEngine(cfg, w, kv_int8=False, page=16, num_blocks=64, max_batch=8, max_seq_len=128, device=DEV)
+    prompts = [[5, 9, 2, 7], [11, 3], [8, 8, 8, 1, 4, 6]]
+    bt = torch.arange(3 * 8, dtype=torch.int32).reshape(3, 8)
+    greedy = mk().generate(prompts, bt, 12)
+    assert mk().generate_sampled(prompts, bt, 12, top_k=1) == greedy
+    assert mk().generate_sampled(prompts, bt, 12, top_k=0, top_p=1e-6, temperature=0.7) == greedy
+    a = mk().generate_sampled(prompts, bt, 12, top_k=8, top_p=0.9, temperature=1.3, seed=5)
+    assert a == mk().generate_sampled(prompts, bt, 12, top_k=8, top_p=0.9, temperature=1.3, seed=5)
+    assert a != mk().generate_sampled(prompts, bt, 12, top_k=8, top_p=0.9, temperature=1.3, seed=6)
+    ng = mk().generate_sampled(prompts, bt, 24, top_k=1, no_repeat_ngram_size=2)
+    for b in range(3):
+        seq = prompts[b] + ng[b]
+        for j in range(len(prompts[b]), len(seq)):            # no generated token completes a bigram that occurred before
+            assert (seq[j - 1], seq[j]) not in set(zip(seq[: j - 1], seq[1:j])), (b, j, seq)
+    pp = mk().generate_sampled(prompts, bt, 16, top_k=1, presence_penalty=1e4)
+    for b in range(3):
+        assert len(set(pp[b])) == 16 and not set(pp[b]) & set(prompts[b]), (b, pp[b])
