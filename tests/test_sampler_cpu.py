@@ -138,3 +138,54 @@ def test_oracle_ban_repeat_ngram_reproduces_reference_known_answer():
     assert torch.equal(out[:2], c["logits"][:2])
     assert sorted(torch.nonzero(out[2] == float("-inf")).flatten().tolist()) == [1, 2]
     assert sorted(torch.nonzero(out[3] == float("-inf")).flatten().tolist()) == [6, 8, 9]
+
+
+def _threshold_model(probs, top_k, top_p):
+    """The kernel's algorithm (csrc/sampling.hip top_k_top_p_sample_kernel) restated with exact arithmetic: thresholds on the
+    fp32 bit pattern -- kb = k-th largest pattern, vb = the smallest pattern whose strictly-larger mass fits top_p -- and, for the
+    entries equal to vb, as many in index order as S + j v <= p allows.  Checked against the reference-shaped oracle (sort +
+    cumsum) so that the sort-free formulation itself is pinned on the CPU."""
+    out = []
+    for r in range(probs.shape[0]):
+        q = probs[r].numpy().astype(np.float32)
+        V = len(q)
+        b = q.view(np.uint32).astype(np.int64)
+        k = int(top_k[r])
+        tp = np.float32(top_p[r])
+        if abs(tp) < 1e-7:
+            tp = np.float32(1)
+        keep = np.ones(V, dtype=bool)
+        if 0 < k < V:
+            keep &= b >= np.sort(b)[::-1][k - 1]
+        if abs(tp - 1) >= 1e-7 and q.sum(dtype=np.float64) > tp:
+            vb = next(t for t in np.unique(b) if q[b > t].sum(dtype=np.float64) <= tp)
+            S = q[b > vb].sum(dtype=np.float64)
+            v = float(np.array([vb], dtype=np.uint32).view(np.float32)[0])
+            kp = b > vb
+            rank = 0
+            for j in range(V):
+                if b[j] == vb:
+                    if S + rank * v > tp:
+                        break
+                    kp[j] = True
+                    rank += 1
+            keep &= kp
+        f = np.where(keep, q, 0).astype(np.float32)
+        out.append(f / np.float32(max(f.sum(dtype=np.float32), 1e-10)))
+    return torch.from_numpy(np.stack(out))
+
+
+@pytest.mark.parametrize("V,levels", [(50, 4095), (640, 5), (3000, 3), (4095, 4095)])
+def test_sort_free_threshold_formulation_equals_sort_and_cumsum(V, levels):
+    g = torch.Generator().manual_seed(V + levels)
+    R = 6
+    if levels >= V:        # distinct values
+        probs = torch.stack([(torch.randperm(levels, generator=g)[:V] + 1).float() * 2.0 ** -22 for _ in range(R)])
+    else:                  # few distinct values: long runs of equals, the boundary class is kept partially
+        probs = torch.randint(1, levels + 1, (R, V), generator=g).float() * 2.0 ** -20
+    total = probs.sum(-1)
+    top_p = (torch.tensor([0.05, 0.3, 0.5, 0.77, 0.999, 1.0]) * total).float()
+    top_p[-1] = 1.0
+    top_k = torch.tensor([0, 0, V // 3, 7, V + 5, 1], dtype=torch.int32)
+    want = oracle.top_k_top_p_filter(probs, top_k, top_p)
+    assert torch.equal(_threshold_model(probs, top_k, top_p), want)
