@@ -34,14 +34,17 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
 
 // Inverse-CDF draw from the unnormalised non-negative weights f(0..V-1): the first index j with f(j) > 0 whose inclusive
 // prefix sum, taken in index order, exceeds u01 * sum (V - 1 when rounding leaves none: sampling.cu:418).  Thread tx owns
-// the contiguous segment [lo, hi), so the block-level prefix over threads is the prefix over indices.  Result in *s_found
-// (valid for every thread after the call); returns sum.
+// the contiguous segment [lo, hi) (a multiple of 4 long: segments start on 16-byte boundaries of an aligned row), so the block-level
+// prefix over threads is the prefix over indices.  Result in *s_found (valid for every thread after the call); returns sum.
+__device__ __forceinline__ int draw_segment(int V) { return (((V + kThreads - 1) / kThreads) + 3) & ~3; }
+
 template <class F>
 __device__ __forceinline__ float block_draw(F&& f, int V, float u01, float* s_red, float* s_scan, int* s_found) {
     const int tx = threadIdx.x;
-    const int seg = (V + kThreads - 1) / kThreads;
+    const int seg = draw_segment(V);
     const int lo = min(V, tx * seg), hi = min(V, lo + seg);
     float local = 0.f;
+#pragma unroll 4
     for (int j = lo; j < hi; ++j) local += f(j);
     const float total = block_sum(local, s_red);
     const float u = u01 * total;
@@ -68,6 +71,25 @@ __device__ __forceinline__ float block_draw(F&& f, int V, float u01, float* s_re
     }
     __syncthreads();
     return total;
+}
+
+// One pass over a row of V floats by the whole block: g(value) for every element, 16-byte loads with four in flight per thread
+// when the row allows (a scalar loop waits a full L2 round trip per element: 60 us per pass over a 152064-wide row instead of 4).
+template <class G>
+__device__ __forceinline__ void row_pass(const float* __restrict__ q, int V, bool vec, G&& g) {
+    const int tx = threadIdx.x;
+    int done = 0;
+    if (vec) {
+        const f32x4* q4 = reinterpret_cast<const f32x4*>(q);
+        const int V4 = V >> 2;
+#pragma unroll 4
+        for (int j = tx; j < V4; j += kThreads) {
+            const f32x4 v = q4[j];
+            g(v[0]); g(v[1]); g(v[2]); g(v[3]);
+        }
+        done = V4 << 2;
+    }
+    for (int j = done + tx; j < V; j += kThreads) g(q[j]);
 }
 
 struct RejectParams {
@@ -145,8 +167,9 @@ __global__ __launch_bounds__(kThreads) void softmax_rows_kernel(const float* __r
     __shared__ float s_red[kThreads / 64];
     const float* x = logits + (size_t)blockIdx.x * ld;
     float* y = probs + (size_t)blockIdx.x * V;
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0);
     float m = -3.0e38f;
-    for (int j = threadIdx.x; j < V; j += kThreads) m = fmaxf(m, x[j]);
+    row_pass(x, V, vec, [&](float v) { m = fmaxf(m, v); });
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
     __syncthreads();
@@ -154,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void softmax_rows_kernel(const float* __r
     for (int w = 1; w < kThreads / 64; ++w) m = fmaxf(m, s_red[w]);
     __syncthreads();
     float s = 0.f;
-    for (int j = threadIdx.x; j < V; j += kThreads) s += __expf((x[j] - m) * inv_temp);
+    row_pass(x, V, vec, [&](float v) { s += __expf((v - m) * inv_temp); });
     s = block_sum(s, s_red);
     const float inv = 1.f / s;
     for (int j = threadIdx.x; j < V; j += kThreads) y[j] = __expf((x[j] - m) * inv_temp) * inv;
@@ -268,9 +291,10 @@ __global__ __launch_bounds__(kThreads) void top_k_top_p_sample_kernel(const TopK
     if (fabsf(tp) < 1e-7f) tp = 1.0f;
     bool use_p = fabsf(tp - 1.0f) >= 1e-7f;
     uint32_t tk = 0, tq = 0;   // tk: largest t with #(bits >= t) >= k;  tq: largest t with mass(bits > t) > p
+    const bool vec = ((p.ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.probs) & 15) == 0);
     if (use_p) {               // nothing to drop when even the mass above 0 fits
         float m = 0.f, z = 0.f;
-        for (int j = tx; j < V; j += kThreads) m += pos(q[j]);
+        row_pass(q, V, vec, [&](float x) { m += pos(x); });
         block_sum2(m, z, s_pair);
         use_p = m > tp;
     }
@@ -278,12 +302,12 @@ __global__ __launch_bounds__(kThreads) void top_k_top_p_sample_kernel(const TopK
         for (int bit = 30; bit >= 0; --bit) {
             const uint32_t ck = tk | (1u << bit), cq = tq | (1u << bit);
             float cnt = 0.f, mass = 0.f;
-            for (int j = tx; j < V; j += kThreads) {
-                const float v = pos(q[j]);
+            row_pass(q, V, vec, [&](float x) {
+                const float v = pos(x);
                 const uint32_t b = __float_as_uint(v);
                 cnt += (b >= ck) ? 1.f : 0.f;
                 mass += (b > cq) ? v : 0.f;
-            }
+            });
             block_sum2(cnt, mass, s_pair);
             if (use_k && cnt >= (float)k) tk = ck;
             if (use_p && mass > tp) tq = cq;
@@ -293,7 +317,7 @@ __global__ __launch_bounds__(kThreads) void top_k_top_p_sample_kernel(const TopK
     // ranked in index order over the contiguous segments block_draw uses; `cut` = first index of this thread's segment from
     // which they are dropped.
     const uint32_t kb = use_k ? tk : 0u, vbits = use_p ? tq + 1u : 0u;
-    const int seg = (V + kThreads - 1) / kThreads;
+    const int seg = draw_segment(V);
     const int lo = min(V, tx * seg), hi = min(V, lo + seg);
     int cut = hi;
     if (use_p) {
