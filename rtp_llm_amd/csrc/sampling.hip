@@ -229,31 +229,60 @@ __global__ __launch_bounds__(kThreads) void penalties_kernel(const PenaltyParams
     float* x = p.logits + (size_t)row * p.ld;
     const bool pen = p.output_ids != nullptr;
     int32_t* cnt = pen ? p.counts + (size_t)row * p.V : nullptr;
-    if (pen) {
-        const int input_length = p.input_lengths ? p.input_lengths[row] : p.max_input_length;
-        for (int index = tx; index < p.step; index += kThreads) {
-            if (index >= input_length && index < p.max_input_length) continue;
-            const int tok = p.output_ids[(size_t)index * p.batch + row];
-            if (tok >= p.V || tok < 0) continue;
-            atomicAdd(&cnt[tok], 1);
+    // ---- temperature: the whole row, 16-byte accesses
+    if (p.temperature) {
+        const float inv_t = 1.0f / (p.temperature[row] + 1e-6f);
+        int done = 0;
+        if ((p.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p.logits) & 15) == 0) {
+            f32x4* x4 = reinterpret_cast<f32x4*>(x);
+            const int V4 = p.V >> 2;
+#pragma unroll 4
+            for (int j = tx; j < V4; j += kThreads) {
+                f32x4 v = x4[j];
+                v[0] *= inv_t; v[1] *= inv_t; v[2] *= inv_t; v[3] *= inv_t;
+                x4[j] = v;
+            }
+            done = V4 << 2;
         }
-        __syncthreads();
+        for (int j = done + tx; j < p.V; j += kThreads) x[j] *= inv_t;
     }
-    const float inv_t = p.temperature ? 1.0f / (p.temperature[row] + 1e-6f) : 1.0f;
+    if (!pen) return;
+    // ---- penalties: count the ids of the history; the lane whose increment found a zero owns the id and penalises it once the
+    // counts are final -- the work is proportional to the history, not to the vocabulary (histories beyond 32 entries per lane
+    // fall back to a scan of the row)
     const float rep = p.repetition ? p.repetition[row] : 1.0f, pres = p.presence ? p.presence[row] : 0.0f,
                 freq = p.frequency ? p.frequency[row] : 0.0f;
-    for (int j = tx; j < p.V; j += kThreads) {
-        // the counts were written by atomics of other lanes of this block: read them past the CU's vector cache
-        const int c = pen ? __hip_atomic_load(&cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        if (!p.temperature && c == 0) continue;
-        float logit = x[j];
-        if (p.temperature) logit *= inv_t;
-        if (c > 0) {
-            if (p.repetition) logit = logit < 0.0f ? logit * rep : logit / rep;
-            if (p.presence) logit -= pres;
-            if (p.frequency) logit -= freq * (float)c;
-        }
+    auto penalise = [&](int j, int c) {
+        // written by other lanes of this block (temperature pass above): read past the CU's vector cache
+        float logit = __uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t*>(x + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (p.repetition) logit = logit < 0.0f ? logit * rep : logit / rep;
+        if (p.presence) logit -= pres;
+        if (p.frequency) logit -= freq * (float)c;
         x[j] = logit;
+    };
+    const int input_length = p.input_lengths ? p.input_lengths[row] : p.max_input_length;
+    uint32_t mine = 0;                                     // bit s: the s-th history entry of this lane was the first of its id
+    int s = 0;
+    for (int index = tx; index < p.step; index += kThreads, ++s) {
+        if (index >= input_length && index < p.max_input_length) continue;
+        const int tok = p.output_ids[(size_t)index * p.batch + row];
+        if (tok >= p.V || tok < 0) continue;
+        const int old = atomicAdd(&cnt[tok], 1);
+        if (old == 0 && s < 32) mine |= 1u << s;
+    }
+    __syncthreads();
+    if (p.step <= 32 * kThreads) {
+        s = 0;
+        for (int index = tx; index < p.step; index += kThreads, ++s) {
+            if (!((mine >> s) & 1u)) continue;
+            const int tok = p.output_ids[(size_t)index * p.batch + row];
+            penalise(tok, __hip_atomic_load(&cnt[tok], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+    } else {
+        for (int j = tx; j < p.V; j += kThreads) {
+            const int c = __hip_atomic_load(&cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c > 0) penalise(j, c);
+        }
     }
 }
 

@@ -50,7 +50,7 @@ def test_penalties_reproduce_reference_probabilities():
     assert torch.equal(ids, want.int()) and torch.allclose(probs.cpu(), wprobs, atol=1e-6)
 
 
-@pytest.mark.parametrize("B,V,step", [(3, 97, 7), (5, 4099, 300), (4, 152064, 2500)])
+@pytest.mark.parametrize("B,V,step", [(3, 97, 7), (5, 4099, 300), (4, 152064, 2500), (2, 1031, 40000)])   # the last: beyond 32 history entries per lane
 def test_apply_penalties_matches_oracle(B, V, step):
     g = torch.Generator().manual_seed(B * 1000 + step)
     x = torch.randn(B, V, generator=g) * 3
