@@ -227,3 +227,26 @@ def test_wide1_isa_audit():
         assert r.returncode == 0, r.stderr[-2000:]
         a = subprocess.run([sys.executable, os.path.join(root, "tools", "audit_wide1.py"), os.path.join(tmp, "w1.s")], capture_output=True, text=True)
         assert a.returncode == 0, a.stdout + a.stderr
+
+
+def test_sampler_and_collective_entry_points_validate_on_the_host():
+    """The round-2 additions to the ABI: argument errors come back as a status before anything is launched; empty batches are a no-op."""
+    l = _C.lib()
+    assert l.mi355_apply_penalties(None, 0, 10, 10, None, None, None, None, None, None, 0, 0, None, None) == 0          # empty batch
+    assert l.mi355_apply_penalties(None, 2, 10, 10, None, None, None, None, None, None, 0, 0, None, None) == _C.ERR_ARG
+    assert l.mi355_apply_penalties(1, 2, 10, 8, None, None, None, None, None, None, 0, 0, None, None) == _C.ERR_ARG       # ld < V
+    assert l.mi355_apply_penalties(1, 2, 10, 10, None, 1, None, None, None, None, 0, 4, None, None) == _C.ERR_ARG         # penalties without a history
+    assert b"output_ids" in l.mi355_last_error()
+    assert l.mi355_top_k_top_p_sample(None, 0, 10, 10, None, None, None, None, None, 0, None) == 0
+    assert l.mi355_top_k_top_p_sample(1, 2, 10, 10, None, None, None, 1, None, 0, None) == _C.ERR_ARG                      # no uniforms
+    assert l.mi355_top_k_top_p_sample(1, 2, 10, 10, None, None, 1, 1, 1, 8, None) == _C.ERR_ARG                            # ld_out < V
+    assert l.mi355_ban_repeat_ngram(1, 2, 10, 10, None, 4, 1, 1, None) == _C.ERR_ARG
+    assert l.mi355_ban_repeat_ngram(None, 0, 10, 10, None, 4, None, None, None) == 0
+    assert l.mi355_allgather_hidden(None, 1, 1, 4, 64, None) == _C.ERR_ARG and b"not opened" in l.mi355_last_error()
+    assert l.mi355_decoder_set_embedding_split(None, 1) == _C.ERR_ARG
+    from rtp_llm_amd import model
+    emb = torch.arange(6 * 32, dtype=torch.float16).reshape(6, 32)
+    parts = [model.split_embedding_tp(emb, 2, r) for r in range(2)]
+    assert torch.equal(torch.cat(parts, 1), emb) and all(p.is_contiguous() and p.shape == (6, 16) for p in parts)
+    with pytest.raises(ValueError):
+        model.split_embedding_tp(emb, 3, 0)
