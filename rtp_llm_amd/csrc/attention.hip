@@ -44,6 +44,7 @@ struct AttnParams {
     float*         tmp_ml;  // [B][nh][P][2]
     int B, nh, nkv, G, page, max_blocks, P, PS, seq_add, max_seq, num_blocks;
     int q_len, R, ntile;   // rows per sequence, rows per 16-column tile (16 / G), row tiles per sequence
+    uint32_t page_magic;   // 2^32 / page + 1: floor(t / page) == (t * magic) >> 32 for t * page < 2^32
     float scale_log2; // softmax scale * log2(e)
 };
 
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) qs = __builtin_amdgcn_fdot2(as_h2(v[e]), ones, qs, false);
             }
-            qs += __shfl_xor(qs, 16); qs += __shfl_xor(qs, 32);
+            qs = xor32_sum(xor16_sum(qs));
             kq[c] = 1152.f * qs;
         }
     }
@@ -155,39 +156,64 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
         f32x4 ksc[2], vsc[2];
     };
     const int last = seq_len - 1;
-    // block ids of the group starting at token tb: K rows use window (j>>2), V / scales / P use window w
-    auto lookup = [&](int tb, int& kblk, int& vblk) {
-        const int kw_c = min(tb + (j >> 2) * 8, last & ~7), vw_c = min(tb + w * 8, last & ~7);
-        kblk = min(max(bt[kw_c / p.page], 0), p.num_blocks - 1); vblk = min(max(bt[vw_c / p.page], 0), p.num_blocks - 1);
+    // Page addressing is WAVE-UNIFORM work: a 32-token group is four 8-token windows, each inside one page (page % 8 == 0).
+    // The block ids of a group are fetched by SCALAR loads (s_load, lgkmcnt) and turned into the four windows' element
+    // offsets on the scalar unit; a lane then only selects the window of its K rows (j >> 2) and of its V / scale / P
+    // slots (w).  Vector loads here (round 2) were waited for with vmcnt, an IN-ORDER counter: asking for the ids of group
+    // n + 2 drained every K/V load of group n + 1 issued just before, so a wave never had a group in flight while it
+    // computed (one 16 KB group per ~3.5 us of loaded latency per wave = 4.4 TB/s at b = 64 / ctx 1024).
+    struct Wins { int raw[4]; };                       // block ids as loaded (unclamped; clamped where they are used)
+    const int lastw = last & ~7;                       // whole windows are clamped in range (their tokens carry p = 0)
+    // window token -> (page index, token inside the page): floor(t / page) as one s_mul_hi with magic = 2^32 / page + 1,
+    // exact for t * page < 2^32 (checked on the host)
+    auto page_of = [&](int wt) { return (int)__builtin_amdgcn_readfirstlane((int)(((unsigned long long)(unsigned)wt * p.page_magic) >> 32)); };
+    auto lookup = [&](int tb, Wins& wn) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wn.raw[a] = bt[page_of(min(tb + 8 * a, lastw))];
     };
-    auto load_group = [&](Group& g, int tb, int kblk, int vblk) {
-        const int kw_c = min(tb + (j >> 2) * 8, last & ~7), vw_c = min(tb + w * 8, last & ~7); // whole windows clamped in range
-        const size_t khead = ((size_t)kblk * 2 + 0) * p.nkv + kh;
-        const size_t vhead = ((size_t)vblk * 2 + 1) * p.nkv + kh;
-        // K: tile tau row j -> token kw_c + (j&3) + 4*tau
+    // lane -> window selectors, loop invariant
+    const bool k1 = (j >> 2) == 1, k2 = (j >> 2) == 2, k3 = (j >> 2) == 3;
+    const bool v1 = w == 1, v2 = w == 2, v3 = w == 3;
+    auto load_group = [&](Group& g, int tb, const Wins& wn) {
+        long kof[4], vof[4]; int sof[4];               // element offsets of the windows (uniform: scalar unit)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int wt = min(tb + 8 * a, lastw);
+            const int ti = wt - page_of(wt) * p.page;
+            const int blk = min(max(wn.raw[a], 0), p.num_blocks - 1);
+            const long hk = ((long)blk * 2 + 0) * p.nkv + kh, hv = hk + p.nkv;
+            kof[a] = hk * (long)head_elems + (long)ti * HD;
+            vof[a] = hv * (long)head_elems + ti;
+            sof[a] = (int)hk * p.page + ti;
+        }
+        long kb = kof[0]; kb = k1 ? kof[1] : kb; kb = k2 ? kof[2] : kb; kb = k3 ? kof[3] : kb;
+        long vb = vof[0]; vb = v1 ? vof[1] : vb; vb = v2 ? vof[2] : vb; vb = v3 ? vof[3] : vb;
+        // K: tile tau row j -> token (j & 3) + 4 tau of window j >> 2
+        const char* kl = kvb + (kb + (long)((j & 3) * HD)) * ES + (INT8 ? w * 16 : w * 16);
 #pragma unroll
         for (int tau = 0; tau < 2; ++tau) {
-            const int tok_in = (kw_c % p.page) + (j & 3) + 4 * tau;
-            const char* krow = kvb + (khead * head_elems + (size_t)tok_in * HD) * ES;
+            const char* krow = kl + tau * 4 * HD * ES;
             if (INT8) {
 #pragma unroll
-                for (int sp = 0; sp < NSTEP / 2; ++sp) g.kf[tau][sp] = *reinterpret_cast<const u32x4*>(krow + sp * 64 + w * 16);
+                for (int sp = 0; sp < NSTEP / 2; ++sp) g.kf[tau][sp] = *reinterpret_cast<const u32x4*>(krow + sp * 64);
             } else {
 #pragma unroll
-                for (int s = 0; s < NSTEP; ++s) g.kf[tau][s] = *reinterpret_cast<const u32x4*>(krow + (s * 32 + w * 8) * 2);
+                for (int s = 0; s < NSTEP; ++s) g.kf[tau][s] = *reinterpret_cast<const u32x4*>(krow + s * 64);
             }
         }
-        // V: d-block db row j (channel db*16+j), tokens vw_c .. vw_c+7
-        const int tok_in = vw_c % p.page;
+        // V: d-block db row j (channel db*16+j), the 8 tokens of window w
+        const char* vl = kvb + (vb + (long)j * p.page) * ES;
+        const long vstep = (long)16 * p.page * ES;
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
-            const char* vrow = kvb + (vhead * head_elems + (size_t)(db * 16 + j) * p.page + tok_in) * ES;
+            const char* vrow = vl + db * vstep;
             if (INT8) g.vf8[db] = *reinterpret_cast<const u32x2*>(vrow);
             else      g.vf16[db] = *reinterpret_cast<const u32x4*>(vrow);
         }
         if (INT8) { // scale plane [blk][K|V][nkv][page]: the lane's S rows / P slots are the 8 tokens of window w
-            const float* ks = p.scale_base + (((size_t)vblk * 2 + 0) * p.nkv + kh) * p.page + tok_in;
-            const float* vs = p.scale_base + (((size_t)vblk * 2 + 1) * p.nkv + kh) * p.page + tok_in;
+            int so = sof[0]; so = v1 ? sof[1] : so; so = v2 ? sof[2] : so; so = v3 ? sof[3] : so;
+            const float* ks = p.scale_base + so;
+            const float* vs = ks + (size_t)p.nkv * p.page;
             g.ksc[0] = *reinterpret_cast<const f32x4*>(ks); g.ksc[1] = *reinterpret_cast<const f32x4*>(ks + 4);
             g.vsc[0] = *reinterpret_cast<const f32x4*>(vs); g.vsc[1] = *reinterpret_cast<const f32x4*>(vs + 4);
         }
@@ -234,8 +260,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
                     sv[tau * 4 + r] = v;
                     mx = fmaxf(mx, v);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = xor32_max(xor16_max(mx));             // the column's 32 tokens sit in the 4 lanes j, j+16, j+32, j+48
             // Deferred rescale: the running max is only advanced (and O / l rescaled) when some column's max grew by more than
             // 2^kDefer; until then p = exp2(s - m_run) may exceed 1 by that factor, harmless in fp16 / fp32.  In steady state
             // the per-group multiply of the 32 O accumulators (and their AGPR round trip) disappears.
@@ -309,32 +334,56 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
         // with a period of ~L / (NG - 1) per group instead of L (measured L ~ 3.5 us under load at b = 64).
         // (separate named groups, not an array: an indexed array of these structs ends up in scratch memory)
         Group g0, g1, g2;
-        int k0 = 0, v0 = 0, k1 = 0, v1 = 0, k2 = 0, v2 = 0;
+        Wins w0, w1, w2;
         int tb = pstart + wave * 32;
         if constexpr (NG == 2) {
-            if (tb < pend) { lookup(tb, k0, v0); load_group(g0, tb, k0, v0); }
-            if (tb + GS < pend) lookup(tb + GS, k1, v1);
+            if (tb < pend) { lookup(tb, w0); load_group(g0, tb, w0); }
+            if (tb + GS < pend) lookup(tb + GS, w1);
+            // Steady state without a single condition: both groups of the round and both groups it prefetches lie inside the
+            // partition and need no mask.  (Guards around the loads make hipcc's waitcnt pass assume a load may have been
+            // issued and never consumed: it then waits for the OTHER group's loads before it reuses a register.)
+            while (tb + 3 * GS < pend && tb + GS + 32 <= full_end) {
+                load_group(g1, tb + GS, w1);
+                lookup(tb + 2 * GS, w0);
+                compute_group(g0, tb, std::false_type{});
+                load_group(g0, tb + 2 * GS, w0);
+                lookup(tb + 3 * GS, w1);
+                compute_group(g1, tb + GS, std::false_type{});
+                tb += 2 * GS;
+            }
             for (; tb < pend; tb += 2 * GS) {
-                if (tb + GS < pend) load_group(g1, tb + GS, k1, v1);
-                if (tb + 2 * GS < pend) lookup(tb + 2 * GS, k0, v0);
+                if (tb + GS < pend) load_group(g1, tb + GS, w1);
+                if (tb + 2 * GS < pend) lookup(tb + 2 * GS, w0);
                 compute(g0, tb);
-                if (tb + 2 * GS < pend) load_group(g0, tb + 2 * GS, k0, v0);
-                if (tb + 3 * GS < pend) lookup(tb + 3 * GS, k1, v1);
+                if (tb + 2 * GS < pend) load_group(g0, tb + 2 * GS, w0);
+                if (tb + 3 * GS < pend) lookup(tb + 3 * GS, w1);
                 if (tb + GS < pend) compute(g1, tb + GS);
             }
         } else {
-            if (tb < pend) { lookup(tb, k0, v0); load_group(g0, tb, k0, v0); }
-            if (tb + GS < pend) { lookup(tb + GS, k1, v1); load_group(g1, tb + GS, k1, v1); }
-            if (tb + 2 * GS < pend) lookup(tb + 2 * GS, k2, v2);
+            if (tb < pend) { lookup(tb, w0); load_group(g0, tb, w0); }
+            if (tb + GS < pend) { lookup(tb + GS, w1); load_group(g1, tb + GS, w1); }
+            if (tb + 2 * GS < pend) lookup(tb + 2 * GS, w2);
+            while (tb + 5 * GS < pend && tb + 2 * GS + 32 <= full_end) {
+                load_group(g2, tb + 2 * GS, w2);
+                lookup(tb + 3 * GS, w0);
+                compute_group(g0, tb, std::false_type{});
+                load_group(g0, tb + 3 * GS, w0);
+                lookup(tb + 4 * GS, w1);
+                compute_group(g1, tb + GS, std::false_type{});
+                load_group(g1, tb + 4 * GS, w1);
+                lookup(tb + 5 * GS, w2);
+                compute_group(g2, tb + 2 * GS, std::false_type{});
+                tb += 3 * GS;
+            }
             for (; tb < pend; tb += 3 * GS) {
-                if (tb + 2 * GS < pend) load_group(g2, tb + 2 * GS, k2, v2);
-                if (tb + 3 * GS < pend) lookup(tb + 3 * GS, k0, v0);
+                if (tb + 2 * GS < pend) load_group(g2, tb + 2 * GS, w2);
+                if (tb + 3 * GS < pend) lookup(tb + 3 * GS, w0);
                 compute(g0, tb);
-                if (tb + 3 * GS < pend) load_group(g0, tb + 3 * GS, k0, v0);
-                if (tb + 4 * GS < pend) lookup(tb + 4 * GS, k1, v1);
+                if (tb + 3 * GS < pend) load_group(g0, tb + 3 * GS, w0);
+                if (tb + 4 * GS < pend) lookup(tb + 4 * GS, w1);
                 if (tb + GS < pend) compute(g1, tb + GS);
-                if (tb + 4 * GS < pend) load_group(g1, tb + 4 * GS, k1, v1);
-                if (tb + 5 * GS < pend) lookup(tb + 5 * GS, k2, v2);
+                if (tb + 4 * GS < pend) load_group(g1, tb + 4 * GS, w1);
+                if (tb + 5 * GS < pend) lookup(tb + 5 * GS, w2);
                 if (tb + 2 * GS < pend) compute(g2, tb + 2 * GS);
             }
         }
@@ -346,14 +395,13 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
         float lr = l_run[c];
-        lr += __shfl_xor(lr, 16);
-        lr += __shfl_xor(lr, 32);
+        lr = xor32_sum(xor16_sum(lr));
         if (c) __syncthreads();
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
             *reinterpret_cast<f32x4*>(&s_o[wave][j][db * 16 + w * 4]) = o[c][db];
         float l16 = l16_run[c];
-        if (INT8) { l16 += __shfl_xor(l16, 16); l16 += __shfl_xor(l16, 32); }
+        if (INT8) l16 = xor32_sum(xor16_sum(l16));
         if (w == 0) { s_m[wave][j] = m_run[c]; s_l[wave][j] = lr; s_b[wave][j] = 1152.f * l16; }
         __syncthreads();
         // thread -> (column jj, 4 channels); 16 columns * HD/4 vectors
@@ -463,6 +511,8 @@ int launch_attn(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_
     MI355_CHECK_ARG(kv->num_blocks > 0, "paged_attn: num_blocks=%d", kv->num_blocks);
     MI355_CHECK_ARG(max_seq_len > 0 && (long)max_blocks_per_seq * kv->page >= max_seq_len,
                     "paged_attn: max_seq_len=%d exceeds block table", max_seq_len);
+    MI355_CHECK_ARG((long)max_seq_len * kv->page < (1l << 32) && (long)kv->num_blocks * 2 * kv->nkv * kv->page < (1l << 31),
+                    "paged_attn: max_seq_len * page >= 2^32 or scale plane >= 2^31 entries");
     const bool int8 = kv->kv_dtype == MI355_KV_INT8;
     MI355_CHECK_ARG(!int8 || kv->scale_base, "paged_attn: int8 cache needs scale_base");
     AttnParams p;
@@ -471,6 +521,7 @@ int launch_attn(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_
     p.page = kv->page; p.max_blocks = max_blocks_per_seq; p.seq_add = seq_lens_minus_one ? 1 : 0;
     p.max_seq = max_seq_len; p.num_blocks = kv->num_blocks;
     p.q_len = q_len; p.R = 16 / p.G;
+    p.page_magic = (uint32_t)((1ull << 32) / (unsigned)kv->page + 1);
     const int NT = q_len > p.R ? 2 : 1;                 // column tiles per block: 2 x R rows share one pass over the KV
     p.ntile = cdiv(q_len, NT * p.R);
     p.P = plan_partitions(B * p.ntile, kv->nkv, max_seq_len, &p.PS);

@@ -102,6 +102,28 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Combine a value with the lanes 16 / 32 away (lane ^ 16, lane ^ 32) without the LDS crossbar: v_permlane16_swap /
+// v_permlane32_swap trade 16-lane rows between two registers (semantics measured on gfx950, tools/probe/permlane_swap.hip:
+// 16: a -> [A0 B0 A2 B2], b -> [A1 B1 A3 B3]; 32: a -> [A0 A1 B0 B1], b -> [A2 A3 B2 B3]); with a = b = v the two results
+// hold v[lane] and v[lane ^ 16] (resp. ^ 32) in some order, which is all a commutative combine needs.  Pure VALU: no
+// lgkmcnt traffic (ds_bpermute, which __shfl_xor compiles to, shares that counter with scalar loads).
+__device__ __forceinline__ float xor16_max(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+__device__ __forceinline__ float xor16_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // compile-time loop: the body sees its index as a constant expression (std::integral_constant)

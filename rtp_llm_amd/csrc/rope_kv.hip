@@ -40,34 +40,43 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const RopeParams p) 
     const bool act = lane < half;
     const int col0 = h * p.hd + lane, col1 = col0 + half;
 
-    float x0 = 0.f, x1 = 0.f;
-    if (act) {
-        if (p.partials) {
-            const size_t sstride = (size_t)p.T * p.ld;
-            const float* src = p.partials + (size_t)t * p.ld;
-            int s = 0;
-            for (; s + 4 <= p.nsplit; s += 4) { // 4 slabs in flight per round trip, summed in index order
-                float a[4], b[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { a[u] = src[(s + u) * sstride + col0]; b[u] = src[(s + u) * sstride + col1]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { x0 += a[u]; x1 += b[u]; }
-            }
-            for (; s < p.nsplit; ++s) { x0 += src[s * sstride + col0]; x1 += src[s * sstride + col1]; }
-        } else {
-            x0 = (float)p.qkv[(size_t)t * p.ld + col0];
-            x1 = (float)p.qkv[(size_t)t * p.ld + col1];
-        }
-        if (p.bias) { x0 += (float)p.bias[col0]; x1 += (float)p.bias[col1]; }
-        // the QKV linear's output is an fp16 tensor in the reference
-        x0 = (float)(f16)x0; x1 = (float)(f16)x1;
-    }
+    // Everything is requested before the first wait (round 2 walked 8 dependent round trips: 4 slabs, 3 tail slabs one by
+    // one, bias, position, rotation row, block id): the position and the block id are wave-uniform (scalar loads), the
+    // slabs of a column are up to 16 independent loads, the rotation row follows the position.
     const int pos_in = p.positions[t];
     const int pos_lim = min(p.max_pos, p.max_blocks * p.page);
     const int pos = min(max(pos_in, 0), pos_lim - 1);       // clamped: the rotation table and the block table stay in range
     const bool is_v = h >= p.nh + p.nkv;
+    const int blk = (h >= p.nh) ? p.block_table[(size_t)(t / p.q_len) * p.max_blocks + pos / p.page] : 0;
+    float2 cs = {1.f, 0.f};
+    if (!is_v && act) cs = *reinterpret_cast<const float2*>(p.cos_sin + ((size_t)pos * half + lane) * 2);
+    float x0 = 0.f, x1 = 0.f;
+    if (act) {
+        f16 bh0 = (f16)0.f, bh1 = (f16)0.f;
+        if (p.partials) {
+            const size_t sstride = (size_t)p.T * p.ld;
+            const float* src = p.partials + (size_t)t * p.ld;
+            for (int s0 = 0; s0 < p.nsplit; s0 += 8) {      // 8 slabs (16 loads) in flight per round trip, summed in index order
+                float a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {               // slabs past the end: re-read the last one, add zero
+                    const int su = min(s0 + u, p.nsplit - 1);
+                    a[u] = src[su * sstride + col0]; b[u] = src[su * sstride + col1];
+                }
+                if (s0 == 0 && p.bias) { bh0 = p.bias[col0]; bh1 = p.bias[col1]; }   // behind the slabs in the (in-order) queue
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const bool ok = s0 + u < p.nsplit; x0 += ok ? a[u] : 0.f; x1 += ok ? b[u] : 0.f; }
+            }
+        } else {
+            const f16 q0 = p.qkv[(size_t)t * p.ld + col0], q1 = p.qkv[(size_t)t * p.ld + col1];
+            if (p.bias) { bh0 = p.bias[col0]; bh1 = p.bias[col1]; }
+            x0 = (float)q0; x1 = (float)q1;
+        }
+        x0 += (float)bh0; x1 += (float)bh1;
+        // the QKV linear's output is an fp16 tensor in the reference
+        x0 = (float)(f16)x0; x1 = (float)(f16)x1;
+    }
     if (!is_v && act) {
-        const float2 cs = *reinterpret_cast<const float2*>(p.cos_sin + ((size_t)pos * half + lane) * 2);
         const float r0 = cs.x * x0 - cs.y * x1;
         const float r1 = cs.x * x1 + cs.y * x0;
         x0 = (float)(f16)r0; x1 = (float)(f16)r1;
@@ -82,7 +91,6 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const RopeParams p) 
     // ---- K / V into the paged cache
     const int kh  = is_v ? h - p.nh - p.nkv : h - p.nh;
     if (pos_in < 0) return;                                  // padding row of a multi-row step: nothing to store
-    const int blk = p.block_table[(size_t)(t / p.q_len) * p.max_blocks + pos / p.page];
     if (pos != pos_in || blk < 0 || blk >= p.num_blocks) {   // stale position / block id: never write somebody else's page
         if (h == p.nh && lane == 0 && p.oob_count) atomicAdd(p.oob_count, 1);
         return;
