@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--debug-set", default="", help="debug only: 'idx=val,...' forwarded to mi355_debug_set (kernel A/B switches)")
+    ap.add_argument("--prefetch", type=int, default=None, help="weight-prefetch mask (mi355_decoder_set_weight_prefetch); default: the engine's")
     args = ap.parse_args()
 
     if args.debug_set:   # kernel A/B switches exist only in the tuning build (python -m rtp_llm_amd.build --tuning)
@@ -243,6 +244,8 @@ def main():
     log(f"[rank {rank}] setup {time.time() - t0:.1f}s: {args.workload} B={B} ctx={ctx} replicas={dp} "
         f"weights {eng.packed_bytes / 1e9:.2f} GB + lm_head {eng.packed_bytes_lm_head / 1e9:.2f} GB")
     graph = None
+    if args.prefetch is not None:
+        eng.set_weight_prefetch(args.prefetch)
     if not args.no_graph:
         eng.capture(B)
     run = (lambda n: eng.replay(B, n)) if not args.no_graph else (lambda n: [eng.step(B) for _ in range(n)])

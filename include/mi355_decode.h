@@ -475,6 +475,19 @@ int mi355_decoder_attach_allreduce(mi355_decoder_t* d, mi355_allreduce_t* ar, in
  * reference's hidden-split embedding weight, modules/base/common/embedding.py:22-59); every step then looks its slice up and
  * all-gathers the hidden dimension (mi355_allgather_hidden) instead of reading a replicated table.  After attach_allreduce. */
 int mi355_decoder_set_embedding_split(mi355_decoder_t* d, int32_t on);
+/* Weight prefetch one launch ahead (tp_size == 1; under tensor parallelism the all-reduce points prefetch on their own, see
+ * mi355_decoder_attach_allreduce): while a latency-bound launch runs, a side stream pulls the weights of a later linear into
+ * the 256 MB Infinity Cache, joined (event edge, captured into the step graph) right before that linear.  The hook the
+ * reference keeps for this is DeviceResourceConfig{enable_comm_overlap, overlap_comm_type} (rtp_llm/cpp/config/ConfigModules.h:275-282).
+ * mask: MI355_PF_* bits, 0 = off (default).  Invalidates captured graphs. */
+enum {
+    MI355_PF_QKV      = 1,   /* next layer's QKV, requested before the down GEMM is launched */
+    MI355_PF_O        = 2,   /* O, requested behind the QKV GEMM (runs under RoPE / KV write and attention) */
+    MI355_PF_GATE_UP  = 4,   /* gate_up (first 48 MB), requested behind the O GEMM (runs under reduce + RMSNorm) */
+    MI355_PF_QKV_LATE = 16,  /* next layer's QKV, requested behind the down GEMM (runs under reduce + RMSNorm only) */
+    MI355_PF_O_LATE   = 32   /* O, requested behind the RoPE / KV-write launch (runs under attention only) */
+};
+int mi355_decoder_set_weight_prefetch(mi355_decoder_t* d, int32_t mask);
 
 int mi355_decoder_capture(mi355_decoder_t* d, int32_t B);
 int mi355_decoder_replay(mi355_decoder_t* d, int32_t B, int32_t nsteps, mi355_stream_t stream);

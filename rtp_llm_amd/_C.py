@@ -16,6 +16,7 @@ OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_WORKSPACE = 0, -1, -2, -3, -4
 W4, W8, W16 = 4, 8, 16
 KV_FP16, KV_INT8 = 0, 1
 EPI_NONE, EPI_SILU_MUL, EPI_OUT_F32 = 0, 1, 2
+PF_QKV, PF_O, PF_GATE_UP, PF_QKV_LATE, PF_O_LATE = 1, 2, 4, 16, 32   # mi355_decoder_set_weight_prefetch mask bits
 HINT_STAGED, HINT_NO_PERSISTENT = 0x100, 0x200
 ABI_VERSION = 2
 KC_NAMES = ["gemm_quant", "gemm_lmhead", "attn", "rope_kv", "norm", "other", "comm"]
@@ -93,6 +94,7 @@ SIGNATURES = {
     "mi355_allreduce_argmax": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "mi355_decoder_attach_allreduce": (i32, [vp, vp, i32]),
     "mi355_decoder_set_embedding_split": (i32, [vp, i32]),
+    "mi355_decoder_set_weight_prefetch": (i32, [vp, i32]),
     "mi355_allgather_hidden": (i32, [vp, vp, vp, i32, i32, vp]),
     "mi355_decoder_workspace_bytes": (sz, [C.POINTER(ModelConfig)]),
     "mi355_decoder_create": (vp, [C.POINTER(ModelConfig), C.POINTER(LayerWeights), C.POINTER(ModelWeights), C.POINTER(StepBuffers)]),

@@ -107,22 +107,24 @@ __device__ __forceinline__ float wave_max(float v) {
 // 16: a -> [A0 B0 A2 B2], b -> [A1 B1 A3 B3]; 32: a -> [A0 A1 B0 B1], b -> [A2 A3 B2 B3]); with a = b = v the two results
 // hold v[lane] and v[lane ^ 16] (resp. ^ 32) in some order, which is all a commutative combine needs.  Pure VALU: no
 // lgkmcnt traffic (ds_bpermute, which __shfl_xor compiles to, shares that counter with scalar loads).
-__device__ __forceinline__ float xor16_max(float v) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+// Inline asm, not __builtin_amdgcn_permlane{16,32}_swap: with hipcc 7.2 the builtin's two results came out as ONE register
+// whenever they were combined (r[0] + r[1] compiled to v + v; seen in the ISA, caught by the TP engine test).  The leading
+// s_nop 1 gives the 2 wait states a VALU-written operand needs before a permlane swap reads it (the compiler's copy of v
+// into the second register sits right in front of the statement and hipcc pads nothing inside or before an asm).
+__device__ __forceinline__ void swap16(float v, float& r0, float& r1) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    r0 = a; r1 = b;
 }
-__device__ __forceinline__ float xor32_max(float v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+__device__ __forceinline__ void swap32(float v, float& r0, float& r1) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    r0 = a; r1 = b;
 }
-__device__ __forceinline__ float xor16_sum(float v) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
-}
-__device__ __forceinline__ float xor32_sum(float v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
-}
+__device__ __forceinline__ float xor16_max(float v) { float a, b; swap16(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xor32_max(float v) { float a, b; swap32(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xor16_sum(float v) { float a, b; swap16(v, a, b); return a + b; }
+__device__ __forceinline__ float xor32_sum(float v) { float a, b; swap32(v, a, b); return a + b; }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

@@ -48,6 +48,11 @@ struct mi355_decoder {
     hipStream_t side_stream;
     hipEvent_t  ev_fork, ev_join;
     bool        overlap;
+    // weight prefetch one launch ahead (all tp): while a latency- or issue-bound launch runs on the main stream, a side stream
+    // streams the weights of a LATER linear into the Infinity Cache (256 MB, memory side); the linear then starts from cache
+    // instead of paying the first-byte latency of HBM under its own launch burst.  pf_mask: MI355_PF_* bits.
+    int         pf_mask;
+    bool        pf_pending;
     float* partials;
     size_t attn_ws_bytes, argmax_ws_bytes, partials_bytes;
     void*    wide_ws;        // max_batch > 64: buffers of the generic large-batch step (mi355_decoder_prefill with q_len = 1)
@@ -190,6 +195,7 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     d->xn = bufs->hidden; // the normed hidden state lives in the caller-visible buffer
     d->B = 0; d->q_len = 1; d->cap_stream = nullptr; d->prof_on = false; d->ev_used = 0; d->ar = nullptr; d->vocab_offset = 0;
     d->side_stream = nullptr; d->ev_fork = d->ev_join = nullptr; d->overlap = false;
+    d->pf_mask = 0; d->pf_pending = false;
     d->fuse_qkv = cfg->kv_dtype == MI355_KV_FP16 && cfg->rope_dim == cfg->hd;
     d->fuse_o = d->fuse_down = cfg->tp_size == 1;
     d->fuse_rows = 8;
@@ -306,6 +312,54 @@ int comm_with_prefetch(mi355_decoder* d, hipStream_t st, const mi355_weight_t* n
 }
 } // namespace
 
+namespace {
+bool side_ready(mi355_decoder* d) {
+    if (d->side_stream) return d->ev_fork && d->ev_join;
+    const bool ok = hipStreamCreateWithFlags(&d->side_stream, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming) == hipSuccess;
+    (void)hipGetLastError();
+    return ok;
+}
+// fork: from this point of `st` on, the side stream pulls up to `cap` bytes of w into the Infinity Cache
+int pf_issue(mi355_decoder* d, hipStream_t st, const mi355_weight_t* w, size_t cap) {
+    if (!w || !w->qweight || d->pf_pending || !side_ready(d)) return MI355_OK;
+    size_t bytes = (size_t)w->K_pad * w->N_pad * w->wbits / 8;
+    if (bytes > cap) bytes = cap;
+    if (hipEventRecord(d->ev_fork, st) != hipSuccess || hipStreamWaitEvent(d->side_stream, d->ev_fork, 0) != hipSuccess) {
+        mi355_set_error("decoder: fork to the prefetch stream failed: %s", hipGetErrorString(hipGetLastError()));
+        return MI355_ERR_HIP;
+    }
+    const int rc = mi355_prefetch(w->qweight, bytes, d->oob_count + 32, d->side_stream);
+    if (rc < 0) return rc;
+    if (hipEventRecord(d->ev_join, d->side_stream) != hipSuccess) {
+        mi355_set_error("decoder: prefetch stream event failed: %s", hipGetErrorString(hipGetLastError()));
+        return MI355_ERR_HIP;
+    }
+    d->pf_pending = true;
+    return MI355_OK;
+}
+// join: launches issued on `st` after this point wait for the prefetch in flight (it has normally long finished)
+int pf_join(mi355_decoder* d, hipStream_t st) {
+    if (!d->pf_pending) return MI355_OK;
+    d->pf_pending = false;
+    if (hipStreamWaitEvent(st, d->ev_join, 0) != hipSuccess) {
+        mi355_set_error("decoder: join of the prefetch stream failed: %s", hipGetErrorString(hipGetLastError()));
+        return MI355_ERR_HIP;
+    }
+    return MI355_OK;
+}
+constexpr size_t kPfCap = (size_t)48 << 20;
+} // namespace
+
+extern "C" int mi355_decoder_set_weight_prefetch(mi355_decoder_t* d, int32_t mask) {
+    if (!d || mask < 0) { mi355_set_error("decoder_set_weight_prefetch: bad argument"); return MI355_ERR_ARG; }
+    for (auto& kv : d->graphs) hipGraphExecDestroy(kv.second);   // captured steps bake the fork / join edges in
+    d->graphs.clear();
+    d->pf_mask = mask;
+    return MI355_OK;
+}
+
 extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_stream_t stream) {
     if (!d || l < 0 || l >= d->cfg.num_layers || d->B <= 0) { mi355_set_error("decoder_layer_attn: layer=%d", l); return MI355_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
@@ -319,6 +373,8 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
     mi355_kv_layer_t kv = kv_of(d, l);
     const bool small = B <= d->fuse_rows;
     const bool normed = small && d->fuse_norm;            // no norm launches in this step: see fuse_norm
+    const int pf = c.tp_size == 1 ? d->pf_mask : 0;       // (tp > 1: the side stream belongs to comm_with_prefetch)
+    if (int e = pf_join(d, st)) return e;                  // this layer's QKV weights, requested behind the previous down GEMM
     if (d->fuse_qkv && small) {
         // layer 0 reads the rows mi355_decoder_begin normed; later layers normalise the residual rows on load
         const mi355_fused_norm_t fn = {d->ssq, c.hidden / 16, (c.hidden / 16 + 3) & ~3, L.input_norm, c.rms_eps};
@@ -327,22 +383,30 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
                                                          d->model.cos_sin, c.rope_dim, c.max_pos, d->bufs.positions,
                                                          d->bufs.block_table, c.max_blocks_per_seq, d->q_len, c.nh, &kv, d->q_buf,
                                                          d->oob_count, st));
+        if (pf & (MI355_PF_O | MI355_PF_O_LATE)) if (int e = pf_issue(d, st, &L.o, kPfCap)) return e;
     } else {
         RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->xn, B, &L.qkv, d->partials, kMaxSplits, st));
+        if (pf & MI355_PF_O) if (int e = pf_issue(d, st, &L.o, kPfCap)) return e;          // under RoPE + attention
         RUN(MI355_KC_ROPE_KV, mi355_rope_kv_write_rows(nullptr, d->partials, ns, L.qkv.N_pad, L.qkv_bias, d->model.cos_sin, c.rope_dim,
                                                        c.max_pos, d->bufs.positions, d->bufs.block_table, c.max_blocks_per_seq, B,
                                                        d->q_len, c.nh, &kv, d->q_buf, d->oob_count, st));
+        if (pf & MI355_PF_O_LATE) if (int e = pf_issue(d, st, &L.o, kPfCap)) return e;     // under attention only
     }
     // q_len > 1: rows of one sequence share a pass over its KV, causal mask inside the page walk (is_target_verify)
     RUN(MI355_KC_ATTN, mi355_paged_attn_rows(d->q_buf, &kv, d->bufs.block_table, c.max_blocks_per_seq, d->bufs.positions,
                                              B / d->q_len, d->q_len, c.nh, 1.0f / sqrtf((float)c.hd), c.max_seq_len, d->attn_out,
                                              d->attn_ws, d->attn_ws_bytes, st));
+    if (int e = pf_join(d, st)) return e;
     if (d->fuse_o && small) {     // h += fp16(attn W_o) in the GEMM's epilogue: no slabs; the norm moves into gate_up (or stays a launch)
         RUN(MI355_KC_GEMM_QUANT, mi355_linear_residual(d->attn_out, B, &L.o, nullptr, d->resid, d->resid, normed ? d->ssq : nullptr, (c.hidden / 16 + 3) & ~3, st));
-        if (!normed) RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, L.post_norm, c.rms_eps, B, c.hidden, d->xn, st));
+        if (!normed) {
+            if (pf & MI355_PF_GATE_UP) if (int e = pf_issue(d, st, &L.gate_up, kPfCap)) return e;
+            RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, L.post_norm, c.rms_eps, B, c.hidden, d->xn, st));
+        }
         return MI355_OK;
     }
     RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->attn_out, B, &L.o, d->partials, kMaxSplits, st));
+    if (pf & MI355_PF_GATE_UP) if (int e = pf_issue(d, st, &L.gate_up, kPfCap)) return e;   // under the reduce + norm launch
     if (c.tp_size == 1) {
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid, L.post_norm,
                                              c.rms_eps, B, c.hidden, d->xn, st));
@@ -367,6 +431,8 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
     }
     const bool small = B <= d->fuse_rows;
     const bool normed = small && d->fuse_norm && d->fuse_o;
+    const int pf = c.tp_size == 1 ? d->pf_mask : 0;
+    if (int e = pf_join(d, st)) return e;
     if (normed) {   // post-attention RMSNorm on load + gate_up + SiLU-gate in one launch
         const mi355_fused_norm_t fn = {d->ssq, c.hidden / 16, (c.hidden / 16 + 3) & ~3, L.post_norm, c.rms_eps};
         RUN(MI355_KC_GEMM_QUANT, mi355_norm_linear(d->resid, B, &fn, &L.gate_up, nullptr, d->act, MI355_EPI_SILU_MUL, st));
@@ -376,6 +442,8 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
     }
     int ns = 0;
     const void* next_norm = (l + 1 < c.num_layers) ? d->layers[l + 1].input_norm : d->model.final_norm;
+    const mi355_weight_t* next_qkv = (l + 1 < c.num_layers) ? &d->layers[l + 1].qkv : nullptr;
+    if (pf & MI355_PF_QKV) if (int e = pf_issue(d, st, next_qkv, kPfCap)) return e;         // under the down GEMM (+ norm)
     if (d->fuse_down && small) {
         const bool last = l + 1 == c.num_layers;          // the final norm feeds lm_head: that one stays a launch
         RUN(MI355_KC_GEMM_QUANT, mi355_linear_residual(d->act, B, &L.down, nullptr, d->resid, d->resid, (normed && !last) ? d->ssq : nullptr, (c.hidden / 16 + 3) & ~3, st));
@@ -383,6 +451,7 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
         return MI355_OK;
     }
     RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->act, B, &L.down, d->partials, kMaxSplits, st));
+    if (pf & MI355_PF_QKV_LATE) if (int e = pf_issue(d, st, next_qkv, kPfCap)) return e;    // under the reduce + norm launch only
     if (c.tp_size == 1) {
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
                                              c.rms_eps, B, c.hidden, d->xn, st));
@@ -506,6 +575,7 @@ extern "C" int mi355_decoder_finish(mi355_decoder_t* d, int32_t sample, mi355_st
     if (!d || d->B <= 0) { mi355_set_error("decoder_finish: no step in flight"); return MI355_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     const auto& c = d->cfg; const int B = d->B;
+    if (int e = pf_join(d, st)) return e;
     if (c.tp_size > 1 && !d->ar) {
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(d->bufs.ar_buf, nullptr, 0, 0, nullptr, d->resid, d->resid, d->model.final_norm,
                                              c.rms_eps, B, c.hidden, d->xn, st));

@@ -44,6 +44,7 @@ extern "C" int mi355_gemm_fullk_rope(const void* gp, int wbits, int group_size, 
 
 #ifdef MI355_TUNING
 int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern unsigned long long* g_wide_stamps;   // gemm_wide.hip: device buffer set by mi355_debug_ptr
 #endif
 
 namespace {
@@ -83,6 +84,13 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MI355_TUNING
+    unsigned long long stp[5] = {0, 0, 0, 0, 0};
+    if (p.stamps) stp[0] = wall_clock64();
+#define WQ_STAMP(i) do { if (p.stamps) stp[i] = wall_clock64(); } while (0)
+#else
+#define WQ_STAMP(i) do { } while (0)
+#endif
     const int wn   = wave % NWN;                   // n-wave index
     const int kg   = wave / NWN;                   // k-group
     const int tg   = tid - kg * GT;                // thread index inside the k-group
@@ -212,6 +220,7 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
     for (int d = 0; d < D; ++d) load_w(d, d);
     store_x(0, 0);
     __syncthreads();
+    WQ_STAMP(1);
 
     auto compute = [&](int d, int buf) {
 #pragma unroll
@@ -363,6 +372,7 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
         for (int d = 0; d < D; ++d) slot(d, it + d);
     }
 
+    WQ_STAMP(2);
     // ------------------------------------------------------------ merge k-groups, epilogue
     if (KG > 1) {
         if (kg > 0) {
@@ -424,6 +434,18 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
             }
         }
     }
+#ifdef MI355_TUNING
+    if (p.stamps) {
+        stp[3] = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stp[4] = wall_clock64();
+        if (tid == 0) {
+            unsigned long long* d = p.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 5;
+            for (int i = 0; i < 5; ++i) d[i] = stp[i];
+        }
+    }
+#endif
+#undef WQ_STAMP
 }
 
 // Sum split-K slabs (+bias) and apply the epilogue.  One thread per 4 columns.
@@ -539,6 +561,9 @@ void fill_params(GemmParams& p, const void* x, int M, const mi355_weight_t* w) {
     p.meta_bytes = (uint32_t)((uint64_t)ngroups * w->N_pad * 4);
     p.x_bytes = (uint32_t)((uint64_t)M * w->K * 2);
     p.bias = nullptr; p.y = nullptr; p.partials = nullptr; p.ldy = 0;
+#ifdef MI355_TUNING
+    p.stamps = (TUNE(7) == 2) ? g_wide_stamps : nullptr;
+#endif
 }
 
 // Block shape + split-K plan.  The kernel is a per-block pipeline of n_it chunk iterations (one barrier each);

@@ -63,6 +63,9 @@ struct GemmParams {
     int mode;                 // 0 partial slabs, 1 fp16, 2 fp16 silu-mul, 3 fp32
     int ldy;
     uint32_t qw_bytes, meta_bytes, x_bytes;
+#ifdef MI355_TUNING
+    unsigned long long* stamps;   // tools/wq_stamps.py: wall_clock64 of wave 0 at entry / prologue done / loop done / stores issued / exit, per block
+#endif
 };
 
 enum { MODE_PARTIAL = 0, MODE_F16 = 1, MODE_SILU = 2, MODE_F32 = 3 };

@@ -574,6 +574,11 @@ class DecoderEngine:
         _C.check(self.lib.mi355_decoder_attach_allreduce(self.handle, ar.handle, int(vocab_offset)), "decoder_attach_allreduce")
         self._ar = ar
 
+    def set_weight_prefetch(self, mask: int):
+        """Weight prefetch one launch ahead on a side stream (mi355_decoder_set_weight_prefetch, _C.PF_* bits; 0 = off).
+        Captured graphs are dropped: capture again."""
+        _C.check(self.lib.mi355_decoder_set_weight_prefetch(self.handle, int(mask)), "decoder_set_weight_prefetch")
+
     def set_embedding_split(self, on: bool = True):
         """The embedding tensor of this engine is the rank's [vocab, hidden / tp] column slice (split_embedding_tp): look it up and
         all-gather the hidden dimension every step (modules/base/common/embedding.py:50-58).  After attach_allreduce."""
