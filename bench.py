@@ -372,6 +372,8 @@ def main():
             tcfg, teng, treset = build_engine(tpn, rank % tpn, rank // tpn)
             ar = distributed.CustomAllReduce(max_bytes=B * cfg_full.hidden * 2, group=grp)
             teng.attach_allreduce(ar, (rank % tpn) * tcfg.vocab)
+            if args.prefetch is not None:
+                teng.set_weight_prefetch(args.prefetch)
             treset()
             captured = not args.no_graph
             if captured:

@@ -479,13 +479,16 @@ int mi355_decoder_set_embedding_split(mi355_decoder_t* d, int32_t on);
  * mi355_decoder_attach_allreduce): while a latency-bound launch runs, a side stream pulls the weights of a later linear into
  * the 256 MB Infinity Cache, joined (event edge, captured into the step graph) right before that linear.  The hook the
  * reference keeps for this is DeviceResourceConfig{enable_comm_overlap, overlap_comm_type} (rtp_llm/cpp/config/ConfigModules.h:275-282).
- * mask: MI355_PF_* bits, 0 = off (default).  Invalidates captured graphs. */
+ * mask: MI355_PF_* bits, 0 = off (default: profiles/r03_prefetch_sidestream_ab.txt -- every fork / join pair costs ~17 us of
+ * step time inside a hipGraph on this stack).  Invalidates captured graphs. */
 enum {
     MI355_PF_QKV      = 1,   /* next layer's QKV, requested before the down GEMM is launched */
     MI355_PF_O        = 2,   /* O, requested behind the QKV GEMM (runs under RoPE / KV write and attention) */
     MI355_PF_GATE_UP  = 4,   /* gate_up (first 48 MB), requested behind the O GEMM (runs under reduce + RMSNorm) */
     MI355_PF_QKV_LATE = 16,  /* next layer's QKV, requested behind the down GEMM (runs under reduce + RMSNorm only) */
-    MI355_PF_O_LATE   = 32   /* O, requested behind the RoPE / KV-write launch (runs under attention only) */
+    MI355_PF_O_LATE   = 32,  /* O, requested behind the RoPE / KV-write launch (runs under attention only) */
+    MI355_PF_TP_COMM  = 64   /* tp_size > 1: the next linear's shard while the fused all-reduce launch runs (round 2's default; off since
+                              * the round-3 A/B: a fork / join pair inside the step graph costs more than the prefetch saves) */
 };
 int mi355_decoder_set_weight_prefetch(mi355_decoder_t* d, int32_t mask);
 

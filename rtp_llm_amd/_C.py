@@ -16,7 +16,7 @@ OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_WORKSPACE = 0, -1, -2, -3, -4
 W4, W8, W16 = 4, 8, 16
 KV_FP16, KV_INT8 = 0, 1
 EPI_NONE, EPI_SILU_MUL, EPI_OUT_F32 = 0, 1, 2
-PF_QKV, PF_O, PF_GATE_UP, PF_QKV_LATE, PF_O_LATE = 1, 2, 4, 16, 32   # mi355_decoder_set_weight_prefetch mask bits
+PF_QKV, PF_O, PF_GATE_UP, PF_QKV_LATE, PF_O_LATE, PF_TP_COMM = 1, 2, 4, 16, 32, 64   # mi355_decoder_set_weight_prefetch mask bits
 HINT_STAGED, HINT_NO_PERSISTENT = 0x100, 0x200
 ABI_VERSION = 2
 KC_NAMES = ["gemm_quant", "gemm_lmhead", "attn", "rope_kv", "norm", "other", "comm"]

@@ -291,7 +291,7 @@ namespace {
 // plain event edges, so the pair is captured into the step graph like everything else)
 template <class F>
 int comm_with_prefetch(mi355_decoder* d, hipStream_t st, const mi355_weight_t* next_w, F&& comm) {
-    const bool ov = d->overlap && next_w && next_w->qweight;
+    const bool ov = d->overlap && (d->pf_mask & MI355_PF_TP_COMM) && next_w && next_w->qweight;
     if (ov) {
         const size_t bytes = (size_t)next_w->K_pad * next_w->N_pad * next_w->wbits / 8;
         if (hipEventRecord(d->ev_fork, st) != hipSuccess || hipStreamWaitEvent(d->side_stream, d->ev_fork, 0) != hipSuccess) {
