@@ -478,11 +478,14 @@ int g_attn_ps_override = 0; // tuning hook (tools/attn_bench.py), tuning build o
 int plan_partitions(int B, int nkv, int max_seq_len, int* ps_out) {
     if (ATTN_PS_OVERRIDE > 0) { *ps_out = ATTN_PS_OVERRIDE; return cdiv(max_seq_len, ATTN_PS_OVERRIDE); }
     // Long partitions stream best (measured b=64, ctx 1024: one 1024-token partition per (seq, kv head) reaches
-    // 5.2 TB/s, five 256-token ones 4.0 TB/s and need the reduce kernel): split the sequence only as far as
-    // needed to put one block on every CU, never below 128 tokens.
-    int PS = 1 << 30;
-    while (PS > 128 && (long)B * nkv * cdiv(max_seq_len, PS) < 256) PS >>= 1;
-    if (PS > max_seq_len) PS = ((max_seq_len + 127) / 128) * 128;
+    // 5.2 TB/s, five 256-token ones 4.0 TB/s and need the reduce kernel), and a CU holds ONE block of this kernel (> 256
+    // registers per wave): split the sequence only while all blocks still fit one round of the 256 CUs, never below 128
+    // tokens (one pass of the block's 4 waves).  Round 2 split until there were AT LEAST 256 blocks: 224 (sequence, kv head)
+    // pairs became 448 half-length blocks = two rounds + the reduce launch, and b = 33..63 ran slower than b = 64.
+    const long pairs = (long)B * nkv;
+    int pmax = pairs >= 256 ? 1 : (int)(256 / pairs);
+    int PS = cdiv(cdiv(max_seq_len, pmax), 128) * 128;
+    if (PS < 128) PS = 128;
     *ps_out = PS;
     return cdiv(max_seq_len, PS);
 }
