@@ -37,10 +37,12 @@ constexpr int kFlagRow   = 16;             // dwords per block row: slots 0..7 f
 constexpr unsigned long long kSpinTicks = 200000000ull;   // 2 s of the 100 MHz wall clock
 constexpr int kOneShotRows = 64;          // tensors with more rows take the two-shot form (world > 2)
 constexpr size_t kAuxBytes = 32768;        // per parity, after the tensor region: 8-byte records of the argmax exchange.
-// Every location of a registered buffer has ONE owner block for all time (tensor row r and record r belong to block
-// r % kMaxBlocks whatever T is), and a block alternates parities with its own epoch: a location is rewritten two of its
-// owner's calls after it was last read, and a peer can only have raised the flag of the call in between after finishing
-// every earlier kernel on its stream.
+// Every location of a registered buffer has ONE owner block for all time, whatever the geometry (T, H) of the call: the tensor
+// and result regions are cut into kMaxBlocks fixed SLOTS, block b keeps its rows b, b + grid, b + 2 grid, ... back to back
+// inside slot b (row_off below), record r belongs to block r % kMaxBlocks.  A block alternates parities with its own epoch,
+// so a location is rewritten two of its owner's calls after it was last read, and a peer can only have raised the flag of
+// the call in between after finishing every earlier kernel on its stream.  (Round 2 laid rows out at r * H: the owner of a
+// byte then changed with H, and back-to-back calls of different widths could overwrite rows a slow peer was still reading.)
 
 struct ArDev {                             // device-visible part of the context (passed by value to kernels)
     f16*            my_data;               // registered buffer: 2 parities x max_elems
@@ -51,6 +53,7 @@ struct ArDev {                             // device-visible part of the context
     size_t          parity_elems;          // elements between the two parities
     size_t          aux_elems;             // element offset of the record region inside a parity
     size_t          res_elems;             // element offset of the result region inside a parity (two-shot: rows this rank reduced)
+    size_t          slot_elems;            // elements of one block's slot (tensor and result regions: kMaxBlocks slots each)
     uint32_t        data_bytes;            // bytes of one peer buffer (both parities): buffer range of the remote loads
     int             rank, world;
 };
@@ -68,6 +71,12 @@ struct FusedParams {
     float        eps;
     int          T, H;
 };
+
+// element offset (inside a region) of row `row` of a [T][H] tensor handled by a grid of `grid` blocks: slot row % grid, rows of
+// one block back to back
+__device__ __forceinline__ size_t row_off(const ArDev& ar, int row, int grid, int H) {
+    return (size_t)(row % grid) * ar.slot_elems + (size_t)(row / grid) * (size_t)H;
+}
 
 // system-scope 16-byte load from a peer buffer (sc0 sc1: served by the owner's memory, never by a stale local line)
 __device__ __forceinline__ u32x4 load_sys(__amdgpu_buffer_rsrc_t r, uint32_t off) {
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
             } else {
                 o = *reinterpret_cast<const f16x8*>(p.x + (size_t)row * p.H + c0);
             }
-            *reinterpret_cast<f16x8*>(ar.my_data + par + (size_t)row * p.H + c0) = o;
+            *reinterpret_cast<f16x8*>(ar.my_data + par + row_off(ar, row, gridDim.x, p.H) + c0) = o;
         }
     }
     peer_barrier(ar, b, epoch);
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
             for (int t = 0; t < VPT; ++t) {
                 const int vi = tid + t * NTH;
                 if (vi >= nvec) continue;
-                const uint32_t off = (uint32_t)((par + (size_t)row * p.H + vi * 8) * 2);
+                const uint32_t off = (uint32_t)((par + row_off(ar, row, gridDim.x, p.H) + vi * 8) * 2);
                 u32x4 in[kMaxWorld];
 #pragma unroll
                 for (int r = 0; r < kMaxWorld; ++r)
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
                 f16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (f16)a[e];
-                *reinterpret_cast<f16x8*>(ar.my_data + par + ar.res_elems + (size_t)row * p.H + vi * 8) = o;
+                *reinterpret_cast<f16x8*>(ar.my_data + par + ar.res_elems + row_off(ar, row, gridDim.x, p.H) + vi * 8) = o;
             }
         }
         peer_barrier(ar, b, epoch, 8);
@@ -196,11 +205,11 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
             const int vi = tid + t * NTH;
             if (vi >= nvec) continue;
             const int c0 = vi * 8;
-            const uint32_t off = (uint32_t)((par + (size_t)row * p.H + c0) * 2);
+            const uint32_t off = (uint32_t)((par + row_off(ar, row, gridDim.x, p.H) + c0) * 2);
             u32x4 in[kMaxWorld];
             if constexpr (TWO) {                                            // the row as its owner reduced it
                 const int owner = row % ar.world;
-                const uint32_t roff = (uint32_t)((par + ar.res_elems + (size_t)row * p.H + c0) * 2);
+                const uint32_t roff = (uint32_t)((par + ar.res_elems + row_off(ar, row, gridDim.x, p.H) + c0) * 2);
 #pragma unroll
                 for (int r = 0; r < kMaxWorld; ++r)
                     if (r == owner) in[0] = load_sys(rp[r], roff);
@@ -269,8 +278,8 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
 // All-gather along the hidden dimension over the same transport: every rank publishes its [T][n] column slice, then copies
 // the N slices side by side -- out[t][r n + j] = slice_r[t][j], the result of the reference's hidden-split embedding
 // (all_gather + reshape(tp, m, n).transpose(0, 1).reshape(m, -1), modules/base/common/embedding.py:50-58).  Rows keep the
-// FULL row stride n * world inside the registered buffer, so a row has the same owner block as under the all-reduce (the
-// one-owner rule above) and both kinds of call may alternate freely.
+// FULL row width n * world inside their block's slot (row_off), like the rows of an all-reduce: both kinds of call may
+// alternate freely on one context.
 struct GatherParams {
     ArDev      ar;
     const f16* x;      // [T][n]
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(256) void allgather_hidden_kernel(const GatherParam
     const size_t par = (epoch & 1) * ar.parity_elems;
     for (int row = b; row < p.T; row += gridDim.x)
         for (int vi = tid; vi < nv; vi += 256)
-            *reinterpret_cast<f16x8*>(ar.my_data + par + (size_t)row * H + vi * 8) = *reinterpret_cast<const f16x8*>(p.x + (size_t)row * p.n + vi * 8);
+            *reinterpret_cast<f16x8*>(ar.my_data + par + row_off(ar, row, gridDim.x, H) + vi * 8) = *reinterpret_cast<const f16x8*>(p.x + (size_t)row * p.n + vi * 8);
     peer_barrier(ar, b, epoch);
 #pragma unroll
     for (int r = 0; r < kMaxWorld; ++r) {
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(256) void allgather_hidden_kernel(const GatherParam
         __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)ar.peer_data[r], 0, ar.data_bytes, 0x00020000u);
         for (int row = b; row < p.T; row += gridDim.x)
             for (int vi = tid; vi < nv; vi += 256) {
-                const u32x4 v = load_sys(rp, (uint32_t)((par + (size_t)row * H + vi * 8) * 2));
+                const u32x4 v = load_sys(rp, (uint32_t)((par + row_off(ar, row, gridDim.x, H) + vi * 8) * 2));
                 *reinterpret_cast<u32x4*>(p.out + (size_t)row * H + (size_t)r * p.n + vi * 8) = v;
             }
     }
@@ -359,7 +368,8 @@ __global__ __launch_bounds__(64) void allreduce_argmax_kernel(const ArgmaxParams
 struct mi355_allreduce {
     int     rank, world;
     size_t  max_bytes;                 // largest message (one parity)
-    void*   data;                      // 2 parities x (tensor max_bytes | records | results max_bytes), IPC-exported
+    size_t  slot_bytes;                // one block's slot: >= its share of the largest message + one full-width row
+    void*   data;                      // 2 parities x (tensor kMaxBlocks slots | records | results kMaxBlocks slots), IPC-exported
     void*   flags;                     // kMaxBlocks x kFlagRow dwords, IPC-exported
     void*   peer_data[kMaxWorld];
     void*   peer_flags[kMaxWorld];
@@ -404,10 +414,12 @@ ArDev dev_view(const mi355_allreduce* a) {
         d.peer_flags[r] = (uint32_t*)a->peer_flags[r < a->world ? r : 0];
     }
     d.epoch = a->epoch; d.status = a->status;
-    d.parity_elems = (2 * a->max_bytes + kAuxBytes) / 2;
-    d.aux_elems = a->max_bytes / 2;
-    d.res_elems = (a->max_bytes + kAuxBytes) / 2;
-    d.data_bytes = (uint32_t)(2 * (2 * a->max_bytes + kAuxBytes));
+    const size_t region = (size_t)kMaxBlocks * a->slot_bytes;
+    d.parity_elems = (2 * region + kAuxBytes) / 2;
+    d.aux_elems = region / 2;
+    d.res_elems = (region + kAuxBytes) / 2;
+    d.slot_elems = a->slot_bytes / 2;
+    d.data_bytes = (uint32_t)(2 * (2 * region + kAuxBytes));
     d.rank = a->rank; d.world = a->world;
     return d;
 }
@@ -417,8 +429,10 @@ ArDev dev_view(const mi355_allreduce* a) {
 extern "C" size_t mi355_allreduce_handle_bytes(void) { return sizeof(HandleBlob); }
 
 extern "C" mi355_allreduce_t* mi355_allreduce_create(int32_t rank, int32_t world, size_t max_bytes, void* handle_out) {
+    // slot: the block's share of the largest message (rows of a block sit back to back) + one row of the widest tensor (8192 fp16)
+    const size_t slot_bytes = ((max_bytes + kMaxBlocks - 1) / kMaxBlocks + 16384 + 255) & ~(size_t)255;
     if (rank < 0 || world < 1 || world > kMaxWorld || rank >= world || !handle_out || max_bytes == 0 ||
-        2 * (2 * max_bytes + kAuxBytes) >= 0xFFFFFF00ull) {
+        2 * (2 * (size_t)kMaxBlocks * slot_bytes + kAuxBytes) >= 0xFFFFFF00ull) {
         mi355_set_error("allreduce_create: rank=%d world=%d (1..%d) max_bytes=%zu", rank, world, kMaxWorld, max_bytes);
         return nullptr;
     }
@@ -426,10 +440,11 @@ extern "C" mi355_allreduce_t* mi355_allreduce_create(int32_t rank, int32_t world
     if (!a) return nullptr;
     a->rank = rank; a->world = world; a->ready = false;
     a->max_bytes = (max_bytes + 255) & ~(size_t)255;
+    a->slot_bytes = slot_bytes;
     for (int r = 0; r < kMaxWorld; ++r) { a->peer_data[r] = a->peer_flags[r] = nullptr; a->opened[r] = false; }
     HandleBlob hb;
     memset(&hb, 0, sizeof(hb));
-    a->data  = alloc_shared(2 * (2 * a->max_bytes + kAuxBytes), &hb.data);   // per parity: tensor | records | two-shot results
+    a->data  = alloc_shared(2 * (2 * (size_t)kMaxBlocks * slot_bytes + kAuxBytes), &hb.data);   // per parity: tensor slots | records | two-shot result slots
     a->flags = alloc_shared((size_t)kMaxBlocks * kFlagRow * 4, &hb.flags);
     a->epoch = nullptr; a->status = nullptr;
     if (!a->data || !a->flags || hipMalloc((void**)&a->epoch, kMaxBlocks * 4 + 256) != hipSuccess ||
@@ -503,6 +518,7 @@ extern "C" int mi355_allreduce_fused(mi355_allreduce_t* a, const void* x_f16, co
     p.res_in = (const f16*)residual_in; p.res_out = (f16*)residual_out; p.weight = (const f16*)weight; p.y = (f16*)y;
     p.eps = eps; p.T = T; p.H = H;
     const int grid = T < kMaxBlocks ? T : kMaxBlocks;
+    MI355_CHECK_ARG((size_t)cdiv(T, grid) * H * 2 <= a->slot_bytes, "allreduce: %d rows of %d per block exceed the %zu-byte slot", cdiv(T, grid), H, a->slot_bytes);
     hipStream_t st = (hipStream_t)stream;
     const bool two = T > kOneShotRows && a->world > 2;   // (N - 1) vs 2 (N - 1) / N reads per element: equal at N = 2
     if (H / 8 <= 512) { if (two) hipLaunchKernelGGL((allreduce_fused_kernel<1, true>), dim3(grid), dim3(512), 0, st, p);
@@ -529,6 +545,7 @@ extern "C" int mi355_allgather_hidden(mi355_allreduce_t* a, const void* x_f16, v
     p.ar = dev_view(a);
     p.x = (const f16*)x_f16; p.out = (f16*)out_f16; p.T = T; p.n = n;
     const int grid = T < kMaxBlocks ? T : kMaxBlocks;
+    MI355_CHECK_ARG((size_t)cdiv(T, grid) * n * a->world * 2 <= a->slot_bytes, "allgather: rows per block exceed the %zu-byte slot", a->slot_bytes);
     hipLaunchKernelGGL(allgather_hidden_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     MI355_CHECK_LAUNCH("allgather_hidden_kernel");
     return MI355_OK;
