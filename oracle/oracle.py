@@ -141,8 +141,14 @@ def greedy(logits_f32: torch.Tensor) -> torch.Tensor:
 class OracleKV:
     """Natural-layout KV store per layer: lists of [nkv, hd] rows per sequence (fp16 or int8+scale)."""
 
-    def __init__(self, num_layers: int, batch: int, int8: bool):
+    def __init__(self, num_layers: int, batch: int, int8: bool, forced=None):
+        """forced (INT8 only, test plumbing): callable (layer, sequence, token index) -> (k_codes [nkv,hd] int8, k_scale [nkv],
+        v_codes, v_scale) or None.  When it returns codes, THEY are stored instead of this store's own quantisation of (k, v)
+        -- the attention that follows then reads exactly the int8 codes the kernel under test wrote, so a code flipped by a
+        1-ulp fp16 difference upstream cannot contribute to the comparison; the flips are counted in `flips` / `codes`."""
         self.int8 = int8
+        self.forced = forced
+        self.flips = self.codes = self.max_delta = 0
         self.k = [[[] for _ in range(batch)] for _ in range(num_layers)]
         self.v = [[[] for _ in range(batch)] for _ in range(num_layers)]
         self.ks = [[[] for _ in range(batch)] for _ in range(num_layers)]
@@ -151,6 +157,13 @@ class OracleKV:
     def append(self, layer: int, b: int, k: torch.Tensor, v: torch.Tensor):
         if self.int8:
             kq, ksc = quant_kv_int8(k); vq, vsc = quant_kv_int8(v)
+            f = self.forced(layer, b, len(self.k[layer][b])) if self.forced is not None else None
+            if f is not None:
+                fk, fks, fv, fvs = f
+                for own, got in ((kq, fk), (vq, fv)):
+                    d = (own.int() - got.int()).abs()
+                    self.flips += int((d > 0).sum()); self.codes += d.numel(); self.max_delta = max(self.max_delta, int(d.max()))
+                kq, ksc, vq, vsc = fk.to(kq.dtype), fks.to(ksc.dtype), fv.to(vq.dtype), fvs.to(vsc.dtype)
             self.k[layer][b].append(kq); self.v[layer][b].append(vq)
             self.ks[layer][b].append(ksc); self.vs[layer][b].append(vsc)
         else:

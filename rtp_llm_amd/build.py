@@ -20,8 +20,7 @@ LIB = os.path.join(LIBDIR, "libmi355_decode.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 SOURCES = ["gemm.hip", "gemm_smallm.hip", "gemm_wide.hip", "gemm_fullk.hip", "gemm_prefill.hip", "attention.hip", "rope_kv.hip", "elementwise.hip", "sampling.hip", "allreduce.hip", "engine.cpp", "error.cpp"]
-TUNING_ONLY = ["gemm_pc.hip", "gemm_wide1.hip"]   # experiments kept for tools/ (producer / consumer waves; one wave per SIMD: measured behind gemm_wide)
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "gemm_wide1_phases.inc"), os.path.join(CSRC, "internal.h"), os.path.join(INCLUDE, "mi355_decode.h")]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "internal.h"), os.path.join(INCLUDE, "mi355_decode.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
@@ -51,7 +50,7 @@ def build(force=False, verbose=True, tuning=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     LIB = os.path.join(LIBDIR, "libmi355_decode_tuning.so" if tuning else "libmi355_decode.so")
-    srcs = SOURCES + (TUNING_ONLY if tuning else [])
+    srcs = SOURCES
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         res = list(ex.map(lambda s: _compile(s, force, tuning), srcs))
     objs = [o for o, _ in res]

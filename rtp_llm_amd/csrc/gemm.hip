@@ -28,12 +28,6 @@ extern "C" int mi355_gemm_smallm(const void* gp, int wbits, int group_size, int 
 extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int want_partial, int max_splits,
                                mi355_stream_t stream);
 extern "C" int mi355_gemm_prefill(const void* gp, int wbits, int group_size, mi355_stream_t stream);
-#ifdef MI355_TUNING   // one-wave-per-SIMD experiment (gemm_wide1.hip), tuning build only: switch 5 = 6
-extern "C" int mi355_gemm_wide1(const void* gp, int wbits, int group_size, mi355_stream_t stream);
-#endif
-#ifdef MI355_TUNING   // producer / consumer experiment (gemm_pc.hip), tuning build only: switch 5 = 3 routes M > 32 W4 shapes to it
-extern "C" int mi355_gemm_pc(const void* gp, int wbits, int group_size, int want_partial, int max_splits, mi355_stream_t stream);
-#endif
 extern "C" int mi355_gemm_fullk(const void* gp, int wbits, int group_size, const void* norm, mi355_stream_t stream);
 extern "C" int mi355_gemm_fullk_residual(const void* gp, int wbits, int group_size, const void* residual_in, void* residual_out,
                                          float* ssq_out, int ssq_ld, mi355_stream_t stream);
@@ -651,12 +645,6 @@ extern "C" int mi355_linear_partial(const void* x, int32_t M, const mi355_weight
         const int rc = mi355_gemm_smallm(&p, w->wbits, w->group_size, 1, max_splits, stream);
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
-#ifdef MI355_TUNING
-    if (M > 32 && w->wbits == 4 && TUNE(5) == 3) {
-        const int rc = mi355_gemm_pc(&p, w->wbits, w->group_size, 1, max_splits, stream);
-        if (rc != MI355_ERR_UNSUPPORTED) return rc;
-    }
-#endif
     if (M > 16 && w->wbits != 16 && TUNE(5) != 1) { // register-resident activations, K split over the waves (gemm_wide.hip)
         const int rc = mi355_gemm_wide(&p, w->wbits, w->group_size, 1, max_splits, stream);
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
@@ -700,12 +688,6 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
             GemmParams ps; fill_params(ps, (const f16*)x + (size_t)m0 * w->K, Mc, w);
             ps.mode = mode; ps.bias = (const f16*)bias; ps.y = (char*)y + (size_t)m0 * ldy * ysz; ps.ldy = ldy;
             int rc = MI355_ERR_UNSUPPORTED;
-#ifdef MI355_TUNING
-            if (Mc > 32 && w->wbits == 4 && TUNE(5) == 3) rc = mi355_gemm_pc(&ps, w->wbits, w->group_size, 0, 1, stream);
-#endif
-#ifdef MI355_TUNING
-            if (rc == MI355_ERR_UNSUPPORTED && Mc > 32 && TUNE(5) == 6) rc = mi355_gemm_wide1(&ps, w->wbits, w->group_size, stream);
-#endif
             if (rc == MI355_ERR_UNSUPPORTED) rc = mi355_gemm_wide(&ps, w->wbits, w->group_size, 0, 1, stream);
             if (rc >= 0) continue;
             if (rc != MI355_ERR_UNSUPPORTED) return rc;
@@ -751,12 +733,6 @@ extern "C" int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_
     }
     if (M > 16 && w->wbits != 16 && !(epilogue & MI355_HINT_STAGED) && TUNE(5) != 1) {
         int rc = MI355_ERR_UNSUPPORTED;
-#ifdef MI355_TUNING
-        if (M > 32 && w->wbits == 4 && TUNE(5) == 3) rc = mi355_gemm_pc(&p, w->wbits, w->group_size, 0, 1, stream);
-#endif
-#ifdef MI355_TUNING
-        if (rc == MI355_ERR_UNSUPPORTED && M > 32 && TUNE(5) == 6) rc = mi355_gemm_wide1(&p, w->wbits, w->group_size, stream);
-#endif
         if (rc == MI355_ERR_UNSUPPORTED) rc = mi355_gemm_wide(&p, w->wbits, w->group_size, 0, 1, stream);
         if (rc >= 0) return MI355_OK;
         if (rc != MI355_ERR_UNSUPPORTED) return rc;

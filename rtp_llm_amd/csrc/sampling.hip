@@ -61,13 +61,13 @@ __device__ __forceinline__ float block_draw(F&& f, int V, float u01, float* s_re
     const float incl = s_scan[tx], excl = incl - local;
     if (local > 0.f && excl <= u && incl > u) {   // the prefix crosses u inside this segment (at most one thread)
         float c = excl;
-        int found = hi - 1;
-        for (int j = lo; j < hi; ++j) {
-            const float r = f(j);
+        int found = -1, last_pos = -1;              // the rescan rounds differently from the scanned prefix: if c never exceeds u here,
+        for (int j = lo; j < hi; ++j) {             // fall back to the LAST index of the segment with weight > 0 -- never to a token the
+            const float r = f(j);                   // filter / ban / residual removed (weight 0)
             c += r;
-            if (r > 0.f && c > u) { found = j; break; }
+            if (r > 0.f) { last_pos = j; if (c > u) { found = j; break; } }
         }
-        *s_found = found;
+        *s_found = found >= 0 ? found : last_pos;   // local > 0: the segment holds at least one positive weight
     }
     __syncthreads();
     return total;

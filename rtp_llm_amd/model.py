@@ -403,7 +403,14 @@ class DecoderEngine:
                                 f"(max_seq_len {self.max_seq_len}, max_pos {self.cfg.max_pos}, block table {self.max_blocks_per_seq} x {self.page})")
 
     def oob_count(self) -> int:
-        """Tokens the KV writer refused since creation (stale position / block id).  Synchronises."""
+        """Tokens the KV writer refused since creation (stale position / block id).  Synchronises.  Under tensor parallelism it
+        also raises when a peer never arrived at an all-reduce within the kernel's spin bound (the step's outputs are then
+        garbage, not an error code: checked wherever the out-of-range count is)."""
+        ar = getattr(self, "_ar", None)
+        if ar is not None:
+            st = ar.status()
+            if st:
+                raise _C.Mi355Error(f"tensor-parallel all-reduce: a peer did not arrive within the spin bound (status {st}); results are invalid")
         n = self.lib.mi355_decoder_oob_count(self.handle, self._st())
         if n < 0:
             _C.check(int(n), "decoder_oob_count")

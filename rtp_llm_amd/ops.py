@@ -118,6 +118,8 @@ def norm_linear(h: torch.Tensor, norm, w: PackedWeight, bias: Optional[torch.Ten
     """epilogue(RMSNorm(h) @ W + bias) in one launch; norm = (tile_sumsq, weight, eps) as left by linear_residual.  None when
     not taken (more than 16 rows, non-W4 weights)."""
     _chk(h, torch.float16, "norm_linear.h")
+    if norm is None:
+        raise _C.Mi355Error("norm_linear needs norm = (tile_sumsq, weight, eps) as left by linear_residual")
     M = h.numel() // w.K
     fn = _fused_norm(norm, M, w.K)
     n_out = w.N // 2 if epilogue & _C.EPI_SILU_MUL else w.N

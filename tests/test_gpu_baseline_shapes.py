@@ -147,6 +147,95 @@ def test_engine_full_width_step_vs_oracle(kind, kv_int8, B, ctx):
         top2 = ref_logits.topk(2, dim=-1).values
         safe = (top2[:, 0] - top2[:, 1]) > 1e-2
         assert int(safe.sum()) >= (B + 1) // 2
-        assert torch.equal(eng.token_ids[:B].cpu()[safe], ref_next[safe])
+        got_next = eng.token_ids[:B].cpu()
+        assert torch.equal(got_next[safe], ref_next[safe])
+        # north_star asks for bit-exact greedy ids: report how many rows match the oracle's argmax outright (rows whose top-2
+        # margin is below the logits tolerance may legitimately differ; they are the only ones allowed to)
+        exact = int((got_next == ref_next).sum())
+        print(f"step {step}: greedy ids identical to the oracle on {exact}/{B} rows ({int(safe.sum())} rows have a top-2 margin > 1e-2)")
+        assert exact >= int(safe.sum())
         tok = ref_next
         eng.token_ids[:B].copy_(tok)
+
+
+# ------------------------------------------------------------------ large-M GEMM at the real gate_up / down shapes (untested)
+PREFILL_CASES = [(m, name) for m in (model.QWEN2_7B, model.LLAMA3_70B) for name in ("gate_up", "down")]
+
+
+@pytest.mark.parametrize("cfg,name", PREFILL_CASES, ids=[f"{m.name}-{n}" for m, n in PREFILL_CASES])
+def test_linear_prefill_baseline_shapes_vs_oracle(cfg, name):
+    """M in {128, 200, 1000} rows through mi355_linear_forward at the 7B and 70B gate_up / down shapes: the compute-shaped
+    kernel (gemm_prefill.hip; narrow outputs at moderate M stay on 64-row slabs of the decode kernels) against
+    oracle.linear.  The oracle multiplies 1000 rows once; smaller M are its leading rows."""
+    K, N = _shapes(cfg)[name]
+    gen = torch.Generator(device=DEV).manual_seed(K * 3 + N)
+    c_dev = model.synth_linear(K, N, "w4", DEV, gen)
+    packed = c_dev.pack(gate_up=(name == "gate_up"))
+    W = _dense(model.weights_to({"w": c_dev}, "cpu")["w"])
+    x = (torch.randn(1000, K, generator=torch.Generator().manual_seed(9)) * 0.5).half()
+    ref = oracle.linear(x, W)
+    if name == "gate_up":
+        ref = oracle.silu_mul(ref)
+    del W
+    xd = x.to(DEV)
+    for M in (128, 200, 1000):
+        y = ops.linear(xd[:M].contiguous(), packed, None, epilogue=_C.EPI_SILU_MUL if name == "gate_up" else _C.EPI_NONE)
+        torch.cuda.synchronize()
+        err = float((y.cpu().float() - ref[:M].float()).abs().max())
+        assert torch.allclose(y.cpu().float(), ref[:M].float(), **TOL), f"{cfg.name} {name} M={M}: max err {err}"
+
+
+def test_prefill_full_width_chunk_vs_oracle():
+    """One full-width (Qwen2-7B dims, 2 layers) prefill of three ragged prompts in one 64-row-per-sequence chunk pass: large-M
+    GEMMs at the real shapes, rows-mode KV writer, causal multi-row attention, then the logits of each prompt's last token
+    against the oracle fed token by token."""
+    cfg = model.ModelConfig("qwen2-7b-2l", 2, 3584, 28, 4, 128, 18944, 152064, max_pos=256)
+    w_dev = model.synth_model(cfg, "w4", DEV, seed=23, zeros="centered")
+    w = model.weights_to(w_dev, "cpu")
+    lens, page = [37, 64, 50], 16
+    B = len(lens)
+    g = torch.Generator().manual_seed(31)
+    prompts = [torch.randint(0, cfg.vocab, (n,), generator=g, dtype=torch.int32).tolist() for n in lens]
+    eng = model.DecoderEngine(cfg, w_dev, kv_int8=False, page=page, num_blocks=B * 8, max_batch=4, max_seq_len=128, device=DEV)
+    del w_dev
+    bt = torch.randperm(B * 8, generator=g).reshape(B, 8).to(torch.int32)
+    logits = eng.prefill(prompts, bt, chunk=64).cpu()
+    odec = oracle.OracleDecoder({**cfg.__dict__}, _oracle_weights(w))
+    okv = oracle.OracleKV(cfg.num_layers, B, False)
+    ref_last = []
+    for b, pr in enumerate(prompts):
+        _, lg = odec.forward_tokens(torch.tensor(pr, dtype=torch.int32), torch.arange(len(pr), dtype=torch.int32), okv, [b] * len(pr))
+        ref_last.append(lg[-1])
+    ref_last = torch.stack(ref_last)
+    assert torch.allclose(logits, ref_last, **TOL), float((logits - ref_last).abs().max())
+    assert eng.oob_count() == 0
+
+
+def test_single_layer_uniform_zero_points_vs_oracle():
+    """SURVEY 8d's synthetic recipe verbatim (z ~ U{0..15}: weights of mean -scale) at full Qwen2-7B width, ONE layer, B = 64:
+    compared at the LAYER OUTPUT (the normed hidden state the engine exposes) instead of the logits -- with these zero points
+    the all-ones direction has gain ~40 in the down projection, so a second layer would saturate the softmax, but one layer
+    is a well-conditioned check of every kernel on the 8d weights (the end-to-end cases above draw z from {7, 8})."""
+    cfg = model.ModelConfig("qwen2-7b-1l", 1, 3584, 28, 4, 128, 18944, 1024, max_pos=64)
+    w_dev = model.synth_model(cfg, "w4", DEV, seed=27, zeros="uniform")
+    w = model.weights_to(w_dev, "cpu")
+    B, page, ctx = 64, 16, 33
+    eng = model.DecoderEngine(cfg, w_dev, kv_int8=False, page=page, num_blocks=B * 4, max_batch=B, max_seq_len=64, device=DEV)
+    del w_dev
+    odec = oracle.OracleDecoder({**cfg.__dict__}, _oracle_weights(w))
+    okv = oracle.OracleKV(1, B, False)
+    g = torch.Generator().manual_seed(6)
+    bt = torch.randperm(B * 4, generator=g).reshape(B, 4).to(torch.int32)
+    for b in range(B):
+        K = torch.randn(ctx - 1, cfg.nkv, cfg.hd, generator=g).half(); V = torch.randn(ctx - 1, cfg.nkv, cfg.hd, generator=g).half()
+        kvcache.write_tokens(eng.kv[0], None, bt[b], 0, K, V)
+        okv.k[0][b], okv.v[0][b] = list(K), list(V)
+    tok = torch.randint(0, cfg.vocab, (B,), generator=g, dtype=torch.int32)
+    eng.set_inputs(tok.tolist(), [ctx - 1] * B, bt)
+    eng.capture(B); eng.replay(B, 1)
+    torch.cuda.synchronize()
+    hn_ref, _ = odec.forward_tokens(tok, torch.full((B,), ctx - 1, dtype=torch.int32), okv, list(range(B)))
+    hn = eng.hidden[:B].cpu().float()
+    # the final RMSNorm brings the residual stream (|h| up to a few hundred here) back to O(1): RMSNorm tolerance of the reference (5e-2 abs)
+    # is far too loose for a parity gate, use the linear / attention tolerance
+    assert torch.allclose(hn, hn_ref.float(), **TOL), float((hn - hn_ref.float()).abs().max())

@@ -54,10 +54,16 @@ def test_rope_kv_and_paged_attention_op_classes(int8):
     v_ref = qkv[:, (nh + nkv) * hd:].reshape(B, nkv, hd)
     assert torch.allclose(q.cpu().float(), q_ref.float(), **TOL)
     for b in range(B):
+        if int8:   # the oracle attends over the codes the kernel wrote for the new token (a 1-ulp fp16 difference in the rotated K may
+            #        flip one; the flips are bounded below), so the attention itself is compared at 1e-2 like the fp16 case
+            Kc, Vc, ksc, vsc = kvcache.read_tokens(kv, sc, bt[b], ctx[b] + 1)
+            okv.forced = lambda l, bb, t, f=(Kc[-1].cpu(), ksc[-1].cpu(), Vc[-1].cpu(), vsc[-1].cpu()): f
         okv.append(0, b, k_ref[b], v_ref[b])
         K, V, ks, vs = okv.get(0, b)
         ref = oracle.attention_decode(q_ref[b], K, V, 1 / math.sqrt(hd), ks, vs).reshape(-1)
-        assert torch.allclose(out[b].cpu().float(), ref.float(), atol=1.5e-2 if int8 else 1e-2, rtol=1e-2), b
+        assert torch.allclose(out[b].cpu().float(), ref.float(), atol=1e-2, rtol=1e-2), b
+    if int8:
+        assert okv.max_delta <= 1 and okv.flips <= 0.10 * okv.codes, (okv.flips, okv.codes)
     # same kernels as the ctypes path: bit-equal
     q2 = cops.rope_kv_write(qkv.to(DEV), None, cs.to(DEV), pos.to(DEV), bt.to(DEV), kv, sc, nh, nkv, hd, page)
     out2 = cops.paged_decode_attention(q2, kv, sc, bt.to(DEV), (pos + 1).to(DEV), nkv, page, M * page)

@@ -254,58 +254,45 @@ def test_engine_greedy_decode_matches_oracle(kind, kv_int8):
     w = model.synth_model(cfg, kind, "cpu", seed=3, zeros="centered")
     B, page, prompt_len, gen_len = 3, 16, 5, 8
     odec = oracle.OracleDecoder({**cfg.__dict__}, _oracle_weights(w))
-    okv = oracle.OracleKV(cfg.num_layers, B, kv_int8)
     wd = model.weights_to(w, DEV)
     eng = model.DecoderEngine(cfg, wd, kv_int8=kv_int8, page=page, num_blocks=64, max_batch=4, max_seq_len=64, device=DEV)
     bt = torch.randperm(64, generator=_gen(1))[: B * 4].reshape(B, 4).to(torch.int32)
+
+    # INT8 KV: the oracle attends over the int8 codes THE KERNEL wrote (the engine steps first, OracleKV.forced reads its
+    # cache), so that a code flipped by a 1-ulp fp16 difference in a rotated K cannot move a logit: the comparison holds
+    # north_star's 1e-2 like every other case, and the flips are asserted separately below.
+    def kernel_codes(l, b, t):
+        K, V, ks, vs = kvcache.read_tokens(eng.kv[l], eng.kv_scale[l], bt[b], t + 1)
+        return K[t].cpu(), ks[t].cpu(), V[t].cpu(), vs[t].cpu()
+    okv = oracle.OracleKV(cfg.num_layers, B, kv_int8, forced=kernel_codes if kv_int8 else None)
     prompt = torch.randint(0, cfg.vocab, (B, prompt_len), generator=_gen(2), dtype=torch.int32)
     tok = prompt[:, 0].clone()
     eng.set_inputs(tok.tolist(), [0] * B, bt)
-    use_graph = True
     eng.capture(B)
-    max_err, beyond, n_logits = 0.0, 0, 0
+    max_err, exact_ids, n_ids = 0.0, 0, 0
     for step in range(prompt_len + gen_len - 1):
         pos = torch.full((B,), step, dtype=torch.int32)
-        _, ref_logits = odec.forward_tokens(tok, pos, okv, list(range(B)))
-        eng.replay(B, 1) if use_graph else eng.step(B)
+        eng.replay(B, 1)
         torch.cuda.synchronize()
+        _, ref_logits = odec.forward_tokens(tok, pos, okv, list(range(B)))
         got = eng.logits[:B].cpu()
-        # north_star's 1e-2 (fp16 KV here; INT8 KV at realistic context lengths: test_gpu_baseline_shapes.py, ctx 4096).
-        # This toy case attends over <= 12 tokens whose K/V were ALL quantised on both sides: a 1-ulp fp16 difference in a
-        # rotated K flips an int8 code (1/127 of the head's amax) and, with so few keys, one flipped code moves a logit by
-        # up to ~1.2e-2.  The flips are counted below (profiles/r02_int8_kv_flip_stats.json); bound used here: 1.5e-2.
-        tol = dict(atol=1.5e-2, rtol=1.5e-2) if kv_int8 else TOL
-        assert torch.allclose(got, ref_logits, **tol), (step, (got - ref_logits).abs().max())
-        beyond += int(((got - ref_logits).abs() > 1e-2 + 1e-2 * ref_logits.abs()).sum()); n_logits += got.numel()
+        assert torch.allclose(got, ref_logits, **TOL), (step, (got - ref_logits).abs().max())
         ref_next = oracle.greedy(ref_logits)
-        # greedy ids must agree wherever the oracle's top-2 margin exceeds the logits tolerance
+        # greedy ids must agree wherever the oracle's top-2 margin exceeds the logits tolerance; the exact-match rate is reported
         top2 = ref_logits.topk(2, dim=-1).values
         safe = (top2[:, 0] - top2[:, 1]) > 1e-2
         got_next = eng.token_ids[:B].cpu()
         assert torch.equal(got_next[safe], ref_next[safe])
+        exact_ids += int((got_next == ref_next).sum()); n_ids += B
         assert torch.equal(eng.positions[:B].cpu(), pos + 1)
         tok = prompt[:, step + 1].clone() if step + 1 < prompt_len else ref_next
         eng.token_ids[:B].copy_(tok)                          # teacher-force the oracle's token (keeps streams aligned)
         max_err = max(max_err, float((got - ref_logits).abs().max()))
+    print(f"greedy ids: {exact_ids}/{n_ids} rows identical to the oracle's argmax; max |logit error| {max_err:.2e}")
     if kv_int8:
-        # Quantify the INT8-KV tolerance: how many cache codes differ between the HIP writer and the oracle (a 1-ulp fp16
-        # difference in a rotated K / a V projection flips rne at a .5 boundary), and the logits error that came with it.
-        n_tok = prompt_len + gen_len - 1
-        flips = total = worst = 0
-        for l in range(cfg.num_layers):
-            for b in range(B):
-                K, V, ks, vs = kvcache.read_tokens(eng.kv[l], eng.kv_scale[l], bt[b], n_tok)
-                Ko, Vo, _, _ = okv.get(l, b)
-                for a, o in ((K.cpu(), Ko), (V.cpu(), Vo)):
-                    d = (a.int() - o.int()).abs()
-                    flips += int((d > 0).sum()); total += d.numel(); worst = max(worst, int(d.max()))
-        stats = {"int8_kv_codes": total, "codes_differing": flips, "max_code_delta": worst, "max_logit_err": max_err,
-                 "logits_beyond_1e-2": beyond, "logits_compared": n_logits, "model": "tiny-qwen2 3 layers, %d tokens x %d sequences" % (n_tok, B), "weights": kind}
-        print("INT8-KV flip stats:", stats)
-        import json, os
-        os.makedirs("gpurun_out", exist_ok=True)
-        json.dump(stats, open(os.path.join("gpurun_out", "int8_kv_flip_stats.json"), "w"))
-        assert worst <= 1 and flips <= 0.10 * total   # a 1-ulp change of a head's amax moves its scale by 2^-11: every code near a .5 boundary may flip
+        # a 1-ulp change of a head's amax moves its scale by 2^-11: every code near a .5 boundary may flip by ONE
+        print(f"INT8-KV codes differing between the HIP writer and the oracle's own quantisation: {okv.flips} of {okv.codes}, max delta {okv.max_delta}")
+        assert okv.codes > 0 and okv.max_delta <= 1 and okv.flips <= 0.10 * okv.codes
 
 
 def test_generate_with_ragged_prompts_matches_oracle():
@@ -570,27 +557,33 @@ def test_prefill_ragged_prompts_multi_chunk_matches_oracle(kv_int8):
     bt = torch.randperm(B * 16, generator=g).reshape(B, 16).to(torch.int32)
     logits = eng.prefill(prompts, bt, chunk=64).cpu()
     odec = oracle.OracleDecoder({**cfg.__dict__}, _oracle_weights(w))
-    okv = oracle.OracleKV(cfg.num_layers, B, kv_int8)
+
+    def kernel_codes(l, b, t):                                # INT8: the oracle reads the codes the kernel wrote (see OracleKV.forced)
+        K, V, ks, vs = kvcache.read_tokens(eng.kv[l], eng.kv_scale[l], bt[b], t + 1)
+        return K[t].cpu(), ks[t].cpu(), V[t].cpu(), vs[t].cpu()
+    okv = oracle.OracleKV(cfg.num_layers, B, kv_int8, forced=kernel_codes if kv_int8 else None)
     ref_last = []
     for b, pr in enumerate(prompts):                          # the oracle eats the prompt token by token
         for pos, tok in enumerate(pr):
             _, lg = odec.forward_tokens(torch.tensor([tok], dtype=torch.int32), torch.tensor([pos], dtype=torch.int32), okv, [b])
         ref_last.append(lg[0])
     ref_last = torch.stack(ref_last)
-    tol = dict(atol=1.5e-2, rtol=1.5e-2) if kv_int8 else TOL
+    tol = TOL
     assert torch.allclose(logits, ref_last, **tol), float((logits - ref_last).abs().max())
     # continue decoding from the prefilled cache
     tok = oracle.greedy(ref_last)
     eng.set_inputs(tok.tolist(), lens, bt)
     for step in range(3):
         pos = torch.tensor([n + step for n in lens], dtype=torch.int32)
-        _, ref = odec.forward_tokens(tok, pos, okv, list(range(B)))
         eng.step(B)
         torch.cuda.synchronize()
+        _, ref = odec.forward_tokens(tok, pos, okv, list(range(B)))
         assert torch.allclose(eng.logits[:B].cpu(), ref, **tol), (step, float((eng.logits[:B].cpu() - ref).abs().max()))
         tok = oracle.greedy(ref)
         eng.token_ids[:B].copy_(tok)
     assert eng.oob_count() == 0
+    if kv_int8:
+        assert okv.codes > 0 and okv.max_delta <= 1 and okv.flips <= 0.10 * okv.codes, (okv.flips, okv.codes, okv.max_delta)
 
 
 def test_engine_large_batch_step_matches_oracle():
