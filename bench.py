@@ -38,6 +38,7 @@ WORKLOADS = {
     "qwen2-7b-w4a16": ("qwen2-7b", "w4", False, 64, 1024, 16),           # BASELINE.json metric (GPTQ g128, fp16 KV)
     "qwen2-7b-w8a16": ("qwen2-7b", "int8", False, 16, 1024, 16),         # configs[1]
     "qwen2-7b-w4a16-kv8": ("qwen2-7b", "w4", True, 64, 4096, 16),        # configs[2]
+    "qwen2-7b-w4a16-page64": ("qwen2-7b", "w4", False, 64, 1024, 64),    # the metric's config on the reference's default block size (seq_size_per_block = 64)
     "qwen2-0.5b-fp16": ("qwen2-0.5b", "fp16", False, 1, 128, 16),        # configs[0] shape (GPU run of the plumbing config)
     "llama3-70b-awq": ("llama3-70b", "w4", False, 32, 2048, 16),         # configs[3]: needs --gpus 8 (tp8) or --shard-of 8
     "qwen2-72b-w4a16": ("qwen2-72b", "w4", False, 8, 1024, 16),          # configs[4] target model: --gpus 8 or --shard-of 8
@@ -46,6 +47,17 @@ WORKLOADS = {
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def gemm_sources_sha():
+    """Hash of the sources of the dominant kernel family: a committed PMC traffic file is only quoted for the kernels it measured."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rtp_llm_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.startswith("gemm") and (f.endswith(".hip") or f.endswith(".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def bytes_per_step(cfg, eng, B, ctx, kv_int8):
@@ -252,12 +264,18 @@ def main():
     elapsed, p50 = timed(run, reset)
     ms_per_step = elapsed / args.steps * 1e3
     tokens_per_s = B * dp * args.steps / elapsed
+    # spread: the K timed steps are ~70 ms of device time at the driver's K = 20; three more blocks of K steps (not part of
+    # `value`) show how far one block can sit from the typical one
+    repeats = []
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); run(args.steps); torch.cuda.synchronize()
+        repeats.append(round((time.perf_counter() - t0) / args.steps * 1e3, 4))
 
     out = {
         "metric": "decode tokens/sec + p50 latency, Qwen2-7B W4A16 b=1..64 @1/2/4/8 GPU" if args.workload == "qwen2-7b-w4a16"
                   else f"decode tokens/sec + p50 latency ({args.workload})",
         "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "p50_ms": round(p50, 4), "higher_is_better": True,
+        "ms_per_step": round(ms_per_step, 4), "p50_ms": round(p50, 4), "ms_per_step_repeats": repeats, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f16",
         "data": "synthetic (random-init weights of the named architecture, random KV cache, greedy decode)",
         "config": {"workload": f"{args.workload}: {mname} decode, weights {kind}"
@@ -286,11 +304,15 @@ def main():
         ach = alg_bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_src = None, None
         try:  # HBM read + write bytes per launch of THESE launches (the engine's four linears per layer), from the committed
-            # rocprofv3 --pmc passes over `bench.py --no-graph` (tools/engine_traffic.sh -> profiles/r02_traffic.json); PMC
-            # collection needs its own profiled runs, so it cannot happen inside this timed invocation: the value is static
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json"))).get(args.workload)
+            # rocprofv3 --pmc passes over `bench.py --no-graph` (tools/engine_traffic.sh -> profiles/r03_traffic.json); PMC
+            # collection needs its own profiled runs, so it cannot happen inside this timed invocation: the value is static --
+            # and only quoted while the GEMM sources still hash to what was measured (a stale file reports null)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json"))).get(args.workload)
             if tj and tj.get("batch") == B:
-                traffic, traffic_src = int(tj["gemm_quant_bytes_per_launch"]), tj.get("source")
+                if tj.get("gemm_sources_sha") == gemm_sources_sha():
+                    traffic, traffic_src = int(tj["gemm_quant_bytes_per_launch"]), tj.get("source")
+                else:
+                    traffic_src = "stale: profiles/r03_traffic.json was collected for different gemm*.hip sources (re-run tools/engine_traffic.sh)"
         except Exception:  # noqa: BLE001
             traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": "gemm_wq_kernel / gemm_wide_kernel (the four quantised linears of a layer: qkv, o, gate_up, down)", "achieved": round(ach, 1),
@@ -318,8 +340,25 @@ def main():
         # b=64, ctx 4096; configs[1] = W8A16 (load-time autoquant), b=16, ctx 1024
         if args.workload == "qwen2-7b-w4a16" and not args.no_sweep and not args.no_graph and not args.batch and not args.ctx and not args.layers:
             others = {}
+            # ---- prefill of the same weights: 8 prompts x 512 tokens as one chunk pass through the large-M
+            # GEMMs + causal paged attention; tokens/s, TFLOP/s (2 x linear params x tokens + attention) and TTFT of the batch
+            try:
+                npr, plen = min(B, 8), 512          # 4096 rows per launch: the size the large-M kernels were validated at
+                pr = [torch.randint(0, cfg_full.vocab, (plen,), generator=torch.Generator().manual_seed(50 + i), dtype=torch.int32).tolist() for i in range(npr)]
+                bt_p = torch.arange(npr * ((plen + page - 1) // page), dtype=torch.int32).reshape(npr, -1)
+                eng.prefill(pr, bt_p, chunk=plen); torch.cuda.synchronize()
+                t0 = time.perf_counter(); eng.prefill(pr, bt_p, chunk=plen); torch.cuda.synchronize()
+                tp = time.perf_counter() - t0
+                n_lin = cfg.num_layers * (cfg.hidden * (cfg.nh + 2 * cfg.nkv) * cfg.hd + cfg.nh * cfg.hd * cfg.hidden + cfg.hidden * 2 * cfg.inter + cfg.inter * cfg.hidden)
+                flops = 2.0 * n_lin * npr * plen + 4.0 * cfg.num_layers * cfg.nh * cfg.hd * npr * (plen * (plen + 1) / 2) + 2.0 * cfg.hidden * cfg.vocab * npr
+                others["qwen2-7b-w4a16-prefill"] = {"prompts": npr, "prompt_len": plen, "tokens": npr * plen, "seconds": round(tp, 4),
+                                                    "tokens_per_s": round(npr * plen / tp, 1), "tflops": round(flops / tp / 1e12, 1),
+                                                    "frac_of_2500_tflops_dense_f16": round(flops / tp / 2.5e15, 4),
+                                                    "note": "one chunk pass of 8 x 512 prompt tokens incl. lm_head on the last tokens; TTFT of the batch = seconds"}
+            except Exception as e:  # noqa: BLE001
+                others["qwen2-7b-w4a16-prefill"] = {"error": f"{type(e).__name__}: {e}"}
             del eng
-            for name in ("qwen2-7b-w4a16-kv8", "qwen2-7b-w8a16"):
+            for name in ("qwen2-7b-w4a16-kv8", "qwen2-7b-w8a16", "qwen2-7b-w4a16-page64"):
                 torch.cuda.empty_cache()
                 mn, kd, k8, b2, c2, pg = WORKLOADS[name]
                 cfg2, eng2, reset2 = build_engine(1, 0, 0, (model.MODELS[mn], kd, k8, b2, c2, pg))

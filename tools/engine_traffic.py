@@ -39,7 +39,9 @@ for c in sorted(set(fetch) | set(write)):
     print(f"{c:20s} {fetch[c][1]:9d} {rd / 1e6:15.2f} {wr / 1e6:16.2f}")
 g = out.get("gemm_quant")
 if g:
-    js = {"qwen2-7b-w4a16": {"batch": 64, "gemm_quant_read_bytes_per_launch": g["read_bytes_per_launch"],
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    js = {"qwen2-7b-w4a16": {"batch": 64, "gemm_sources_sha": bench.gemm_sources_sha(), "gemm_quant_read_bytes_per_launch": g["read_bytes_per_launch"],
                              "gemm_quant_write_bytes_per_launch": g["write_bytes_per_launch"],
                              "gemm_quant_bytes_per_launch": g["read_bytes_per_launch"] + g["write_bytes_per_launch"],
                              "per_class": out,

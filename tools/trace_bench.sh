@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-kernel timing of bench.py under rocprofv3 (kernel trace only).  usage (on the GPU box): bash tools/trace_bench.sh TAG [bench args...]
 # Output: gpurun_out/$ROUND/kernel_stats_TAG.txt + bench_under_rocprof_TAG.json   (ROUND defaults to r02)
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND:-r02}; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND:-r03}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 tag=$1; shift
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_$tag -o run -- python $R/bench.py "$@" > $O/bench_under_rocprof_$tag.log 2>&1
