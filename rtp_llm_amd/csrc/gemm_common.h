@@ -134,10 +134,19 @@ __device__ __forceinline__ float dpp_add(float v) {
 }
 
 
+// Split-K slabs are stored write-through (sc1, 16 bytes per lane through a buffer descriptor over the slab region): see the
+// staged kernel's epilogue in gemm.hip for the measurement.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_rsrc(const GemmParams& p, int nsplit) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p.partials, 0, p.mode == MODE_PARTIAL ? (int)((size_t)nsplit * p.M * p.N_pad * 4) : 0, 0x00020000u);
+}
+__device__ __forceinline__ void st_slab(__amdgpu_buffer_rsrc_t r, uint32_t off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 16 /*sc1*/);
+}
+
 // Epilogue for one lane's 4 consecutive output columns n0..n0+3 of batch row m (v already scaled).
 __device__ __forceinline__ void gemm_store(const GemmParams& p, f32x4 v, int m, int n0, int split) {
     if (p.mode == MODE_PARTIAL) {
-        *reinterpret_cast<f32x4*>(p.partials + ((size_t)split * p.M + m) * p.N_pad + n0) = v;
+        st_slab(slab_rsrc(p, p.nsplit), (uint32_t)((((size_t)split * p.M + m) * p.N_pad + n0) * 4), v);
         return;
     }
     if (n0 >= p.N) return;
