@@ -383,6 +383,7 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
             for (int mb = 0; mb < MB; ++mb) acc[nb][mb] += red[((wn * NBW + nb) * MB + mb) * 64 + lane];
     }
     __amdgpu_buffer_rsrc_t rp_slab = slab_rsrc(p, gridDim.y);
+    __amdgpu_buffer_rsrc_t ry_f32 = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.mode == MODE_F32 ? (int)min((size_t)0x7FFFFFF0, (size_t)p.M * p.ldy * 4) : 0, FLAGS);
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         if (!tile_ok[nb]) continue;
@@ -412,8 +413,8 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
                 }
-                if (p.mode == MODE_F32) {
-                    *reinterpret_cast<f32x4*>((float*)p.y + (size_t)m * p.ldy + n0) = v;
+                if (p.mode == MODE_F32) {   // lm_head logits (39 MB at b = 64): write-through like the slabs, nothing left dirty at the end
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry_f32, (uint32_t)(((size_t)m * p.ldy + n0) * 4), 0, 16 /*sc1*/);
                 } else if (p.mode == MODE_F16) {
                     f16x4 o;
 #pragma unroll
