@@ -409,8 +409,20 @@ def main():
                     grp = gnew
             distributed.set_tp_group(grp)
             tcfg, teng, treset = build_engine(tpn, rank % tpn, rank // tpn)
-            ar = distributed.CustomAllReduce(max_bytes=B * cfg_full.hidden * 2, group=grp)
-            teng.attach_allreduce(ar, (rank % tpn) * tcfg.vocab)
+            # transport of the TP points: the hand-written IPC all-reduce; if the peer mapping is refused on any rank (every
+            # rank raises together), RCCL inside the captured step instead -- the reference's own fallback under capture
+            # (rocm_rccl.py:511-572) -- so the TP layout survives an IPC failure rather than dropping to replicas
+            ar = transport = None
+            try:
+                if os.environ.get("MI355_BENCH_FORCE_RCCL") == "1":
+                    raise RuntimeError("MI355_BENCH_FORCE_RCCL=1")
+                ar = distributed.CustomAllReduce(max_bytes=B * cfg_full.hidden * 2, group=grp)
+                teng.attach_allreduce(ar, (rank % tpn) * tcfg.vocab)
+            except Exception as e:  # noqa: BLE001
+                log(f"[rank {rank}] IPC all-reduce unavailable ({type(e).__name__}: {e}); falling back to RCCL inside the step")
+                ar = None
+                transport = distributed.RcclTransport(group=grp)
+                teng.attach_collective(transport, (rank % tpn) * tcfg.vocab)
             if args.prefetch is not None:
                 teng.set_weight_prefetch(args.prefetch)
             treset()
@@ -419,14 +431,16 @@ def main():
                 teng.capture(B)
             trun = (lambda n: teng.replay(B, n)) if captured else (lambda n: [teng.step(B) for _ in range(n)])
             t_el, t_p50 = timed(trun, treset)
-            st = ar.status()
+            st = ar.status() if ar is not None else 0
             if st != 0:
                 raise RuntimeError(f"all-reduce spin timed out (status {st})")
             tp_info = {"parallelism": f"tp{tpn}" + (f" x dp{dpn}" if dpn > 1 else ""), "global_batch": B * dpn,
                        "tokens_per_s": round(B * dpn * args.steps / t_el, 1), "ms_per_step": round(t_el / args.steps * 1e3, 4),
                        "p50_ms": round(t_p50, 4), "graph": captured,
-                       "collectives": "hand-written one-shot peer-read all-reduce over IPC/xGMI, fused with split-K reduce + residual + "
-                                      "RMSNorm (2 per layer) + cross-rank greedy argmax; no RCCL on the data path"}
+                       "collectives": ("hand-written one-shot peer-read all-reduce over IPC/xGMI, fused with split-K reduce + residual + "
+                                       "RMSNorm (2 per layer) + cross-rank greedy argmax; no RCCL on the data path") if ar is not None else
+                                      ("RCCL fallback (IPC peer mapping unavailable): ncclAllReduce on the local split-K fold (2 per layer) + "
+                                       "ncclAllGather of one (max, index) pair per row, all inside the captured step")}
             # headline := the TP layout
             out.update(value=tp_info["tokens_per_s"], ms_per_step=tp_info["ms_per_step"], p50_ms=tp_info["p50_ms"],
                        scaling="strong" if dpn == 1 else "strong within a tp group, weak across the dp groups")

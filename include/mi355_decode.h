@@ -471,6 +471,32 @@ int    mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_ids, const
  * mi355_allreduce_argmax, so mi355_decoder_step / _capture / _replay drive the whole tensor-parallel step from C++ with
  * no host round trip per layer.  vocab_offset: first vocabulary column of this rank's lm_head slice. */
 int mi355_decoder_attach_allreduce(mi355_decoder_t* d, mi355_allreduce_t* ar, int32_t vocab_offset);
+/* External collective transport: the fallback when the peer mapping of mi355_allreduce_open is not available (IPC refused
+ * across devices / containers).  The reference does the same under graph capture: its custom kernel when it applies, raw
+ * ncclAllReduce on the capture stream otherwise (rtp_llm/models_py/distributed/rocm_rccl.py:511-572, dispatch
+ * collective_torch.py:694-722).  Both callbacks enqueue on `stream` and must be capturable (RCCL's are); they return 0 on
+ * success.  With a transport attached, mi355_decoder_step / _capture / _replay / _prefill run for tp_size > 1 without an
+ * mi355_allreduce_t: each row-parallel linear is reduced locally (split-K fold -> fp16), summed in place over the ranks by
+ * all_reduce_f16, then residual + RMSNorm as one launch; greedy sampling all-gathers one (max, global index) pair per row. */
+typedef struct mi355_collective {
+    void*   ctx;
+    int   (*all_reduce_f16)(void* ctx, void* buf, size_t count, mi355_stream_t stream);   /* in-place SUM of `count` fp16 */
+    int   (*all_gather)(void* ctx, const void* send, void* recv, size_t bytes_per_rank, mi355_stream_t stream); /* recv = [world][bytes] */
+    int32_t rank, world;
+} mi355_collective_t;
+int mi355_decoder_attach_collective(mi355_decoder_t* d, const mi355_collective_t* coll, int32_t vocab_offset);
+
+/* RCCL behind mi355_collective_t.  librccl is resolved at run time (dlopen of lib_path, NULL = "librccl.so"; a process that
+ * already loaded torch's copy passes that path and shares it), so libmi355_decode.so has no link-time dependency on it.
+ * Rank 0 makes the unique id (mi355_rccl_unique_id_bytes() bytes), the host passes it to the other ranks (any control
+ * plane: gloo, a file, the reference's TCPStore), every rank opens. */
+typedef struct mi355_rccl mi355_rccl_t;
+size_t        mi355_rccl_unique_id_bytes(void);
+int           mi355_rccl_unique_id(const char* lib_path, void* id_out);
+mi355_rccl_t* mi355_rccl_open(const char* lib_path, const void* unique_id, int32_t rank, int32_t world);
+int           mi355_rccl_collective(mi355_rccl_t* r, mi355_collective_t* out);
+void          mi355_rccl_close(mi355_rccl_t* r);
+
 /* on != 0: the embedding table given at creation holds only this rank's hidden / tp_size columns ([vocab][hidden / tp], the
  * reference's hidden-split embedding weight, modules/base/common/embedding.py:22-59); every step then looks its slice up and
  * all-gathers the hidden dimension (mi355_allgather_hidden) instead of reading a replicated table.  After attach_allreduce. */

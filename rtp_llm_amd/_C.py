@@ -58,6 +58,16 @@ class StepBuffers(C.Structure):  # mi355_step_buffers_t
                 ("ar_buf", vp), ("workspace", vp), ("workspace_bytes", sz)]
 
 
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class Collective(C.Structure):
+    """mi355_collective_t: an external transport for the TP points of the step (RCCL fallback)."""
+    _fields_ = [("ctx", C.c_void_p), ("all_reduce_f16", ALL_REDUCE_FN), ("all_gather", ALL_GATHER_FN),
+                ("rank", C.c_int32), ("world", C.c_int32)]
+
+
 # symbol -> (restype, argtypes); every symbol include/mi355_decode.h declares
 SIGNATURES = {
     "mi355_abi_version": (i32, []),
@@ -94,6 +104,12 @@ SIGNATURES = {
     "mi355_allreduce_argmax": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "mi355_decoder_attach_allreduce": (i32, [vp, vp, i32]),
     "mi355_decoder_set_embedding_split": (i32, [vp, i32]),
+    "mi355_decoder_attach_collective": (i32, [vp, C.POINTER(Collective), i32]),
+    "mi355_rccl_unique_id_bytes": (sz, []),
+    "mi355_rccl_unique_id": (i32, [C.c_char_p, vp]),
+    "mi355_rccl_open": (vp, [C.c_char_p, vp, i32, i32]),
+    "mi355_rccl_collective": (i32, [vp, C.POINTER(Collective)]),
+    "mi355_rccl_close": (None, [vp]),
     "mi355_decoder_set_weight_prefetch": (i32, [vp, i32]),
     "mi355_allgather_hidden": (i32, [vp, vp, vp, i32, i32, vp]),
     "mi355_decoder_workspace_bytes": (sz, [C.POINTER(ModelConfig)]),

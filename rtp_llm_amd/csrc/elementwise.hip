@@ -216,6 +216,33 @@ __global__ __launch_bounds__(64) void argmax_stage2(const float* __restrict__ ca
     }
 }
 
+// Vocab-split greedy over an external transport: stage 2 leaves one (max, GLOBAL index) pair per row, the pairs of all
+// ranks are all-gathered, argmax_pick takes the best per row (ties: lowest global index, as a full-row argmax would).
+struct ArgPair { float v; int i; };
+
+__global__ __launch_bounds__(64) void argmax_pair(const float* __restrict__ cand_v, const int* __restrict__ cand_i, int nparts,
+                                                  int vocab_offset, ArgPair* __restrict__ out) {
+    const int b = blockIdx.x, l = threadIdx.x;
+    float bv = l < nparts ? cand_v[b * nparts + l] : -INFINITY;
+    int bi = l < nparts ? cand_i[b * nparts + l] : 0x7FFFFFFF;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+        argmax_combine(bv, bi, ov, oi);
+    }
+    if (l == 0) out[b] = ArgPair{bv, bi == 0x7FFFFFFF ? bi : bi + vocab_offset};
+}
+
+__global__ __launch_bounds__(64) void argmax_pick(const ArgPair* __restrict__ pairs, int world, int B, int32_t* __restrict__ ids,
+                                                  int32_t* __restrict__ positions) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    float bv = -INFINITY; int bi = 0x7FFFFFFF;
+    for (int r = 0; r < world; ++r) { const ArgPair p = pairs[(size_t)r * B + b]; argmax_combine(bv, bi, p.v, p.i); }
+    ids[b] = bi;
+    if (positions) positions[b] += 1;
+}
+
 } // namespace
 
 extern "C" int mi355_add_rmsnorm(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
@@ -298,4 +325,25 @@ extern "C" int mi355_argmax_candidates(const float* logits, int32_t B, int32_t V
 extern "C" int mi355_argmax(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t* ids, void* workspace,
                             size_t workspace_bytes, mi355_stream_t stream) {
     return mi355_argmax_ex(logits, B, V, ld, ids, nullptr, workspace, workspace_bytes, stream);
+}
+
+// vocab-split greedy, local half: one (max, global index) pair per row -> pairs_out [B] (8 bytes each)
+extern "C" int mi355_argmax_pairs(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t vocab_offset, void* pairs_out,
+                                  void* workspace, size_t workspace_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(pairs_out && vocab_offset >= 0, "argmax_pairs: bad argument");
+    if (int e = mi355_argmax_candidates(logits, B, V, ld, workspace, workspace_bytes, stream)) return e;
+    const float* cv = (const float*)workspace; const int* ci = (const int*)(cv + (size_t)B * 64);
+    hipLaunchKernelGGL(argmax_pair, dim3(B), dim3(64), 0, (hipStream_t)stream, cv, ci, 64, vocab_offset, (ArgPair*)pairs_out);
+    MI355_CHECK_LAUNCH("argmax_pair");
+    return MI355_OK;
+}
+
+// global half: pairs_all [world][B] (all-gathered) -> ids [B], positions[b] += 1
+extern "C" int mi355_argmax_pick(const void* pairs_all, int32_t world, int32_t B, int32_t* ids, int32_t* positions,
+                                 mi355_stream_t stream) {
+    MI355_CHECK_ARG(pairs_all && ids && world > 0 && B > 0, "argmax_pick: world=%d B=%d", world, B);
+    hipLaunchKernelGGL(argmax_pick, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, (const ArgPair*)pairs_all, world, B, ids,
+                       positions);
+    MI355_CHECK_LAUNCH("argmax_pick");
+    return MI355_OK;
 }

@@ -42,6 +42,11 @@ struct mi355_decoder {
     int32_t* oob_count; // tokens refused by the KV writer (stale position / block id)
     mi355_allreduce_t* ar; // attached all-reduce context (tp_size > 1): the TP step runs entirely from C++
     int    vocab_offset;
+    // external transport (RCCL) for the same points when the peer mapping is not available: local fold -> fp16 ar_buf ->
+    // in-place all-reduce -> residual + norm launch; greedy = all-gather of one (max, global index) pair per row
+    mi355_collective_t ext;
+    bool   has_ext;
+    void  *pairs_local, *pairs_all;
     bool   embed_split;   // the embedding table holds this rank's hidden / tp columns: lookup + all-gather (embedding.py:50-58)
     // comm / weight-stream overlap: while the (latency-bound, <= 64 blocks) all-reduce kernel runs on the main stream, a
     // side stream pulls the NEXT GEMM's weight shard into the Infinity Cache
@@ -194,6 +199,7 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     carve_all(d, *cfg, bufs->workspace);
     d->xn = bufs->hidden; // the normed hidden state lives in the caller-visible buffer
     d->B = 0; d->q_len = 1; d->cap_stream = nullptr; d->prof_on = false; d->ev_used = 0; d->ar = nullptr; d->vocab_offset = 0;
+    d->has_ext = false; d->pairs_local = d->pairs_all = nullptr;
     d->side_stream = nullptr; d->ev_fork = d->ev_join = nullptr; d->overlap = false;
     d->pf_mask = 0; d->pf_pending = false;
     d->fuse_qkv = cfg->kv_dtype == MI355_KV_FP16 && cfg->rope_dim == cfg->hd;
@@ -228,6 +234,7 @@ extern "C" void mi355_decoder_destroy(mi355_decoder_t* d) {
     if (d->ev_fork) hipEventDestroy(d->ev_fork);
     if (d->ev_join) hipEventDestroy(d->ev_join);
     for (auto e : d->ev) hipEventDestroy(e);
+    if (d->pairs_local) hipFree(d->pairs_local);
     delete d;
 }
 
@@ -274,6 +281,37 @@ extern "C" int mi355_decoder_attach_allreduce(mi355_decoder_t* d, mi355_allreduc
     }
     return MI355_OK;
 }
+
+extern "C" int mi355_decoder_attach_collective(mi355_decoder_t* d, const mi355_collective_t* coll, int32_t vocab_offset) {
+    if (!d || !coll || d->cfg.tp_size <= 1 || vocab_offset < 0 || !coll->all_reduce_f16 || !coll->all_gather ||
+        coll->world != d->cfg.tp_size || coll->rank < 0 || coll->rank >= coll->world) {
+        mi355_set_error("decoder_attach_collective: needs a decoder created with tp_size > 1 and a transport of that world size");
+        return MI355_ERR_ARG;
+    }
+    if (d->ar) { mi355_set_error("decoder_attach_collective: an all-reduce context is already attached"); return MI355_ERR_ARG; }
+    for (auto& kv : d->graphs) hipGraphExecDestroy(kv.second);
+    d->graphs.clear();
+    if (!d->pairs_local) {
+        const size_t one = align256((size_t)d->cfg.max_batch * 8);
+        if (hipMalloc(&d->pairs_local, one * (1 + (size_t)coll->world)) != hipSuccess) {
+            mi355_set_error("decoder_attach_collective: %s", hipGetErrorString(hipGetLastError())); return MI355_ERR_HIP;
+        }
+        d->pairs_all = (char*)d->pairs_local + one;
+    }
+    d->ext = *coll; d->has_ext = true; d->vocab_offset = vocab_offset;
+    return MI355_OK;
+}
+
+namespace {
+// in-place sum of `count` fp16 over the TP ranks through the attached transport (no-op without one: the segment caller
+// all-reduces ar_buf itself between the calls)
+int ext_all_reduce(mi355_decoder* d, void* buf, size_t count, hipStream_t st) {
+    if (!d->has_ext) return MI355_OK;
+    const int rc = d->ext.all_reduce_f16(d->ext.ctx, buf, count, (mi355_stream_t)st);
+    if (rc != 0) { mi355_set_error("decoder: the attached transport's all-reduce failed (%d)", rc); return MI355_ERR_HIP; }
+    return MI355_OK;
+}
+} // namespace
 
 extern "C" int mi355_decoder_set_embedding_split(mi355_decoder_t* d, int32_t on) {
     if (!d || (on && (!d->ar || d->cfg.tp_size <= 1 || d->cfg.hidden % (8 * d->cfg.tp_size) != 0))) {
@@ -417,6 +455,7 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
     } else { // local split-K reduce -> fp16 tensor for the TP all-reduce
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.o.N_pad, nullptr, nullptr, d->bufs.ar_buf, nullptr,
                                              c.rms_eps, B, c.hidden, nullptr, st));
+        RUN(MI355_KC_COMM, ext_all_reduce(d, d->bufs.ar_buf, (size_t)B * c.hidden, st));
     }
     return MI355_OK;
 }
@@ -463,6 +502,7 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
     } else {
         RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.down.N_pad, nullptr, nullptr, d->bufs.ar_buf, nullptr,
                                              c.rms_eps, B, c.hidden, nullptr, st));
+        RUN(MI355_KC_COMM, ext_all_reduce(d, d->bufs.ar_buf, (size_t)B * c.hidden, st));
     }
     return MI355_OK;
 }
@@ -521,7 +561,9 @@ extern "C" int mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_id
     }
     const auto& c = d->cfg;
     const int T = nseq * q_len;
-    if (c.tp_size > 1 && !d->ar) { mi355_set_error("decoder_prefill: tp_size > 1 needs mi355_decoder_attach_allreduce"); return MI355_ERR_ARG; }
+    if (c.tp_size > 1 && !d->ar && !d->has_ext) {
+        mi355_set_error("decoder_prefill: tp_size > 1 needs mi355_decoder_attach_allreduce or _attach_collective"); return MI355_ERR_ARG;
+    }
     PrefillBufs b;
     const size_t need = carve_prefill(c, T, nseq, workspace, &b);
     if (need > workspace_bytes) { mi355_set_error("decoder_prefill: workspace %zu < %zu", workspace_bytes, need); return MI355_ERR_WORKSPACE; }
@@ -544,7 +586,8 @@ extern "C" int mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_id
         RUN(MI355_KC_ATTN, mi355_paged_attn_rows(b.q, &kv, block_table, c.max_blocks_per_seq, positions, nseq, q_len, c.nh, scale,
                                                  c.max_seq_len, b.attn, b.attn_ws, b.attn_ws_bytes, st));
         RUN(MI355_KC_GEMM_QUANT, mi355_linear_forward(b.attn, T, &L.o, nullptr, b.tmp, MI355_EPI_NONE, b.gemm_ws, b.gemm_ws_bytes, st));
-        if (c.tp_size == 1) {
+        if (c.tp_size > 1 && !d->ar) RUN(MI355_KC_COMM, ext_all_reduce(d, b.tmp, (size_t)T * c.hidden, st));
+        if (c.tp_size == 1 || !d->ar) {
             RUN(MI355_KC_NORM, mi355_add_rmsnorm(b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, L.post_norm, c.rms_eps, T, c.hidden, b.xn, st));
         } else {
             RUN(MI355_KC_COMM, mi355_allreduce_fused(d->ar, b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, L.post_norm, c.rms_eps, T,
@@ -553,7 +596,8 @@ extern "C" int mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_id
         RUN(MI355_KC_GEMM_QUANT, mi355_linear_forward(b.xn, T, &L.gate_up, nullptr, b.act, MI355_EPI_SILU_MUL, b.gemm_ws, b.gemm_ws_bytes, st));
         RUN(MI355_KC_GEMM_QUANT, mi355_linear_forward(b.act, T, &L.down, nullptr, b.tmp, MI355_EPI_NONE, b.gemm_ws, b.gemm_ws_bytes, st));
         const void* next_norm = (l + 1 < c.num_layers) ? d->layers[l + 1].input_norm : d->model.final_norm;
-        if (c.tp_size == 1) {
+        if (c.tp_size > 1 && !d->ar) RUN(MI355_KC_COMM, ext_all_reduce(d, b.tmp, (size_t)T * c.hidden, st));
+        if (c.tp_size == 1 || !d->ar) {
             RUN(MI355_KC_NORM, mi355_add_rmsnorm(b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, next_norm, c.rms_eps, T, c.hidden, b.xn, st));
         } else {
             RUN(MI355_KC_COMM, mi355_allreduce_fused(d->ar, b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, next_norm, c.rms_eps, T,
@@ -571,6 +615,19 @@ extern "C" int mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_id
     return MI355_OK;
 }
 
+namespace {
+// vocab-split greedy through the external transport: (max, global index) per row, all-gathered, best per row
+int ext_argmax(mi355_decoder* d, int B, hipStream_t st) {
+    const auto& c = d->cfg;
+    RUN(MI355_KC_OTHER, mi355_argmax_pairs(d->bufs.logits, B, c.vocab, c.vocab, d->vocab_offset, d->pairs_local, d->argmax_ws,
+                                           d->argmax_ws_bytes, st));
+    RUN(MI355_KC_COMM, d->ext.all_gather(d->ext.ctx, d->pairs_local, d->pairs_all, (size_t)B * 8, (mi355_stream_t)st) == 0
+                           ? MI355_OK : (mi355_set_error("decoder: the attached transport's all-gather failed"), MI355_ERR_HIP));
+    RUN(MI355_KC_OTHER, mi355_argmax_pick(d->pairs_all, d->ext.world, B, d->bufs.token_ids, d->bufs.positions, st));
+    return MI355_OK;
+}
+} // namespace
+
 extern "C" int mi355_decoder_finish(mi355_decoder_t* d, int32_t sample, mi355_stream_t stream) {
     if (!d || d->B <= 0) { mi355_set_error("decoder_finish: no step in flight"); return MI355_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
@@ -584,6 +641,8 @@ extern "C" int mi355_decoder_finish(mi355_decoder_t* d, int32_t sample, mi355_st
     if (sample && d->ar) {   // vocab-split lm_head: (max, index) pairs cross the ranks, not the logits
         RUN(MI355_KC_COMM, mi355_allreduce_argmax(d->ar, d->bufs.logits, B, c.vocab, c.vocab, d->vocab_offset, d->bufs.token_ids,
                                                   d->bufs.positions, d->argmax_ws, d->argmax_ws_bytes, st));
+    } else if (sample && d->has_ext) {
+        if (int e = ext_argmax(d, B, st)) return e;
     } else if (sample) {
         RUN(MI355_KC_OTHER, mi355_argmax_ex(d->bufs.logits, B, c.vocab, c.vocab, d->bufs.token_ids, d->bufs.positions,
                                             d->argmax_ws, d->argmax_ws_bytes, st));
@@ -592,8 +651,8 @@ extern "C" int mi355_decoder_finish(mi355_decoder_t* d, int32_t sample, mi355_st
 }
 
 extern "C" int mi355_decoder_step(mi355_decoder_t* d, int32_t B, mi355_stream_t stream) {
-    if (!d || (d->cfg.tp_size != 1 && !d->ar)) {
-        mi355_set_error("decoder_step: tp_size > 1 needs mi355_decoder_attach_allreduce (or the segment calls)");
+    if (!d || (d->cfg.tp_size != 1 && !d->ar && !d->has_ext)) {
+        mi355_set_error("decoder_step: tp_size > 1 needs mi355_decoder_attach_allreduce / _attach_collective (or the segment calls)");
         return MI355_ERR_ARG;
     }
     if (B > 64) {   // large batch: the generic path (large-M GEMMs, fp16 intermediates), one row per sequence
@@ -606,6 +665,8 @@ extern "C" int mi355_decoder_step(mi355_decoder_t* d, int32_t B, mi355_stream_t 
         if (d->ar) {
             RUN(MI355_KC_COMM, mi355_allreduce_argmax(d->ar, d->bufs.logits, B, c.vocab, c.vocab, d->vocab_offset, d->bufs.token_ids,
                                                       d->bufs.positions, d->argmax_ws, d->argmax_ws_bytes, st));
+        } else if (d->has_ext) {
+            if (int e = ext_argmax(d, B, st)) return e;
         } else {
             RUN(MI355_KC_OTHER, mi355_argmax_ex(d->bufs.logits, B, c.vocab, c.vocab, d->bufs.token_ids, d->bufs.positions, d->argmax_ws,
                                                 d->argmax_ws_bytes, st));

@@ -19,6 +19,9 @@ int mi355_fullk_weight_ok(const mi355_weight_t* w);
 int mi355_prefetch(const void* ptr, size_t bytes, void* sink, mi355_stream_t stream);
 int mi355_argmax_candidates(const float* logits, int32_t B, int32_t V, int32_t ld, void* workspace, size_t workspace_bytes,
                             mi355_stream_t stream);
+int mi355_argmax_pairs(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t vocab_offset, void* pairs_out,
+                       void* workspace, size_t workspace_bytes, mi355_stream_t stream);
+int mi355_argmax_pick(const void* pairs_all, int32_t world, int32_t B, int32_t* ids, int32_t* positions, mi355_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

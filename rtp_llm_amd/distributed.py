@@ -71,13 +71,20 @@ class CustomAllReduce:
         n = self.lib.mi355_allreduce_handle_bytes()
         blob = C.create_string_buffer(n)
         self.handle = self.lib.mi355_allreduce_create(self.rank, self.world, int(max_bytes), blob)
-        if not self.handle:
-            raise _C.Mi355Error("allreduce_create failed: " + self.lib.mi355_last_error().decode())
+        err = None if self.handle else "allreduce_create failed: " + self.lib.mi355_last_error().decode()
         blobs = [None] * self.world
-        dist.all_gather_object(blobs, blob.raw, group=group)           # host bytes: works over gloo and over nccl groups
-        self._all = C.create_string_buffer(b"".join(blobs), n * self.world)
-        _C.check(self.lib.mi355_allreduce_open(self.handle, self._all), "allreduce_open")
-        dist.barrier(group=group)                                     # every rank has mapped every peer before first use
+        dist.all_gather_object(blobs, None if err else blob.raw, group=group)   # host bytes: works over gloo and over nccl groups
+        if err is None and all(b is not None for b in blobs):
+            self._all = C.create_string_buffer(b"".join(blobs), n * self.world)
+            if self.lib.mi355_allreduce_open(self.handle, self._all) < 0:
+                err = "allreduce_open failed: " + self.lib.mi355_last_error().decode()
+        # every rank learns whether every rank mapped every peer (this exchange is also the barrier before first use): a
+        # failure anywhere raises everywhere, so the callers' fallback (RcclTransport) is taken by all ranks together
+        errs = [None] * self.world
+        dist.all_gather_object(errs, err, group=group)
+        if any(errs):
+            self.close()
+            raise _C.Mi355Error("; ".join(f"rank {r}: {e}" for r, e in enumerate(errs) if e))
         self.max_bytes = int(max_bytes)
 
     def _st(self):
@@ -125,6 +132,53 @@ class CustomAllReduce:
     def close(self):
         if getattr(self, "handle", None):
             self.lib.mi355_allreduce_destroy(self.handle)
+            self.handle = None
+
+
+class RcclTransport:
+    """RCCL communicator behind ``mi355_collective_t`` (csrc/rccl_transport.cpp): the transport the C++ step falls back to
+    when CustomAllReduce cannot map its peers -- ncclAllReduce / ncclAllGather enqueued on the step's stream, so they are
+    captured into the step graph like the kernels around them (the reference: rocm_rccl.py:511-572).  The unique id made
+    by rank 0 travels through the (CPU-capable) process group, as the reference's does through its TCPStore
+    (rocm_rccl.py:150-260).  librccl is the copy torch ships, shared with torch.distributed's "nccl" backend."""
+
+    def __init__(self, group=None, rank: Optional[int] = None, world: Optional[int] = None, lib_path: Optional[str] = None):
+        import ctypes as C
+        from . import _C
+        self._C, self.lib = _C, _C.lib()
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        if lib_path is None:
+            cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            lib_path = cand if os.path.exists(cand) else ""
+        path = lib_path.encode()
+        n = self.lib.mi355_rccl_unique_id_bytes()
+        blob = C.create_string_buffer(n)
+        if self.rank == 0:
+            _C.check(self.lib.mi355_rccl_unique_id(path, blob), "rccl_unique_id")
+        if self.world > 1:
+            box = [blob.raw]
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+            blob = C.create_string_buffer(box[0], n)
+        self.handle = self.lib.mi355_rccl_open(path, blob, self.rank, self.world)
+        if not self.handle:
+            raise _C.Mi355Error("rccl_open failed: " + self.lib.mi355_last_error().decode())
+        self.collective = _C.Collective()
+        _C.check(self.lib.mi355_rccl_collective(self.handle, C.byref(self.collective)), "rccl_collective")
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place SUM of an fp16 tensor over the ranks, on the current stream."""
+        if not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous()):
+            raise ValueError("RcclTransport.all_reduce: contiguous fp16 device tensor expected")
+        rc = self.collective.all_reduce_f16(self.collective.ctx, t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise self._C.Mi355Error("ncclAllReduce failed: " + self.lib.mi355_last_error().decode())
+        return t
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mi355_rccl_close(self.handle)
             self.handle = None
 
 

@@ -581,6 +581,14 @@ class DecoderEngine:
         _C.check(self.lib.mi355_decoder_attach_allreduce(self.handle, ar.handle, int(vocab_offset)), "decoder_attach_allreduce")
         self._ar = ar
 
+    def attach_collective(self, transport, vocab_offset: int):
+        """tp > 1 without the IPC all-reduce: run the TP points through an external transport inside the C++ step
+        (distributed.RcclTransport: ncclAllReduce / ncclAllGather on the step's stream, capturable) -- the reference's
+        fallback under graph capture (rocm_rccl.py:511-572).  step() / capture() / replay() then work as with attach_allreduce."""
+        _C.check(self.lib.mi355_decoder_attach_collective(self.handle, C.byref(transport.collective), int(vocab_offset)),
+                 "decoder_attach_collective")
+        self._transport = transport
+
     def set_weight_prefetch(self, mask: int):
         """Weight prefetch one launch ahead on a side stream (mi355_decoder_set_weight_prefetch, _C.PF_* bits; 0 = off).
         Captured graphs are dropped: capture again."""
@@ -595,6 +603,8 @@ class DecoderEngine:
 
     # ---- tp > 1: the step cut at the all-reduce points (causal_attention.py:91-92, dense_mlp.py:104-105)
     def step_tp(self, B: int, sample: bool = True):
+        if getattr(self, "_transport", None) is not None:
+            raise _C.Mi355Error("step_tp: a transport is attached, the C++ step already all-reduces: use step()")
         st, h, lib = self._st(), self.handle, self.lib
         ar = self.ar_buf[:B]
         _C.check(lib.mi355_decoder_begin(h, B, st), "decoder_begin")

@@ -213,6 +213,11 @@ def test_sampler_and_collective_entry_points_validate_on_the_host():
     assert l.mi355_ban_repeat_ngram(None, 0, 10, 10, None, 4, None, None, None) == 0
     assert l.mi355_allgather_hidden(None, 1, 1, 4, 64, None) == _C.ERR_ARG and b"not opened" in l.mi355_last_error()
     assert l.mi355_decoder_set_embedding_split(None, 1) == _C.ERR_ARG
+    assert l.mi355_decoder_attach_collective(None, None, 0) == _C.ERR_ARG
+    assert l.mi355_rccl_unique_id_bytes() == 128
+    assert l.mi355_rccl_unique_id(b"/nonexistent/librccl.so", ctypes.create_string_buffer(128)) < 0 and b"dlopen" in l.mi355_last_error()
+    assert not l.mi355_rccl_open(b"", ctypes.create_string_buffer(128), 2, 2)                                               # rank out of range
+    assert l.mi355_rccl_collective(None, None) == _C.ERR_ARG
     from rtp_llm_amd import model
     emb = torch.arange(6 * 32, dtype=torch.float16).reshape(6, 32)
     parts = [model.split_embedding_tp(emb, 2, r) for r in range(2)]

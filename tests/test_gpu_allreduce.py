@@ -189,6 +189,63 @@ def _worker(rank, world, port, q, mode):
                 torch.cuda.synchronize()
                 assert torch.equal(eng2.logits[:B], eng3.logits[:B]) and torch.equal(eng2.token_ids[:B], eng3.token_ids[:B]), step
             assert ar.status() == 0
+        elif mode == "transport":
+            # the external-transport form of the TP step (mi355_decoder_attach_collective: the RCCL fallback).  RCCL cannot
+            # bootstrap in this sandbox, so the transport under test is a stub with the same contract whose callbacks enqueue
+            # the IPC kernels: local fold -> in-place all-reduce -> residual + norm, pair all-gather for greedy; captured.
+            from rtp_llm_amd import _C
+
+            class StubTransport:
+                def __init__(self, ar):
+                    lib = _C.lib()
+                    self.H = 512
+
+                    def all_reduce(ctx, buf, count, stream):
+                        return lib.mi355_allreduce_sum(ar.handle, buf, buf, count // self.H, self.H, stream)
+
+                    def all_gather(ctx, send, recv, nbytes, stream):
+                        assert nbytes % 16 == 0
+                        return lib.mi355_allgather_hidden(ar.handle, send, recv, 1, nbytes // 2, stream)
+                    self._fns = (_C.ALL_REDUCE_FN(all_reduce), _C.ALL_GATHER_FN(all_gather))
+                    self.collective = _C.Collective(None, self._fns[0], self._fns[1], ar.rank, ar.world)
+
+            cfg = model.ModelConfig("tiny-tp", 2, 512, 8, 2, 64, 768, 1024, max_pos=256)
+            w = model.synth_model(cfg, "w4", "cpu", seed=22, zeros="centered")
+            V = cfg.vocab
+            layers = [model.split_layer_tp(L, cfg, world, rank) for L in w["layers"]]
+            head = w["lm_head"].cols(rank * (V // world), (rank + 1) * (V // world))
+            shard = {"layers": layers, "embedding": w["embedding"], "final_norm": w["final_norm"], "lm_head": head}
+            B, page = 6, 16
+            mk = lambda mb: model.DecoderEngine(cfg.per_rank(world), model.weights_to(shard, dev), kv_int8=False, page=page,
+                                                num_blocks=mb * 2, max_batch=mb, max_seq_len=32, device=dev, tp_size=world, vocab_full=V)
+            eng, ref_eng = mk(B), mk(B)
+            with pytest.raises(_C.Mi355Error):
+                eng.step(B)                                           # tp > 1 with nothing attached
+            eng.attach_collective(StubTransport(ar), rank * (V // world))
+            ref_eng.attach_allreduce(ar, rank * (V // world))         # the fused IPC step: same sums, same rounding points
+            with pytest.raises(_C.Mi355Error):
+                eng.step_tp(B)
+            bt = torch.arange(B * 2, dtype=torch.int32).reshape(B, 2)
+            tok = torch.randint(0, V, (B,), generator=torch.Generator().manual_seed(5), dtype=torch.int32)
+            for e in (eng, ref_eng):
+                e.set_inputs(tok.tolist(), [0] * B, bt)
+            dist.barrier()
+            eng.capture(B); ref_eng.capture(B)
+            for step in range(5):
+                eng.replay(B, 1); ref_eng.replay(B, 1)
+                torch.cuda.synchronize()
+                a, b = eng.logits[:B].cpu(), ref_eng.logits[:B].cpu()
+                assert torch.allclose(a, b, atol=2e-3, rtol=2e-3), (step, float((a - b).abs().max()))
+                full = torch.cat(_gather_cpu(a, world), dim=1)
+                mine = eng.token_ids[:B].cpu()
+                assert torch.equal(mine, torch.argmax(full, -1).int()), step
+                assert torch.equal(eng.positions[:B].cpu(), torch.full((B,), step + 1, dtype=torch.int32))
+                ref_eng.token_ids[:B].copy_(eng.token_ids[:B])
+            # eager steps take the same path
+            eng.step(B)
+            torch.cuda.synchronize()
+            assert torch.equal(eng.positions[:B].cpu(), torch.full((B,), 6, dtype=torch.int32))
+            assert ar.status() == 0 and eng.oob_count() == 0
         elif mode == "twoshot":
             # world = 3 on one GPU: tensors of more than 64 rows take the two-shot form (rank r reduces rows r, r + 3, ...; second
             # flag barrier; every row fetched once from its owner) -- same numbers as the one-shot: fp32 sum in rank order, one rounding
@@ -331,7 +388,7 @@ def _worker(rank, world, port, q, mode):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mode,world", [("kernels", 2), ("engine", 2), ("timeout", 2), ("twoshot", 3), ("mixed", 2), ("kernels", 4),
+@pytest.mark.parametrize("mode,world", [("kernels", 2), ("engine", 2), ("transport", 2), ("timeout", 2), ("twoshot", 3), ("mixed", 2), ("kernels", 4),
                                         ("kernels", 8), ("twoshot", 4), ("twoshot", 8), ("engine70", 8)])
 def test_custom_allreduce_processes_on_one_gpu(mode, world):
     assert torch.cuda.is_available()
@@ -345,3 +402,74 @@ def test_custom_allreduce_processes_on_one_gpu(mode, world):
     for p in procs:
         p.join(30)
     assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+@pytest.mark.gpu
+def test_rccl_transport_world1_all_reduce_is_capturable():
+    """csrc/rccl_transport.cpp on the real librccl (torch's copy, dlopen'ed): communicator from a unique id, ncclAllReduce on the
+    caller's stream, eager and captured into a graph.  One GPU -> world 1 (RCCL refuses two ranks on one device)."""
+    from rtp_llm_amd import distributed
+    t = distributed.RcclTransport(rank=0, world=1)
+    x = torch.arange(4096, dtype=torch.float16, device="cuda:0")
+    ref = x.clone()
+    t.all_reduce(x)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            x.mul_(2.0)
+            t.all_reduce(x)
+    x.copy_(ref)
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref * 4)
+    with pytest.raises(ValueError):
+        t.all_reduce(torch.zeros(8, device="cuda:0"))
+    t.close()
+
+
+@pytest.mark.gpu
+def test_rccl_calls_inside_the_captured_cpp_step():
+    """The fallback transport inside mi355_decoder_capture: a tp_size = 2 rank-0 shard whose TP points call the real
+    ncclAllReduce / ncclAllGather (a world-1 communicator: one GPU) from the C++ step while it is being captured.  Replay must
+    reproduce the eager step bit for bit -- i.e. the RCCL launches are captured, not dropped or run at capture time."""
+    import ctypes as C
+    from rtp_llm_amd import _C, distributed, model
+    dev, world, rank = "cuda:0", 2, 0
+    t = distributed.RcclTransport(rank=0, world=1)
+    real = t.collective
+
+    def all_gather(ctx, send, recv, nbytes, stream):       # fill both rank slots with this rank's pairs
+        rc = real.all_gather(real.ctx, send, recv, nbytes, stream)
+        return rc or real.all_gather(real.ctx, send, recv + nbytes, nbytes, stream)
+    fn = _C.ALL_GATHER_FN(all_gather)
+
+    class Two:
+        collective = _C.Collective(real.ctx, real.all_reduce_f16, fn, 0, 2)
+
+    cfg = model.ModelConfig("tiny-tp", 2, 512, 8, 2, 64, 768, 1024, max_pos=256)
+    w = model.synth_model(cfg, "w4", "cpu", seed=23, zeros="centered")
+    V = cfg.vocab
+    shard = {"layers": [model.split_layer_tp(L, cfg, world, rank) for L in w["layers"]], "embedding": w["embedding"],
+             "final_norm": w["final_norm"], "lm_head": w["lm_head"].cols(0, V // world)}
+    B, page = 6, 16
+    mk = lambda: model.DecoderEngine(cfg.per_rank(world), model.weights_to(shard, dev), kv_int8=False, page=page, num_blocks=B * 2,
+                                     max_batch=B, max_seq_len=32, device=dev, tp_size=world, vocab_full=V)
+    eager, graph = mk(), mk()
+    bt = torch.arange(B * 2, dtype=torch.int32).reshape(B, 2)
+    tok = torch.randint(0, V, (B,), generator=torch.Generator().manual_seed(6), dtype=torch.int32)
+    for e in (eager, graph):
+        e.attach_collective(Two, 0)
+        e.set_inputs(tok.tolist(), [0] * B, bt)
+    graph.capture(B)
+    for step in range(4):
+        eager.step(B); graph.replay(B, 1)
+        torch.cuda.synchronize()
+        assert torch.isfinite(eager.logits[:B]).all()
+        assert torch.equal(eager.logits[:B], graph.logits[:B]), step
+        assert torch.equal(eager.token_ids[:B], graph.token_ids[:B]) and int(eager.token_ids[:B].max()) < V // world
+        assert torch.equal(graph.positions[:B].cpu(), torch.full((B,), step + 1, dtype=torch.int32))
+    assert eager.oob_count() == 0 and graph.oob_count() == 0
+    t.close()
