@@ -23,7 +23,7 @@ this path, each function citing the reference lines it follows.  Pinning status
     and the FasterTransformer-lineage KV convention (scale = amax/127 per token*kv_head).
 """
 import math
-from typing import List, Optional
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -85,6 +85,57 @@ def rope_cos_sin(rope_dim: int, theta: float, max_pos: int, rope_scale: float = 
     t = torch.arange(int(max_pos * rope_scale)).float() / rope_scale
     freqs = torch.outer(t, inv_freq)
     return torch.stack((freqs.cos(), freqs.sin()), dim=-1).contiguous()  # [max_pos, dim/2, 2]
+
+
+def rope_inv_freq(rope_dim: int, theta: float, scaling: Optional[dict] = None) -> Tuple[torch.Tensor, float]:
+    """Per-frequency angular step and cos/sin multiplier of the reference's RoPE styles, fp32
+    (apply_rope dispatch, bindings/common/kernels/rotary_position_embedding.h:904-970; config mapping models/llama.py:87-117):
+      * base / linear: inv_freq / scale                       LinearScaleRope, :355-364
+      * llama3: wavelength-banded rescale                     Llama3Rope, :418-442
+      * yarn: ramp between interpolated and extrapolated      YarnRope, :366-416 (correction range from beta_fast / beta_slow,
+        original max positions; cos / sin scaled by mscale = 0.1 ln(factor) + 1, Llama.get_mscale models/llama.py:30-34)
+    scaling: {"type", "factor", ...} with HF's key names.  DynamicNTK styles are not tabulable (base depends on the request
+    length) and are refused."""
+    idx = torch.arange(0, rope_dim, 2).float()
+    inv = 1.0 / torch.pow(torch.tensor(float(theta)), idx / rope_dim)
+    if not scaling:
+        return inv, 1.0
+    kind = scaling.get("rope_type", scaling.get("type"))
+    factor = float(scaling.get("factor", 1.0))
+    if kind in (None, "default"):
+        return inv, 1.0
+    if kind == "linear":
+        return inv / factor, 1.0
+    if kind == "llama3":
+        old = float(scaling["original_max_position_embeddings"])
+        lo_f, hi_f = float(scaling["low_freq_factor"]), float(scaling["high_freq_factor"])
+        wavelen = 2 * math.pi / inv
+        smooth = (old / wavelen - lo_f) / (hi_f - lo_f)
+        mid = (1 - smooth) * inv / factor + smooth * inv
+        out = torch.where(wavelen < old / hi_f, inv, torch.where(wavelen > old / lo_f, inv / factor, mid))
+        return out, 1.0
+    if kind == "yarn":
+        orig = int(scaling["original_max_position_embeddings"])
+        beta_fast, beta_slow = int(scaling.get("beta_fast", 32)), int(scaling.get("beta_slow", 1))
+        extrapolation = float(scaling.get("extrapolation_factor", 1.0))
+        corr = lambda rot: rope_dim * math.log(orig / (rot * 2 * math.pi)) / (2 * math.log(int(theta)))
+        low, high = float(max(math.floor(corr(beta_fast)), 0)), float(min(math.ceil(corr(beta_slow)), rope_dim - 1))
+        if low == high:
+            high += 0.001
+        ramp = torch.clamp((torch.arange(rope_dim // 2).float() - low) / (high - low), 0, 1)
+        mask = (1 - ramp) * extrapolation
+        out = (inv / factor) * (1 - mask) + inv * mask
+        mscale = float(scaling.get("mscale_override", 0.1 * math.log(factor) + 1.0 if factor > 1 else 1.0))
+        return out, mscale
+    raise ValueError(f"rope scaling {kind!r} has no position-indexed table (dynamic NTK depends on the request length)")
+
+
+def rope_cos_sin_scaled(rope_dim: int, theta: float, max_pos: int, scaling: Optional[dict] = None) -> torch.Tensor:
+    """{cos, sin} table [max_pos][dim/2][2] of a scaled style: angle = pos * rope_inv_freq, both scaled by mscale
+    (normal_rope + sin_cos_scale(), rotary_position_embedding.h:350-416)."""
+    inv, mscale = rope_inv_freq(rope_dim, theta, scaling)
+    freqs = torch.outer(torch.arange(max_pos).float(), inv)
+    return torch.stack((freqs.cos() * mscale, freqs.sin() * mscale), dim=-1).contiguous()
 
 
 def apply_rope(x: torch.Tensor, positions: torch.Tensor, cos_sin: torch.Tensor) -> torch.Tensor:
@@ -185,7 +236,8 @@ class OracleDecoder:
 
     def __init__(self, cfg: dict, weights: dict):
         self.cfg, self.w = cfg, weights
-        self.cos_sin = rope_cos_sin(cfg["hd"], cfg["rope_theta"], cfg["max_pos"])
+        self.cos_sin = (rope_cos_sin_scaled(cfg["hd"], cfg["rope_theta"], cfg["max_pos"], cfg["rope_scaling"]) if cfg.get("rope_scaling")
+                        else rope_cos_sin(cfg["hd"], cfg["rope_theta"], cfg["max_pos"]))
 
     def forward_tokens(self, token_ids: torch.Tensor, positions: torch.Tensor, kv: OracleKV, seq_idx: List[int]):
         """Process T tokens (token t belongs to sequence seq_idx[t] at position positions[t]); the

@@ -25,6 +25,14 @@
 
 #include "../../../include/mi355_decode.h"
 
+// Inside (or against) the reference tree -- -DMI355_REFERENCE_TREE -I<reference root> -- the data contract comes from the
+// reference's own headers (both only need torch): AttentionConfigs + RopeConfig, and the ParamsBase the attention ops'
+// params objects derive from.  tests/test_reference_plugin.py compiles this file that way when the tree is present.
+#ifdef MI355_REFERENCE_TREE
+#include "rtp_llm/cpp/model_utils/AttentionConfig.h"
+#include "rtp_llm/models_py/bindings/ParamsBase.h"
+#endif
+
 namespace py = pybind11;
 
 namespace mi355 {
@@ -34,8 +42,63 @@ struct AttentionConfigs {            // rtp_llm/cpp/model_utils/AttentionConfig.
     int64_t head_num = 0, kv_head_num = 0, size_per_head = 0, tokens_per_block = 16, max_seq_len = 8192;
     int64_t rope_dim = 0;
     double  rope_base = 10000.0, softmax_extra_scale = 1.0;
+    // RopeConfig.h:7-40: style (1 Base, 5 Yarn, 6 Llama3; linear = Base with scale), scale = HF factor, factor1 / factor2 =
+    // beta_slow / beta_fast (yarn) or low_freq_factor / high_freq_factor (llama3), rope_max_pos = original max positions
+    int64_t rope_style = 1, rope_max_pos = 0;
+    double  rope_scale = 1.0, rope_factor1 = 1.0, rope_factor2 = 1.0, rope_extrapolation_factor = 1.0, rope_mscale = 1.0;
     bool    use_int8_kv_cache = false;   // KvCacheDataType value 1, the slot the reference removed (AttentionConfig.h:9-12)
 };
+
+#ifdef MI355_REFERENCE_TREE
+// the reference's own struct -> the fields this path reads
+inline AttentionConfigs from_reference(const rtp_llm::AttentionConfigs& r) {
+    AttentionConfigs c;
+    c.head_num = (int64_t)r.head_num; c.kv_head_num = (int64_t)r.kv_head_num; c.size_per_head = (int64_t)r.size_per_head;
+    c.tokens_per_block = (int64_t)(r.kernel_tokens_per_block ? r.kernel_tokens_per_block : r.tokens_per_block);
+    c.max_seq_len = (int64_t)r.max_seq_len;
+    c.rope_dim = r.rope_config.dim; c.rope_base = r.rope_config.base; c.softmax_extra_scale = r.softmax_extra_scale;
+    c.rope_style = (int64_t)r.rope_config.style; c.rope_max_pos = r.rope_config.max_pos; c.rope_scale = r.rope_config.scale;
+    c.rope_factor1 = r.rope_config.factor1; c.rope_factor2 = r.rope_config.factor2;
+    c.rope_extrapolation_factor = r.rope_config.extrapolation_factor; c.rope_mscale = r.rope_config.mscale;
+    TORCH_CHECK(!r.use_mla && r.is_causal && r.dtype == c10::ScalarType::Half, "mi355 decode ops: MHA / GQA, causal, fp16 only");
+    TORCH_CHECK(r.kv_cache_dtype == rtp_llm::KvCacheDataType::BASE, "mi355 decode ops: fp16 or INT8 KV cache (the INT8 slot is keyed "
+                "off the cache tensor's dtype, see kv_of)");
+    return c;
+}
+#endif
+
+// fp32 {cos, sin} table [max_seq_len][hd / 2][2] of the configured style, on the host (genBaseCache / genYarnCache,
+// RopeCache.cc:16-81; Llama3Rope / YarnRope / LinearScaleRope of rotary_position_embedding.h:355-442 tabulated the same way)
+inline torch::Tensor build_rope_table(const AttentionConfigs& c) {
+    const int64_t hd = c.size_per_head;
+    auto idx  = torch::arange(0, hd, 2).to(torch::kFloat32);
+    auto step = 1.0 / torch::pow(torch::tensor((float)c.rope_base), idx / (double)hd);
+    double gain = 1.0;
+    const double pi = 3.14159265358979323846;
+    if (c.rope_style == 1) {                         // Base (+ linear position scale)
+        if (c.rope_scale != 1.0) step = step / c.rope_scale;
+    } else if (c.rope_style == 6) {                  // Llama3: factor1 = low_freq_factor, factor2 = high_freq_factor
+        const double ctx = (double)c.rope_max_pos;
+        auto wavelen = 2 * pi / step;
+        auto blend   = (ctx / wavelen - c.rope_factor1) / (c.rope_factor2 - c.rope_factor1);
+        auto banded  = (1 - blend) * step / c.rope_scale + blend * step;
+        step = torch::where(wavelen < ctx / c.rope_factor2, step, torch::where(wavelen > ctx / c.rope_factor1, step / c.rope_scale, banded));
+    } else if (c.rope_style == 5) {                  // Yarn: factor1 = beta_slow, factor2 = beta_fast
+        auto chan = [&](int rotations) {
+            return (double)hd * std::log((double)c.rope_max_pos / (rotations * 2 * pi)) / (2 * std::log((double)(int64_t)c.rope_base));
+        };
+        double first = std::max(std::floor(chan((int)c.rope_factor2)), 0.0), last = std::min(std::ceil(chan((int)c.rope_factor1)), (double)hd - 1);
+        if (first == last) last += 0.001;
+        auto keep = (1 - torch::clamp((torch::arange(hd / 2).to(torch::kFloat32) - first) / (last - first), 0, 1)) * c.rope_extrapolation_factor;
+        step = (step / c.rope_scale) * (1 - keep) + step * keep;
+        gain = c.rope_mscale;
+    } else {
+        TORCH_CHECK(false, "rope style ", c.rope_style, ": only Base / linear, Yarn (5) and Llama3 (6) fold into the position table; the "
+                    "dynamic-NTK styles depend on the request length");
+    }
+    auto freqs = torch::outer(torch::arange(c.max_seq_len).to(torch::kFloat32), step);
+    return torch::stack({freqs.cos() * gain, freqs.sin() * gain}, -1).contiguous();
+}
 
 struct LayerKVCache {                // bindings/OpDefs.h:29-51
     torch::Tensor kv_cache_base, kv_scale_base;
@@ -59,7 +122,20 @@ inline void need(const torch::Tensor& t, c10::ScalarType dt, const char* name) {
 }
 
 // ---- params object shared by the two attention ops (the role of CKAttn, FusedRopeKVCacheOp.cc:648-653) -------------
+#ifdef MI355_REFERENCE_TREE
+struct AttnParams: public rtp_llm::ParamsBase {   // ParamsBase.h:8-22: the framework refills recycled params through fillParams
+    void fillParams(torch::Tensor sequence_lengths, torch::Tensor input_lengths, torch::Tensor kv_cache_block_id_host, int batch_size,
+                    int seq_size_per_block, torch::Tensor prefix_lengths = torch::Tensor()) override {
+        (void)input_lengths; (void)seq_size_per_block; (void)prefix_lengths;
+        TORCH_CHECK(positions.defined() && batch_size <= positions.size(0), "fillParams: batch exceeds the prepared params");
+        positions.slice(0, 0, batch_size).copy_(sequence_lengths.slice(0, 0, batch_size).to(torch::kInt32), true);
+        torch::add_out(seq_lens, positions, 1);
+        if (kv_cache_block_id_host.defined())
+            block_table.slice(0, 0, batch_size).copy_(kv_cache_block_id_host.slice(0, 0, batch_size).to(torch::kInt32), true);
+    }
+#else
 struct AttnParams {
+#endif
     torch::Tensor positions;     // int32 [B] device: tokens already in the cache (= sequence_lengths)
     torch::Tensor seq_lens;      // int32 [B] device: positions + 1
     torch::Tensor block_table;   // int32 [B, M] device
@@ -112,13 +188,12 @@ public:
     explicit Mi355RopeKVCacheDecodeOp(const AttentionConfigs& c): cfg_(c) {
         TORCH_CHECK(c.head_num > 0 && c.kv_head_num > 0 && (c.size_per_head == 64 || c.size_per_head == 128),
                     "Mi355RopeKVCacheDecodeOp: unsupported head configuration");
-        TORCH_CHECK(c.rope_dim == 0 || c.rope_dim == c.size_per_head, "rope_dim must equal size_per_head (Base style)");
-        // fp32 {cos, sin} table [max_pos][hd/2][2] built on the host exactly like genBaseCache (RopeCache.cc:16-41)
-        const auto hd = c.size_per_head;
-        auto inv_freq = 1.0 / torch::pow(torch::tensor((float)c.rope_base), torch::arange(0, hd, 2).to(torch::kFloat32) / (double)hd);
-        auto freqs    = torch::outer(torch::arange(c.max_seq_len).to(torch::kFloat32), inv_freq);
-        cos_sin_host_ = torch::stack({freqs.cos(), freqs.sin()}, -1).contiguous();
+        TORCH_CHECK(c.rope_dim == 0 || c.rope_dim == c.size_per_head, "rope_dim must equal size_per_head (full-width rotation)");
+        cos_sin_host_ = build_rope_table(c);
     }
+#ifdef MI355_REFERENCE_TREE
+    explicit Mi355RopeKVCacheDecodeOp(const rtp_llm::AttentionConfigs& r): Mi355RopeKVCacheDecodeOp(from_reference(r)) {}
+#endif
     AttnParamsPtr prepare(const PyAttentionInputs& in) { return make_params(in); }
 
     torch::Tensor forward(const torch::Tensor& qkv, std::optional<LayerKVCache> kv_cache, const AttnParamsPtr& params) {
@@ -150,6 +225,9 @@ public:
     explicit Mi355PagedAttnDecodeOp(const AttentionConfigs& c): cfg_(c) {
         TORCH_CHECK(c.head_num % c.kv_head_num == 0 && c.head_num / c.kv_head_num <= 16, "GQA group must be <= 16");
     }
+#ifdef MI355_REFERENCE_TREE
+    explicit Mi355PagedAttnDecodeOp(const rtp_llm::AttentionConfigs& r): Mi355PagedAttnDecodeOp(from_reference(r)) {}
+#endif
     AttnParamsPtr prepare(const PyAttentionInputs& in) { return make_params(in); }
 
     torch::Tensor forward(const torch::Tensor& q, std::optional<LayerKVCache> kv_cache, const AttnParamsPtr& params) {
@@ -251,7 +329,14 @@ namespace rtp_llm {
 // The hook the reference links per build flavour (RegisterOps.h:9).
 void registerPyModuleOps(py::module& m) {
     using namespace mi355;
+    using AttentionConfigs = mi355::AttentionConfigs;   // (rtp_llm::AttentionConfigs is in scope too when built against the tree)
+#ifdef MI355_REFERENCE_TREE
+    // the tree registers its own AttentionConfigs / PyAttentionInputs bindings (RegisterBaseBindings.hpp): the mirror keeps a
+    // distinct Python name and the ops also construct from the tree's struct
+    py::class_<AttentionConfigs>(m, "Mi355AttentionConfigs")
+#else
     py::class_<AttentionConfigs>(m, "AttentionConfigs")
+#endif
         .def(py::init<>())
         .def_readwrite("head_num", &AttentionConfigs::head_num)
         .def_readwrite("kv_head_num", &AttentionConfigs::kv_head_num)
@@ -261,6 +346,13 @@ void registerPyModuleOps(py::module& m) {
         .def_readwrite("rope_dim", &AttentionConfigs::rope_dim)
         .def_readwrite("rope_base", &AttentionConfigs::rope_base)
         .def_readwrite("softmax_extra_scale", &AttentionConfigs::softmax_extra_scale)
+        .def_readwrite("rope_style", &AttentionConfigs::rope_style)
+        .def_readwrite("rope_max_pos", &AttentionConfigs::rope_max_pos)
+        .def_readwrite("rope_scale", &AttentionConfigs::rope_scale)
+        .def_readwrite("rope_factor1", &AttentionConfigs::rope_factor1)
+        .def_readwrite("rope_factor2", &AttentionConfigs::rope_factor2)
+        .def_readwrite("rope_extrapolation_factor", &AttentionConfigs::rope_extrapolation_factor)
+        .def_readwrite("rope_mscale", &AttentionConfigs::rope_mscale)
         .def_readwrite("use_int8_kv_cache", &AttentionConfigs::use_int8_kv_cache);
     py::class_<LayerKVCache>(m, "LayerKVCache")
         .def(py::init<>())
@@ -287,11 +379,17 @@ void registerPyModuleOps(py::module& m) {
         .def_readonly("block_table", &AttnParams::block_table);
     py::class_<Mi355RopeKVCacheDecodeOp>(m, "Mi355RopeKVCacheDecodeOp")
         .def(py::init<const AttentionConfigs&>(), py::arg("attn_configs"))
+#ifdef MI355_REFERENCE_TREE
+        .def(py::init<const rtp_llm::AttentionConfigs&>(), py::arg("attn_configs"))
+#endif
         .def("prepare", &Mi355RopeKVCacheDecodeOp::prepare, py::arg("attn_inputs"))
         .def("forward", &Mi355RopeKVCacheDecodeOp::forward, py::arg("qkv"), py::arg("kv_cache"), py::arg("params"))
         .def("oob_count", &Mi355RopeKVCacheDecodeOp::oob_count);
     py::class_<Mi355PagedAttnDecodeOp>(m, "Mi355PagedAttnDecodeOp")
         .def(py::init<const AttentionConfigs&>(), py::arg("attn_configs"))
+#ifdef MI355_REFERENCE_TREE
+        .def(py::init<const rtp_llm::AttentionConfigs&>(), py::arg("attn_configs"))
+#endif
         .def("prepare", &Mi355PagedAttnDecodeOp::prepare, py::arg("attn_inputs"))
         .def("forward", &Mi355PagedAttnDecodeOp::forward, py::arg("q"), py::arg("kv_cache"), py::arg("params"));
     py::class_<Mi355WeightOnlyLinear>(m, "Mi355WeightOnlyLinear")
@@ -306,6 +404,7 @@ void registerPyModuleOps(py::module& m) {
     m.def("silu_and_mul", &silu_and_mul, "SiLU-gate", py::arg("output"), py::arg("gate_up"), py::arg("hip_stream") = 0);
     m.def("embedding", &embedding, "Embedding lookup kernel", py::arg("output"), py::arg("input"), py::arg("weight"));
     m.def("greedy_argmax", &greedy_argmax, "argmax over fp32 logits, lowest index on ties", py::arg("logits"));
+    m.def("rope_table", &build_rope_table, "fp32 {cos, sin} table [max_seq_len][hd / 2][2] of the configured RoPE style", py::arg("attn_configs"));
     m.def("abi_version", []() { return mi355_abi_version(); });
 }
 

@@ -65,9 +65,13 @@ def config_from_hf(cfg: dict, name: str = "hf-model") -> Tuple[ModelConfig, dict
                      rms_eps=float(cfg.get("rms_norm_eps", 1e-6)), qkv_bias=False,
                      max_pos=int(cfg.get("max_position_embeddings", 8192)))
     rs = cfg.get("rope_scaling") or {}
-    if rs and rs.get("rope_type", rs.get("type", "default")) not in ("default", None):
-        raise NotImplementedError(f"rope_scaling={rs}: only the base RoPE style is on this decode path (linear / dynamic / yarn / "
-                                  "llama3 scaling would decode with wrong rotations)")
+    kind = rs.get("rope_type", rs.get("type", "default")) if rs else "default"
+    if kind not in ("default", None):
+        # linear / llama3 / yarn fold into the position-indexed cos/sin table (model.rope_frequencies); the dynamic-NTK styles
+        # (base as a function of the request length) would decode with wrong rotations and stay refused
+        if kind not in ("linear", "llama3", "yarn"):
+            raise NotImplementedError(f"rope_scaling={rs}: only base / linear / llama3 / yarn RoPE are on this decode path")
+        mc.rope_scaling = dict(rs)
     if cfg.get("use_sliding_window"):
         raise NotImplementedError("sliding-window attention is not on this decode path")
     q = cfg.get("quantization_config") or {}

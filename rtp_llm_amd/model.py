@@ -42,6 +42,9 @@ class ModelConfig:
     rms_eps: float = 1e-6
     qkv_bias: bool = True
     max_pos: int = 8192
+    # scaled RoPE style, HF's `rope_scaling` dict ({"rope_type": "linear" | "llama3" | "yarn", "factor", ...}); None = base
+    # (RopeStyle / RopeConfig, rtp_llm/cpp/model_utils/RopeConfig.h:7-40; mapping from config.json: models/llama.py:87-117)
+    rope_scaling: Optional[dict] = None
 
     def per_rank(self, tp: int) -> "ModelConfig":
         """Per-rank attention/FFN dims (model_config.getAttentionConfigs(tp), qwen3.py:33;
@@ -244,11 +247,50 @@ def split_layer_tp(layer: Dict, cfg: ModelConfig, tp: int, rank: int) -> Dict:
     return out
 
 
+def rope_frequencies(hd: int, theta: float, scaling: Optional[dict]):
+    """(angular step per channel pair [hd / 2] fp32, cos / sin multiplier) of the configured RoPE style.  The kernels only see
+    the position-indexed table, so a style is whatever can be folded into it:
+      * base, linear (positions / factor)                            LinearScaleRope, rotary_position_embedding.h:355-364
+      * llama3: long wavelengths / factor, short ones kept, a linear blend between the two bands      Llama3Rope, :418-442
+      * yarn: blend of interpolated (1 / factor) and original steps along a ramp over the channel index, whose ends come from
+        beta_fast / beta_slow rotations over the original context; table scaled by 0.1 ln(factor) + 1      YarnRope, :366-416
+    Dynamic-NTK styles (:889-902) change the base with the request length: not a function of the position alone, refused."""
+    step = 1.0 / torch.pow(torch.tensor(float(theta)), torch.arange(0, hd, 2).float() / hd)
+    kind = (scaling or {}).get("rope_type", (scaling or {}).get("type"))
+    if kind in (None, "default"):
+        return step, 1.0
+    factor = float(scaling.get("factor", 1.0))
+    if kind == "linear":
+        return step / factor, 1.0
+    if kind == "llama3":
+        ctx = float(scaling["original_max_position_embeddings"])
+        lo, hi = float(scaling["low_freq_factor"]), float(scaling["high_freq_factor"])
+        wavelen = 2 * math.pi / step
+        blend = (ctx / wavelen - lo) / (hi - lo)
+        banded = (1 - blend) * step / factor + blend * step
+        return torch.where(wavelen < ctx / hi, step, torch.where(wavelen > ctx / lo, step / factor, banded)), 1.0
+    if kind == "yarn":
+        ctx = int(scaling["original_max_position_embeddings"])
+        fast, slow = int(scaling.get("beta_fast", 32)), int(scaling.get("beta_slow", 1))
+        chan = lambda rotations: hd * math.log(ctx / (rotations * 2 * math.pi)) / (2 * math.log(int(theta)))
+        first, last = float(max(math.floor(chan(fast)), 0)), float(min(math.ceil(chan(slow)), hd - 1))
+        if first == last:
+            last += 0.001
+        keep = (1 - torch.clamp((torch.arange(hd // 2).float() - first) / (last - first), 0, 1)) * float(scaling.get("extrapolation_factor", 1.0))
+        gain = 0.1 * math.log(factor) + 1.0 if factor > 1 else 1.0
+        return (step / factor) * (1 - keep) + step * keep, gain
+    raise NotImplementedError(f"rope_scaling type {kind!r}: dynamic-NTK bases depend on the request length; only base / linear / "
+                              "llama3 / yarn fold into the position-indexed table of this path")
+
+
 def rope_table(cfg: ModelConfig, device) -> torch.Tensor:
-    """fp32 {cos,sin} table [max_pos][hd/2][2] (genBaseCache, cpp/model_utils/RopeCache.cc:16-41); built on the
-    host in fp32 so every rank holds identical bits."""
-    inv_freq = 1.0 / torch.pow(torch.tensor(float(cfg.rope_theta)), torch.arange(0, cfg.hd, 2).float() / cfg.hd)
-    freqs = torch.outer(torch.arange(cfg.max_pos).float(), inv_freq)
+    """fp32 {cos,sin} table [max_pos][hd/2][2] (genBaseCache / genYarnCache, cpp/model_utils/RopeCache.cc:16-81; the styles the
+    reference computes in-kernel on ROCm are tabulated the same way: rope_frequencies); built on the host in fp32 so every
+    rank holds identical bits."""
+    step, gain = rope_frequencies(cfg.hd, cfg.rope_theta, cfg.rope_scaling)
+    freqs = torch.outer(torch.arange(cfg.max_pos).float(), step)
+    if gain != 1.0:
+        return torch.stack((freqs.cos() * gain, freqs.sin() * gain), dim=-1).contiguous().to(device)
     return torch.stack((freqs.cos(), freqs.sin()), dim=-1).contiguous().to(device)
 
 

@@ -224,3 +224,57 @@ def test_sampler_and_collective_entry_points_validate_on_the_host():
     assert torch.equal(torch.cat(parts, 1), emb) and all(p.is_contiguous() and p.shape == (6, 16) for p in parts)
     with pytest.raises(ValueError):
         model.split_embedding_tp(emb, 3, 0)
+
+
+def test_rope_styles_oracle_pinned_and_product_table(golden_dir=os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")):
+    """Scaled RoPE styles: the oracle reproduces the committed golden vectors bit for bit -- yarn: the reference's own torch
+    restatement (mla_attention_ref.py:58-160, run by oracle/gen_rope_golden.py); llama3: transformers' published formula the
+    reference's Llama3Rope implements -- and the table the product builds equals the oracle's; HF config mapping as models/llama.py."""
+    import numpy as np
+    from rtp_llm_amd import loader
+    g = np.load(os.path.join(golden_dir, "rope_styles.npz"))
+    for tag in ("yarn_a", "yarn_b"):
+        dim, base, factor, orig, npos = g[tag + "_cfg"]
+        sc = {"type": "yarn", "factor": float(factor), "original_max_position_embeddings": int(orig), "beta_fast": 32, "beta_slow": 1}
+        inv, ms = oracle.rope_inv_freq(int(dim), float(base), sc)
+        assert torch.equal(inv, torch.tensor(g[tag + "_inv_freq"])) and abs(ms - float(g[tag + "_mscale"][0])) < 1e-12
+        t = oracle.rope_cos_sin_scaled(int(dim), float(base), int(npos), sc)
+        assert torch.equal(t[..., 0], torch.tensor(g[tag + "_cos"])) and torch.equal(t[..., 1], torch.tensor(g[tag + "_sin"]))
+        cfg = model.ModelConfig("t", 1, 256, 2, 2, int(dim), 512, 1024, rope_theta=float(base), max_pos=int(npos), rope_scaling=sc)
+        assert torch.equal(model.rope_table(cfg, "cpu"), t)
+    for tag in ("llama3_a", "llama3_b"):
+        hd, theta, f, lo, hi, old = g[tag + "_cfg"]
+        sc = {"rope_type": "llama3", "factor": float(f), "low_freq_factor": float(lo), "high_freq_factor": float(hi),
+              "original_max_position_embeddings": int(old)}
+        inv, ms = oracle.rope_inv_freq(int(hd), float(theta), sc)
+        assert torch.equal(inv, torch.tensor(g[tag + "_inv_freq"])) and ms == 1.0
+        cfg = model.ModelConfig("t", 1, 256, 2, 2, int(hd), 512, 1024, rope_theta=float(theta), max_pos=128, rope_scaling=sc)
+        assert torch.equal(model.rope_table(cfg, "cpu"), oracle.rope_cos_sin_scaled(int(hd), float(theta), 128, sc))
+    # linear == the reference's genBaseCache with rope_scale (RopeCache.cc:16-41): positions / scale
+    lin = model.ModelConfig("t", 1, 256, 2, 2, 64, 512, 1024, rope_theta=1e4, max_pos=64, rope_scaling={"type": "linear", "factor": 4.0})
+    assert torch.allclose(model.rope_table(lin, "cpu"), oracle.rope_cos_sin(64, 1e4, 16, 4.0), atol=1e-6)
+    hf = {"num_attention_heads": 4, "num_hidden_layers": 1, "hidden_size": 256, "intermediate_size": 512, "vocab_size": 1024,
+          "rope_theta": 500000.0, "max_position_embeddings": 131072,
+          "rope_scaling": {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 8192}}
+    mc, _ = loader.config_from_hf(hf)
+    assert mc.rope_scaling["rope_type"] == "llama3"
+    with pytest.raises(NotImplementedError):
+        loader.config_from_hf({**hf, "rope_scaling": {"type": "dynamic", "factor": 2.0}})
+    with pytest.raises(NotImplementedError):
+        model.rope_table(model.ModelConfig("t", 1, 256, 2, 2, 64, 512, 1024, rope_scaling={"type": "dynamic", "factor": 2.0}), "cpu")
+    # the native shim tabulates the same styles from RopeConfig's field meanings (style 5 / 6, factor1 / factor2, max_pos, mscale)
+    from rtp_llm_amd import native_ops
+    ops = native_ops.load()
+    c = ops.AttentionConfigs()
+    c.head_num, c.kv_head_num, c.size_per_head, c.max_seq_len, c.rope_base = 4, 4, 128, 96, 1000000.0
+    c.rope_style, c.rope_scale, c.rope_factor1, c.rope_factor2, c.rope_max_pos = 5, 4.0, 1.0, 32.0, 32768
+    c.rope_mscale = 0.1 * math.log(4.0) + 1.0
+    want = oracle.rope_cos_sin_scaled(128, 1e6, 96, {"type": "yarn", "factor": 4.0, "original_max_position_embeddings": 32768})
+    assert torch.allclose(ops.rope_table(c), want, atol=2e-6, rtol=0)
+    c.rope_base, c.rope_style, c.rope_scale, c.rope_factor1, c.rope_factor2, c.rope_max_pos, c.rope_mscale = 500000.0, 6, 8.0, 1.0, 4.0, 8192, 1.0
+    want = oracle.rope_cos_sin_scaled(128, 5e5, 96, {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                                     "original_max_position_embeddings": 8192})
+    assert torch.allclose(ops.rope_table(c), want, atol=2e-6, rtol=0)
+    c.rope_style = 3
+    with pytest.raises(RuntimeError):
+        ops.rope_table(c)

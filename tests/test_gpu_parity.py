@@ -613,3 +613,51 @@ def test_engine_large_batch_step_matches_oracle():
         tok = nxt
         eng.token_ids[:B].copy_(tok)
     assert eng.oob_count() == 0
+
+
+@pytest.mark.parametrize("scaling", [
+    {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 16},
+    {"type": "yarn", "factor": 4.0, "original_max_position_embeddings": 16, "beta_fast": 32, "beta_slow": 1},
+    {"type": "linear", "factor": 2.0}])
+def test_engine_scaled_rope_styles_match_oracle(scaling):
+    """RoPE styles beyond Base (rotary_position_embedding.h:904-970: Llama-3.1 `llama3`, yarn, linear): a style only changes
+    the position-indexed cos/sin table, so the kernels are the Base ones -- what is checked is that the table the engine
+    builds (model.rope_frequencies) rotates Q / K like the oracle's restatement of Llama3Rope / YarnRope / LinearScaleRope,
+    end to end over a decode that runs past the (tiny) original context, where scaled and unscaled angles differ by radians."""
+    cfg = model.ModelConfig("tiny-rope", 2, 512, 8, 2, 64, 1024, 2048, rope_theta=10000.0, max_pos=512, rope_scaling=scaling)
+    base = model.ModelConfig("tiny-rope", 2, 512, 8, 2, 64, 1024, 2048, rope_theta=10000.0, max_pos=512)
+    assert float((model.rope_table(cfg, "cpu")[20] - model.rope_table(base, "cpu")[20]).abs().max()) > 0.5
+    w = model.synth_model(cfg, "w4", "cpu", seed=31, zeros="centered")
+    B, page, steps = 3, 16, 24
+    odec = oracle.OracleDecoder({**cfg.__dict__}, _oracle_weights(w))
+    eng = model.DecoderEngine(cfg, model.weights_to(w, DEV), kv_int8=False, page=page, num_blocks=64, max_batch=4, max_seq_len=64, device=DEV)
+    bt = torch.randperm(64, generator=_gen(1))[: B * 4].reshape(B, 4).to(torch.int32)
+    okv = oracle.OracleKV(cfg.num_layers, B, False)
+    tok = torch.randint(0, cfg.vocab, (B,), generator=_gen(2), dtype=torch.int32)
+    eng.set_inputs(tok.tolist(), [0] * B, bt)
+    eng.capture(B)
+    worst = 0.0
+    for step in range(steps):
+        pos = torch.full((B,), step, dtype=torch.int32)
+        eng.replay(B, 1)
+        torch.cuda.synchronize()
+        _, ref_logits = odec.forward_tokens(tok, pos, okv, list(range(B)))
+        got = eng.logits[:B].cpu()
+        assert torch.allclose(got, ref_logits, **TOL), (step, (got - ref_logits).abs().max())
+        worst = max(worst, float((got - ref_logits).abs().max()))
+        tok = oracle.greedy(ref_logits)
+        eng.token_ids[:B].copy_(tok)
+    # and the unscaled table would NOT have passed: the style is live in the comparison
+    ob = oracle.OracleDecoder({**base.__dict__}, _oracle_weights(w))
+    okb = oracle.OracleKV(cfg.num_layers, B, False)
+    t0 = torch.randint(0, cfg.vocab, (B,), generator=_gen(2), dtype=torch.int32)
+    diverged = False
+    okv2 = oracle.OracleKV(cfg.num_layers, B, False)
+    for step in range(steps):
+        pos = torch.full((B,), step, dtype=torch.int32)
+        _, a = odec.forward_tokens(t0, pos, okv2, list(range(B)))
+        _, b = ob.forward_tokens(t0, pos, okb, list(range(B)))
+        diverged |= not torch.allclose(a, b, **TOL)
+        t0 = oracle.greedy(a)
+    assert diverged
+    print(f"scaled RoPE {scaling.get('rope_type', scaling.get('type'))}: max |logit error| {worst:.2e} over {steps} steps")
