@@ -359,6 +359,41 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
                 if (tb + 3 * GS < pend) lookup(tb + 3 * GS, w1);
                 if (tb + GS < pend) compute(g1, tb + GS);
             }
+        } else if constexpr (NG == 4) {
+            Group g3; Wins w3;
+            if (tb < pend) { lookup(tb, w0); load_group(g0, tb, w0); }
+            if (tb + GS < pend) { lookup(tb + GS, w1); load_group(g1, tb + GS, w1); }
+            if (tb + 2 * GS < pend) { lookup(tb + 2 * GS, w2); load_group(g2, tb + 2 * GS, w2); }
+            if (tb + 3 * GS < pend) lookup(tb + 3 * GS, w3);
+            while (tb + 7 * GS < pend && tb + 3 * GS + 32 <= full_end) {
+                load_group(g3, tb + 3 * GS, w3);
+                lookup(tb + 4 * GS, w0);
+                compute_group(g0, tb, std::false_type{});
+                load_group(g0, tb + 4 * GS, w0);
+                lookup(tb + 5 * GS, w1);
+                compute_group(g1, tb + GS, std::false_type{});
+                load_group(g1, tb + 5 * GS, w1);
+                lookup(tb + 6 * GS, w2);
+                compute_group(g2, tb + 2 * GS, std::false_type{});
+                load_group(g2, tb + 6 * GS, w2);
+                lookup(tb + 7 * GS, w3);
+                compute_group(g3, tb + 3 * GS, std::false_type{});
+                tb += 4 * GS;
+            }
+            for (; tb < pend; tb += 4 * GS) {
+                if (tb + 3 * GS < pend) load_group(g3, tb + 3 * GS, w3);
+                if (tb + 4 * GS < pend) lookup(tb + 4 * GS, w0);
+                compute(g0, tb);
+                if (tb + 4 * GS < pend) load_group(g0, tb + 4 * GS, w0);
+                if (tb + 5 * GS < pend) lookup(tb + 5 * GS, w1);
+                if (tb + GS < pend) compute(g1, tb + GS);
+                if (tb + 5 * GS < pend) load_group(g1, tb + 5 * GS, w1);
+                if (tb + 6 * GS < pend) lookup(tb + 6 * GS, w2);
+                if (tb + 2 * GS < pend) compute(g2, tb + 2 * GS);
+                if (tb + 6 * GS < pend) load_group(g2, tb + 6 * GS, w2);
+                if (tb + 7 * GS < pend) lookup(tb + 7 * GS, w3);
+                if (tb + 3 * GS < pend) compute(g3, tb + 3 * GS);
+            }
         } else {
             if (tb < pend) { lookup(tb, w0); load_group(g0, tb, w0); }
             if (tb + GS < pend) { lookup(tb + GS, w1); load_group(g1, tb + GS, w1); }
@@ -541,9 +576,11 @@ int launch_attn(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_
     dim3 grid(p.P, kv->nkv, B * p.ntile);
 #define L_(HD_, I8_, NT_, NW_, NG_) hipLaunchKernelGGL((paged_attn_kernel<HD_, I8_, NT_, NW_, NG_>), grid, dim3(64 * NW_), 0, st, p)
 #ifdef MI355_TUNING
-#define L2_(HD_, I8_) do { if (NT == 1) { if (TUNE(6) == 3) L_(HD_, I8_, 1, 4, 3); else L_(HD_, I8_, 1, 4, 2); } else L_(HD_, I8_, 2, 4, 2); } while (0)
+#define L2_(HD_, I8_) do { if (NT == 1) { if (TUNE(6) == 3) L_(HD_, I8_, 1, 4, 3); else if (TUNE(6) == 4) L_(HD_, I8_, 1, 4, 4); else L_(HD_, I8_, 1, 4, 2); } else L_(HD_, I8_, 2, 4, 2); } while (0)
 #else
-#define L2_(HD_, I8_) do { if (NT == 1) L_(HD_, I8_, 1, 4, 2); else L_(HD_, I8_, 2, 4, 2); } while (0)
+// INT8 groups are 8 KB: four of them in flight per wave (the bytes two fp16 groups hold); measured b = 64, ctx 4096: 77.2 -> 66.7 us
+// (NG = 3: 72.7), ctx 1024 unchanged; fp16 loses with more than two (28.4 -> 30.6 us at ctx 1024)
+#define L2_(HD_, I8_) do { if (NT == 1) L_(HD_, I8_, 1, 4, (I8_ ? 4 : 2)); else L_(HD_, I8_, 2, 4, 2); } while (0)
 #endif
     if (kv->hd == 128) { if (int8) L2_(128, true); else L2_(128, false); }
     else               { if (int8) L2_(64, true);  else L2_(64, false); }
