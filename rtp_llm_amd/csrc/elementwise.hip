@@ -47,6 +47,22 @@ __global__ __launch_bounds__(512) void add_rmsnorm_kernel(const f16* __restrict_
                 const size_t sstride = (size_t)M * ld;
                 const float* src0 = partials + (size_t)row * ld + c0;
                 int s = 0;
+                if (nsplit > 8) { // 9..16 slabs (down_proj at 64 rows: 15): all of them in ONE round trip, summed in index order as below
+                    f32x4 a[16], b[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const bool ok = u < nsplit;
+                        const float* sp = src0 + (ok ? u : 0) * sstride;
+                        a[u] = *reinterpret_cast<const f32x4*>(sp);
+                        b[u] = *reinterpret_cast<const f32x4*>(sp + 4);
+                        if (!ok) { a[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; b[u] = a[u]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[t][e] += a[u][e]; v[t][4 + e] += b[u][e]; }
+                    s = 16;
+                }
                 for (; s + 8 <= nsplit; s += 8) {
                     f32x4 a[8], b[8];
 #pragma unroll

@@ -40,6 +40,17 @@ def main():
     for kv, sc in caches[:2]:
         ops.paged_decode_attention(q, kv, sc, bt, sl, nkv, page, ctx)
     torch.cuda.synchronize()
+    if a.tune:   # the switched kernel against the default one on the same cache (ragged contexts included)
+        slr = torch.randint(1, ctx + 1, (B,), generator=torch.Generator().manual_seed(2), dtype=torch.int32).to(dev)
+        for lens in (sl, slr):
+            got = ops.paged_decode_attention(q, caches[0][0], caches[0][1], bt, lens, nkv, page, ctx).clone()
+            for kv_ in filter(None, a.tune.split(",")):
+                lib.mi355_debug_set(int(kv_.split("=")[0]), 0)
+            ref = ops.paged_decode_attention(q, caches[0][0], caches[0][1], bt, lens, nkv, page, ctx).clone()
+            for kv_ in filter(None, a.tune.split(",")):
+                lib.mi355_debug_set(int(kv_.split("=")[0]), int(kv_.split("=")[1]))
+            torch.cuda.synchronize()
+            print(f"  tune [{a.tune}] vs default: max |diff| {float((got.float() - ref.float()).abs().max()):.3e}, bit-equal {bool(torch.equal(got, ref))}")
     st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     st.record()
     for i in range(a.iters):
