@@ -352,6 +352,7 @@ extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int wa
             case 2: rc = launch_wide_t<4, 4, 4, T, 2>(wp, st); break;
             case 3: rc = launch_wide_t<4, 4, 4, T, 3>(wp, st); break;
             case 4: rc = launch_wide_t<4, 4, 4, T, 4>(wp, st); break;
+            case 7: rc = launch_wide_t<4, 4, 4, T, 7>(wp, st); break;   // stamps of the traffic-free instruction stream
 #endif
             default: rc = launch_wide_t<4, 4, 4, T>(wp, st);
         }

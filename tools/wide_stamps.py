@@ -16,7 +16,7 @@ x = (torch.randn(M, K, device=dev, generator=gen) * 0.5).half()
 st = torch.zeros(256 * 8 * 4, dtype=torch.int64, device=dev)
 lib.mi355_debug_ptr.argtypes = [C.c_void_p]
 lib.mi355_debug_ptr(st.data_ptr())
-lib.mi355_debug_set(0, 4)
+lib.mi355_debug_set(0, int(sys.argv[2]) if len(sys.argv) > 2 else 4)   # 7: the same stamps without the loop's memory traffic
 for _ in range(3):
     ops.linear(x, w, None, _C.EPI_SILU_MUL)
 torch.cuda.synchronize()
