@@ -87,13 +87,25 @@ def test_bf16_checkpoint_tensors_are_converted(tmp_path):
         assert torch.equal(L0["qkv_bias"], L1["qkv_bias"]) and torch.equal(L0["qkv"].q, L1["qkv"].q)
 
 
-@pytest.mark.parametrize("extra", [{"rope_scaling": {"rope_type": "llama3", "factor": 8.0}}, {"rope_scaling": {"type": "linear", "factor": 2.0}},
+@pytest.mark.parametrize("extra", [{"rope_scaling": {"rope_type": "dynamic", "factor": 8.0}}, {"rope_scaling": {"type": "longrope", "factor": 2.0}},
                                    {"use_sliding_window": True}])
 def test_unsupported_position_schemes_are_rejected(tmp_path, extra):
     canon = model.synth_model(CFG, "fp16", "cpu", seed=9)
     _write_ckpt(str(tmp_path), "fp16", CFG, canon, extra_cfg=extra)
     with pytest.raises(NotImplementedError):
         loader.load_hf_checkpoint(str(tmp_path))
+
+
+@pytest.mark.parametrize("rs", [{"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 64},
+                                {"type": "yarn", "factor": 4.0, "original_max_position_embeddings": 64}, {"type": "linear", "factor": 2.0}])
+def test_scaled_rope_styles_load_into_the_model_config(tmp_path, rs):
+    """rope_scaling of the tabulable styles (models/llama.py:87-117) reaches ModelConfig and changes the rotation table."""
+    canon = model.synth_model(CFG, "fp16", "cpu", seed=9)
+    _write_ckpt(str(tmp_path), "fp16", CFG, canon, extra_cfg={"rope_scaling": rs})
+    mc, _ = loader.load_hf_checkpoint(str(tmp_path))
+    assert mc.rope_scaling == rs
+    base = model.ModelConfig(**{**mc.__dict__, "rope_scaling": None})
+    assert not torch.equal(model.rope_table(mc, "cpu"), model.rope_table(base, "cpu"))
 
 
 def test_padded_vocab_follows_the_tensor(tmp_path):
