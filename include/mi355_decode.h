@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 2
+#define MI355_ABI_VERSION 3
 
 typedef void* mi355_stream_t; /* hipStream_t */
 
@@ -47,7 +47,13 @@ enum {
 enum { MI355_W4 = 4, MI355_W8 = 8, MI355_W16 = 16 };
 /* KV-cache element kinds (reference: KvCacheDataType, cpp/model_utils/AttentionConfig.h:9-12;
  * value 1 is the INT8 slot the reference removed, kept here) */
-enum { MI355_KV_FP16 = 0, MI355_KV_INT8 = 1 };
+enum { MI355_KV_FP16 = 0, MI355_KV_INT8 = 1, MI355_KV_BF16 = 2 };
+/* activation dtype of a call (x / bias / y of a linear, the rows of a norm, Q and the attention output): the reference path is
+ * fp16 / bf16 throughout (f16_linear.py:100-112; dtype grid of modules/base/rocm/test/rocm_norm_test.py).  bf16 is carried by
+ *   mi355_weight_t.act_dtype (linears), mi355_kv_layer_t.kv_dtype == MI355_KV_BF16 (RoPE / KV write / attention: Q, K, V, the cache
+ *   and the output are bf16), the *_dt entry points of the norm family and mi355_model_config_t.act_dtype (step driver).
+ * bf16 takes W4 group-wise and 16-bit (then bf16) weights and a bf16 KV cache; W8 weights and the INT8 cache are fp16-only. */
+enum { MI355_ACT_F16 = 0, MI355_ACT_BF16 = 1 };
 
 int         mi355_abi_version(void);
 const char* mi355_last_error(void);
@@ -89,6 +95,7 @@ typedef struct {
     int32_t     K_pad;   /* multiple of 128 */
     int32_t     N_pad;   /* multiple of 16 */
     int32_t     group_size; /* 32, 64, 128, or 0 = per-channel */
+    int32_t     act_dtype;  /* MI355_ACT_F16 / MI355_ACT_BF16: dtype of x, bias, y (and of the elements of a W16 weight) */
 } mi355_weight_t;
 
 /* epilogue flags for mi355_linear_forward */

@@ -14,11 +14,12 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmi355_decode_tuning.so" if TUNING else
 
 OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_WORKSPACE = 0, -1, -2, -3, -4
 W4, W8, W16 = 4, 8, 16
-KV_FP16, KV_INT8 = 0, 1
+KV_FP16, KV_INT8, KV_BF16 = 0, 1, 2
+ACT_F16, ACT_BF16 = 0, 1
 EPI_NONE, EPI_SILU_MUL, EPI_OUT_F32 = 0, 1, 2
 PF_QKV, PF_O, PF_GATE_UP, PF_QKV_LATE, PF_O_LATE, PF_TP_COMM = 1, 2, 4, 16, 32, 64   # mi355_decoder_set_weight_prefetch mask bits
 HINT_STAGED, HINT_NO_PERSISTENT = 0x100, 0x200
-ABI_VERSION = 2
+ABI_VERSION = 3
 KC_NAMES = ["gemm_quant", "gemm_lmhead", "attn", "rope_kv", "norm", "other", "comm"]
 
 vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
@@ -26,7 +27,7 @@ vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
 
 class Weight(C.Structure):  # mi355_weight_t
     _fields_ = [("qweight", vp), ("meta", vp), ("wbits", i32), ("K", i32), ("N", i32),
-                ("K_pad", i32), ("N_pad", i32), ("group_size", i32)]
+                ("K_pad", i32), ("N_pad", i32), ("group_size", i32), ("act_dtype", i32)]
 
 
 class KVLayer(C.Structure):  # mi355_kv_layer_t

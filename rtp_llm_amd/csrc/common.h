@@ -11,6 +11,9 @@ typedef _Float16 f16;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16   bf16;
+typedef __bf16   bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16   bf16x8 __attribute__((ext_vector_type(8)));
 typedef float    f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -53,6 +56,35 @@ __device__ __forceinline__ f16x2 as_h2(uint32_t v) { return __builtin_bit_cast(f
 
 __device__ __forceinline__ f32x4 mfma16x16x32(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// ---- activation dtype: kernels that exist in an fp16 and a bf16 form are templated on BF and move 16-bit data as raw dwords
+// (two elements each); only the MFMA and the conversions below know the type.  gfx950 has v_mfma_f32_16x16x32_bf16,
+// v_dot2_f32_bf16 and v_cvt_pk_bf16_f32 but no packed bf16 add / mul: bf16 arithmetic goes through fp32.
+template <bool BF>
+__device__ __forceinline__ f32x4 mfma_act(u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else              return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <bool BF> __device__ __forceinline__ float act_lo(uint32_t v) {   // element 0 of a packed pair
+    if constexpr (BF) return __builtin_bit_cast(float, v << 16);
+    else              return (float)__builtin_bit_cast(f16x2, v)[0];
+}
+template <bool BF> __device__ __forceinline__ float act_hi(uint32_t v) {   // element 1
+    if constexpr (BF) return __builtin_bit_cast(float, v & 0xFFFF0000u);
+    else              return (float)__builtin_bit_cast(f16x2, v)[1];
+}
+template <bool BF> __device__ __forceinline__ uint32_t act_pack(float a, float b) {   // round to nearest even, {a, b} -> one dword
+    if constexpr (BF) { bf16x2 o; o[0] = (bf16)a; o[1] = (bf16)b; return __builtin_bit_cast(uint32_t, o); }
+    else              { f16x2 o;  o[0] = (f16)a;  o[1] = (f16)b;  return __builtin_bit_cast(uint32_t, o); }
+}
+template <bool BF> __device__ __forceinline__ float act_round(float v) {   // the value a 16-bit tensor of this dtype would hold
+    if constexpr (BF) return (float)(bf16)v;
+    else              return (float)(f16)v;
+}
+template <bool BF> __device__ __forceinline__ float act_dot_ones(uint32_t v, float acc) {   // acc + v[0] + v[1]
+    if constexpr (BF) { const bf16x2 ones = {(bf16)1.f, (bf16)1.f}; return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v), ones, acc, false); }
+    else              { const f16x2 ones = {(f16)1.f, (f16)1.f};   return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v), ones, acc, false); }
 }
 
 // 8 unsigned nibbles (native W4 order: nibble e at bit 4*(e/2)+16*(e&1)) -> 8 fp16

@@ -523,7 +523,7 @@ size_t linear_ws_bound(const mi355_model_config_t& c) {
     for (const auto& sh : shapes)
         for (int wbits : {4, 8, 16}) {
             mi355_weight_t w;
-            w.qweight = &need; w.meta = &need; w.wbits = wbits; w.K = sh[0]; w.N = sh[1];
+            w.qweight = &need; w.meta = &need; w.wbits = wbits; w.K = sh[0]; w.N = sh[1]; w.act_dtype = MI355_ACT_F16;
             w.K_pad = (sh[0] + 127) & ~127; w.N_pad = (sh[1] + 15) & ~15; w.group_size = wbits == 4 ? 128 : 0;
             need = std::max(need, mi355_linear_workspace_bytes(64, &w));
         }

@@ -56,14 +56,18 @@ namespace {
 //     y += scale * that.
 // Cost: 2 v_fma_mix per output element per group instead of 2 packed ops per weight pair — 2x fewer VALU
 // at M <= 16, where the dequant ALU work was the measured limiter (VALU issues 1 wave-instruction per 4 cycles).
-template <int WBITS, int MB, int NBW, int GS, int D, int NWN, int KG>
+// BF: bf16 activations (x, bias, y and, for WBITS = 16, the weights).  The W4 codes enter the bf16 MFMA as 128 + u and zero /
+// scale are applied on the accumulator side at EVERY row-block count (there is no packed bf16 arithmetic for an operand-side
+// dequant); the reference's bf16 linear is f16_linear.py:100-112 with a bf16 tensor.
+template <int WBITS, int MB, int NBW, int GS, int D, int NWN, int KG, bool BF = false>
 __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams p) {
+    static_assert(!BF || WBITS != 8, "bf16 activations: W4 group-wise and 16-bit weights only");
     constexpr int LPC    = WBITS / 4;              // wave-loads per (tile, chunk)
     constexpr int NSUB   = (GS > 0) ? 4 / GS : 1;  // quantisation groups per chunk (per-channel: 1 pseudo group)
     constexpr int SPG    = 4 / NSUB;               // MFMA k-steps per group
     constexpr bool QUANT = WBITS != 16;
     constexpr bool GROUPED = GS > 0;               // per-group scale (else one scale per column, applied at the end)
-    constexpr bool CSIDE = QUANT && MB <= 2;       // zero/scale on the accumulator side (cheap for few row blocks);
+    constexpr bool CSIDE = QUANT && (MB <= 2 || BF); // zero/scale on the accumulator side (cheap for few row blocks);
                                                    // MB >= 3: classic operand-side dequant, cost independent of MB
     constexpr int GT     = 64 * NWN;               // threads per k-group
     constexpr int XSLOTS = 256 * MB;               // 16-byte slots per x chunk tile
@@ -173,7 +177,11 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
                 const f16x2 ones = {(f16)1.f, (f16)1.f};
                 const u32x4 v = xr[d][u];
                 float s0, s1;
-                if (WBITS == 4) {
+                if (BF) {           // one code bias (128) for every position of the group
+                    s0 = act_dot_ones<true>(v[0], 0.f); s0 = act_dot_ones<true>(v[1], s0);
+                    s0 = act_dot_ones<true>(v[2], s0); s0 = act_dot_ones<true>(v[3], s0);
+                    s1 = 0.f;
+                } else if (WBITS == 4) {
                     s0 = __builtin_amdgcn_fdot2(as_h2(v[0]), ones, 0.f, false);
                     s1 = __builtin_amdgcn_fdot2(as_h2(v[1]), ones, 0.f, false);
                     s0 = __builtin_amdgcn_fdot2(as_h2(v[2]), ones, s0, false);
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
                 s0 = dpp_add<0xB1>(s0); s0 = dpp_add<0x4E>(s0);           // quad: xor 1, xor 2
                 if (PPG >= 8) s0 = dpp_add<0x141>(s0);                     // row_half_mirror: 8 lanes
                 if (PPG >= 16) s0 = dpp_add<0x140>(s0);                    // row_mirror: 16 lanes
-                if (WBITS == 4) {
+                if (WBITS == 4 && !BF) {
                     s1 = dpp_add<0xB1>(s1); s1 = dpp_add<0x4E>(s1);
                     if (PPG >= 8) s1 = dpp_add<0x141>(s1);
                     if (PPG >= 16) s1 = dpp_add<0x140>(s1);
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
                     const float x0 = xsum[kg][buf][gi * 2 + 0][mb * 16 + jj];
                     const float x1 = xsum[kg][buf][gi * 2 + 1][mb * 16 + jj];
                     XS[mb] = x0 + x1;
-                    xb = 960.f * x1;
+                    xb = BF ? 0.f : 960.f * x1;
                 }
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb) ag[nb][mb] = (f32x4){xb, xb, xb, xb};
@@ -236,23 +244,21 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
 #pragma unroll
             for (int ss = 0; ss < SPG; ++ss) {
                 const int s = gi * SPG + ss;
-                f16x8 b[MB];
+                u32x4 b[MB];
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const u32x4 v = xs[kg][buf][(s * 4 + q) * (16 * MB) + mb * 16 + (jj ^ q)];
-                    b[mb] = __builtin_bit_cast(f16x8, v);
-                }
+                for (int mb = 0; mb < MB; ++mb) b[mb] = xs[kg][buf][(s * 4 + q) * (16 * MB) + mb * 16 + (jj ^ q)];
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb) {
-                    f16x8 a;
+                    u32x4 a;
                     if (WBITS == 16) {
-                        a = __builtin_bit_cast(f16x8, wr[d][nb][s % LPC]);
+                        a = wr[d][nb][s % LPC];
                     } else if (CSIDE) {
                         if (WBITS == 4) {
-                            a = widen_w4(wr[d][nb][0][s], w4c);
+                            if (BF) a = widen_w4_bf16(wr[d][nb][0][s]);
+                            else    a = __builtin_bit_cast(u32x4, widen_w4(wr[d][nb][0][s], w4c));
                         } else {
                             const u32x4 w = wr[d][nb][(s >> 1) % LPC];
-                            a = widen_w8(w[(s & 1) * 2], w[(s & 1) * 2 + 1]);
+                            a = __builtin_bit_cast(u32x4, widen_w8(w[(s & 1) * 2], w[(s & 1) * 2 + 1]));
                         }
                     } else { // operand-side dequant: (code - z) [* scale] in fp16, exact subtract, one rounding
                         const uint32_t m = GROUPED ? mr[d][nb][gi] : mch[nb];
@@ -260,16 +266,16 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
                         const f16x2 sc2   = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
                         if (WBITS == 4) {
                             const f16x2 c960 = {(f16)960.f, (f16)960.f};
-                            a = dequant_w4_vc(wr[d][nb][0][s], zneg2, zneg2 + c960, sc2, w4c);
+                            a = __builtin_bit_cast(u32x4, dequant_w4_vc(wr[d][nb][0][s], zneg2, zneg2 + c960, sc2, w4c));
                         } else {
                             const u32x4 w = wr[d][nb][(s >> 1) % LPC];
-                            a = dequant_w8<GROUPED>(w[(s & 1) * 2], w[(s & 1) * 2 + 1], zneg2, sc2);
+                            a = __builtin_bit_cast(u32x4, dequant_w8<GROUPED>(w[(s & 1) * 2], w[(s & 1) * 2 + 1], zneg2, sc2));
                         }
                     }
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) {
-                        if (CSIDE) ag[nb][mb] = mfma16x16x32(a, b[mb], ag[nb][mb]);
-                        else       acc[nb][mb] = mfma16x16x32(a, b[mb], acc[nb][mb]);
+                        if (CSIDE) ag[nb][mb] = mfma_act<BF>(a, b[mb], ag[nb][mb]);
+                        else       acc[nb][mb] = mfma_act<BF>(a, b[mb], acc[nb][mb]);
                     }
                 }
             }
@@ -287,7 +293,8 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
                     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float t = __builtin_fmaf((float)m4[r][0], XS[mb], ag[nb][mb][r]);
+                            // meta holds zneg = -(1024 + z); the bf16 codes are biased by 128
+                            const float t = __builtin_fmaf(BF ? (float)m4[r][0] + 896.f : (float)m4[r][0], XS[mb], ag[nb][mb][r]);
                             acc[nb][mb][r] = __builtin_fmaf((float)m4[r][1], t, acc[nb][mb][r]);
                         }
                 } else { // per-channel int8: zero code 128 for every column, scale applied in the epilogue
@@ -409,25 +416,23 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
             } else {
                 if (n0 >= p.N) continue;
                 if (p.bias) {
-                    const f16x4 bv = *reinterpret_cast<const f16x4*>(p.bias + n0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
+                    const u32x2 bv = *reinterpret_cast<const u32x2*>(p.bias + n0);
+                    v[0] += act_lo<BF>(bv[0]); v[1] += act_hi<BF>(bv[0]); v[2] += act_lo<BF>(bv[1]); v[3] += act_hi<BF>(bv[1]);
                 }
                 if (p.mode == MODE_F32) {   // lm_head logits (39 MB at b = 64): write-through like the slabs, nothing left dirty at the end
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry_f32, (uint32_t)(((size_t)m * p.ldy + n0) * 4), 0, 16 /*sc1*/);
                 } else if (p.mode == MODE_F16) {
-                    f16x4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (f16)v[r];
-                    *reinterpret_cast<f16x4*>((f16*)p.y + (size_t)m * p.ldy + n0) = o;
-                } else { // MODE_SILU: (gate, up) interleaved; round GEMM output to fp16 first
-                    f16x2 o;
+                    u32x2 o;
+                    o[0] = act_pack<BF>(v[0], v[1]); o[1] = act_pack<BF>(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>((f16*)p.y + (size_t)m * p.ldy + n0) = o;
+                } else { // MODE_SILU: (gate, up) interleaved; round GEMM output to the activation dtype first
+                    float sg[2];
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        const float g = (float)(f16)v[2 * t], u = (float)(f16)v[2 * t + 1];
-                        o[t] = (f16)((g / (1.f + __expf(-g))) * u);
+                        const float g = act_round<BF>(v[2 * t]), u = act_round<BF>(v[2 * t + 1]);
+                        sg[t] = (g / (1.f + __expf(-g))) * u;
                     }
-                    *reinterpret_cast<f16x2*>((f16*)p.y + (size_t)m * p.ldy + (n0 >> 1)) = o;
+                    *reinterpret_cast<uint32_t*>((f16*)p.y + (size_t)m * p.ldy + (n0 >> 1)) = act_pack<BF>(sg[0], sg[1]);
                 }
             }
         }
@@ -447,6 +452,7 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
 }
 
 // Sum split-K slabs (+bias) and apply the epilogue.  One thread per 4 columns.
+template <bool BF>
 __global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* __restrict__ partials, int nsplit,
                                                               int M, int N, int N_pad, const f16* __restrict__ bias,
                                                               void* y, int ldy, int mode) {
@@ -459,26 +465,31 @@ __global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* __res
     for (int s = 0; s < nsplit; ++s)
         v += *reinterpret_cast<const f32x4*>(partials + ((size_t)s * M + m) * N_pad + n0);
     if (bias) {
-        const f16x4 bv = *reinterpret_cast<const f16x4*>(bias + n0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
+        const u32x2 bv = *reinterpret_cast<const u32x2*>(bias + n0);
+        v[0] += act_lo<BF>(bv[0]); v[1] += act_hi<BF>(bv[0]); v[2] += act_lo<BF>(bv[1]); v[3] += act_hi<BF>(bv[1]);
     }
     if (mode == MODE_F32) {
         *reinterpret_cast<f32x4*>((float*)y + (size_t)m * ldy + n0) = v;
     } else if (mode == MODE_F16) {
-        f16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (f16)v[r];
-        *reinterpret_cast<f16x4*>((f16*)y + (size_t)m * ldy + n0) = o;
+        u32x2 o;
+        o[0] = act_pack<BF>(v[0], v[1]); o[1] = act_pack<BF>(v[2], v[3]);
+        *reinterpret_cast<u32x2*>((f16*)y + (size_t)m * ldy + n0) = o;
     } else {
-        f16x2 o;
+        float sg[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const float g = (float)(f16)v[2 * t], u = (float)(f16)v[2 * t + 1];
-            o[t] = (f16)((g / (1.f + __expf(-g))) * u);
+            const float g = act_round<BF>(v[2 * t]), u = act_round<BF>(v[2 * t + 1]);
+            sg[t] = (g / (1.f + __expf(-g))) * u;
         }
-        *reinterpret_cast<f16x2*>((f16*)y + (size_t)m * ldy + (n0 >> 1)) = o;
+        *reinterpret_cast<uint32_t*>((f16*)y + (size_t)m * ldy + (n0 >> 1)) = act_pack<BF>(sg[0], sg[1]);
     }
+}
+
+void launch_reduce_epilogue(const float* partials, int nsplit, int M, int N, int N_pad, const f16* bias, void* y, int ldy, int mode, bool bf,
+                            hipStream_t st) {
+    const int total = M * (N_pad / 4);
+    if (bf) hipLaunchKernelGGL(reduce_epilogue_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, st, partials, nsplit, M, N, N_pad, bias, y, ldy, mode);
+    else    hipLaunchKernelGGL(reduce_epilogue_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, st, partials, nsplit, M, N, N_pad, bias, y, ldy, mode);
 }
 
 // ------------------------------------------------------------------ dispatch
@@ -521,7 +532,30 @@ int launch_gemm_t(const GemmParams& p, int cfg, hipStream_t st) {
     return MI355_OK;
 }
 
+// bf16 activations: the three shapes the planner picks by row-block count (+ the narrow-N shape 8), nothing else instantiated
+template <int WBITS, int GS, int D1, int D2, int DW>
+int launch_gemm_bf16_t(const GemmParams& p, int cfg, hipStream_t st) {
+    dim3 grid(cdiv(p.NT * 16, kCfgBN[cfg]), p.nsplit);
+    switch (cfg) {
+        case 1: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 1, 2, GS, D1, 4, 2, true>), grid, dim3(512), 0, st, p); break;
+        case 5: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 1, 1, GS, D1, 4, 1, true>), grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 2, 1, GS, D2, 8, 1, true>), grid, dim3(512), 0, st, p); break;
+        case 8: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 1, GS, DW, 8, 1, true>), grid, dim3(512), 0, st, p); break;
+        default: mi355_set_error("gemm (bf16): block shape %d not built", cfg); return MI355_ERR_UNSUPPORTED;
+    }
+    MI355_CHECK_LAUNCH("gemm_wq_kernel<bf16>");
+    return MI355_OK;
+}
+
 int launch_gemm(const GemmParams& p, int wbits, int group_size, int cfg, hipStream_t st) {
+    if (p.bf16) {
+        if (wbits == 16) return launch_gemm_bf16_t<16, 0, 2, 2, 2>(p, cfg, st);
+        if (wbits == 4 && group_size == 128) return launch_gemm_bf16_t<4, 4, 4, 4, 4>(p, cfg, st);
+        if (wbits == 4 && group_size == 64) return launch_gemm_bf16_t<4, 2, 4, 4, 4>(p, cfg, st);
+        if (wbits == 4 && group_size == 32) return launch_gemm_bf16_t<4, 1, 4, 4, 4>(p, cfg, st);
+        mi355_set_error("gemm: bf16 activations take W4 group-wise or 16-bit weights (wbits=%d group_size=%d)", wbits, group_size);
+        return MI355_ERR_UNSUPPORTED;
+    }
     if (wbits == 16) return launch_gemm_t<16, 0, 2, 2, 2>(p, cfg, st);
     if (wbits == 4) {
 #ifdef MI355_TUNING
@@ -548,6 +582,11 @@ int check_weight(const mi355_weight_t* w) {
     MI355_CHECK_ARG(w->N_pad % 16 == 0 && w->N_pad >= w->N, "linear: N_pad=%d", w->N_pad);
     MI355_CHECK_ARG(w->wbits == 16 || w->meta, "linear: quantized weight needs meta");
     MI355_CHECK_ARG((uint64_t)w->K_pad * w->N_pad * w->wbits / 8 < 0xFFFFFFF0ull, "linear: weight image >= 4 GiB");
+    MI355_CHECK_ARG(w->act_dtype == MI355_ACT_F16 || w->act_dtype == MI355_ACT_BF16, "linear: act_dtype=%d", w->act_dtype);
+    if (w->act_dtype == MI355_ACT_BF16 && !(w->wbits == 16 || (w->wbits == 4 && w->group_size > 0))) {
+        mi355_set_error("linear: bf16 activations take W4 group-wise or 16-bit (bf16) weights, not wbits=%d group_size=%d", w->wbits, w->group_size);
+        return MI355_ERR_UNSUPPORTED;
+    }
     return MI355_OK;
 }
 
@@ -559,6 +598,7 @@ void fill_params(GemmParams& p, const void* x, int M, const mi355_weight_t* w) {
     p.meta_bytes = (uint32_t)((uint64_t)ngroups * w->N_pad * 4);
     p.x_bytes = (uint32_t)((uint64_t)M * w->K * 2);
     p.bias = nullptr; p.y = nullptr; p.partials = nullptr; p.ldy = 0;
+    p.bf16 = w->act_dtype == MI355_ACT_BF16;
 #ifdef MI355_TUNING
     p.stamps = (TUNE(7) == 2) ? g_wide_stamps : nullptr;
 #endif
@@ -576,6 +616,7 @@ GemmPlan plan_gemm(int M, const mi355_weight_t* w, int max_splits) {
     const int MB = cdiv(M, 16) == 3 ? 4 : cdiv(M, 16);
     GemmPlan g;
     g.cfg = (MB == 1) ? (NT >= 4096 ? 1 : 5) : (MB == 2 ? 2 : 4); // measured best per row-block count
+    if (w->act_dtype == MI355_ACT_BF16 && MB >= 3) g.cfg = 8;   // accumulator-side dequant at four row blocks: one tile per wave fits the registers
     if (TUNE(2) > 0) g.cfg = TUNE(2) - 1;
     g.bn = kCfgBN[g.cfg];
     const int blocks_n = cdiv(NT * 16, g.bn);
@@ -645,11 +686,12 @@ extern "C" int mi355_linear_partial(const void* x, int32_t M, const mi355_weight
     p.mode = MODE_PARTIAL; p.partials = partials;
     // (gemm_smallm.hip is not used here: inside the decode step, where the consumer kernel folds the slabs anyway,
     // it measured 3-8 % behind the staged kernel -- b=1 linears 1.55 vs 1.48 ms/step; tuning switch 4 = 2 re-enables it)
-    if (M <= 8 && w->wbits != 16 && TUNE(4) == 2) {
+    const bool bf = p.bf16;    // bf16 activations: the staged kernel is the only family built for them
+    if (!bf && M <= 8 && w->wbits != 16 && TUNE(4) == 2) {
         const int rc = mi355_gemm_smallm(&p, w->wbits, w->group_size, 1, max_splits, stream);
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
-    if (M > 16 && w->wbits != 16 && TUNE(5) != 1) { // register-resident activations, K split over the waves (gemm_wide.hip)
+    if (!bf && M > 16 && w->wbits != 16 && TUNE(5) != 1) { // register-resident activations, K split over the waves (gemm_wide.hip)
         const int rc = mi355_gemm_wide(&p, w->wbits, w->group_size, 1, max_splits, stream);
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
@@ -671,7 +713,8 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
     // prefill-sized M: the compute-shaped kernel reads every weight once per 128 rows.  Its grid is (N / 256) x (M / 128)
     // blocks without a K split: narrow outputs at moderate M (down_proj, N = 3584: 14 blocks per 128 rows) would leave
     // most CUs idle (measured M = 128: 246 us vs 2 x 21 us as 64-row slabs), so those stay on the decode kernels
-    if (M >= 128 && w->wbits != 16 && cdiv(w->N_pad / 16, 16) * cdiv(M, 128) >= 128) {
+    const bool bf = w->act_dtype == MI355_ACT_BF16;   // bf16 activations: 64-row slabs through the staged kernel at every M
+    if (!bf && M >= 128 && w->wbits != 16 && cdiv(w->N_pad / 16, 16) * cdiv(M, 128) >= 128) {
         GemmParams ps; fill_params(ps, x, M, w);
         ps.mode = mode; ps.bias = (const f16*)bias; ps.y = y; ps.ldy = ldy;
         const int rc = mi355_gemm_prefill(&ps, w->wbits, w->group_size, stream);
@@ -680,7 +723,7 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
     for (int m0 = 0; m0 < M; m0 += 64) {
         const int Mc = (M - m0) > 64 ? 64 : (M - m0);
         GemmParams p; fill_params(p, (const f16*)x + (size_t)m0 * w->K, Mc, w);
-        if (Mc <= 8 && w->wbits != 16 && !(epilogue & MI355_HINT_NO_PERSISTENT) && TUNE(4) != 1) { // persistent x-resident kernel: fused epilogue, no slabs, no
+        if (!bf && Mc <= 8 && w->wbits != 16 && !(epilogue & MI355_HINT_NO_PERSISTENT) && TUNE(4) != 1) { // persistent x-resident kernel: fused epilogue, no slabs, no
                                                              // reduce launch (stand-alone call: qkv 9.1 vs 14.6 us at M = 1)
             GemmParams ps; fill_params(ps, (const f16*)x + (size_t)m0 * w->K, Mc, w);
             ps.mode = mode; ps.bias = (const f16*)bias; ps.y = (char*)y + (size_t)m0 * ldy * ysz; ps.ldy = ldy;
@@ -688,7 +731,7 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
             if (rc >= 0) continue;
             if (rc != MI355_ERR_UNSUPPORTED) return rc;
         }
-        if (Mc > 16 && w->wbits != 16 && !(epilogue & MI355_HINT_STAGED) && TUNE(5) != 1) {
+        if (!bf && Mc > 16 && w->wbits != 16 && !(epilogue & MI355_HINT_STAGED) && TUNE(5) != 1) {
             GemmParams ps; fill_params(ps, (const f16*)x + (size_t)m0 * w->K, Mc, w);
             ps.mode = mode; ps.bias = (const f16*)bias; ps.y = (char*)y + (size_t)m0 * ldy * ysz; ps.ldy = ldy;
             int rc = MI355_ERR_UNSUPPORTED;
@@ -710,9 +753,7 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
         } else {
             p.mode = MODE_PARTIAL; p.partials = (float*)workspace;
             if (int e = launch_gemm(p, w->wbits, w->group_size, g.cfg, st)) return e;
-            const int total = Mc * (w->N_pad / 4);
-            hipLaunchKernelGGL(reduce_epilogue_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)workspace,
-                               ns, Mc, w->N, w->N_pad, (const f16*)bias, yc, ldy, mode);
+            launch_reduce_epilogue((const float*)workspace, ns, Mc, w->N, w->N_pad, (const f16*)bias, yc, ldy, mode, bf, st);
             MI355_CHECK_LAUNCH("reduce_epilogue_kernel");
         }
     }
@@ -730,12 +771,13 @@ extern "C" int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_
     GemmParams p; fill_params(p, x, M, w);
     p.mode = mode; p.bias = (const f16*)bias; p.y = y;
     p.ldy = (mode == MODE_SILU) ? w->N / 2 : w->N;
-    if (M <= 8 && w->wbits != 16 && (TUNE(4) == 2 || TUNE(7) == 1)) {
+    const bool bf = p.bf16;
+    if (!bf && M <= 8 && w->wbits != 16 && (TUNE(4) == 2 || TUNE(7) == 1)) {
         const int rc = mi355_gemm_smallm(&p, w->wbits, w->group_size, 0, 1, stream);
         if (rc >= 0) return MI355_OK;
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
-    if (M > 16 && w->wbits != 16 && !(epilogue & MI355_HINT_STAGED) && TUNE(5) != 1) {
+    if (!bf && M > 16 && w->wbits != 16 && !(epilogue & MI355_HINT_STAGED) && TUNE(5) != 1) {
         int rc = MI355_ERR_UNSUPPORTED;
         if (rc == MI355_ERR_UNSUPPORTED) rc = mi355_gemm_wide(&p, w->wbits, w->group_size, 0, 1, stream);
         if (rc >= 0) return MI355_OK;
@@ -753,15 +795,15 @@ extern "C" int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_
     if (g.nsplit == 1) return launch_gemm(p, w->wbits, w->group_size, g.cfg, (hipStream_t)stream);
     p.mode = MODE_PARTIAL; p.partials = (float*)workspace; p.bias = nullptr; p.y = nullptr;
     if (int e = launch_gemm(p, w->wbits, w->group_size, g.cfg, (hipStream_t)stream)) return e;
-    const int total = M * (w->N_pad / 4);
-    hipLaunchKernelGGL(reduce_epilogue_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
-                       g.nsplit, M, w->N, w->N_pad, (const f16*)bias, y, (mode == MODE_SILU) ? w->N / 2 : w->N, mode);
+    launch_reduce_epilogue((const float*)workspace, g.nsplit, M, w->N, w->N_pad, (const f16*)bias, y, (mode == MODE_SILU) ? w->N / 2 : w->N, mode, bf,
+                           (hipStream_t)stream);
     MI355_CHECK_LAUNCH("reduce_epilogue_kernel");
     return MI355_OK;
 }
 
 // ------------------------------------------------------------------ full-K kernels with fused consumers (gemm_fullk.hip)
 extern "C" int mi355_fullk_weight_ok(const mi355_weight_t* w) {
+    if (w && w->act_dtype != MI355_ACT_F16) return 0;   // the full-K fused launches exist for fp16 activations only
     const bool fmt = w && w->qweight && ((w->wbits == 4 && w->meta && (w->group_size == 128 || w->group_size == 64 || w->group_size == 32)) || w->wbits == 16);
     return fmt && w->K % 128 == 0 && w->K_pad == w->K && w->K_pad / 128 >= 4 && w->N % 16 == 0;
 }

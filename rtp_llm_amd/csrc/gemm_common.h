@@ -62,6 +62,7 @@ struct GemmParams {
     int nsplit, cps;          // chunks per split
     int mode;                 // 0 partial slabs, 1 fp16, 2 fp16 silu-mul, 3 fp32
     int ldy;
+    int bf16;                 // activations (x, bias, y; W16 weights) are bf16: staged kernel only
     uint32_t qw_bytes, meta_bytes, x_bytes;
 #ifdef MI355_TUNING
     unsigned long long* stamps;   // tools/wq_stamps.py: wall_clock64 of wave 0 at entry / prologue done / loop done / stores issued / exit, per block
@@ -102,6 +103,17 @@ __device__ __forceinline__ f16x8 widen_w4(uint32_t w, const W4Consts& c) {
     r[2] = and_or(w8, c.m0, c.e0);
     r[3] = and_or(w8, c.m1, c.e1);
     return __builtin_bit_cast(f16x8, r);
+}
+// bf16: 7 mantissa bits hold a nibble only at the bottom: all four code pairs become 128 + u (0x4300 | u), one bias for the
+// whole group, at the price of a shift per pair: 7 VALU per 8 weights.
+__device__ __forceinline__ u32x4 widen_w4_bf16(uint32_t w) {
+    const uint32_t M = 0x000F000Fu, E = 0x43004300u;
+    u32x4 r;
+    r[0] = (w & M) | E;
+    r[1] = ((w >> 4) & M) | E;
+    r[2] = ((w >> 8) & M) | E;
+    r[3] = ((w >> 12) & M) | E;
+    return r;
 }
 __device__ __forceinline__ f16x8 widen_w8(uint32_t lo, uint32_t hi) {
     const uint32_t C = 0x64646464u;

@@ -262,7 +262,7 @@ public:
         TORCH_CHECK(qweight_.is_cuda() && qweight_.is_contiguous(), "qweight must be a contiguous GPU tensor");
         w_.qweight = qweight_.data_ptr();
         w_.meta    = meta_.defined() ? meta_.data_ptr() : nullptr;
-        w_.wbits = (int)wbits; w_.K = (int)K; w_.N = (int)N; w_.K_pad = (int)K_pad; w_.N_pad = (int)N_pad; w_.group_size = (int)group_size;
+        w_.wbits = (int)wbits; w_.K = (int)K; w_.N = (int)N; w_.K_pad = (int)K_pad; w_.N_pad = (int)N_pad; w_.group_size = (int)group_size; w_.act_dtype = MI355_ACT_F16;
         if (bias_.defined()) need(bias_, torch::kFloat16, "bias");
     }
     torch::Tensor forward(const torch::Tensor& x, int64_t epilogue) {

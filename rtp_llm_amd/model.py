@@ -96,10 +96,12 @@ class CanonLinear:
     z_eff: Optional[torch.Tensor] = None    # [K/g, N] effective zero codes (w4)
     group_size: int = 0
 
-    def pack(self, gate_up: bool = False) -> PackedWeight:
+    def pack(self, gate_up: bool = False, dtype: torch.dtype = torch.float16) -> PackedWeight:
+        """dtype: activation dtype the packed weight will run with -- only a 16-bit weight image depends on it (its elements are
+        converted); W4 / W8 images serve fp16 and bf16 activations alike."""
         il = (lambda t: quant.interleave_gate_up(t, -1)) if gate_up else (lambda t: t)
         if self.kind == "fp16":
-            return quant.pack_fp16(il(self.w))
+            return quant.pack_fp16(il(self.w).to(dtype))
         if self.kind == "int8":
             return quant.pack_int8_per_channel(il(self.q), il(self.scales))
         return quant.pack_groupwise_w4(il(self.q), il(self.z_eff), il(self.scales), self.group_size)

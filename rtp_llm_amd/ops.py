@@ -30,9 +30,21 @@ def _chk(t: torch.Tensor, dtype, name: str):
         raise _C.Mi355Error(f"{name}: tensor must be contiguous")
 
 
-def weight_struct(w: PackedWeight) -> _C.Weight:
+ACT_DTYPES = (torch.float16, torch.bfloat16)
+
+
+def _chk_act(t: torch.Tensor, name: str, like: Optional[torch.Tensor] = None):
+    """An activation tensor: fp16 or bf16 (the reference's dtype grid), on the GPU, contiguous; `like` fixes the dtype of a call."""
+    if t.dtype not in ACT_DTYPES:
+        raise _C.Mi355Error(f"{name}: expected float16 or bfloat16, got {t.dtype}")
+    _chk(t, t.dtype if like is None else like.dtype, name)
+
+
+def weight_struct(w: PackedWeight, act: torch.dtype = torch.float16) -> _C.Weight:
+    if w.wbits == 16 and w.qweight.dtype != act:
+        raise _C.Mi355Error(f"linear: 16-bit weight image is {w.qweight.dtype}, activations are {act}")
     return _C.Weight(w.qweight.data_ptr(), 0 if w.meta is None else w.meta.data_ptr(), w.wbits, w.K, w.N,
-                     w.K_pad, w.N_pad, w.group_size)
+                     w.K_pad, w.N_pad, w.group_size, _C.ACT_BF16 if act == torch.bfloat16 else _C.ACT_F16)
 
 
 def kv_struct(kv_base: torch.Tensor, scale_base: Optional[torch.Tensor], page: int, nkv: int, hd: int) -> _C.KVLayer:
@@ -59,16 +71,18 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 def linear(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None, epilogue: int = _C.EPI_NONE,
            out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = x @ W (+bias); epilogue EPI_SILU_MUL -> [M, N/2], EPI_OUT_F32 -> fp32."""
-    _chk(x, torch.float16, "linear.x")
+    """y = x @ W (+bias); epilogue EPI_SILU_MUL -> [M, N/2], EPI_OUT_F32 -> fp32.  x fp16 or bf16 (bias and y follow)."""
+    _chk_act(x, "linear.x")
+    if bias is not None:
+        _chk_act(bias, "linear.bias", x)
     M = x.numel() // w.K
     if x.shape[-1] != w.K:
         raise _C.Mi355Error(f"linear: x last dim {x.shape[-1]} != K {w.K}")
     n_out = w.N // 2 if epilogue & _C.EPI_SILU_MUL else w.N   # (HINT_* bits of `epilogue` only select the kernel family)
-    dt = torch.float32 if epilogue & _C.EPI_OUT_F32 else torch.float16
+    dt = torch.float32 if epilogue & _C.EPI_OUT_F32 else x.dtype
     if out is None:
         out = torch.empty(*x.shape[:-1], n_out, dtype=dt, device=x.device)
-    ws_struct = weight_struct(w)
+    ws_struct = weight_struct(w, x.dtype)
     need = _C.lib().mi355_linear_workspace_bytes(M, C.byref(ws_struct))
     ws = _workspace(need, x.device)
     _C.check(_C.lib().mi355_linear_forward(x.data_ptr(), M, C.byref(ws_struct), _p(bias), out.data_ptr(), epilogue,

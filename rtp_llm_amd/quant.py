@@ -118,8 +118,8 @@ def pack_w8(q: torch.Tensor) -> torch.Tensor:
 
 
 def pack_w16(w: torch.Tensor) -> torch.Tensor:
-    """fp16 [K,N] -> fp16 image [NT, KC, 4 steps, 64 lanes, 8 halfs]."""
-    assert w.dtype == torch.float16
+    """fp16 / bf16 [K,N] -> image of the same dtype [NT, KC, 4 steps, 64 lanes, 8 elements]."""
+    assert w.dtype in (torch.float16, torch.bfloat16)
     K, N = w.shape
     K_pad, N_pad = _ceil_to(K, 128), _ceil_to(N, 16)
     w = _pad2(w, K_pad, N_pad)
