@@ -145,6 +145,14 @@ int mi355_linear_partial(const void* x, int32_t M, const mi355_weight_t* w, floa
  * ---------------------------------------------------------------------- */
 int mi355_rmsnorm(const void* x, const void* weight, float eps, int32_t M, int32_t H, void* y,
                   mi355_stream_t stream);
+/* the same family with the rows / weight / bias in act_dtype (MI355_ACT_F16 = the entry points without the suffix, MI355_ACT_BF16);
+ * mi355_embedding copies 16-bit rows and serves both */
+int mi355_rmsnorm_dt(const void* x, const void* weight, float eps, int32_t M, int32_t H, void* y, int32_t act_dtype,
+                     mi355_stream_t stream);
+int mi355_add_rmsnorm_dt(const void* x, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
+                         const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M, int32_t H,
+                         void* y, int32_t act_dtype, mi355_stream_t stream);
+int mi355_silu_mul_dt(const void* gate_up, int32_t M, int32_t I, void* out, int32_t act_dtype, mi355_stream_t stream);
 
 int mi355_add_rmsnorm(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld,
                       const void* bias, const void* residual_in, void* residual_out,

@@ -79,6 +79,9 @@ SIGNATURES = {
     "mi355_rmsnorm": (i32, [vp, vp, f32, i32, i32, vp, vp]),
     "mi355_add_rmsnorm": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, vp]),
     "mi355_silu_mul": (i32, [vp, i32, i32, vp, vp]),
+    "mi355_rmsnorm_dt": (i32, [vp, vp, f32, i32, i32, vp, i32, vp]),
+    "mi355_add_rmsnorm_dt": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, i32, vp]),
+    "mi355_silu_mul_dt": (i32, [vp, i32, i32, vp, i32, vp]),
     "mi355_embedding": (i32, [vp, i32, vp, i32, i32, vp, vp]),
     "mi355_rope_kv_write": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
     "mi355_rope_kv_write_rows": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),

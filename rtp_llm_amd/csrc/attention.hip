@@ -66,8 +66,11 @@ __device__ __forceinline__ f16x8 widen_kv8(uint32_t lo, uint32_t hi) {
     return __builtin_bit_cast(f16x8, r);
 }
 
-template <int HD, bool INT8, int NT, int NW, int NG>
+// BF: Q, the 16-bit cache and the output are bf16 (kv_dtype MI355_KV_BF16): bf16 MFMAs for S = K q^T and O = V^T P, P rounded to
+// bf16; the INT8 cache pairs with fp16 activations only (its widening builds fp16 operands).
+template <int HD, bool INT8, int NT, int NW, int NG, bool BF = false>
 __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p) {
+    static_assert(!(BF && INT8), "bf16 activations with the INT8 cache are not built");
     constexpr int NTHR = 64 * NW, GS = 32 * NW;    // threads; tokens one round of the block's waves covers
     constexpr int NSTEP = HD / 32; // QK k-steps
     constexpr int NDB   = HD / 16; // PV d-blocks
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
     const int j = lane & 15, w = lane >> 4;
 
     // column j of tile c = (row c*R + j/G, head kh*G + j%G); q fragments (B operand), zero for unused columns
-    f16x8 qf[NT][NSTEP];
+    u32x4 qf[NT][NSTEP];
     int   limit[NT];       // tokens [0, limit) are visible to this lane's column (causal mask); 0 = nothing
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
@@ -109,8 +112,8 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             const int d = INT8 ? (s >> 1) * 64 + w * 16 + (s & 1) * 8 : s * 32 + w * 8;
-            f16x8 v = *reinterpret_cast<const f16x8*>(qrow + d);
-            if (!ok) v = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            u32x4 v = *reinterpret_cast<const u32x4*>(qrow + d);
+            if (!ok) v = (u32x4){0u, 0u, 0u, 0u};
             qf[c][s] = v;
         }
     }
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             float qs = 0.f;
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) {
-                const u32x4 v = __builtin_bit_cast(u32x4, qf[c][s]);
+                const u32x4 v = qf[c][s];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) qs = __builtin_amdgcn_fdot2(as_h2(v[e]), ones, qs, false);
             }
@@ -222,19 +225,19 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
         constexpr bool MASKED = decltype(masked_c)::value;   // false: every token of the group is visible to every column
         const int vwin = tb + w * 8; // first token of this lane's S rows / P slots
         // ---- widen K once, S^T = K q^T for every column tile
-        f16x8 ka[2][NSTEP];
+        u32x4 ka[2][NSTEP];
 #pragma unroll
         for (int tau = 0; tau < 2; ++tau)
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) {
                 if (INT8) {
                     const u32x4 kk = g.kf[tau][s >> 1];
-                    ka[tau][s] = widen_kv8(kk[(s & 1) * 2], kk[(s & 1) * 2 + 1]);
+                    ka[tau][s] = __builtin_bit_cast(u32x4, widen_kv8(kk[(s & 1) * 2], kk[(s & 1) * 2 + 1]));
                 } else {
-                    ka[tau][s] = __builtin_bit_cast(f16x8, g.kf[tau][s]);
+                    ka[tau][s] = g.kf[tau][s];
                 }
             }
-        f16x8 pf[NT];
+        u32x4 pf[NT];
         float alpha[NT];
         bool rescale = false;
 #pragma unroll
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             for (int tau = 0; tau < 2; ++tau) {
                 sacc[tau] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < NSTEP; ++s) sacc[tau] = mfma16x16x32(ka[tau][s], qf[c][s], sacc[tau]);
+                for (int s = 0; s < NSTEP; ++s) sacc[tau] = mfma_act<BF>(ka[tau][s], qf[c][s], sacc[tau]);
             }
             // ---- scale, causal mask, online softmax (log2 domain)
             float sv[8];
@@ -271,18 +274,20 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             rescale |= grow;
             m_run[c] = m_new;
             float psum = 0.f;
+            float pes[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const bool valid = !MASKED || vwin + e < limit[c];
                 float pe = valid ? __builtin_amdgcn_exp2f(sv[e] - m_new) : 0.f;
                 psum += pe;
                 if (INT8) pe = valid ? pe * g.vsc[e >> 2][e & 3] : 0.f; // scale bytes past the context may be garbage
-                pf[c][e] = (f16)pe;
+                pes[e] = pe;
             }
+            pf[c] = act_pack8<BF>(pes);
             l_run[c] = l_run[c] * alpha[c] + psum;
             if (INT8) {
                 const f16x2 ones = {(f16)1.f, (f16)1.f};
-                const u32x4 pv = __builtin_bit_cast(u32x4, pf[c]);
+                const u32x4 pv = pf[c];
                 float s16 = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) s16 = __builtin_amdgcn_fdot2(as_h2(pv[e]), ones, s16, false);
@@ -298,19 +303,20 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
         // ---- O^T += V^T P
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
-            f16x8 a;
+            u32x4 a;
             if (INT8) {
-                a = widen_kv8(g.vf8[db][0], g.vf8[db][1]);
+                a = __builtin_bit_cast(u32x4, widen_kv8(g.vf8[db][0], g.vf8[db][1]));
             } else {
-                a = __builtin_bit_cast(f16x8, g.vf16[db]);
+                a = g.vf16[db];
             }
             // tokens past the block's context carry p = 0 but V bytes there may be garbage (NaN/Inf): zero them
             if (MASKED && vwin + 7 >= seq_len) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) if (vwin + e >= seq_len) a[e] = (f16)0.f;
+                for (int e = 0; e < 8; ++e)
+                    if (vwin + e >= seq_len) a[e >> 1] &= (e & 1) ? 0x0000FFFFu : 0xFFFF0000u;
             }
 #pragma unroll
-            for (int c = 0; c < NT; ++c) o[c][db] = mfma16x16x32(a, pf[c], o[c][db]);
+            for (int c = 0; c < NT; ++c) o[c][db] = mfma_act<BF>(a, pf[c], o[c][db]);
         }
     };
 
@@ -461,10 +467,9 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             const int row = row0 + rl, h = kh * p.G + (jj - (jj / p.G) * p.G);
             if (p.P == 1) {
                 const float inv = l > 0.f ? 1.f / l : 0.f;          // padding row / empty context: zeros, not NaN
-                f16x4 ov;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ov[r] = (f16)(acc[r] * inv);
-                *reinterpret_cast<f16x4*>(p.out + ((size_t)row * p.nh + h) * HD + d0) = ov;
+                u32x2 ov;
+                ov[0] = act_pack<BF>(acc[0] * inv, acc[1] * inv); ov[1] = act_pack<BF>(acc[2] * inv, acc[3] * inv);
+                *reinterpret_cast<u32x2*>(p.out + ((size_t)row * p.nh + h) * HD + d0) = ov;
             } else {
                 const size_t slot = ((size_t)row * p.nh + h) * p.P + part;
                 *reinterpret_cast<f32x4*>(p.tmp_out + slot * HD + d0) = acc;
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
 }
 
 // Merge partitions: one wave per (sequence, head); lane owns HD/64 channels.
-template <int HD>
+template <int HD, bool BF = false>
 __global__ __launch_bounds__(256) void attn_reduce_kernel(const AttnParams p) {
     const int lane = threadIdx.x & 63;
     const int gid = blockIdx.x * 4 + (threadIdx.x >> 6); // (row, h)
@@ -498,9 +503,9 @@ __global__ __launch_bounds__(256) void attn_reduce_kernel(const AttnParams p) {
         for (int c = 0; c < CPL; ++c) acc[c] += src[c] * f;
     }
     const float inv = l > 0.f ? 1.f / l : 0.f;
-    f16* dst = p.out + (size_t)gid * HD + lane * CPL;
+    uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + (size_t)gid * HD + lane * CPL;
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) dst[c] = (f16)(acc[c] * inv);
+    for (int c = 0; c < CPL; ++c) dst[c] = act_to_bits<BF>(acc[c] * inv);
 }
 
 #ifdef MI355_TUNING
@@ -582,14 +587,22 @@ int launch_attn(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_
 // (NG = 3: 72.7), ctx 1024 unchanged; fp16 loses with more than two (28.4 -> 30.6 us at ctx 1024)
 #define L2_(HD_, I8_) do { if (NT == 1) L_(HD_, I8_, 1, 4, (I8_ ? 4 : 2)); else L_(HD_, I8_, 2, 4, 2); } while (0)
 #endif
-    if (kv->hd == 128) { if (int8) L2_(128, true); else L2_(128, false); }
+    const bool bf = kv->kv_dtype == MI355_KV_BF16;
+#define LB_(HD_) do { if (NT == 1) hipLaunchKernelGGL((paged_attn_kernel<HD_, false, 1, 4, 2, true>), grid, dim3(256), 0, st, p); \
+                      else         hipLaunchKernelGGL((paged_attn_kernel<HD_, false, 2, 4, 2, true>), grid, dim3(256), 0, st, p); } while (0)
+    if (bf)            { if (kv->hd == 128) LB_(128); else LB_(64); }
+    else if (kv->hd == 128) { if (int8) L2_(128, true); else L2_(128, false); }
     else               { if (int8) L2_(64, true);  else L2_(64, false); }
+#undef LB_
 #undef L2_
 #undef L_
     MI355_CHECK_LAUNCH("paged_attn_kernel");
     if (p.P > 1) {
         const int nblk = cdiv((int)rows * nh, 4);
-        if (kv->hd == 128) hipLaunchKernelGGL(attn_reduce_kernel<128>, dim3(nblk), dim3(256), 0, st, p);
+        if (bf) {
+            if (kv->hd == 128) hipLaunchKernelGGL((attn_reduce_kernel<128, true>), dim3(nblk), dim3(256), 0, st, p);
+            else               hipLaunchKernelGGL((attn_reduce_kernel<64, true>), dim3(nblk), dim3(256), 0, st, p);
+        } else if (kv->hd == 128) hipLaunchKernelGGL(attn_reduce_kernel<128>, dim3(nblk), dim3(256), 0, st, p);
         else               hipLaunchKernelGGL(attn_reduce_kernel<64>, dim3(nblk), dim3(256), 0, st, p);
         MI355_CHECK_LAUNCH("attn_reduce_kernel");
     }

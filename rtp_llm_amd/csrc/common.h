@@ -87,6 +87,25 @@ template <bool BF> __device__ __forceinline__ float act_dot_ones(uint32_t v, flo
     else              { const f16x2 ones = {(f16)1.f, (f16)1.f};   return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v), ones, acc, false); }
 }
 
+template <bool BF> __device__ __forceinline__ float act_from_bits(uint16_t b) {   // one 16-bit element
+    if constexpr (BF) return __builtin_bit_cast(float, (uint32_t)b << 16);
+    else              return (float)__builtin_bit_cast(f16, b);
+}
+template <bool BF> __device__ __forceinline__ uint16_t act_to_bits(float v) {
+    if constexpr (BF) return __builtin_bit_cast(uint16_t, (bf16)v);
+    else              return __builtin_bit_cast(uint16_t, (f16)v);
+}
+template <bool BF> __device__ __forceinline__ void act_unpack8(u32x4 v, float (&o)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[2 * i] = act_lo<BF>(v[i]); o[2 * i + 1] = act_hi<BF>(v[i]); }
+}
+template <bool BF> __device__ __forceinline__ u32x4 act_pack8(const float (&o)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = act_pack<BF>(o[2 * i], o[2 * i + 1]);
+    return v;
+}
+
 // 8 unsigned nibbles (native W4 order: nibble e at bit 4*(e/2)+16*(e&1)) -> 8 fp16
 // holding scale * (u - z) with zneg2 = {-(1024+z)} x2, s2 = {scale} x2.
 // (u | 0x6400) is the fp16 1024+u exactly; the add is exact; one rounding in the mul.

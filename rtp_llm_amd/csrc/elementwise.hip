@@ -13,7 +13,7 @@ namespace {
 // Reference numerics (rtp_llm/models_py/modules/base/common/norm.py:83-92):
 //   var = mean(x_f32^2); xn = (x_f32 * rsqrt(var + eps)).to(fp16); y = weight * xn
 // One block (256 threads) per row; each thread owns 8-element vectors.
-template <int VPT> // vectors (of 8 halfs) per thread; 512 threads per row
+template <int VPT, bool BF> // vectors (of 8 elements) per thread; 512 threads per row; BF: the rows / weight / bias are bf16
 __global__ __launch_bounds__(512) void add_rmsnorm_kernel(const f16* __restrict__ x, const float* __restrict__ partials,
                                                           int nsplit, int ld, int M, const f16* __restrict__ bias,
                                                           const f16* __restrict__ res_in, f16* __restrict__ res_out,
@@ -23,16 +23,17 @@ __global__ __launch_bounds__(512) void add_rmsnorm_kernel(const f16* __restrict_
     const int row = blockIdx.x;
     const int tid = threadIdx.x;
     const int nvec = H >> 3;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
     float v[VPT][8];
-    f16x8 rin[VPT], bin[VPT], win[VPT];
+    u32x4 rin[VPT], bin[VPT], win[VPT];
     // everything that does not depend on the slab sum is requested first (one memory round trip for all of it)
 #pragma unroll
     for (int t = 0; t < VPT; ++t) {
         const int vi = tid + t * NTH;
         const int c0 = (vi < nvec ? vi : 0) * 8;
-        rin[t] = res_in ? *reinterpret_cast<const f16x8*>(res_in + (size_t)row * H + c0) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        bin[t] = bias ? *reinterpret_cast<const f16x8*>(bias + c0) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        win[t] = (y && weight) ? *reinterpret_cast<const f16x8*>(weight + c0) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        rin[t] = res_in ? *reinterpret_cast<const u32x4*>(res_in + (size_t)row * H + c0) : zero4;
+        bin[t] = bias ? *reinterpret_cast<const u32x4*>(bias + c0) : zero4;
+        win[t] = (y && weight) ? *reinterpret_cast<const u32x4*>(weight + c0) : zero4;
     }
     float ss = 0.f;
 #pragma unroll
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(512) void add_rmsnorm_kernel(const f16* __restrict_
             if (partials) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[t][e] = 0.f;
-                // slabs are summed in index order (deterministic); 8 slabs are in flight per memory round trip
+                // slabs are summed in index order (deterministic)
                 const size_t sstride = (size_t)M * ld;
                 const float* src0 = partials + (size_t)row * ld + c0;
                 int s = 0;
@@ -91,28 +92,24 @@ __global__ __launch_bounds__(512) void add_rmsnorm_kernel(const f16* __restrict_
                         for (int e = 0; e < 4; ++e) { v[t][e] += a[u][e]; v[t][4 + e] += b[u][e]; }
                 }
             } else {
-                const f16x8 a = *reinterpret_cast<const f16x8*>(x + (size_t)row * H + c0);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[t][e] = (float)a[e];
+                act_unpack8<BF>(*reinterpret_cast<const u32x4*>(x + (size_t)row * H + c0), v[t]);
             }
+            float aux[8];
             if (bias) {
+                act_unpack8<BF>(bin[t], aux);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[t][e] += (float)bin[t][e];
+                for (int e = 0; e < 8; ++e) v[t][e] += aux[e];
             }
-            if (partials) { // the GEMM output is an fp16 tensor in the reference: round once
+            if (partials) { // the GEMM output is a 16-bit tensor in the reference: round once
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[t][e] = (float)(f16)v[t][e];
+                for (int e = 0; e < 8; ++e) v[t][e] = act_round<BF>(v[t][e]);
             }
             if (res_in) {
+                act_unpack8<BF>(rin[t], aux);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[t][e] = (float)(f16)(v[t][e] + (float)rin[t][e]);
+                for (int e = 0; e < 8; ++e) v[t][e] = act_round<BF>(v[t][e] + aux[e]);
             }
-            if (res_out) {
-                f16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (f16)v[t][e];
-                *reinterpret_cast<f16x8*>(res_out + (size_t)row * H + c0) = o;
-            }
+            if (res_out) *reinterpret_cast<u32x4*>(res_out + (size_t)row * H + c0) = act_pack8<BF>(v[t]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) ss += v[t][e] * v[t][e];
         }
@@ -131,28 +128,27 @@ __global__ __launch_bounds__(512) void add_rmsnorm_kernel(const f16* __restrict_
         const int vi = tid + t * NTH;
         if (vi < nvec) {
             const int c0 = vi * 8;
-            f16x8 o;
+            float wv[8], o[8];
+            act_unpack8<BF>(win[t], wv);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = win[t][e] * (f16)(v[t][e] * rs);
-            *reinterpret_cast<f16x8*>(y + (size_t)row * H + c0) = o;
+            for (int e = 0; e < 8; ++e) o[e] = wv[e] * act_round<BF>(v[t][e] * rs);   // product of two 16-bit tensors: rounded once by the pack
+            *reinterpret_cast<u32x4*>(y + (size_t)row * H + c0) = act_pack8<BF>(o);
         }
     }
 }
 
+template <bool BF>
 __global__ __launch_bounds__(256) void silu_mul_kernel(const f16* __restrict__ gu, int M, int I, f16* __restrict__ out) {
     const int nvec = I >> 3;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= M * nvec) return;
     const int m = idx / nvec, c0 = (idx - m * nvec) * 8;
-    const f16x8 g = *reinterpret_cast<const f16x8*>(gu + (size_t)m * 2 * I + c0);
-    const f16x8 u = *reinterpret_cast<const f16x8*>(gu + (size_t)m * 2 * I + I + c0);
-    f16x8 o;
+    float g[8], u[8], o[8];
+    act_unpack8<BF>(*reinterpret_cast<const u32x4*>(gu + (size_t)m * 2 * I + c0), g);
+    act_unpack8<BF>(*reinterpret_cast<const u32x4*>(gu + (size_t)m * 2 * I + I + c0), u);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float gf = (float)g[e];
-        o[e] = (f16)((gf / (1.f + __expf(-gf))) * (float)u[e]);
-    }
-    *reinterpret_cast<f16x8*>(out + (size_t)m * I + c0) = o;
+    for (int e = 0; e < 8; ++e) o[e] = (g[e] / (1.f + __expf(-g[e]))) * u[e];
+    *reinterpret_cast<u32x4*>(out + (size_t)m * I + c0) = act_pack8<BF>(o);
 }
 
 __global__ __launch_bounds__(256) void embedding_kernel(const int32_t* __restrict__ ids, int T, const f16* __restrict__ table,
@@ -261,37 +257,57 @@ __global__ __launch_bounds__(64) void argmax_pick(const ArgPair* __restrict__ pa
 
 } // namespace
 
-extern "C" int mi355_add_rmsnorm(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
-                                 const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M,
-                                 int32_t H, void* y, mi355_stream_t stream) {
+extern "C" int mi355_add_rmsnorm_dt(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
+                                    const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M,
+                                    int32_t H, void* y, int32_t act_dtype, mi355_stream_t stream) {
     MI355_CHECK_ARG((x_f16 != nullptr) != (partials != nullptr), "add_rmsnorm: exactly one of x_f16 / partials");
     MI355_CHECK_ARG(M > 0 && H > 0 && H % 8 == 0 && H <= 8 * 512 * 2, "add_rmsnorm: M=%d H=%d (H %% 8 == 0, H <= 8192)", M, H);
     MI355_CHECK_ARG(!partials || (nsplit >= 1 && ld >= H && ld % 4 == 0), "add_rmsnorm: nsplit=%d ld=%d", nsplit, ld);
     MI355_CHECK_ARG(!y || weight, "add_rmsnorm: weight required");
+    MI355_CHECK_ARG(act_dtype == MI355_ACT_F16 || act_dtype == MI355_ACT_BF16, "add_rmsnorm: act_dtype=%d", act_dtype);
     hipStream_t st = (hipStream_t)stream;
     const int vpt = cdiv(H / 8, 512);
-#define L_(V)                                                                                                        \
-    hipLaunchKernelGGL(add_rmsnorm_kernel<V>, dim3(M), dim3(512), 0, st, (const f16*)x_f16, partials, nsplit, ld, M, \
+#define L_(V, B)                                                                                                        \
+    hipLaunchKernelGGL((add_rmsnorm_kernel<V, B>), dim3(M), dim3(512), 0, st, (const f16*)x_f16, partials, nsplit, ld, M, \
                        (const f16*)bias, (const f16*)residual_in, (f16*)residual_out, (const f16*)weight, eps, H, (f16*)y)
-    if (vpt <= 1) L_(1); else L_(2);
+    if (act_dtype == MI355_ACT_BF16) { if (vpt <= 1) L_(1, true); else L_(2, true); }
+    else                             { if (vpt <= 1) L_(1, false); else L_(2, false); }
 #undef L_
     MI355_CHECK_LAUNCH("add_rmsnorm_kernel");
     return MI355_OK;
 }
 
+extern "C" int mi355_add_rmsnorm(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
+                                 const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M,
+                                 int32_t H, void* y, mi355_stream_t stream) {
+    return mi355_add_rmsnorm_dt(x_f16, partials, nsplit, ld, bias, residual_in, residual_out, weight, eps, M, H, y, MI355_ACT_F16, stream);
+}
+
+extern "C" int mi355_rmsnorm_dt(const void* x, const void* weight, float eps, int32_t M, int32_t H, void* y, int32_t act_dtype,
+                                mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && weight && y, "rmsnorm: null pointer");
+    return mi355_add_rmsnorm_dt(x, nullptr, 0, 0, nullptr, nullptr, nullptr, weight, eps, M, H, y, act_dtype, stream);
+}
+
 extern "C" int mi355_rmsnorm(const void* x, const void* weight, float eps, int32_t M, int32_t H, void* y,
                              mi355_stream_t stream) {
-    MI355_CHECK_ARG(x && weight && y, "rmsnorm: null pointer");
-    return mi355_add_rmsnorm(x, nullptr, 0, 0, nullptr, nullptr, nullptr, weight, eps, M, H, y, stream);
+    return mi355_rmsnorm_dt(x, weight, eps, M, H, y, MI355_ACT_F16, stream);
+}
+
+extern "C" int mi355_silu_mul_dt(const void* gate_up, int32_t M, int32_t I, void* out, int32_t act_dtype, mi355_stream_t stream) {
+    MI355_CHECK_ARG(gate_up && out && M > 0 && I > 0 && I % 8 == 0, "silu_mul: M=%d I=%d", M, I);
+    MI355_CHECK_ARG(act_dtype == MI355_ACT_F16 || act_dtype == MI355_ACT_BF16, "silu_mul: act_dtype=%d", act_dtype);
+    const int total = M * (I / 8);
+    if (act_dtype == MI355_ACT_BF16)
+        hipLaunchKernelGGL(silu_mul_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)gate_up, M, I, (f16*)out);
+    else
+        hipLaunchKernelGGL(silu_mul_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)gate_up, M, I, (f16*)out);
+    MI355_CHECK_LAUNCH("silu_mul_kernel");
+    return MI355_OK;
 }
 
 extern "C" int mi355_silu_mul(const void* gate_up, int32_t M, int32_t I, void* out, mi355_stream_t stream) {
-    MI355_CHECK_ARG(gate_up && out && M > 0 && I > 0 && I % 8 == 0, "silu_mul: M=%d I=%d", M, I);
-    const int total = M * (I / 8);
-    hipLaunchKernelGGL(silu_mul_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)gate_up, M, I,
-                       (f16*)out);
-    MI355_CHECK_LAUNCH("silu_mul_kernel");
-    return MI355_OK;
+    return mi355_silu_mul_dt(gate_up, M, I, out, MI355_ACT_F16, stream);
 }
 
 extern "C" int mi355_embedding(const int32_t* ids, int32_t T, const void* table, int32_t H, int32_t vocab, void* out,

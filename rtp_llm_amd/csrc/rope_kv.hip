@@ -30,7 +30,10 @@ struct RopeParams {
     f16*           q_out;
 };
 
+// BF: qkv / bias / q_out and the (16-bit) cache are bf16 (kv_dtype MI355_KV_BF16); the INT8 cache pairs with fp16 activations only
+template <bool BF>
 __global__ __launch_bounds__(256) void rope_kv_write_kernel(const RopeParams p) {
+    using raw16 = uint16_t;
     const int t    = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int h    = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -52,7 +55,8 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const RopeParams p) 
     if (!is_v && act) cs = *reinterpret_cast<const float2*>(p.cos_sin + ((size_t)pos * half + lane) * 2);
     float x0 = 0.f, x1 = 0.f;
     if (act) {
-        f16 bh0 = (f16)0.f, bh1 = (f16)0.f;
+        float bh0 = 0.f, bh1 = 0.f;
+        const raw16* bias = reinterpret_cast<const raw16*>(p.bias);
         if (p.partials) {
             const size_t sstride = (size_t)p.T * p.ld;
             const float* src = p.partials + (size_t)t * p.ld;
@@ -63,28 +67,29 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const RopeParams p) 
                     const int su = min(s0 + u, p.nsplit - 1);
                     a[u] = src[su * sstride + col0]; b[u] = src[su * sstride + col1];
                 }
-                if (s0 == 0 && p.bias) { bh0 = p.bias[col0]; bh1 = p.bias[col1]; }   // behind the slabs in the (in-order) queue
+                if (s0 == 0 && p.bias) { bh0 = act_from_bits<BF>(bias[col0]); bh1 = act_from_bits<BF>(bias[col1]); }   // behind the slabs in the (in-order) queue
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { const bool ok = s0 + u < p.nsplit; x0 += ok ? a[u] : 0.f; x1 += ok ? b[u] : 0.f; }
             }
         } else {
-            const f16 q0 = p.qkv[(size_t)t * p.ld + col0], q1 = p.qkv[(size_t)t * p.ld + col1];
-            if (p.bias) { bh0 = p.bias[col0]; bh1 = p.bias[col1]; }
-            x0 = (float)q0; x1 = (float)q1;
+            const raw16* qkv = reinterpret_cast<const raw16*>(p.qkv);
+            const raw16 q0 = qkv[(size_t)t * p.ld + col0], q1 = qkv[(size_t)t * p.ld + col1];
+            if (p.bias) { bh0 = act_from_bits<BF>(bias[col0]); bh1 = act_from_bits<BF>(bias[col1]); }
+            x0 = act_from_bits<BF>(q0); x1 = act_from_bits<BF>(q1);
         }
-        x0 += (float)bh0; x1 += (float)bh1;
-        // the QKV linear's output is an fp16 tensor in the reference
-        x0 = (float)(f16)x0; x1 = (float)(f16)x1;
+        x0 += bh0; x1 += bh1;
+        // the QKV linear's output is a 16-bit tensor in the reference
+        x0 = act_round<BF>(x0); x1 = act_round<BF>(x1);
     }
     if (!is_v && act) {
         const float r0 = cs.x * x0 - cs.y * x1;
         const float r1 = cs.x * x1 + cs.y * x0;
-        x0 = (float)(f16)r0; x1 = (float)(f16)r1;
+        x0 = act_round<BF>(r0); x1 = act_round<BF>(r1);
     }
     if (h < p.nh) {
         if (act) {
-            f16* dst = p.q_out + ((size_t)t * p.nh + h) * p.hd;
-            dst[lane] = (f16)x0; dst[lane + half] = (f16)x1;
+            raw16* dst = reinterpret_cast<raw16*>(p.q_out) + ((size_t)t * p.nh + h) * p.hd;
+            dst[lane] = act_to_bits<BF>(x0); dst[lane + half] = act_to_bits<BF>(x1);
         }
         return;
     }
@@ -103,8 +108,8 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const RopeParams p) 
     else       { s0 = lane * p.page + tok; s1 = (lane + half) * p.page + tok; }
     if (!p.kv_int8) {
         if (act) {
-            f16* dst = (f16*)p.kv_base + blk_base * head_elems;
-            dst[s0] = (f16)x0; dst[s1] = (f16)x1;
+            raw16* dst = (raw16*)p.kv_base + blk_base * head_elems;
+            dst[s0] = act_to_bits<BF>(x0); dst[s1] = act_to_bits<BF>(x1);
         }
     } else {
         float amax = act ? fmaxf(fabsf(x0), fabsf(x1)) : 0.f;
@@ -145,7 +150,7 @@ extern "C" int mi355_rope_kv_write_rows(const void* qkv_f16, const float* partia
     MI355_CHECK_ARG(rope_dim == kv->hd, "rope_kv_write: rope_dim=%d must equal hd=%d", rope_dim, kv->hd);
     MI355_CHECK_ARG(kv->page > 0 && T > 0 && nh > 0 && kv->nkv > 0 && max_pos > 0 && max_blocks_per_seq > 0 && kv->num_blocks > 0,
                     "rope_kv_write: bad dims");
-    MI355_CHECK_ARG(kv->kv_dtype == MI355_KV_FP16 || (kv->kv_dtype == MI355_KV_INT8 && kv->scale_base),
+    MI355_CHECK_ARG(kv->kv_dtype == MI355_KV_FP16 || kv->kv_dtype == MI355_KV_BF16 || (kv->kv_dtype == MI355_KV_INT8 && kv->scale_base),
                     "rope_kv_write: int8 cache needs scale_base");
     const int nheads = nh + 2 * kv->nkv;
     MI355_CHECK_ARG(ld >= nheads * kv->hd, "rope_kv_write: ld=%d", ld);
@@ -155,7 +160,10 @@ extern "C" int mi355_rope_kv_write_rows(const void* qkv_f16, const float* partia
     p.T = T; p.nh = nh; p.nkv = kv->nkv; p.hd = kv->hd; p.page = kv->page; p.kv_base = kv->kv_base;
     p.max_pos = max_pos; p.num_blocks = kv->num_blocks; p.oob_count = oob_count; p.q_len = q_len;
     p.scale_base = kv->scale_base; p.kv_int8 = kv->kv_dtype == MI355_KV_INT8; p.q_out = (f16*)q_out;
-    hipLaunchKernelGGL(rope_kv_write_kernel, dim3(T, cdiv(nheads, 4)), dim3(256), 0, (hipStream_t)stream, p);
+    if (kv->kv_dtype == MI355_KV_BF16)
+        hipLaunchKernelGGL(rope_kv_write_kernel<true>, dim3(T, cdiv(nheads, 4)), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(rope_kv_write_kernel<false>, dim3(T, cdiv(nheads, 4)), dim3(256), 0, (hipStream_t)stream, p);
     MI355_CHECK_LAUNCH("rope_kv_write_kernel");
     return MI355_OK;
 }

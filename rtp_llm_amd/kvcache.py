@@ -21,8 +21,10 @@ from typing import Optional, Tuple
 import torch
 
 
-def alloc_layer_cache(num_blocks: int, nkv: int, page: int, hd: int, int8: bool, device) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    dt = torch.int8 if int8 else torch.float16
+def alloc_layer_cache(num_blocks: int, nkv: int, page: int, hd: int, int8: bool, device,
+                      dtype: torch.dtype = torch.float16) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """dtype: element type of a 16-bit cache (fp16 or bf16 -- the activation dtype of the model); ignored for INT8."""
+    dt = torch.int8 if int8 else dtype
     kv = torch.zeros(num_blocks, 2, nkv, page, hd, dtype=dt, device=device)
     sc = torch.ones(num_blocks, 2, nkv, page, dtype=torch.float32, device=device) if int8 else None
     return kv, sc

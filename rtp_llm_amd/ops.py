@@ -52,8 +52,17 @@ def kv_struct(kv_base: torch.Tensor, scale_base: Optional[torch.Tensor], page: i
     if int8 and scale_base is None:
         raise _C.Mi355Error("int8 KV cache requires the fp32 scale plane")
     nblk = kv_base.numel() // (2 * nkv * page * hd)
-    return _C.KVLayer(kv_base.data_ptr(), 0 if scale_base is None else scale_base.data_ptr(),
-                      _C.KV_INT8 if int8 else _C.KV_FP16, page, nkv, hd, nblk)
+    kvd = _C.KV_INT8 if int8 else (_C.KV_BF16 if kv_base.dtype == torch.bfloat16 else _C.KV_FP16)
+    return _C.KVLayer(kv_base.data_ptr(), 0 if scale_base is None else scale_base.data_ptr(), kvd, page, nkv, hd, nblk)
+
+
+def _act_of_cache(kv_base: torch.Tensor) -> torch.dtype:
+    """Q / K / V / attention-output dtype that goes with a cache: bf16 cache <-> bf16 activations; fp16 and INT8 caches <-> fp16."""
+    return torch.bfloat16 if kv_base.dtype == torch.bfloat16 else torch.float16
+
+
+def _dt(t: torch.Tensor) -> int:
+    return _C.ACT_BF16 if t.dtype == torch.bfloat16 else _C.ACT_F16
 
 
 # ------------------------------------------------------------------ linear
@@ -167,35 +176,37 @@ def qkv_rope_kv_write(x: torch.Tensor, wqkv: PackedWeight, qkv_bias, cos_sin, po
 
 # ------------------------------------------------------------------ norms / elementwise
 def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
-    _chk(x, torch.float16, "rmsnorm.x"); _chk(weight, torch.float16, "rmsnorm.weight")
+    _chk_act(x, "rmsnorm.x"); _chk_act(weight, "rmsnorm.weight", x)
     H = x.shape[-1]
     y = torch.empty_like(x)
-    _C.check(_C.lib().mi355_rmsnorm(x.data_ptr(), weight.data_ptr(), eps, x.numel() // H, H, y.data_ptr(), _stream()), "rmsnorm")
+    _C.check(_C.lib().mi355_rmsnorm_dt(x.data_ptr(), weight.data_ptr(), eps, x.numel() // H, H, y.data_ptr(), _dt(x), _stream()), "rmsnorm")
     return y
 
 
 def add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float, bias: Optional[torch.Tensor] = None):
-    """(y, residual_out): residual_out = x (+bias) + residual;  y = rmsnorm(residual_out) * weight."""
-    _chk(x, torch.float16, "add_rmsnorm.x"); _chk(residual, torch.float16, "add_rmsnorm.residual")
+    """(y, residual_out): residual_out = x (+bias) + residual;  y = rmsnorm(residual_out) * weight.  fp16 or bf16 throughout."""
+    _chk_act(x, "add_rmsnorm.x"); _chk_act(residual, "add_rmsnorm.residual", x); _chk_act(weight, "add_rmsnorm.weight", x)
+    if bias is not None:
+        _chk_act(bias, "add_rmsnorm.bias", x)
     H = x.shape[-1]
     y, res_out = torch.empty_like(x), torch.empty_like(x)
-    _C.check(_C.lib().mi355_add_rmsnorm(x.data_ptr(), None, 0, 0, _p(bias), residual.data_ptr(), res_out.data_ptr(),
-                                        weight.data_ptr(), eps, x.numel() // H, H, y.data_ptr(), _stream()), "add_rmsnorm")
+    _C.check(_C.lib().mi355_add_rmsnorm_dt(x.data_ptr(), None, 0, 0, _p(bias), residual.data_ptr(), res_out.data_ptr(),
+                                           weight.data_ptr(), eps, x.numel() // H, H, y.data_ptr(), _dt(x), _stream()), "add_rmsnorm")
     return y, res_out
 
 
 def silu_mul(gate_up: torch.Tensor) -> torch.Tensor:
-    _chk(gate_up, torch.float16, "silu_mul.gate_up")
+    _chk_act(gate_up, "silu_mul.gate_up")
     I = gate_up.shape[-1] // 2
-    out = torch.empty(*gate_up.shape[:-1], I, dtype=torch.float16, device=gate_up.device)
-    _C.check(_C.lib().mi355_silu_mul(gate_up.data_ptr(), gate_up.numel() // (2 * I), I, out.data_ptr(), _stream()), "silu_mul")
+    out = torch.empty(*gate_up.shape[:-1], I, dtype=gate_up.dtype, device=gate_up.device)
+    _C.check(_C.lib().mi355_silu_mul_dt(gate_up.data_ptr(), gate_up.numel() // (2 * I), I, out.data_ptr(), _dt(gate_up), _stream()), "silu_mul")
     return out
 
 
 def embedding(ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
-    _chk(ids, torch.int32, "embedding.ids"); _chk(table, torch.float16, "embedding.table")
+    _chk(ids, torch.int32, "embedding.ids"); _chk_act(table, "embedding.table")
     T, (V, H) = ids.numel(), table.shape
-    out = torch.empty(T, H, dtype=torch.float16, device=table.device)
+    out = torch.empty(T, H, dtype=table.dtype, device=table.device)
     _C.check(_C.lib().mi355_embedding(ids.data_ptr(), T, table.data_ptr(), H, V, out.data_ptr(), _stream()), "embedding")
     return out
 
@@ -340,10 +351,12 @@ def rope_kv_write(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], cos_sin: 
                   hd: int, page: int, oob_count: Optional[torch.Tensor] = None) -> torch.Tensor:
     """RoPE + bias + Q-extract + paged KV write for decode tokens; returns q [T, nh, hd].  Tokens with a position or
     block id out of range are not written; `oob_count` (int32 [1], device) counts them."""
-    _chk(qkv, torch.float16, "rope_kv_write.qkv"); _chk(cos_sin, torch.float32, "rope_kv_write.cos_sin")
+    _chk(qkv, _act_of_cache(kv_base), "rope_kv_write.qkv"); _chk(cos_sin, torch.float32, "rope_kv_write.cos_sin")
     _chk(positions, torch.int32, "rope_kv_write.positions"); _chk(block_table, torch.int32, "rope_kv_write.block_table")
+    if qkv_bias is not None:
+        _chk(qkv_bias, qkv.dtype, "rope_kv_write.qkv_bias")
     T = qkv.shape[0]
-    q_out = torch.empty(T, nh, hd, dtype=torch.float16, device=qkv.device)
+    q_out = torch.empty(T, nh, hd, dtype=qkv.dtype, device=qkv.device)
     kv = kv_struct(kv_base, scale_base, page, nkv, hd)
     _C.check(_C.lib().mi355_rope_kv_write(qkv.data_ptr(), None, 0, qkv.shape[1], _p(qkv_bias), cos_sin.data_ptr(), hd,
                                           cos_sin.shape[0], positions.data_ptr(), block_table.data_ptr(),
@@ -355,9 +368,11 @@ def rope_kv_write(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], cos_sin: 
 def rope_kv_write_rows(qkv: torch.Tensor, qkv_bias, cos_sin, positions, block_table, kv_base, scale_base, nh: int, nkv: int,
                        hd: int, page: int, q_len: int, oob_count: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q_len rows per sequence: qkv [B*q_len, ...], positions [B*q_len] (< 0 = padding row), block_table [B, M]."""
-    _chk(qkv, torch.float16, "rope_kv_write_rows.qkv"); _chk(positions, torch.int32, "positions"); _chk(block_table, torch.int32, "block_table")
+    _chk(qkv, _act_of_cache(kv_base), "rope_kv_write_rows.qkv"); _chk(positions, torch.int32, "positions"); _chk(block_table, torch.int32, "block_table")
+    if qkv_bias is not None:
+        _chk(qkv_bias, qkv.dtype, "rope_kv_write_rows.qkv_bias")
     T = qkv.shape[0]
-    q_out = torch.empty(T, nh, hd, dtype=torch.float16, device=qkv.device)
+    q_out = torch.empty(T, nh, hd, dtype=qkv.dtype, device=qkv.device)
     kv = kv_struct(kv_base, scale_base, page, nkv, hd)
     _C.check(_C.lib().mi355_rope_kv_write_rows(qkv.data_ptr(), None, 0, qkv.shape[1], _p(qkv_bias), cos_sin.data_ptr(), hd,
                                                cos_sin.shape[0], positions.data_ptr(), block_table.data_ptr(), block_table.shape[1],
@@ -369,10 +384,10 @@ def rope_kv_write_rows(qkv: torch.Tensor, qkv_bias, cos_sin, positions, block_ta
 def paged_attention_rows(q: torch.Tensor, kv_base, scale_base, block_table: torch.Tensor, positions: torch.Tensor, nkv: int,
                          page: int, q_len: int, max_seq_len: int, scale: Optional[float] = None) -> torch.Tensor:
     """q [B*q_len, nh, hd]; row i of sequence b attends tokens 0..positions[b*q_len+i] (causal over the paged cache)."""
-    _chk(q, torch.float16, "paged_attention_rows.q"); _chk(block_table, torch.int32, "block_table"); _chk(positions, torch.int32, "positions")
+    _chk(q, _act_of_cache(kv_base), "paged_attention_rows.q"); _chk(block_table, torch.int32, "block_table"); _chk(positions, torch.int32, "positions")
     T, nh, hd = q.shape
     kv = kv_struct(kv_base, scale_base, page, nkv, hd)
-    out = torch.empty(T, nh * hd, dtype=torch.float16, device=q.device)
+    out = torch.empty(T, nh * hd, dtype=q.dtype, device=q.device)
     need = _C.lib().mi355_paged_attn_workspace_bytes(T, nh, hd, max_seq_len)
     ws = _workspace(need, q.device)
     _C.check(_C.lib().mi355_paged_attn_rows(q.data_ptr(), C.byref(kv), block_table.data_ptr(), block_table.shape[1], positions.data_ptr(),
@@ -385,11 +400,11 @@ def paged_decode_attention(q: torch.Tensor, kv_base: torch.Tensor, scale_base: O
                            block_table: torch.Tensor, seq_lens: torch.Tensor, nkv: int, page: int,
                            max_seq_len: int, scale: Optional[float] = None) -> torch.Tensor:
     """q [B, nh, hd] -> out [B, nh*hd]; seq_lens = context length including the new token."""
-    _chk(q, torch.float16, "paged_decode_attention.q"); _chk(block_table, torch.int32, "block_table")
+    _chk(q, _act_of_cache(kv_base), "paged_decode_attention.q"); _chk(block_table, torch.int32, "block_table")
     _chk(seq_lens, torch.int32, "seq_lens")
     B, nh, hd = q.shape
     kv = kv_struct(kv_base, scale_base, page, nkv, hd)
-    out = torch.empty(B, nh * hd, dtype=torch.float16, device=q.device)
+    out = torch.empty(B, nh * hd, dtype=q.dtype, device=q.device)
     need = _C.lib().mi355_paged_attn_workspace_bytes(B, nh, hd, max_seq_len)
     ws = _workspace(need, q.device)
     _C.check(_C.lib().mi355_paged_decode_attn(q.data_ptr(), C.byref(kv), block_table.data_ptr(), block_table.shape[1],

@@ -1,0 +1,150 @@
+"""bf16 activations (the reference path is fp16 / bf16 throughout: impl/rocm/f16_linear.py:100-112, dtype grid of
+modules/base/rocm/test/rocm_norm_test.py): every kernel of the decode step in its bf16 form against the oracle run on bf16 tensors
+(the oracle is dtype-generic: fp32 math, rounding to the input dtype at the points the reference's tensors have that dtype).
+Tolerance: bf16 keeps 8 significant bits (fp16: 11), so the 1e-2 of the fp16 tests becomes 2e-2 relative + 2e-2 absolute on O(1)
+values (one bf16 ulp at 2.0 is 1.6e-2); integer / copy results stay bit-exact."""
+import math
+
+import pytest
+import torch
+
+from oracle import oracle
+from rtp_llm_amd import _C, kvcache, model, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+TOL = dict(atol=2e-2, rtol=2e-2)
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _x(M, K, seed, scale=0.5):
+    return (torch.randn(M, K, generator=_gen(seed)) * scale).to(BF)
+
+
+def _dense(c):
+    return c.w.to(BF).float() if c.kind == "fp16" else oracle.dequant_groupwise(c.q, c.z_eff, c.scales, c.group_size)
+
+
+@pytest.mark.parametrize("kind,group", [("w4", 128), ("w4", 64), ("w4", 32), ("fp16", 0)])
+@pytest.mark.parametrize("M", [1, 7, 16, 33, 64, 83, 200])
+@pytest.mark.parametrize("K,N", [(256, 64), (1024, 4608), (3584, 512), (9472, 896)])
+def test_linear_bf16(kind, group, M, K, N):
+    c = model.synth_linear(K, N, kind, "cpu", _gen(10 + K + N), group or 128)
+    x = _x(M, K, M)
+    bias = (torch.randn(N, generator=_gen(3)) * 0.1).to(BF) if N % 3 == 0 else None
+    w = c.pack(dtype=BF).to(DEV)
+    y = ops.linear(x.to(DEV), w, None if bias is None else bias.to(DEV))
+    assert y.dtype == BF
+    assert torch.allclose(y.cpu().float(), oracle.linear(x, _dense(c), bias).float(), **TOL)
+    # fp32 output (lm_head contract): no output rounding left, the accumulator-side dequant is exact up to fp32 summation order
+    y32 = ops.linear(x.to(DEV), w, None if bias is None else bias.to(DEV), _C.EPI_OUT_F32)
+    ref32 = oracle.linear(x, _dense(c), bias, out_f32=True)
+    assert torch.allclose(y32.cpu(), ref32, atol=2e-4, rtol=1e-4), float((y32.cpu() - ref32).abs().max())
+
+
+def test_linear_bf16_silu_epilogue_and_refusals():
+    K, I = 1024, 2432
+    c = model.synth_linear(K, 2 * I, "w4", "cpu", _gen(5))
+    x = _x(33, K, 6)
+    y = ops.linear(x.to(DEV), c.pack(gate_up=True).to(DEV), None, _C.EPI_SILU_MUL)
+    ref = oracle.silu_mul(oracle.linear(x, _dense(c)))
+    assert y.dtype == BF and torch.allclose(y.cpu().float(), ref.float(), **TOL)
+    c8 = model.synth_linear(256, 64, "int8", "cpu", _gen(7))
+    with pytest.raises(_C.Mi355Error):            # W8 weights: fp16 activations only
+        ops.linear(_x(4, 256, 1).to(DEV), c8.pack().to(DEV))
+    c16 = model.synth_linear(256, 64, "fp16", "cpu", _gen(8))
+    with pytest.raises(_C.Mi355Error):            # a 16-bit weight image has the dtype it was packed with
+        ops.linear(_x(4, 256, 1).to(DEV), c16.pack().to(DEV))
+
+
+@pytest.mark.parametrize("M", [1, 7, 64, 83])
+@pytest.mark.parametrize("H", [768, 3584, 8192])
+def test_rmsnorm_add_silu_embedding_bf16(M, H):
+    x, r = _x(M, H, 1), _x(M, H, 2)
+    w = (1 + 0.1 * torch.randn(H, generator=_gen(3))).to(BF)
+    y = ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-6)
+    assert y.dtype == BF and torch.allclose(y.cpu().float(), oracle.rmsnorm(x, w, 1e-6).float(), atol=5e-2, rtol=5e-2)
+    y2, res = ops.add_rmsnorm(x.to(DEV), r.to(DEV), w.to(DEV), 1e-6)
+    assert torch.equal(res.cpu(), x + r)                     # one correctly rounded bf16 add: bit equal
+    assert torch.allclose(y2.cpu().float(), oracle.rmsnorm(x + r, w, 1e-6).float(), atol=5e-2, rtol=5e-2)
+    gu = _x(M, 2 * H, 5)
+    assert torch.allclose(ops.silu_mul(gu.to(DEV)).cpu().float(), oracle.silu_mul(gu).float(), **TOL)
+    ids = torch.randint(0, M, (9,), generator=_gen(7), dtype=torch.int32)
+    assert torch.equal(ops.embedding(ids.to(DEV), x.to(DEV)).cpu(), x[ids.long()])
+    with pytest.raises(_C.Mi355Error):
+        ops.rmsnorm(x.to(DEV), w.half().to(DEV), 1e-6)       # mixed dtypes are an error, not a conversion
+
+
+@pytest.mark.parametrize("nh,nkv,hd,page", [(28, 4, 128, 16), (14, 2, 64, 64), (8, 1, 128, 16)])
+def test_rope_kv_write_bf16(nh, nkv, hd, page):
+    T, max_blocks, nblk = 6, 8, 64
+    cs = oracle.rope_cos_sin(hd, 1e6, max_blocks * page)
+    qkv = _x(T, (nh + 2 * nkv) * hd, 11)
+    bias = (torch.randn((nh + 2 * nkv) * hd, generator=_gen(12)) * 0.1).to(BF)
+    pos = torch.tensor([0, 1, 15, 16, 37, max_blocks * page - 1], dtype=torch.int32)
+    bt = torch.randperm(nblk, generator=_gen(2))[: T * max_blocks].reshape(T, max_blocks).to(torch.int32)
+    kv, sc = kvcache.alloc_layer_cache(nblk, nkv, page, hd, False, DEV, dtype=BF)
+    q = ops.rope_kv_write(qkv.to(DEV), bias.to(DEV), cs.to(DEV), pos.to(DEV), bt.to(DEV), kv, sc, nh, nkv, hd, page)
+    torch.cuda.synchronize()
+    qb = (qkv.float() + bias.float()).to(BF)                  # the QKV linear's output tensor (bias inside the linear)
+    qh = qb[:, : nh * hd].reshape(T, nh, hd)
+    kh = qb[:, nh * hd: (nh + nkv) * hd].reshape(T, nkv, hd)
+    vh = qb[:, (nh + nkv) * hd:].reshape(T, nkv, hd)
+    q_ref, k_ref = oracle.apply_rope(qh, pos, cs), oracle.apply_rope(kh, pos, cs)
+    assert q.dtype == BF and torch.allclose(q.cpu().float(), q_ref.float(), **TOL)
+    for t in range(T):
+        K, V, _, _ = kvcache.read_tokens(kv, sc, bt[t], int(pos[t]) + 1)
+        assert torch.allclose(K[-1].cpu().float(), k_ref[t].float(), **TOL)
+        assert torch.equal(V[-1].cpu(), vh[t])               # V is bias add + copy: bit exact
+    with pytest.raises(_C.Mi355Error):
+        ops.rope_kv_write(qkv.half().to(DEV), None, cs.to(DEV), pos.to(DEV), bt.to(DEV), kv, sc, nh, nkv, hd, page)   # fp16 rows, bf16 cache
+
+
+def _fill_cache(B, ctx_lens, nkv, hd, page, nblk, seed):
+    g = _gen(seed)
+    max_blocks = (max(ctx_lens) + page - 1) // page
+    bt = torch.randperm(nblk, generator=g)[: B * max_blocks].reshape(B, max_blocks).to(torch.int32)
+    kv, sc = kvcache.alloc_layer_cache(nblk, nkv, page, hd, False, DEV, dtype=BF)
+    nat = []
+    for b in range(B):
+        K = torch.randn(ctx_lens[b], nkv, hd, generator=g).to(BF)
+        V = torch.randn(ctx_lens[b], nkv, hd, generator=g).to(BF)
+        kvcache.write_tokens(kv, sc, bt[b], 0, K, V)
+        nat.append((K, V))
+    return kv, sc, bt, nat
+
+
+@pytest.mark.parametrize("nh,nkv,hd,page", [(28, 4, 128, 16), (32, 8, 128, 16), (14, 2, 64, 64), (8, 1, 128, 64)])
+def test_paged_attention_bf16(nh, nkv, hd, page):
+    ctx = [1, 7, 8, 15, 16, 17, 31, 33, 127, 128, 129, 500, 1024, 1500]
+    B = len(ctx)
+    nblk = sum((c + page - 1) // page for c in ctx) + B * ((max(ctx) + page - 1) // page)
+    kv, sc, bt, nat = _fill_cache(B, ctx, nkv, hd, page, nblk, 21)
+    q = torch.randn(B, nh, hd, generator=_gen(4)).to(BF)
+    out = ops.paged_decode_attention(q.to(DEV), kv, sc, bt.to(DEV), torch.tensor(ctx, dtype=torch.int32, device=DEV), nkv, page, max(ctx))
+    torch.cuda.synchronize()
+    assert out.dtype == BF
+    for b in range(B):
+        K, V = nat[b]
+        ref = oracle.attention_decode(q[b], K, V, 1 / math.sqrt(hd)).reshape(-1)
+        assert torch.allclose(out[b].cpu().float(), ref.float(), **TOL), (b, ctx[b], float((out[b].cpu().float() - ref.float()).abs().max()))
+
+
+def test_paged_attention_rows_causal_bf16():
+    nh, nkv, hd, page, q_len, B = 28, 4, 128, 16, 5, 3
+    start = [0, 37, 250]
+    ctx = [s + q_len for s in start]
+    kv, sc, bt, nat = _fill_cache(B, ctx, nkv, hd, page, 128, 31)
+    q = torch.randn(B * q_len, nh, hd, generator=_gen(5)).to(BF)
+    pos = torch.tensor([s + i for s in start for i in range(q_len)], dtype=torch.int32)
+    out = ops.paged_attention_rows(q.to(DEV), kv, sc, bt.to(DEV), pos.to(DEV), nkv, page, q_len, max(ctx))
+    for b in range(B):
+        K, V = nat[b]
+        for i in range(q_len):
+            n = start[b] + i + 1
+            ref = oracle.attention_decode(q[b * q_len + i], K[:n], V[:n], 1 / math.sqrt(hd)).reshape(-1)
+            assert torch.allclose(out[b * q_len + i].cpu().float(), ref.float(), **TOL), (b, i)
