@@ -408,6 +408,9 @@ typedef struct {
     int32_t kv_dtype, page, num_blocks;
     int32_t max_batch, max_blocks_per_seq, max_seq_len;
     int32_t tp_size;
+    int32_t act_dtype;   /* MI355_ACT_F16 / MI355_ACT_BF16: dtype of the embedding table, norm weights, biases, the hidden / ar_buf step
+                          * buffers and of every linear (each mi355_weight_t.act_dtype must agree); bf16 needs kv_dtype ==
+                          * MI355_KV_BF16 and tp_size == 1 (the collectives are fp16) */
 } mi355_model_config_t;
 
 typedef struct {

@@ -42,7 +42,7 @@ class FusedNorm(C.Structure):  # mi355_fused_norm_t
 class ModelConfig(C.Structure):  # mi355_model_config_t
     _fields_ = [(n, i32) for n in ("num_layers", "hidden", "nh", "nkv", "hd", "inter", "vocab", "rope_dim", "max_pos")] + \
                [("rms_eps", f32)] + \
-               [(n, i32) for n in ("kv_dtype", "page", "num_blocks", "max_batch", "max_blocks_per_seq", "max_seq_len", "tp_size")]
+               [(n, i32) for n in ("kv_dtype", "page", "num_blocks", "max_batch", "max_blocks_per_seq", "max_seq_len", "tp_size", "act_dtype")]
 
 
 class LayerWeights(C.Structure):  # mi355_layer_weights_t

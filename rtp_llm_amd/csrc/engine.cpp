@@ -145,6 +145,7 @@ int run_op(mi355_decoder* d, int kclass, hipStream_t st, F&& f) {
     return rc;
 }
 
+#define ADT (d->cfg.act_dtype)   /* activation dtype of every norm call below */
 #define RUN(kclass, expr)                                                  \
     do {                                                                   \
         int rc__ = run_op(d, kclass, st, [&]() -> int { return (expr); }); \
@@ -182,6 +183,19 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
         mi355_set_error("decoder_create: max_seq_len=%d must be <= max_pos=%d (rotation table) and <= max_blocks_per_seq*page=%ld",
                         cfg->max_seq_len, cfg->max_pos, (long)cfg->max_blocks_per_seq * cfg->page);
         return nullptr;
+    }
+    {   // activation dtype: one for the whole step
+        const bool bf = cfg->act_dtype == MI355_ACT_BF16;
+        bool ok = (cfg->act_dtype == MI355_ACT_F16 || bf) && (bf == (cfg->kv_dtype == MI355_KV_BF16)) && (!bf || cfg->tp_size == 1);
+        auto lin_ok = [&](const mi355_weight_t& w) { return w.act_dtype == cfg->act_dtype && !(bf && w.wbits == 8); };   // W8: fp16 only
+        ok = ok && lin_ok(model->lm_head);
+        for (int l = 0; ok && l < cfg->num_layers; ++l)
+            ok = lin_ok(layers[l].qkv) && lin_ok(layers[l].o) && lin_ok(layers[l].gate_up) && lin_ok(layers[l].down);
+        if (!ok) {
+            mi355_set_error("decoder_create: act_dtype=%d needs every linear in that dtype%s, a %s KV cache%s", cfg->act_dtype,
+                            bf ? " (W4 group-wise or 16-bit weights)" : "", bf ? "bf16" : "fp16 or INT8", bf ? " and tp_size 1" : "");
+            return nullptr;
+        }
     }
     const size_t need = carve_all(nullptr, *cfg, nullptr);
     if (!bufs->workspace || bufs->workspace_bytes < need) {
@@ -260,13 +274,13 @@ extern "C" int mi355_decoder_begin_rows(mi355_decoder_t* d, int32_t nseq, int32_
         RUN(MI355_KC_OTHER, mi355_embedding(d->bufs.token_ids, B, d->model.embedding, c.hidden, d->model.vocab_full, d->resid, st));
     }
     if (c.tp_size == 1 || d->ar) {
-        RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, d->layers[0].input_norm, c.rms_eps, B, c.hidden, d->xn, st));
+        RUN(MI355_KC_NORM, mi355_rmsnorm_dt(d->resid, d->layers[0].input_norm, c.rms_eps, B, c.hidden, d->xn, ADT, st));
     }
     return MI355_OK;
 }
 
 extern "C" int mi355_decoder_attach_allreduce(mi355_decoder_t* d, mi355_allreduce_t* ar, int32_t vocab_offset) {
-    if (!d || !ar || d->cfg.tp_size <= 1 || vocab_offset < 0) {
+    if (!d || !ar || d->cfg.tp_size <= 1 || vocab_offset < 0 || d->cfg.act_dtype != MI355_ACT_F16) {
         mi355_set_error("decoder_attach_allreduce: needs a decoder created with tp_size > 1 and an opened context");
         return MI355_ERR_ARG;
     }
@@ -284,7 +298,7 @@ extern "C" int mi355_decoder_attach_allreduce(mi355_decoder_t* d, mi355_allreduc
 
 extern "C" int mi355_decoder_attach_collective(mi355_decoder_t* d, const mi355_collective_t* coll, int32_t vocab_offset) {
     if (!d || !coll || d->cfg.tp_size <= 1 || vocab_offset < 0 || !coll->all_reduce_f16 || !coll->all_gather ||
-        coll->world != d->cfg.tp_size || coll->rank < 0 || coll->rank >= coll->world) {
+        coll->world != d->cfg.tp_size || coll->rank < 0 || coll->rank >= coll->world || d->cfg.act_dtype != MI355_ACT_F16) {
         mi355_set_error("decoder_attach_collective: needs a decoder created with tp_size > 1 and a transport of that world size");
         return MI355_ERR_ARG;
     }
@@ -403,9 +417,9 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
     hipStream_t st = (hipStream_t)stream;
     const auto& c = d->cfg; const auto& L = d->layers[l]; const int B = d->B;
     if (c.tp_size > 1 && !d->ar) {
-        if (l == 0) RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, L.input_norm, c.rms_eps, B, c.hidden, d->xn, st));
-        else RUN(MI355_KC_NORM, mi355_add_rmsnorm(d->bufs.ar_buf, nullptr, 0, 0, nullptr, d->resid, d->resid, L.input_norm,
-                                                   c.rms_eps, B, c.hidden, d->xn, st));
+        if (l == 0) RUN(MI355_KC_NORM, mi355_rmsnorm_dt(d->resid, L.input_norm, c.rms_eps, B, c.hidden, d->xn, ADT, st));
+        else RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(d->bufs.ar_buf, nullptr, 0, 0, nullptr, d->resid, d->resid, L.input_norm,
+                                                   c.rms_eps, B, c.hidden, d->xn, ADT, st));
     }
     int ns = 0;
     mi355_kv_layer_t kv = kv_of(d, l);
@@ -439,22 +453,22 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
         RUN(MI355_KC_GEMM_QUANT, mi355_linear_residual(d->attn_out, B, &L.o, nullptr, d->resid, d->resid, normed ? d->ssq : nullptr, (c.hidden / 16 + 3) & ~3, st));
         if (!normed) {
             if (pf & MI355_PF_GATE_UP) if (int e = pf_issue(d, st, &L.gate_up, kPfCap)) return e;
-            RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, L.post_norm, c.rms_eps, B, c.hidden, d->xn, st));
+            RUN(MI355_KC_NORM, mi355_rmsnorm_dt(d->resid, L.post_norm, c.rms_eps, B, c.hidden, d->xn, ADT, st));
         }
         return MI355_OK;
     }
     RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->attn_out, B, &L.o, d->partials, kMaxSplits, st));
     if (pf & MI355_PF_GATE_UP) if (int e = pf_issue(d, st, &L.gate_up, kPfCap)) return e;   // under the reduce + norm launch
     if (c.tp_size == 1) {
-        RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid, L.post_norm,
-                                             c.rms_eps, B, c.hidden, d->xn, st));
+        RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid, L.post_norm,
+                                             c.rms_eps, B, c.hidden, d->xn, ADT, st));
     } else if (d->ar) { // split-K reduce + all-reduce + residual + post-attention norm in one launch
         RUN(MI355_KC_COMM, comm_with_prefetch(d, st, &L.gate_up, [&]() {
             return mi355_allreduce_fused(d->ar, nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid, L.post_norm,
                                          c.rms_eps, B, c.hidden, d->xn, st); }));
     } else { // local split-K reduce -> fp16 tensor for the TP all-reduce
-        RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.o.N_pad, nullptr, nullptr, d->bufs.ar_buf, nullptr,
-                                             c.rms_eps, B, c.hidden, nullptr, st));
+        RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(nullptr, d->partials, ns, L.o.N_pad, nullptr, nullptr, d->bufs.ar_buf, nullptr,
+                                             c.rms_eps, B, c.hidden, nullptr, ADT, st));
         RUN(MI355_KC_COMM, ext_all_reduce(d, d->bufs.ar_buf, (size_t)B * c.hidden, st));
     }
     return MI355_OK;
@@ -465,8 +479,8 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
     hipStream_t st = (hipStream_t)stream;
     const auto& c = d->cfg; const auto& L = d->layers[l]; const int B = d->B;
     if (c.tp_size > 1 && !d->ar) {
-        RUN(MI355_KC_NORM, mi355_add_rmsnorm(d->bufs.ar_buf, nullptr, 0, 0, nullptr, d->resid, d->resid, L.post_norm, c.rms_eps,
-                                             B, c.hidden, d->xn, st));
+        RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(d->bufs.ar_buf, nullptr, 0, 0, nullptr, d->resid, d->resid, L.post_norm, c.rms_eps,
+                                             B, c.hidden, d->xn, ADT, st));
     }
     const bool small = B <= d->fuse_rows;
     const bool normed = small && d->fuse_norm && d->fuse_o;
@@ -486,22 +500,22 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
     if (d->fuse_down && small) {
         const bool last = l + 1 == c.num_layers;          // the final norm feeds lm_head: that one stays a launch
         RUN(MI355_KC_GEMM_QUANT, mi355_linear_residual(d->act, B, &L.down, nullptr, d->resid, d->resid, (normed && !last) ? d->ssq : nullptr, (c.hidden / 16 + 3) & ~3, st));
-        if (!normed || last) RUN(MI355_KC_NORM, mi355_rmsnorm(d->resid, next_norm, c.rms_eps, B, c.hidden, d->xn, st));
+        if (!normed || last) RUN(MI355_KC_NORM, mi355_rmsnorm_dt(d->resid, next_norm, c.rms_eps, B, c.hidden, d->xn, ADT, st));
         return MI355_OK;
     }
     RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->act, B, &L.down, d->partials, kMaxSplits, st));
     if (pf & MI355_PF_QKV_LATE) if (int e = pf_issue(d, st, next_qkv, kPfCap)) return e;    // under the reduce + norm launch only
     if (c.tp_size == 1) {
-        RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
-                                             c.rms_eps, B, c.hidden, d->xn, st));
+        RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
+                                             c.rms_eps, B, c.hidden, d->xn, ADT, st));
     } else if (d->ar) {
         const mi355_weight_t* next_w = (l + 1 < c.num_layers) ? &d->layers[l + 1].qkv : &d->model.lm_head;
         RUN(MI355_KC_COMM, comm_with_prefetch(d, st, next_w, [&]() {
             return mi355_allreduce_fused(d->ar, nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
                                          c.rms_eps, B, c.hidden, d->xn, st); }));
     } else {
-        RUN(MI355_KC_NORM, mi355_add_rmsnorm(nullptr, d->partials, ns, L.down.N_pad, nullptr, nullptr, d->bufs.ar_buf, nullptr,
-                                             c.rms_eps, B, c.hidden, nullptr, st));
+        RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(nullptr, d->partials, ns, L.down.N_pad, nullptr, nullptr, d->bufs.ar_buf, nullptr,
+                                             c.rms_eps, B, c.hidden, nullptr, ADT, st));
         RUN(MI355_KC_COMM, ext_all_reduce(d, d->bufs.ar_buf, (size_t)B * c.hidden, st));
     }
     return MI355_OK;
@@ -576,7 +590,7 @@ extern "C" int mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_id
     } else {
         RUN(MI355_KC_OTHER, mi355_embedding(token_ids, T, d->model.embedding, c.hidden, d->model.vocab_full, b.resid, st));
     }
-    RUN(MI355_KC_NORM, mi355_rmsnorm(b.resid, d->layers[0].input_norm, c.rms_eps, T, c.hidden, b.xn, st));
+    RUN(MI355_KC_NORM, mi355_rmsnorm_dt(b.resid, d->layers[0].input_norm, c.rms_eps, T, c.hidden, b.xn, ADT, st));
     for (int l = 0; l < c.num_layers; ++l) {
         const auto& L = d->layers[l];
         mi355_kv_layer_t kv = kv_of(d, l);
@@ -588,7 +602,7 @@ extern "C" int mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_id
         RUN(MI355_KC_GEMM_QUANT, mi355_linear_forward(b.attn, T, &L.o, nullptr, b.tmp, MI355_EPI_NONE, b.gemm_ws, b.gemm_ws_bytes, st));
         if (c.tp_size > 1 && !d->ar) RUN(MI355_KC_COMM, ext_all_reduce(d, b.tmp, (size_t)T * c.hidden, st));
         if (c.tp_size == 1 || !d->ar) {
-            RUN(MI355_KC_NORM, mi355_add_rmsnorm(b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, L.post_norm, c.rms_eps, T, c.hidden, b.xn, st));
+            RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, L.post_norm, c.rms_eps, T, c.hidden, b.xn, ADT, st));
         } else {
             RUN(MI355_KC_COMM, mi355_allreduce_fused(d->ar, b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, L.post_norm, c.rms_eps, T,
                                                      c.hidden, b.xn, st));
@@ -598,7 +612,7 @@ extern "C" int mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_id
         const void* next_norm = (l + 1 < c.num_layers) ? d->layers[l + 1].input_norm : d->model.final_norm;
         if (c.tp_size > 1 && !d->ar) RUN(MI355_KC_COMM, ext_all_reduce(d, b.tmp, (size_t)T * c.hidden, st));
         if (c.tp_size == 1 || !d->ar) {
-            RUN(MI355_KC_NORM, mi355_add_rmsnorm(b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, next_norm, c.rms_eps, T, c.hidden, b.xn, st));
+            RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, next_norm, c.rms_eps, T, c.hidden, b.xn, ADT, st));
         } else {
             RUN(MI355_KC_COMM, mi355_allreduce_fused(d->ar, b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, next_norm, c.rms_eps, T,
                                                      c.hidden, b.xn, st));
@@ -634,8 +648,8 @@ extern "C" int mi355_decoder_finish(mi355_decoder_t* d, int32_t sample, mi355_st
     const auto& c = d->cfg; const int B = d->B;
     if (int e = pf_join(d, st)) return e;
     if (c.tp_size > 1 && !d->ar) {
-        RUN(MI355_KC_NORM, mi355_add_rmsnorm(d->bufs.ar_buf, nullptr, 0, 0, nullptr, d->resid, d->resid, d->model.final_norm,
-                                             c.rms_eps, B, c.hidden, d->xn, st));
+        RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(d->bufs.ar_buf, nullptr, 0, 0, nullptr, d->resid, d->resid, d->model.final_norm,
+                                             c.rms_eps, B, c.hidden, d->xn, ADT, st));
     }
     RUN(MI355_KC_GEMM_LMHEAD, mi355_linear_direct(d->xn, B, &d->model.lm_head, nullptr, d->bufs.logits, MI355_EPI_OUT_F32, nullptr, 0, st));
     if (sample && d->ar) {   // vocab-split lm_head: (max, index) pairs cross the ranks, not the logits

@@ -364,7 +364,17 @@ class DecoderEngine:
     """Owns the device buffers and drives csrc/engine.cpp.  Greedy decode only (top_k = 1)."""
 
     def __init__(self, cfg: ModelConfig, weights: Dict, *, kv_int8: bool, page: int, num_blocks: int, max_batch: int,
-                 max_seq_len: int, device, tp_size: int = 1, vocab_full: Optional[int] = None):
+                 max_seq_len: int, device, tp_size: int = 1, vocab_full: Optional[int] = None, dtype: torch.dtype = torch.float16):
+        """dtype: activation dtype of the step (torch.float16 or torch.bfloat16; the reference runs either).  bf16: every 16-bit
+        tensor of the model (embedding, norm weights, biases, a 16-bit lm_head / linear) is converted once here, the KV cache is
+        bf16, W4 weights are shared as they are; W8 weights, the INT8 cache and tp_size > 1 are fp16-only."""
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError(f"DecoderEngine: dtype {dtype}")
+        bf = dtype == torch.bfloat16
+        if bf and (kv_int8 or tp_size != 1):
+            raise _C.Mi355Error("DecoderEngine: bf16 activations take a bf16 KV cache and tp_size 1")
+        self.dtype = dtype
+        cast = (lambda t: None if t is None else t.to(dtype)) if bf else (lambda t: t)
         self.cfg, self.device, self.tp_size = cfg, device, tp_size
         self.page, self.num_blocks, self.max_batch, self.max_seq_len = page, num_blocks, max_batch, max_seq_len
         self.max_blocks_per_seq = (max_seq_len + page - 1) // page
@@ -374,33 +384,34 @@ class DecoderEngine:
         lw = (_C.LayerWeights * cfg.num_layers)()
         self.kv, self.kv_scale = [], []
         for i, L in enumerate(weights["layers"]):
-            p = {k: L[k].pack(gate_up=(k == "gate_up")) for k in ("qkv", "o", "gate_up", "down")}
-            self._keep.append((p, L))
+            p = {k: L[k].pack(gate_up=(k == "gate_up"), dtype=dtype) for k in ("qkv", "o", "gate_up", "down")}
+            aux = {k: cast(L[k]) for k in ("qkv_bias", "input_norm", "post_norm")}
+            self._keep.append((p, L, aux))
             self.packed_bytes += sum(v.nbytes for v in p.values())
-            kvb, kvs = alloc_layer_cache(num_blocks, cfg.nkv, page, cfg.hd, kv_int8, device)
+            kvb, kvs = alloc_layer_cache(num_blocks, cfg.nkv, page, cfg.hd, kv_int8, device, dtype=dtype)
             self.kv.append(kvb); self.kv_scale.append(kvs)
-            lw[i].qkv, lw[i].o = ops.weight_struct(p["qkv"]), ops.weight_struct(p["o"])
-            lw[i].gate_up, lw[i].down = ops.weight_struct(p["gate_up"]), ops.weight_struct(p["down"])
-            lw[i].qkv_bias = 0 if L["qkv_bias"] is None else L["qkv_bias"].data_ptr()
-            lw[i].input_norm, lw[i].post_norm = L["input_norm"].data_ptr(), L["post_norm"].data_ptr()
+            lw[i].qkv, lw[i].o = ops.weight_struct(p["qkv"], dtype), ops.weight_struct(p["o"], dtype)
+            lw[i].gate_up, lw[i].down = ops.weight_struct(p["gate_up"], dtype), ops.weight_struct(p["down"], dtype)
+            lw[i].qkv_bias = 0 if aux["qkv_bias"] is None else aux["qkv_bias"].data_ptr()
+            lw[i].input_norm, lw[i].post_norm = aux["input_norm"].data_ptr(), aux["post_norm"].data_ptr()
             lw[i].kv_base = kvb.data_ptr()
             lw[i].kv_scale_base = 0 if kvs is None else kvs.data_ptr()
-        self.lm_head = weights["lm_head"].pack() if isinstance(weights["lm_head"], CanonLinear) else weights["lm_head"]
+        self.lm_head = weights["lm_head"].pack(dtype=dtype) if isinstance(weights["lm_head"], CanonLinear) else weights["lm_head"]
         self.packed_bytes_lm_head = self.lm_head.nbytes
-        self.embedding, self.final_norm = weights["embedding"], weights["final_norm"]
+        self.embedding, self.final_norm = cast(weights["embedding"]), cast(weights["final_norm"])
         self.cos_sin = rope_table(cfg, device)
         mc = _C.ModelConfig(cfg.num_layers, cfg.hidden, cfg.nh, cfg.nkv, cfg.hd, cfg.inter, cfg.vocab, cfg.hd, cfg.max_pos,
-                            cfg.rms_eps, _C.KV_INT8 if kv_int8 else _C.KV_FP16, page, num_blocks, max_batch,
-                            self.max_blocks_per_seq, max_seq_len, tp_size)
+                            cfg.rms_eps, _C.KV_INT8 if kv_int8 else (_C.KV_BF16 if bf else _C.KV_FP16), page, num_blocks, max_batch,
+                            self.max_blocks_per_seq, max_seq_len, tp_size, _C.ACT_BF16 if bf else _C.ACT_F16)
         mw = _C.ModelWeights(self.embedding.data_ptr(), vocab_full or self.embedding.shape[0], self.final_norm.data_ptr(),
-                             ops.weight_struct(self.lm_head), self.cos_sin.data_ptr())
+                             ops.weight_struct(self.lm_head, dtype), self.cos_sin.data_ptr())
         i32 = dict(dtype=torch.int32, device=device)
         self.token_ids = torch.zeros(max_batch, **i32)
         self.positions = torch.zeros(max_batch, **i32)
         self.block_table = torch.zeros(max_batch, self.max_blocks_per_seq, **i32)
         self.logits = torch.zeros(max_batch, cfg.vocab, dtype=torch.float32, device=device)
-        self.hidden = torch.zeros(max_batch, cfg.hidden, dtype=torch.float16, device=device)
-        self.ar_buf = torch.zeros(max_batch, cfg.hidden, dtype=torch.float16, device=device)
+        self.hidden = torch.zeros(max_batch, cfg.hidden, dtype=dtype, device=device)
+        self.ar_buf = torch.zeros(max_batch, cfg.hidden, dtype=dtype, device=device)
         ws_bytes = self.lib.mi355_decoder_workspace_bytes(C.byref(mc))
         self.workspace = torch.zeros(ws_bytes, dtype=torch.uint8, device=device)
         sb = _C.StepBuffers(self.token_ids.data_ptr(), self.positions.data_ptr(), self.block_table.data_ptr(),

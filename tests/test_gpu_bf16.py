@@ -148,3 +148,90 @@ def test_paged_attention_rows_causal_bf16():
             n = start[b] + i + 1
             ref = oracle.attention_decode(q[b * q_len + i], K[:n], V[:n], 1 / math.sqrt(hd)).reshape(-1)
             assert torch.allclose(out[b * q_len + i].cpu().float(), ref.float(), **TOL), (b, i)
+
+
+def _oracle_weights_bf16(w):
+    bf = lambda t: None if t is None else t.to(BF)
+    return {"embedding": bf(w["embedding"]), "final_norm": bf(w["final_norm"]), "lm_head": _dense(w["lm_head"]),
+            "layers": [{"input_norm": bf(L["input_norm"]), "post_norm": bf(L["post_norm"]), "qkv_bias": bf(L["qkv_bias"]),
+                        **{k: _dense(L[k]) for k in ("qkv", "o", "gate_up", "down")}} for L in w["layers"]]}
+
+
+@pytest.mark.parametrize("kind,B", [("w4", 3), ("fp16", 3), ("w4", 40)])
+def test_engine_bf16_greedy_decode_matches_oracle(kind, B):
+    """The whole decode step in bf16 (DecoderEngine(dtype=torch.bfloat16): bf16 embedding / norms / biases / KV cache, W4 or bf16
+    linears through the bf16 MFMA kernels), hipGraph-replayed, against the oracle run on bf16 tensors; prompt fed token by token,
+    then greedy generation with the oracle's tokens teacher-forced.  Logits within 3e-2 (three significant bits fewer than fp16
+    through 3 layers); greedy ids wherever the oracle's top-2 margin exceeds that."""
+    cfg = model.ModelConfig("tiny-qwen2", 3, 512, 8, 2, 64, 1024, 2048, max_pos=512)
+    w = model.synth_model(cfg, kind, "cpu", seed=3, zeros="centered")
+    page, steps = 16, 10
+    odec = oracle.OracleDecoder({**cfg.__dict__}, _oracle_weights_bf16(w))
+    eng = model.DecoderEngine(cfg, model.weights_to(w, DEV), kv_int8=False, page=page, num_blocks=4 * B, max_batch=B, max_seq_len=64,
+                              device=DEV, dtype=BF)
+    assert eng.hidden.dtype == BF and eng.kv[0].dtype == BF
+    bt = torch.randperm(4 * B, generator=_gen(1)).reshape(B, 4).to(torch.int32)
+    okv = oracle.OracleKV(cfg.num_layers, B, False)
+    tok = torch.randint(0, cfg.vocab, (B,), generator=_gen(2), dtype=torch.int32)
+    eng.set_inputs(tok.tolist(), [0] * B, bt)
+    eng.capture(B)
+    exact, n, worst = 0, 0, 0.0
+    for step in range(steps):
+        pos = torch.full((B,), step, dtype=torch.int32)
+        eng.replay(B, 1)
+        torch.cuda.synchronize()
+        _, ref = odec.forward_tokens(tok, pos, okv, list(range(B)))
+        got = eng.logits[:B].cpu()
+        assert torch.allclose(got, ref, atol=3e-2, rtol=3e-2), (step, float((got - ref).abs().max()))
+        worst = max(worst, float((got - ref).abs().max()))
+        ref_next = oracle.greedy(ref)
+        top2 = ref.topk(2, dim=-1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 3e-2
+        got_next = eng.token_ids[:B].cpu()
+        assert torch.equal(got_next[safe], ref_next[safe])
+        exact += int((got_next == ref_next).sum()); n += B
+        assert torch.equal(eng.positions[:B].cpu(), pos + 1)
+        tok = ref_next
+        eng.token_ids[:B].copy_(tok)
+    assert eng.oob_count() == 0
+    print(f"bf16 {kind} B={B}: greedy ids {exact}/{n} identical to the oracle's argmax; max |logit error| {worst:.2e}")
+
+
+def test_engine_bf16_prefill_then_decode_matches_oracle():
+    """Ragged prompts through mi355_decoder_prefill in bf16 (64-row slabs of the staged GEMM, rows-mode attention over the bf16 cache),
+    then decode steps on the same cache."""
+    cfg = model.ModelConfig("tiny-qwen2", 2, 512, 8, 2, 64, 1024, 2048, max_pos=512)
+    w = model.synth_model(cfg, "w4", "cpu", seed=5, zeros="centered")
+    odec = oracle.OracleDecoder({**cfg.__dict__}, _oracle_weights_bf16(w))
+    B, page = 3, 16
+    eng = model.DecoderEngine(cfg, model.weights_to(w, DEV), kv_int8=False, page=page, num_blocks=48, max_batch=4, max_seq_len=256,
+                              device=DEV, dtype=BF)
+    lens = [70, 33, 5]
+    prompts = [torch.randint(0, cfg.vocab, (n,), generator=_gen(10 + i), dtype=torch.int32).tolist() for i, n in enumerate(lens)]
+    bt = torch.arange(48, dtype=torch.int32).reshape(B, 16)
+    logits = eng.prefill(prompts, bt, chunk=32).cpu()
+    okv = oracle.OracleKV(cfg.num_layers, B, False)
+    for b in range(B):
+        _, ref = odec.forward_tokens(torch.tensor(prompts[b], dtype=torch.int32), torch.arange(lens[b], dtype=torch.int32), okv, [b] * lens[b])
+        assert torch.allclose(logits[b], ref[-1], atol=3e-2, rtol=3e-2), (b, float((logits[b] - ref[-1]).abs().max()))
+    tok = oracle.greedy(logits)
+    eng.set_inputs(tok.tolist(), lens, bt)
+    for step in range(3):
+        pos = torch.tensor([n + step for n in lens], dtype=torch.int32)
+        eng.step(B)
+        torch.cuda.synchronize()
+        _, ref = odec.forward_tokens(tok, pos, okv, list(range(B)))
+        got = eng.logits[:B].cpu()
+        assert torch.allclose(got, ref, atol=3e-2, rtol=3e-2), (step, float((got - ref).abs().max()))
+        tok = oracle.greedy(ref)
+        eng.token_ids[:B].copy_(tok)
+
+
+def test_engine_bf16_refusals():
+    cfg = model.ModelConfig("tiny-qwen2", 1, 512, 8, 2, 64, 1024, 2048, max_pos=512)
+    w = model.synth_model(cfg, "w4", "cpu", seed=6, zeros="centered")
+    with pytest.raises(_C.Mi355Error):
+        model.DecoderEngine(cfg, model.weights_to(w, DEV), kv_int8=True, page=16, num_blocks=8, max_batch=2, max_seq_len=64, device=DEV, dtype=BF)
+    w8 = model.synth_model(cfg, "int8", "cpu", seed=6)
+    with pytest.raises(_C.Mi355Error):
+        model.DecoderEngine(cfg, model.weights_to(w8, DEV), kv_int8=False, page=16, num_blocks=8, max_batch=2, max_seq_len=64, device=DEV, dtype=BF)
