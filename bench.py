@@ -76,7 +76,7 @@ def fill_kv_random(eng, B, ctx, seed):
             kv.copy_(torch.randint(-127, 128, kv.shape, device=eng.device, generator=g, dtype=torch.int8))
             eng.kv_scale[l].copy_(torch.rand(eng.kv_scale[l].shape, device=eng.device, generator=g) * 0.02 + 0.005)
         else:
-            kv.copy_(torch.randn(kv.shape, device=eng.device, generator=g, dtype=torch.float16))
+            kv.copy_(torch.randn(kv.shape, device=eng.device, generator=g, dtype=torch.float16).to(kv.dtype))
 
 
 def cpu_baseline(cfg, kind, kv_int8, B, ctx, budget_s=25.0):
@@ -196,7 +196,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return float(t.item())
 
-    def build_engine(tp, tp_rank, replica, spec=None):
+    def build_engine(tp, tp_rank, replica, spec=None, dtype=torch.float16):
         """Synthetic weights generated per rank directly at per-rank shapes (the TP split of random tensors is random
         tensors; norms / embedding use the same seed on every rank).  spec = (cfg_full, kind, kv_int8, B, ctx, page)
         overrides the command-line workload (the extra driver-timed workloads of the default run)."""
@@ -220,7 +220,7 @@ def main():
             "lm_head": model.synth_linear(cfg.hidden, cfg.vocab, "fp16", dev, gen),
         }
         eng = model.DecoderEngine(cfg, weights, kv_int8=kv_int8, page=page, num_blocks=num_blocks, max_batch=B,
-                                  max_seq_len=max_seq_len, device=dev, tp_size=tp, vocab_full=cfg_full.vocab)
+                                  max_seq_len=max_seq_len, device=dev, tp_size=tp, vocab_full=cfg_full.vocab, dtype=dtype)
         del weights, layers
         torch.cuda.empty_cache()
         fill_kv_random(eng, B, ctx, seed=2 + rank)
@@ -358,17 +358,19 @@ def main():
             except Exception as e:  # noqa: BLE001
                 others["qwen2-7b-w4a16-prefill"] = {"error": f"{type(e).__name__}: {e}"}
             del eng
-            for name in ("qwen2-7b-w4a16-kv8", "qwen2-7b-w8a16", "qwen2-7b-w4a16-page64"):
+            for name in ("qwen2-7b-w4a16-kv8", "qwen2-7b-w8a16", "qwen2-7b-w4a16-page64", "qwen2-7b-w4a16-bf16"):
                 torch.cuda.empty_cache()
-                mn, kd, k8, b2, c2, pg = WORKLOADS[name]
-                cfg2, eng2, reset2 = build_engine(1, 0, 0, (model.MODELS[mn], kd, k8, b2, c2, pg))
+                bf16 = name.endswith("-bf16")       # the metric's config with bf16 activations / KV cache (reference dtype grid)
+                mn, kd, k8, b2, c2, pg = WORKLOADS[name[:-5] if bf16 else name]
+                cfg2, eng2, reset2 = build_engine(1, 0, 0, (model.MODELS[mn], kd, k8, b2, c2, pg), dtype=torch.bfloat16 if bf16 else torch.float16)
                 eng2.capture(b2)
                 reset2(); eng2.replay(b2, 4); torch.cuda.synchronize()
                 n2 = min(args.steps, 32)
                 t0 = time.perf_counter(); eng2.replay(b2, n2); torch.cuda.synchronize()
                 ms = (time.perf_counter() - t0) / n2 * 1e3
                 bb = bytes_per_step(cfg2, eng2, b2, c2, k8)
-                others[name] = {"batch": b2, "seq_len": c2, "weights": kd, "kv": "int8" if k8 else "fp16", "steps": n2,
+                others[name] = {"batch": b2, "seq_len": c2, "weights": kd, "kv": "int8" if k8 else ("bf16" if bf16 else "fp16"),
+                                "activations": "bf16" if bf16 else "f16", "steps": n2,
                                 "tokens_per_s": round(b2 / ms * 1e3, 1), "ms_per_step": round(ms, 4),
                                 "bytes_per_step": int(sum(bb.values())),
                                 "hbm_frac": round(sum(bb.values()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}

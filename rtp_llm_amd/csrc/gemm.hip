@@ -541,6 +541,12 @@ int launch_gemm_bf16_t(const GemmParams& p, int cfg, hipStream_t st) {
         case 5: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 1, 1, GS, D1, 4, 1, true>), grid, dim3(256), 0, st, p); break;
         case 2: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 2, 1, GS, D2, 8, 1, true>), grid, dim3(512), 0, st, p); break;
         case 8: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 1, GS, DW, 8, 1, true>), grid, dim3(512), 0, st, p); break;
+        case 6: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 1, GS, 2, 16, 1, true>), grid, dim3(1024), 0, st, p); break;
+#ifdef MI355_TUNING   // other shapes tried for the four-row-block bf16 case (tools/gemm_bench.py --bf16 1 --nbw N): all behind 6 / 8
+        case 9: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 2, GS, DW, 4, 1, true>), grid, dim3(256), 0, st, p); break;
+        case 10: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 4, GS, 2, 4, 1, true>), grid, dim3(256), 0, st, p); break;
+        case 12: hipLaunchKernelGGL((gemm_wq_kernel<WBITS, 4, 1, GS, DW, 4, 1, true>), grid, dim3(256), 0, st, p); break;
+#endif
         default: mi355_set_error("gemm (bf16): block shape %d not built", cfg); return MI355_ERR_UNSUPPORTED;
     }
     MI355_CHECK_LAUNCH("gemm_wq_kernel<bf16>");
@@ -616,7 +622,10 @@ GemmPlan plan_gemm(int M, const mi355_weight_t* w, int max_splits) {
     const int MB = cdiv(M, 16) == 3 ? 4 : cdiv(M, 16);
     GemmPlan g;
     g.cfg = (MB == 1) ? (NT >= 4096 ? 1 : 5) : (MB == 2 ? 2 : 4); // measured best per row-block count
-    if (w->act_dtype == MI355_ACT_BF16 && MB >= 3) g.cfg = 8;   // accumulator-side dequant at four row blocks: one tile per wave fits the registers
+    // bf16, four row blocks (accumulator-side dequant): one tile per wave fits the registers; 16 waves x BN = 256 for the big
+    // weights, 8 waves x BN = 128 for the short-K ones (measured M = 64, g128: gate_up 67.2 / 51.4 us, down 23.9 / 21.8 us as
+    // shape 8 / 6; qkv 9.7 / 11.7, o 9.9 / 11.2: profiles/r03_bf16_gemm_m64_shapes.txt)
+    if (w->act_dtype == MI355_ACT_BF16 && MB >= 3) g.cfg = ((uint64_t)w->K_pad * w->N_pad * w->wbits / 8 >= (16u << 20)) ? 6 : 8;
     if (TUNE(2) > 0) g.cfg = TUNE(2) - 1;
     g.bn = kCfgBN[g.cfg];
     const int blocks_n = cdiv(NT * 16, g.bn);

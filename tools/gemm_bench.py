@@ -30,7 +30,9 @@ def main():
     ap.add_argument("--nosmall", type=int, default=0, help="1: disable the persistent small-M kernel")
     ap.add_argument("--tune", default="", help="idx=val,... extra mi355_debug_set switches")
     ap.add_argument("--copies", type=int, default=0, help="weight copies rotated (0: enough to defeat the 256 MiB Infinity Cache; 1: cache-resident)")
+    ap.add_argument("--bf16", type=int, default=0, help="1: bf16 activations (staged kernel, accumulator-side dequant)")
     a = ap.parse_args()
+    adt = torch.bfloat16 if a.bf16 else torch.float16
     lib = _C.lib()
     lib.mi355_debug_set.argtypes = [C.c_int, C.c_int]
     lib.mi355_debug_set(0, a.var); lib.mi355_debug_set(1, a.nsplit); lib.mi355_debug_set(2, a.nbw); lib.mi355_debug_set(4, a.nosmall); lib.mi355_debug_set(5, a.nowide)
@@ -42,17 +44,17 @@ def main():
         for name in a.shapes.split(","):
             K, N = SHAPES[name]
             k = "fp16" if name == "lm_head" else kind
-            base = model.synth_linear(K, N, k, dev, gen).pack(gate_up=(name == "gate_up" or name.startswith("gu_")))
+            base = model.synth_linear(K, N, k, dev, gen).pack(gate_up=(name == "gate_up" or name.startswith("gu_")), dtype=adt)
             ncopy = a.copies if a.copies > 0 else max(2, int(600e6 // base.nbytes) + 1)
             copies = [base] + [type(base)(base.qweight.clone(), None if base.meta is None else base.meta.clone(), base.wbits,
                                           base.K, base.N, base.K_pad, base.N_pad, base.group_size) for _ in range(ncopy - 1)]
             for M in [int(m) for m in a.ms.split(",")]:
-                x = (torch.randn(M, K, device=dev, generator=gen) * 0.5).half()
+                x = (torch.randn(M, K, device=dev, generator=gen) * 0.5).to(adt)
                 epi = _C.EPI_SILU_MUL if name in ("gate_up", "gu_k1792", "gu_k7168", "gu_k14336") else (_C.EPI_OUT_F32 if name == "lm_head" else 0)
                 partial = a.partial and name not in ("gate_up", "lm_head")
                 if partial:
                     slabs = torch.empty(16 * M * base.N_pad, dtype=torch.float32, device=dev)
-                    structs = [ops.weight_struct(c) for c in copies]
+                    structs = [ops.weight_struct(c, adt) for c in copies]
                     stream = torch.cuda.current_stream().cuda_stream
                     run = lambda i: lib.mi355_linear_partial(x.data_ptr(), M, C.byref(structs[i % ncopy]), slabs.data_ptr(), 16, stream)
                     ns = run(0)
