@@ -80,9 +80,15 @@ def config_from_hf(cfg: dict, name: str = "hf-model") -> Tuple[ModelConfig, dict
     return mc, qc
 
 
-def _f16(t: torch.Tensor, name: str) -> torch.Tensor:
-    """Checkpoint tensor -> fp16, the activation type of this path.  bf16 / fp32 checkpoints (Qwen2 ships bf16) are
-    converted once at load time; a value outside the fp16 range would become inf silently, so it is an error."""
+def _f16(t: torch.Tensor, name: str, dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """Checkpoint tensor -> the activation dtype of the model.  fp16 (default): bf16 / fp32 checkpoints (Qwen2 ships bf16) are
+    converted once at load time; a value outside the fp16 range would become inf silently, so it is an error.  bf16
+    (DecoderEngine(dtype=torch.bfloat16)): bf16 tensors stay as they are, fp16 / fp32 ones are rounded to bf16.  Quantisation
+    scales are always fp16 (the meta image of the W4 / W8 kernels)."""
+    if t.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+        raise TypeError(f"{name}: unsupported tensor dtype {t.dtype}")
+    if dtype == torch.bfloat16:
+        return t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16)
     if t.dtype == torch.float16:
         return t
     if t.dtype not in (torch.bfloat16, torch.float32):
@@ -93,8 +99,8 @@ def _f16(t: torch.Tensor, name: str) -> torch.Tensor:
     return o
 
 
-def _linear_fp16(sh: _Shards, prefix: str) -> CanonLinear:
-    w = _f16(sh.get(prefix + ".weight"), prefix)           # HF stores [out, in]
+def _linear_fp16(sh: _Shards, prefix: str, dtype: torch.dtype = torch.float16) -> CanonLinear:
+    w = _f16(sh.get(prefix + ".weight"), prefix, dtype)    # HF stores [out, in]
     return CanonLinear("fp16", w.shape[1], w.shape[0], w=w.t().contiguous())
 
 
@@ -110,12 +116,15 @@ def _linear_quant(sh: _Shards, prefix: str, method: str, group_size: int) -> Can
 
 
 def load_hf_checkpoint(path: str, quantization: Optional[str] = None, tp: int = 1, rank: int = 0,
-                       max_layers: Optional[int] = None, split_embedding: bool = False) -> Tuple[ModelConfig, Dict]:
+                       max_layers: Optional[int] = None, split_embedding: bool = False,
+                       dtype: torch.dtype = torch.float16) -> Tuple[ModelConfig, Dict]:
     """Read an HF Qwen2/Llama checkpoint (fp16, GPTQ-4bit or AWQ-4bit) into the canonical weight dict of
     rtp_llm_amd.model (per-rank tensors when tp > 1).  quantization="int8" autoquantises fp16 linears at load time.
     split_embedding (tp > 1): the embedding table comes back as this rank's [vocab, hidden / tp] column slice, the reference's TP
     layout (utils/model_weight.py:1490 sp_neg1) -- pair it with DecoderEngine.set_embedding_split(); default: replicated table
-    (no collective in the lookup)."""
+    (no collective in the lookup).  dtype: activation dtype the model will run in (see _f16); bf16 excludes quantization="int8"."""
+    if dtype not in (torch.float16, torch.bfloat16) or (dtype == torch.bfloat16 and quantization == "int8"):
+        raise NotImplementedError(f"load_hf_checkpoint: dtype {dtype} with quantization {quantization}")
     cfg_json = json.load(open(os.path.join(path, "config.json")))
     mc, qc = config_from_hf(cfg_json, os.path.basename(os.path.normpath(path)))
     if qc["method"] not in ("none", "gptq", "awq") or (qc["method"] != "none" and qc["bits"] != 4):
@@ -128,14 +137,14 @@ def load_hf_checkpoint(path: str, quantization: Optional[str] = None, tp: int = 
     quantised = qc["method"] != "none"
 
     def lin(name):
-        c = _linear_quant(sh, name, qc["method"], qc["group_size"]) if quantised and sh.has(name + ".qweight") else _linear_fp16(sh, name)
+        c = _linear_quant(sh, name, qc["method"], qc["group_size"]) if quantised and sh.has(name + ".qweight") else _linear_fp16(sh, name, dtype)
         if c.kind == "fp16" and quantization == "int8":
             q, s = quant.symmetric_quantize_int8(c.w)
             c = CanonLinear("int8", c.K, c.N, q=q, scales=s)
         return c
 
     def bias(name):
-        return _f16(sh.get(name + ".bias"), name + ".bias") if sh.has(name + ".bias") else None
+        return _f16(sh.get(name + ".bias"), name + ".bias", dtype) if sh.has(name + ".bias") else None
 
     layers = []
     has_bias = False
@@ -149,13 +158,13 @@ def load_hf_checkpoint(path: str, quantization: Optional[str] = None, tp: int = 
             "gate_up": CanonLinear.cat_cols([lin(p + "mlp.gate_proj"), lin(p + "mlp.up_proj")]),
             "down": lin(p + "mlp.down_proj"),
             "qkv_bias": torch.cat(b).contiguous() if b[0] is not None else None,
-            "input_norm": _f16(sh.get(p + "input_layernorm.weight"), p + "input_layernorm"),
-            "post_norm": _f16(sh.get(p + "post_attention_layernorm.weight"), p + "post_attention_layernorm"),
+            "input_norm": _f16(sh.get(p + "input_layernorm.weight"), p + "input_layernorm", dtype),
+            "post_norm": _f16(sh.get(p + "post_attention_layernorm.weight"), p + "post_attention_layernorm", dtype),
         }
         layers.append(split_layer_tp(layer, mc, tp, rank))
-    emb = _f16(sh.get(pre + "embed_tokens.weight"), "embed_tokens")
+    emb = _f16(sh.get(pre + "embed_tokens.weight"), "embed_tokens", dtype)
     if sh.has("lm_head.weight"):
-        head = _f16(sh.get("lm_head.weight"), "lm_head")
+        head = _f16(sh.get("lm_head.weight"), "lm_head", dtype)
     else:                                                   # tie_word_embeddings (e.g. Qwen2-0.5B)
         head = emb
     V = head.shape[0]                                       # padded-vocab checkpoints: the tensor, not config.json, decides
@@ -169,6 +178,6 @@ def load_hf_checkpoint(path: str, quantization: Optional[str] = None, tp: int = 
     if split_embedding and tp > 1:
         from .model import split_embedding_tp
         emb = split_embedding_tp(emb, tp, rank)
-    weights = {"layers": layers, "embedding": emb, "final_norm": _f16(sh.get(pre + "norm.weight"), "norm"),
+    weights = {"layers": layers, "embedding": emb, "final_norm": _f16(sh.get(pre + "norm.weight"), "norm", dtype),
                "lm_head": CanonLinear("fp16", head.shape[1], head.shape[0], w=head.t().contiguous())}
     return (mc.per_rank(tp) if tp > 1 else mc), weights

@@ -21,16 +21,20 @@ def _dense(c):
     return oracle.dequant_groupwise(c.q, c.z_eff, c.scales, c.group_size)
 
 
-@pytest.mark.parametrize("kind,quantization,bf16_aux", [("gptq", None, True), ("awq", None, False), ("fp16", "int8", True)])
-def test_checkpoint_to_engine_matches_oracle(tmp_path, kind, quantization, bf16_aux):
+@pytest.mark.parametrize("kind,quantization,bf16_aux,dtype", [("gptq", None, True, torch.float16), ("awq", None, False, torch.float16),
+                                                              ("fp16", "int8", True, torch.float16), ("gptq", None, True, torch.bfloat16),
+                                                              ("fp16", None, True, torch.bfloat16)])
+def test_checkpoint_to_engine_matches_oracle(tmp_path, kind, quantization, bf16_aux, dtype):
     assert torch.cuda.is_available()
     _C.lib()
     canon = model.synth_model(CFG, "fp16" if kind == "fp16" else "w4", "cpu", seed=31, method="awq" if kind == "awq" else "gptq")
     write_ckpt(str(tmp_path), kind, CFG, canon, bf16_aux=bf16_aux)
-    mc, w = loader.load_hf_checkpoint(str(tmp_path), quantization=quantization)
-    assert w["layers"][0]["qkv"].kind == ("int8" if quantization else "w4")
+    mc, w = loader.load_hf_checkpoint(str(tmp_path), quantization=quantization, dtype=dtype)
+    assert w["layers"][0]["qkv"].kind == ("int8" if quantization else ("fp16" if kind == "fp16" else "w4"))
+    tol = 1e-2 if dtype == torch.float16 else 3e-2          # bf16: 8 significant bits (tests/test_gpu_bf16.py)
     B, page = 3, 16
-    eng = model.DecoderEngine(mc, model.weights_to(w, DEV), kv_int8=False, page=page, num_blocks=32, max_batch=4, max_seq_len=64, device=DEV)
+    eng = model.DecoderEngine(mc, model.weights_to(w, DEV), kv_int8=False, page=page, num_blocks=32, max_batch=4, max_seq_len=64, device=DEV,
+                              dtype=dtype)
     ow = {"embedding": w["embedding"], "final_norm": w["final_norm"], "lm_head": _dense(w["lm_head"]),
           "layers": [{"input_norm": L["input_norm"], "post_norm": L["post_norm"], "qkv_bias": L["qkv_bias"],
                       **{k: _dense(L[k]) for k in ("qkv", "o", "gate_up", "down")}} for L in w["layers"]]}
@@ -46,10 +50,10 @@ def test_checkpoint_to_engine_matches_oracle(tmp_path, kind, quantization, bf16_
         eng.replay(B, 1)
         torch.cuda.synchronize()
         got = eng.logits[:B].cpu()
-        assert torch.allclose(got, ref, atol=1e-2, rtol=1e-2), (step, float((got - ref).abs().max()))
+        assert torch.allclose(got, ref, atol=tol, rtol=tol), (step, float((got - ref).abs().max()))
         nxt = oracle.greedy(ref)
         top2 = ref.topk(2, -1).values
-        safe = (top2[:, 0] - top2[:, 1]) > 1e-2
+        safe = (top2[:, 0] - top2[:, 1]) > tol
         assert torch.equal(eng.token_ids[:B].cpu()[safe], nxt[safe])
         tok = nxt
         eng.token_ids[:B].copy_(tok)

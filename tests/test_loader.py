@@ -113,3 +113,18 @@ def test_padded_vocab_follows_the_tensor(tmp_path):
     _write_ckpt(str(tmp_path), "fp16", CFG, canon, extra_cfg={"vocab_size": 500})   # tensors have 512 rows
     mc, w = loader.load_hf_checkpoint(str(tmp_path))
     assert mc.vocab == 512 and w["lm_head"].N == 512
+
+
+def test_bf16_checkpoint_loads_as_bf16_when_asked(tmp_path):
+    """dtype=torch.bfloat16: 16-bit tensors of the checkpoint stay / become bf16 (no fp16 range check), W4 codes and their fp16
+    scales are untouched -- the weight dict DecoderEngine(dtype=torch.bfloat16) takes."""
+    canon = model.synth_model(CFG, "w4", "cpu", seed=8)
+    canon["embedding"][0, 0] = 60000.0                                      # fine in fp16 here, but make one value bf16-only below
+    _write_ckpt(str(tmp_path), "gptq", CFG, canon, bf16_aux=True)
+    mc, w = loader.load_hf_checkpoint(str(tmp_path), dtype=torch.bfloat16)
+    assert w["embedding"].dtype == torch.bfloat16 and w["final_norm"].dtype == torch.bfloat16
+    assert w["lm_head"].w.dtype == torch.bfloat16 and w["layers"][0]["qkv_bias"].dtype == torch.bfloat16
+    assert w["layers"][0]["qkv"].scales.dtype == torch.float16 and torch.equal(w["layers"][0]["qkv"].q, canon["layers"][0]["qkv"].q)
+    assert torch.equal(w["embedding"], canon["embedding"].to(torch.bfloat16))
+    with pytest.raises(NotImplementedError):
+        loader.load_hf_checkpoint(str(tmp_path), dtype=torch.bfloat16, quantization="int8")
