@@ -10,8 +10,9 @@
  * Conventions (mirrors the one C-ABI precedent in the reference,
  * rtp_llm/models_py/bindings/rocm/kernels/pa_decode_dot_kernel.h:9 —
  * raw device pointers, explicit stream, integer status):
- *   - every pointer marked "dev" is a HIP device pointer; all 16-bit float
- *     tensors are IEEE fp16; tensors are dense row-major unless stated;
+ *   - every pointer marked "dev" is a HIP device pointer; 16-bit float
+ *     tensors are IEEE fp16 unless the call carries MI355_ACT_BF16 / MI355_KV_BF16
+ *     (see "activation dtype" below); tensors are dense row-major unless stated;
  *   - `stream` is a hipStream_t passed as void*; kernels are only enqueued,
  *     nothing synchronises, nothing allocates (graph-capturable, the
  *     constraint the reference puts on ops under its HIP-graph runner,
