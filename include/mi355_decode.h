@@ -53,7 +53,8 @@ enum { MI355_KV_FP16 = 0, MI355_KV_INT8 = 1, MI355_KV_BF16 = 2 };
  * fp16 / bf16 throughout (f16_linear.py:100-112; dtype grid of modules/base/rocm/test/rocm_norm_test.py).  bf16 is carried by
  *   mi355_weight_t.act_dtype (linears), mi355_kv_layer_t.kv_dtype == MI355_KV_BF16 (RoPE / KV write / attention: Q, K, V, the cache
  *   and the output are bf16), the *_dt entry points of the norm family and mi355_model_config_t.act_dtype (step driver).
- * bf16 takes W4 group-wise and 16-bit (then bf16) weights and a bf16 KV cache; W8 weights and the INT8 cache are fp16-only. */
+ * bf16 takes W4 group-wise and 16-bit (then bf16) weights and a bf16 KV cache; W8 weights and the INT8 cache are fp16-only.
+ * Tensor parallelism: the all-reduce family has *_dt forms and the RCCL transport a bf16 callback. */
 enum { MI355_ACT_F16 = 0, MI355_ACT_BF16 = 1 };
 
 int         mi355_abi_version(void);
@@ -384,6 +385,14 @@ int mi355_allreduce_fused(mi355_allreduce_t* ar, const void* x_f16, const float*
                           const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
                           int32_t T, int32_t H, void* y, mi355_stream_t stream);
 
+/* the same two calls with the tensors in act_dtype (MI355_ACT_BF16: bf16 copies are exchanged, sums stay fp32 in rank order);
+ * mi355_allgather_hidden copies 16-bit elements and mi355_allreduce_argmax works on fp32 logits: both serve either dtype */
+int mi355_allreduce_sum_dt(mi355_allreduce_t* ar, const void* x, void* out, int32_t T, int32_t H, int32_t act_dtype,
+                           mi355_stream_t stream);
+int mi355_allreduce_fused_dt(mi355_allreduce_t* ar, const void* x, const float* partials, int32_t nsplit, int32_t ld,
+                             const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
+                             int32_t T, int32_t H, void* y, int32_t act_dtype, mi355_stream_t stream);
+
 /* Greedy sampling under a vocab-split lm_head: ids[b] = argmax over ALL ranks' logit slices (this rank holds columns
  * [vocab_offset, vocab_offset + V_local)), lowest global index on ties; identical on every rank.  Exchanges 8 bytes per
  * row instead of gathering the logits (PyWrappedModel.cc:915-936).  positions (may be NULL) += 1.
@@ -411,7 +420,7 @@ typedef struct {
     int32_t tp_size;
     int32_t act_dtype;   /* MI355_ACT_F16 / MI355_ACT_BF16: dtype of the embedding table, norm weights, biases, the hidden / ar_buf step
                           * buffers and of every linear (each mi355_weight_t.act_dtype must agree); bf16 needs kv_dtype ==
-                          * MI355_KV_BF16 and tp_size == 1 (the collectives are fp16) */
+                          * MI355_KV_BF16 */
 } mi355_model_config_t;
 
 typedef struct {
@@ -500,6 +509,8 @@ int mi355_decoder_attach_allreduce(mi355_decoder_t* d, mi355_allreduce_t* ar, in
 typedef struct mi355_collective {
     void*   ctx;
     int   (*all_reduce_f16)(void* ctx, void* buf, size_t count, mi355_stream_t stream);   /* in-place SUM of `count` fp16 */
+    int   (*all_reduce_bf16)(void* ctx, void* buf, size_t count, mi355_stream_t stream);  /* the same for bf16; may be NULL (then a
+                                                                                            * bf16 decoder refuses the transport) */
     int   (*all_gather)(void* ctx, const void* send, void* recv, size_t bytes_per_rank, mi355_stream_t stream); /* recv = [world][bytes] */
     int32_t rank, world;
 } mi355_collective_t;

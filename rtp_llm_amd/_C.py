@@ -65,7 +65,7 @@ ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_siz
 
 class Collective(C.Structure):
     """mi355_collective_t: an external transport for the TP points of the step (RCCL fallback)."""
-    _fields_ = [("ctx", C.c_void_p), ("all_reduce_f16", ALL_REDUCE_FN), ("all_gather", ALL_GATHER_FN),
+    _fields_ = [("ctx", C.c_void_p), ("all_reduce_f16", ALL_REDUCE_FN), ("all_reduce_bf16", ALL_REDUCE_FN), ("all_gather", ALL_GATHER_FN),
                 ("rank", C.c_int32), ("world", C.c_int32)]
 
 
@@ -105,6 +105,8 @@ SIGNATURES = {
     "mi355_allreduce_status": (i32, [vp, vp]),
     "mi355_allreduce_sum": (i32, [vp, vp, vp, i32, i32, vp]),
     "mi355_allreduce_fused": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, vp]),
+    "mi355_allreduce_fused_dt": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, i32, vp]),
+    "mi355_allreduce_sum_dt": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "mi355_allreduce_argmax": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "mi355_decoder_attach_allreduce": (i32, [vp, vp, i32]),
     "mi355_decoder_set_embedding_split": (i32, [vp, i32]),

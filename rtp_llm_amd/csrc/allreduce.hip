@@ -108,7 +108,8 @@ __device__ __forceinline__ void peer_barrier(const ArDev& ar, int b, uint32_t ep
 // r, r + N, ... (rank-ordered fp32 sum of the N copies, one rounding -- the same numbers as the one-shot), publishes them in
 // its result region, and after a second flag barrier every rank fetches each row ONCE from its owner: 2 (N - 1) / N T H
 // elements per rank instead of (N - 1) T H (trtllm_allreduce_fusion.cu:606-692 is the reference's two-shot form).
-template <int VPT, bool TWO>
+// BF: the tensors (x, bias, residual, weight, y and the exchanged copies) are bf16; the sums stay fp32 in rank order
+template <int VPT, bool TWO, bool BF = false>
 __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams p) {
     constexpr int NTH = 512;
     const ArDev& ar = p.ar;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
             const int vi = tid + t * NTH;
             if (vi >= nvec) continue;
             const int c0 = vi * 8;
-            f16x8 o;
+            u32x4 o;
             if (p.partials) {
                 float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 const size_t sstride = (size_t)p.T * p.ld;
@@ -148,16 +149,16 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
                     for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += c[e]; }
                 }
                 if (p.bias && ar.rank == 0) {
-                    const f16x8 bv = *reinterpret_cast<const f16x8*>(p.bias + c0);
+                    float bv[8];
+                    act_unpack8<BF>(*reinterpret_cast<const u32x4*>(p.bias + c0), bv);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)bv[e];
+                    for (int e = 0; e < 8; ++e) v[e] += bv[e];
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+                o = act_pack8<BF>(v);
             } else {
-                o = *reinterpret_cast<const f16x8*>(p.x + (size_t)row * p.H + c0);
+                o = *reinterpret_cast<const u32x4*>(p.x + (size_t)row * p.H + c0);
             }
-            *reinterpret_cast<f16x8*>(ar.my_data + par + row_off(ar, row, gridDim.x, p.H) + c0) = o;
+            *reinterpret_cast<u32x4*>(ar.my_data + par + row_off(ar, row, gridDim.x, p.H) + c0) = o;
         }
     }
     peer_barrier(ar, b, epoch);
@@ -182,15 +183,13 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
 #pragma unroll
                 for (int r = 0; r < kMaxWorld; ++r) {
                     if (r < ar.world) {
-                        const f16x8 h = __builtin_bit_cast(f16x8, in[r]);
+                        float h[8];
+                        act_unpack8<BF>(in[r], h);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) a[e] += (float)h[e];
+                        for (int e = 0; e < 8; ++e) a[e] += h[e];
                     }
                 }
-                f16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (f16)a[e];
-                *reinterpret_cast<f16x8*>(ar.my_data + par + ar.res_elems + row_off(ar, row, gridDim.x, p.H) + vi * 8) = o;
+                *reinterpret_cast<u32x4*>(ar.my_data + par + ar.res_elems + row_off(ar, row, gridDim.x, p.H) + vi * 8) = act_pack8<BF>(a);
             }
         }
         peer_barrier(ar, b, epoch, 8);
@@ -198,7 +197,7 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
     __shared__ float red[NTH / 64];
     for (int row = b; row < p.T; row += gridDim.x) {
         float v[VPT][8];
-        f16x8 win[VPT];
+        u32x4 win[VPT];
         float ss = 0.f;
 #pragma unroll
         for (int t = 0; t < VPT; ++t) {
@@ -218,37 +217,34 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
                 for (int r = 0; r < kMaxWorld; ++r)
                     if (r < ar.world) in[r] = load_sys(rp[r], off);        // all peers in flight together
             }
-            f16x8 rin = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (p.res_in) rin = *reinterpret_cast<const f16x8*>(p.res_in + (size_t)row * p.H + c0);
-            win[t] = (p.y && p.weight) ? *reinterpret_cast<const f16x8*>(p.weight + c0) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            u32x4 rin = {0u, 0u, 0u, 0u};
+            if (p.res_in) rin = *reinterpret_cast<const u32x4*>(p.res_in + (size_t)row * p.H + c0);
+            win[t] = (p.y && p.weight) ? *reinterpret_cast<const u32x4*>(p.weight + c0) : (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[t][e] = 0.f;
+            float h[8];
             if constexpr (TWO) {
-                const f16x8 h = __builtin_bit_cast(f16x8, in[0]);
+                act_unpack8<BF>(in[0], h);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[t][e] = (float)h[e];
+                for (int e = 0; e < 8; ++e) v[t][e] = h[e];
             } else {
 #pragma unroll
                 for (int r = 0; r < kMaxWorld; ++r) {                       // rank order 0..N-1 on every rank
                     if (r < ar.world) {
-                        const f16x8 h = __builtin_bit_cast(f16x8, in[r]);
+                        act_unpack8<BF>(in[r], h);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[t][e] += (float)h[e];
+                        for (int e = 0; e < 8; ++e) v[t][e] += h[e];
                     }
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[t][e] = (float)(f16)v[t][e];     // the all-reduced tensor is fp16: round once
+            for (int e = 0; e < 8; ++e) v[t][e] = act_round<BF>(v[t][e]);  // the all-reduced tensor is a 16-bit tensor: round once
             if (p.res_in) {
+                act_unpack8<BF>(rin, h);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[t][e] = (float)(f16)(v[t][e] + (float)rin[e]);
+                for (int e = 0; e < 8; ++e) v[t][e] = act_round<BF>(v[t][e] + h[e]);
             }
-            if (p.res_out) {
-                f16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (f16)v[t][e];
-                *reinterpret_cast<f16x8*>(p.res_out + (size_t)row * p.H + c0) = o;
-            }
+            if (p.res_out) *reinterpret_cast<u32x4*>(p.res_out + (size_t)row * p.H + c0) = act_pack8<BF>(v[t]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) ss += v[t][e] * v[t][e];
         }
@@ -265,10 +261,11 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
         for (int t = 0; t < VPT; ++t) {
             const int vi = tid + t * NTH;
             if (vi >= nvec) continue;
-            f16x8 o;
+            float wv[8], o[8];
+            act_unpack8<BF>(win[t], wv);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = win[t][e] * (f16)(v[t][e] * rs);
-            *reinterpret_cast<f16x8*>(p.y + (size_t)row * p.H + vi * 8) = o;
+            for (int e = 0; e < 8; ++e) o[e] = wv[e] * act_round<BF>(v[t][e] * rs);
+            *reinterpret_cast<u32x4*>(p.y + (size_t)row * p.H + vi * 8) = act_pack8<BF>(o);
         }
     }
     __syncthreads();
@@ -505,7 +502,14 @@ extern "C" int mi355_allreduce_status(mi355_allreduce_t* a, mi355_stream_t strea
 extern "C" int mi355_allreduce_fused(mi355_allreduce_t* a, const void* x_f16, const float* partials, int32_t nsplit, int32_t ld,
                                      const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
                                      int32_t T, int32_t H, void* y, mi355_stream_t stream) {
+    return mi355_allreduce_fused_dt(a, x_f16, partials, nsplit, ld, bias, residual_in, residual_out, weight, eps, T, H, y, MI355_ACT_F16, stream);
+}
+
+extern "C" int mi355_allreduce_fused_dt(mi355_allreduce_t* a, const void* x_f16, const float* partials, int32_t nsplit, int32_t ld,
+                                        const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
+                                        int32_t T, int32_t H, void* y, int32_t act_dtype, mi355_stream_t stream) {
     MI355_CHECK_ARG(a && a->ready, "allreduce: context not opened (mi355_allreduce_open)");
+    MI355_CHECK_ARG(act_dtype == MI355_ACT_F16 || act_dtype == MI355_ACT_BF16, "allreduce: act_dtype=%d", act_dtype);
     MI355_CHECK_ARG((x_f16 != nullptr) != (partials != nullptr), "allreduce: exactly one of x_f16 / partials");
     MI355_CHECK_ARG(T > 0 && H > 0 && H % 8 == 0 && H <= 8192, "allreduce: T=%d H=%d (H %% 8 == 0, H <= 8192)", T, H);
     MI355_CHECK_ARG((size_t)T * H * 2 <= a->max_bytes, "allreduce: message %zu bytes > registered %zu", (size_t)T * H * 2, a->max_bytes);
@@ -521,10 +525,15 @@ extern "C" int mi355_allreduce_fused(mi355_allreduce_t* a, const void* x_f16, co
     MI355_CHECK_ARG((size_t)cdiv(T, grid) * H * 2 <= a->slot_bytes, "allreduce: %d rows of %d per block exceed the %zu-byte slot", cdiv(T, grid), H, a->slot_bytes);
     hipStream_t st = (hipStream_t)stream;
     const bool two = T > kOneShotRows && a->world > 2;   // (N - 1) vs 2 (N - 1) / N reads per element: equal at N = 2
-    if (H / 8 <= 512) { if (two) hipLaunchKernelGGL((allreduce_fused_kernel<1, true>), dim3(grid), dim3(512), 0, st, p);
-                        else     hipLaunchKernelGGL((allreduce_fused_kernel<1, false>), dim3(grid), dim3(512), 0, st, p); }
-    else              { if (two) hipLaunchKernelGGL((allreduce_fused_kernel<2, true>), dim3(grid), dim3(512), 0, st, p);
-                        else     hipLaunchKernelGGL((allreduce_fused_kernel<2, false>), dim3(grid), dim3(512), 0, st, p); }
+#define L_(V, W, B) hipLaunchKernelGGL((allreduce_fused_kernel<V, W, B>), dim3(grid), dim3(512), 0, st, p)
+    if (act_dtype == MI355_ACT_BF16) {
+        if (H / 8 <= 512) { if (two) L_(1, true, true); else L_(1, false, true); }
+        else              { if (two) L_(2, true, true); else L_(2, false, true); }
+    } else {
+        if (H / 8 <= 512) { if (two) L_(1, true, false); else L_(1, false, false); }
+        else              { if (two) L_(2, true, false); else L_(2, false, false); }
+    }
+#undef L_
     MI355_CHECK_LAUNCH("allreduce_fused_kernel");
     return MI355_OK;
 }
@@ -532,6 +541,11 @@ extern "C" int mi355_allreduce_fused(mi355_allreduce_t* a, const void* x_f16, co
 extern "C" int mi355_allreduce_sum(mi355_allreduce_t* a, const void* x_f16, void* out_f16, int32_t T, int32_t H,
                                    mi355_stream_t stream) {
     return mi355_allreduce_fused(a, x_f16, nullptr, 0, 0, nullptr, nullptr, out_f16, nullptr, 0.f, T, H, nullptr, stream);
+}
+
+extern "C" int mi355_allreduce_sum_dt(mi355_allreduce_t* a, const void* x, void* out, int32_t T, int32_t H, int32_t act_dtype,
+                                      mi355_stream_t stream) {
+    return mi355_allreduce_fused_dt(a, x, nullptr, 0, 0, nullptr, nullptr, out, nullptr, 0.f, T, H, nullptr, act_dtype, stream);
 }
 
 extern "C" int mi355_allgather_hidden(mi355_allreduce_t* a, const void* x_f16, void* out_f16, int32_t T, int32_t n,

@@ -186,14 +186,14 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     }
     {   // activation dtype: one for the whole step
         const bool bf = cfg->act_dtype == MI355_ACT_BF16;
-        bool ok = (cfg->act_dtype == MI355_ACT_F16 || bf) && (bf == (cfg->kv_dtype == MI355_KV_BF16)) && (!bf || cfg->tp_size == 1);
+        bool ok = (cfg->act_dtype == MI355_ACT_F16 || bf) && (bf == (cfg->kv_dtype == MI355_KV_BF16));
         auto lin_ok = [&](const mi355_weight_t& w) { return w.act_dtype == cfg->act_dtype && !(bf && w.wbits == 8); };   // W8: fp16 only
         ok = ok && lin_ok(model->lm_head);
         for (int l = 0; ok && l < cfg->num_layers; ++l)
             ok = lin_ok(layers[l].qkv) && lin_ok(layers[l].o) && lin_ok(layers[l].gate_up) && lin_ok(layers[l].down);
         if (!ok) {
-            mi355_set_error("decoder_create: act_dtype=%d needs every linear in that dtype%s, a %s KV cache%s", cfg->act_dtype,
-                            bf ? " (W4 group-wise or 16-bit weights)" : "", bf ? "bf16" : "fp16 or INT8", bf ? " and tp_size 1" : "");
+            mi355_set_error("decoder_create: act_dtype=%d needs every linear in that dtype%s and a %s KV cache", cfg->act_dtype,
+                            bf ? " (W4 group-wise or 16-bit weights)" : "", bf ? "bf16" : "fp16 or INT8");
             return nullptr;
         }
     }
@@ -280,7 +280,7 @@ extern "C" int mi355_decoder_begin_rows(mi355_decoder_t* d, int32_t nseq, int32_
 }
 
 extern "C" int mi355_decoder_attach_allreduce(mi355_decoder_t* d, mi355_allreduce_t* ar, int32_t vocab_offset) {
-    if (!d || !ar || d->cfg.tp_size <= 1 || vocab_offset < 0 || d->cfg.act_dtype != MI355_ACT_F16) {
+    if (!d || !ar || d->cfg.tp_size <= 1 || vocab_offset < 0) {
         mi355_set_error("decoder_attach_allreduce: needs a decoder created with tp_size > 1 and an opened context");
         return MI355_ERR_ARG;
     }
@@ -298,7 +298,8 @@ extern "C" int mi355_decoder_attach_allreduce(mi355_decoder_t* d, mi355_allreduc
 
 extern "C" int mi355_decoder_attach_collective(mi355_decoder_t* d, const mi355_collective_t* coll, int32_t vocab_offset) {
     if (!d || !coll || d->cfg.tp_size <= 1 || vocab_offset < 0 || !coll->all_reduce_f16 || !coll->all_gather ||
-        coll->world != d->cfg.tp_size || coll->rank < 0 || coll->rank >= coll->world || d->cfg.act_dtype != MI355_ACT_F16) {
+        coll->world != d->cfg.tp_size || coll->rank < 0 || coll->rank >= coll->world ||
+        (d->cfg.act_dtype == MI355_ACT_BF16 && !coll->all_reduce_bf16)) {
         mi355_set_error("decoder_attach_collective: needs a decoder created with tp_size > 1 and a transport of that world size");
         return MI355_ERR_ARG;
     }
@@ -321,7 +322,7 @@ namespace {
 // all-reduces ar_buf itself between the calls)
 int ext_all_reduce(mi355_decoder* d, void* buf, size_t count, hipStream_t st) {
     if (!d->has_ext) return MI355_OK;
-    const int rc = d->ext.all_reduce_f16(d->ext.ctx, buf, count, (mi355_stream_t)st);
+    const int rc = (d->cfg.act_dtype == MI355_ACT_BF16 ? d->ext.all_reduce_bf16 : d->ext.all_reduce_f16)(d->ext.ctx, buf, count, (mi355_stream_t)st);
     if (rc != 0) { mi355_set_error("decoder: the attached transport's all-reduce failed (%d)", rc); return MI355_ERR_HIP; }
     return MI355_OK;
 }
@@ -464,8 +465,8 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
                                              c.rms_eps, B, c.hidden, d->xn, ADT, st));
     } else if (d->ar) { // split-K reduce + all-reduce + residual + post-attention norm in one launch
         RUN(MI355_KC_COMM, comm_with_prefetch(d, st, &L.gate_up, [&]() {
-            return mi355_allreduce_fused(d->ar, nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid, L.post_norm,
-                                         c.rms_eps, B, c.hidden, d->xn, st); }));
+            return mi355_allreduce_fused_dt(d->ar, nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid, L.post_norm,
+                                         c.rms_eps, B, c.hidden, d->xn, ADT, st); }));
     } else { // local split-K reduce -> fp16 tensor for the TP all-reduce
         RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(nullptr, d->partials, ns, L.o.N_pad, nullptr, nullptr, d->bufs.ar_buf, nullptr,
                                              c.rms_eps, B, c.hidden, nullptr, ADT, st));
@@ -511,8 +512,8 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
     } else if (d->ar) {
         const mi355_weight_t* next_w = (l + 1 < c.num_layers) ? &d->layers[l + 1].qkv : &d->model.lm_head;
         RUN(MI355_KC_COMM, comm_with_prefetch(d, st, next_w, [&]() {
-            return mi355_allreduce_fused(d->ar, nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
-                                         c.rms_eps, B, c.hidden, d->xn, st); }));
+            return mi355_allreduce_fused_dt(d->ar, nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
+                                         c.rms_eps, B, c.hidden, d->xn, ADT, st); }));
     } else {
         RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(nullptr, d->partials, ns, L.down.N_pad, nullptr, nullptr, d->bufs.ar_buf, nullptr,
                                              c.rms_eps, B, c.hidden, nullptr, ADT, st));
@@ -604,8 +605,8 @@ extern "C" int mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_id
         if (c.tp_size == 1 || !d->ar) {
             RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, L.post_norm, c.rms_eps, T, c.hidden, b.xn, ADT, st));
         } else {
-            RUN(MI355_KC_COMM, mi355_allreduce_fused(d->ar, b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, L.post_norm, c.rms_eps, T,
-                                                     c.hidden, b.xn, st));
+            RUN(MI355_KC_COMM, mi355_allreduce_fused_dt(d->ar, b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, L.post_norm, c.rms_eps, T,
+                                                     c.hidden, b.xn, ADT, st));
         }
         RUN(MI355_KC_GEMM_QUANT, mi355_linear_forward(b.xn, T, &L.gate_up, nullptr, b.act, MI355_EPI_SILU_MUL, b.gemm_ws, b.gemm_ws_bytes, st));
         RUN(MI355_KC_GEMM_QUANT, mi355_linear_forward(b.act, T, &L.down, nullptr, b.tmp, MI355_EPI_NONE, b.gemm_ws, b.gemm_ws_bytes, st));
@@ -614,8 +615,8 @@ extern "C" int mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_id
         if (c.tp_size == 1 || !d->ar) {
             RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, next_norm, c.rms_eps, T, c.hidden, b.xn, ADT, st));
         } else {
-            RUN(MI355_KC_COMM, mi355_allreduce_fused(d->ar, b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, next_norm, c.rms_eps, T,
-                                                     c.hidden, b.xn, st));
+            RUN(MI355_KC_COMM, mi355_allreduce_fused_dt(d->ar, b.tmp, nullptr, 0, 0, nullptr, b.resid, b.resid, next_norm, c.rms_eps, T,
+                                                     c.hidden, b.xn, ADT, st));
         }
     }
     if (logit_rows && logits_out) {   // gather the requested rows of the final normed hidden state, then lm_head on nseq rows

@@ -17,7 +17,7 @@ namespace {
 constexpr size_t kIdBytes = 128;            // sizeof(ncclUniqueId) (NCCL_UNIQUE_ID_BYTES)
 struct UniqueId { char internal[kIdBytes]; };
 // rccl.h enum values used here
-constexpr int kNcclSuccess = 0, kNcclFloat16 = 6, kNcclUint8 = 1, kNcclSum = 0;
+constexpr int kNcclSuccess = 0, kNcclFloat16 = 6, kNcclBfloat16 = 9, kNcclUint8 = 1, kNcclSum = 0;
 
 using get_unique_id_t = int (*)(UniqueId*);
 using comm_init_rank_t = int (*)(void** comm, int nranks, UniqueId id, int rank);
@@ -69,6 +69,12 @@ int rccl_all_reduce_f16(void* ctx, void* buf, size_t count, mi355_stream_t strea
     if (rc != kNcclSuccess) mi355_set_error("rccl: ncclAllReduce: %s", err_of(r->api, rc));
     return rc;
 }
+int rccl_all_reduce_bf16(void* ctx, void* buf, size_t count, mi355_stream_t stream) {
+    auto* r = (mi355_rccl*)ctx;
+    const int rc = r->api.all_reduce(buf, buf, count, kNcclBfloat16, kNcclSum, r->comm, (hipStream_t)stream);
+    if (rc != kNcclSuccess) mi355_set_error("rccl: ncclAllReduce(bf16): %s", err_of(r->api, rc));
+    return rc;
+}
 int rccl_all_gather(void* ctx, const void* send, void* recv, size_t bytes_per_rank, mi355_stream_t stream) {
     auto* r = (mi355_rccl*)ctx;
     const int rc = r->api.all_gather(send, recv, bytes_per_rank, kNcclUint8, r->comm, (hipStream_t)stream);
@@ -109,7 +115,7 @@ extern "C" mi355_rccl_t* mi355_rccl_open(const char* lib_path, const void* uniqu
 
 extern "C" int mi355_rccl_collective(mi355_rccl_t* r, mi355_collective_t* out) {
     if (!r || !out) { mi355_set_error("rccl_collective: null argument"); return MI355_ERR_ARG; }
-    out->ctx = r; out->all_reduce_f16 = rccl_all_reduce_f16; out->all_gather = rccl_all_gather;
+    out->ctx = r; out->all_reduce_f16 = rccl_all_reduce_f16; out->all_reduce_bf16 = rccl_all_reduce_bf16; out->all_gather = rccl_all_gather;
     out->rank = r->rank; out->world = r->world;
     return MI355_OK;
 }

@@ -91,21 +91,23 @@ class CustomAllReduce:
         return torch.cuda.current_stream().cuda_stream
 
     def fits(self, t: torch.Tensor) -> bool:
-        return (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and t.dim() >= 1 and t.shape[-1] % 8 == 0
+        return (t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) and t.is_contiguous() and t.dim() >= 1 and t.shape[-1] % 8 == 0
                 and t.shape[-1] <= 8192 and t.numel() * 2 <= self.max_bytes)
 
     def all_reduce(self, t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         out = t if out is None else out
         H = t.shape[-1]
-        self._C.check(self.lib.mi355_allreduce_sum(self.handle, t.data_ptr(), out.data_ptr(), t.numel() // H, H, self._st()), "allreduce_sum")
+        self._C.check(self.lib.mi355_allreduce_sum_dt(self.handle, t.data_ptr(), out.data_ptr(), t.numel() // H, H,
+                                                      self._C.ACT_BF16 if t.dtype == torch.bfloat16 else self._C.ACT_F16, self._st()), "allreduce_sum")
         return out
 
     def all_reduce_add_rmsnorm(self, t, residual, weight, eps):
         """(normed, residual_out) = RMSResNorm(all_reduce(t), residual) in one launch (allreduce_fusion_kernel_1stage)."""
         H = t.shape[-1]
         y, res = torch.empty_like(t), torch.empty_like(t)
-        self._C.check(self.lib.mi355_allreduce_fused(self.handle, t.data_ptr(), None, 0, 0, None, residual.data_ptr(), res.data_ptr(),
-                                                     weight.data_ptr(), float(eps), t.numel() // H, H, y.data_ptr(), self._st()),
+        self._C.check(self.lib.mi355_allreduce_fused_dt(self.handle, t.data_ptr(), None, 0, 0, None, residual.data_ptr(), res.data_ptr(),
+                                                        weight.data_ptr(), float(eps), t.numel() // H, H, y.data_ptr(),
+                                                        self._C.ACT_BF16 if t.dtype == torch.bfloat16 else self._C.ACT_F16, self._st()),
                       "allreduce_fused")
         return y, res
 
@@ -113,7 +115,7 @@ class CustomAllReduce:
         """[T, n] column slice per rank -> [T, n * world], slices side by side in rank order (the all_gather + transpose of the
         reference's hidden-split embedding, modules/base/common/embedding.py:50-58)."""
         T, n = t.shape
-        out = torch.empty(T, n * self.world, dtype=torch.float16, device=t.device)
+        out = torch.empty(T, n * self.world, dtype=t.dtype, device=t.device)
         self._C.check(self.lib.mi355_allgather_hidden(self.handle, t.data_ptr(), out.data_ptr(), T, n, self._st()), "allgather_hidden")
         return out
 
@@ -168,10 +170,11 @@ class RcclTransport:
         _C.check(self.lib.mi355_rccl_collective(self.handle, C.byref(self.collective)), "rccl_collective")
 
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
-        """In-place SUM of an fp16 tensor over the ranks, on the current stream."""
-        if not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous()):
-            raise ValueError("RcclTransport.all_reduce: contiguous fp16 device tensor expected")
-        rc = self.collective.all_reduce_f16(self.collective.ctx, t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream)
+        """In-place SUM of an fp16 / bf16 tensor over the ranks, on the current stream."""
+        if not (t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) and t.is_contiguous()):
+            raise ValueError("RcclTransport.all_reduce: contiguous fp16 / bf16 device tensor expected")
+        fn = self.collective.all_reduce_bf16 if t.dtype == torch.bfloat16 else self.collective.all_reduce_f16
+        rc = fn(self.collective.ctx, t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise self._C.Mi355Error("ncclAllReduce failed: " + self.lib.mi355_last_error().decode())
         return t

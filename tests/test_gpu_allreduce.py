@@ -207,7 +207,7 @@ def _worker(rank, world, port, q, mode):
                         assert nbytes % 16 == 0
                         return lib.mi355_allgather_hidden(ar.handle, send, recv, 1, nbytes // 2, stream)
                     self._fns = (_C.ALL_REDUCE_FN(all_reduce), _C.ALL_GATHER_FN(all_gather))
-                    self.collective = _C.Collective(None, self._fns[0], self._fns[1], ar.rank, ar.world)
+                    self.collective = _C.Collective(None, self._fns[0], _C.ALL_REDUCE_FN(), self._fns[1], ar.rank, ar.world)
 
             cfg = model.ModelConfig("tiny-tp", 2, 512, 8, 2, 64, 768, 1024, max_pos=256)
             w = model.synth_model(cfg, "w4", "cpu", seed=22, zeros="centered")
@@ -245,6 +245,50 @@ def _worker(rank, world, port, q, mode):
             eng.step(B)
             torch.cuda.synchronize()
             assert torch.equal(eng.positions[:B].cpu(), torch.full((B,), 6, dtype=torch.int32))
+            assert ar.status() == 0 and eng.oob_count() == 0
+        elif mode == "bf16":
+            # the collectives and the TP step with bf16 activations: bf16 copies cross the ranks, sums stay fp32 in rank order
+            BF = torch.bfloat16
+            for T, H in ((5, 512), (64, 3584), (cap(200), 1024)):
+                x = (torch.randn(T, H, generator=g) * 0.5).to(BF)
+                y = ar.all_reduce(x.to(dev).clone())
+                torch.cuda.synchronize()
+                parts = _gather_cpu(x, world)
+                ref = sum((p.float() for p in parts[1:]), parts[0].float()).to(BF)     # rank order, fp32, one rounding
+                assert torch.equal(y.cpu(), ref), (T, H)
+            cfg = model.ModelConfig("tiny-tp", 2, 512, 8, 2, 64, 768, 1024, max_pos=256)
+            w = model.synth_model(cfg, "w4", "cpu", seed=24, zeros="centered")
+            V = cfg.vocab
+            layers = [model.split_layer_tp(L, cfg, world, rank) for L in w["layers"]]
+            head = w["lm_head"].cols(rank * (V // world), (rank + 1) * (V // world))
+            shard = {"layers": layers, "embedding": w["embedding"], "final_norm": w["final_norm"], "lm_head": head}
+            B, page = 5, 16
+            eng = model.DecoderEngine(cfg.per_rank(world), model.weights_to(shard, dev), kv_int8=False, page=page, num_blocks=B * 2,
+                                      max_batch=B, max_seq_len=32, device=dev, tp_size=world, vocab_full=V, dtype=BF)
+            eng.attach_allreduce(ar, rank * (V // world))
+            bf = lambda t: None if t is None else t.to(BF)
+            dense = lambda c: (c.w.to(BF).float() if c.kind == "fp16" else oracle.dequant_groupwise(c.q, c.z_eff, c.scales, c.group_size))
+            ow = {"embedding": bf(w["embedding"]), "final_norm": bf(w["final_norm"]), "lm_head": dense(w["lm_head"]),
+                  "layers": [{"input_norm": bf(L["input_norm"]), "post_norm": bf(L["post_norm"]), "qkv_bias": bf(L["qkv_bias"]),
+                              **{k: dense(L[k]) for k in ("qkv", "o", "gate_up", "down")}} for L in w["layers"]]}
+            odec = oracle.OracleDecoder({**cfg.__dict__}, ow)
+            okv = oracle.OracleKV(cfg.num_layers, B, False)
+            bt = torch.arange(B * 2, dtype=torch.int32).reshape(B, 2)
+            tok = torch.randint(0, V, (B,), generator=torch.Generator().manual_seed(3), dtype=torch.int32)
+            eng.set_inputs(tok.tolist(), [0] * B, bt)
+            dist.barrier()
+            eng.capture(B)
+            for step in range(5):
+                pos = torch.full((B,), step, dtype=torch.int32)
+                _, ref = odec.forward_tokens(tok, pos, okv, list(range(B)))
+                eng.replay(B, 1)
+                torch.cuda.synchronize()
+                full = torch.cat(_gather_cpu(eng.logits[:B].cpu(), world), dim=1)
+                assert torch.allclose(full, ref, atol=3e-2, rtol=3e-2), (step, float((full - ref).abs().max()))
+                mine = eng.token_ids[:B].cpu()
+                assert torch.equal(mine, torch.argmax(full, -1).int())
+                tok = oracle.greedy(ref)
+                eng.token_ids[:B].copy_(tok)
             assert ar.status() == 0 and eng.oob_count() == 0
         elif mode == "twoshot":
             # world = 3 on one GPU: tensors of more than 64 rows take the two-shot form (rank r reduces rows r, r + 3, ...; second
@@ -388,7 +432,7 @@ def _worker(rank, world, port, q, mode):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mode,world", [("kernels", 2), ("engine", 2), ("transport", 2), ("timeout", 2), ("twoshot", 3), ("mixed", 2), ("kernels", 4),
+@pytest.mark.parametrize("mode,world", [("kernels", 2), ("engine", 2), ("transport", 2), ("bf16", 2), ("bf16", 4), ("timeout", 2), ("twoshot", 3), ("mixed", 2), ("kernels", 4),
                                         ("kernels", 8), ("twoshot", 4), ("twoshot", 8), ("engine70", 8)])
 def test_custom_allreduce_processes_on_one_gpu(mode, world):
     assert torch.cuda.is_available()
@@ -447,7 +491,7 @@ def test_rccl_calls_inside_the_captured_cpp_step():
     fn = _C.ALL_GATHER_FN(all_gather)
 
     class Two:
-        collective = _C.Collective(real.ctx, real.all_reduce_f16, fn, 0, 2)
+        collective = _C.Collective(real.ctx, real.all_reduce_f16, real.all_reduce_bf16, fn, 0, 2)
 
     cfg = model.ModelConfig("tiny-tp", 2, 512, 8, 2, 64, 768, 1024, max_pos=256)
     w = model.synth_model(cfg, "w4", "cpu", seed=23, zeros="centered")
