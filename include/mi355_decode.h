@@ -51,9 +51,9 @@ enum { MI355_W4 = 4, MI355_W8 = 8, MI355_W16 = 16 };
 enum { MI355_KV_FP16 = 0, MI355_KV_INT8 = 1, MI355_KV_BF16 = 2 };
 /* activation dtype of a call (x / bias / y of a linear, the rows of a norm, Q and the attention output): the reference path is
  * fp16 / bf16 throughout (f16_linear.py:100-112; dtype grid of modules/base/rocm/test/rocm_norm_test.py).  bf16 is carried by
- *   mi355_weight_t.act_dtype (linears), mi355_kv_layer_t.kv_dtype == MI355_KV_BF16 (RoPE / KV write / attention: Q, K, V, the cache
- *   and the output are bf16), the *_dt entry points of the norm family and mi355_model_config_t.act_dtype (step driver).
- * bf16 takes W4 group-wise and 16-bit (then bf16) weights and a bf16 KV cache; W8 weights and the INT8 cache are fp16-only.
+ *   mi355_weight_t.act_dtype (linears), mi355_kv_layer_t.act_dtype (RoPE / KV write / attention: Q, K, V and the output; a 16-bit
+ *   cache is then MI355_KV_BF16, the INT8 cache serves both), the *_dt entry points of the norm family and mi355_model_config_t.act_dtype (step driver).
+ * bf16 takes W4 group-wise, W8 and 16-bit (then bf16) weights and a bf16 or INT8 KV cache.
  * Tensor parallelism: the all-reduce family has *_dt forms and the RCCL transport a bf16 callback. */
 enum { MI355_ACT_F16 = 0, MI355_ACT_BF16 = 1 };
 
@@ -190,6 +190,8 @@ typedef struct {
     int32_t nkv;        /* local kv heads */
     int32_t hd;         /* head dim: 64 or 128 */
     int32_t num_blocks;
+    int32_t act_dtype;  /* dtype of Q / K / V rows and of the attention output: MI355_ACT_F16 / MI355_ACT_BF16.  A 16-bit cache holds
+                         * that dtype (kv_dtype MI355_KV_FP16 <-> F16, MI355_KV_BF16 <-> BF16); the INT8 cache pairs with either */
 } mi355_kv_layer_t;
 
 /*
@@ -419,8 +421,8 @@ typedef struct {
     int32_t max_batch, max_blocks_per_seq, max_seq_len;
     int32_t tp_size;
     int32_t act_dtype;   /* MI355_ACT_F16 / MI355_ACT_BF16: dtype of the embedding table, norm weights, biases, the hidden / ar_buf step
-                          * buffers and of every linear (each mi355_weight_t.act_dtype must agree); bf16 needs kv_dtype ==
-                          * MI355_KV_BF16 */
+                          * buffers and of every linear (each mi355_weight_t.act_dtype must agree); a 16-bit KV cache has the
+                          * same dtype (MI355_KV_BF16 for bf16), the INT8 cache goes with either */
 } mi355_model_config_t;
 
 typedef struct {

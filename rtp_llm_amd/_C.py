@@ -32,7 +32,7 @@ class Weight(C.Structure):  # mi355_weight_t
 
 class KVLayer(C.Structure):  # mi355_kv_layer_t
     _fields_ = [("kv_base", vp), ("scale_base", vp), ("kv_dtype", i32), ("page", i32),
-                ("nkv", i32), ("hd", i32), ("num_blocks", i32)]
+                ("nkv", i32), ("hd", i32), ("num_blocks", i32), ("act_dtype", i32)]
 
 
 class FusedNorm(C.Structure):  # mi355_fused_norm_t

@@ -70,7 +70,7 @@ __device__ __forceinline__ f16x8 widen_kv8(uint32_t lo, uint32_t hi) {
 // bf16; the INT8 cache pairs with fp16 activations only (its widening builds fp16 operands).
 template <int HD, bool INT8, int NT, int NW, int NG, bool BF = false>
 __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p) {
-    static_assert(!(BF && INT8), "bf16 activations with the INT8 cache are not built");
+    constexpr float KVB = BF ? 128.f : 1152.f;     // INT8: what a widened cache byte carries on top of its code (see widen_kv8 / _bf16)
     constexpr int NTHR = 64 * NW, GS = 32 * NW;    // threads; tokens one round of the block's waves covers
     constexpr int NSTEP = HD / 32; // QK k-steps
     constexpr int NDB   = HD / 16; // PV d-blocks
@@ -130,10 +130,10 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             for (int s = 0; s < NSTEP; ++s) {
                 const u32x4 v = qf[c][s];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qs = __builtin_amdgcn_fdot2(as_h2(v[e]), ones, qs, false);
+                for (int e = 0; e < 4; ++e) qs = act_dot_ones<BF>(v[e], qs);
             }
             qs = xor32_sum(xor16_sum(qs));
-            kq[c] = 1152.f * qs;
+            kq[c] = KVB * qs;
         }
     }
     const int32_t* bt = p.block_table + (size_t)b * p.max_blocks;
@@ -232,7 +232,8 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             for (int s = 0; s < NSTEP; ++s) {
                 if (INT8) {
                     const u32x4 kk = g.kf[tau][s >> 1];
-                    ka[tau][s] = __builtin_bit_cast(u32x4, widen_kv8(kk[(s & 1) * 2], kk[(s & 1) * 2 + 1]));
+                    if constexpr (BF) ka[tau][s] = widen_u8_bf16(kk[(s & 1) * 2], kk[(s & 1) * 2 + 1]);
+                    else              ka[tau][s] = __builtin_bit_cast(u32x4, widen_kv8(kk[(s & 1) * 2], kk[(s & 1) * 2 + 1]));
                 } else {
                     ka[tau][s] = g.kf[tau][s];
                 }
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
                 const u32x4 pv = pf[c];
                 float s16 = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s16 = __builtin_amdgcn_fdot2(as_h2(pv[e]), ones, s16, false);
+                for (int e = 0; e < 4; ++e) s16 = act_dot_ones<BF>(pv[e], s16);
                 l16_run[c] = l16_run[c] * alpha[c] + s16;
             }
         }
@@ -305,7 +306,8 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
         for (int db = 0; db < NDB; ++db) {
             u32x4 a;
             if (INT8) {
-                a = __builtin_bit_cast(u32x4, widen_kv8(g.vf8[db][0], g.vf8[db][1]));
+                if constexpr (BF) a = widen_u8_bf16(g.vf8[db][0], g.vf8[db][1]);
+                else              a = __builtin_bit_cast(u32x4, widen_kv8(g.vf8[db][0], g.vf8[db][1]));
             } else {
                 a = g.vf16[db];
             }
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             *reinterpret_cast<f32x4*>(&s_o[wave][j][db * 16 + w * 4]) = o[c][db];
         float l16 = l16_run[c];
         if (INT8) l16 = xor32_sum(xor16_sum(l16));
-        if (w == 0) { s_m[wave][j] = m_run[c]; s_l[wave][j] = lr; s_b[wave][j] = 1152.f * l16; }
+        if (w == 0) { s_m[wave][j] = m_run[c]; s_l[wave][j] = lr; s_b[wave][j] = KVB * l16; }
         __syncthreads();
         // thread -> (column jj, 4 channels); 16 columns * HD/4 vectors
         const int ncol = p.R * p.G;
@@ -587,10 +589,12 @@ int launch_attn(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_
 // (NG = 3: 72.7), ctx 1024 unchanged; fp16 loses with more than two (28.4 -> 30.6 us at ctx 1024)
 #define L2_(HD_, I8_) do { if (NT == 1) L_(HD_, I8_, 1, 4, (I8_ ? 4 : 2)); else L_(HD_, I8_, 2, 4, 2); } while (0)
 #endif
-    const bool bf = kv->kv_dtype == MI355_KV_BF16;
-#define LB_(HD_) do { if (NT == 1) hipLaunchKernelGGL((paged_attn_kernel<HD_, false, 1, 4, 2, true>), grid, dim3(256), 0, st, p); \
-                      else         hipLaunchKernelGGL((paged_attn_kernel<HD_, false, 2, 4, 2, true>), grid, dim3(256), 0, st, p); } while (0)
-    if (bf)            { if (kv->hd == 128) LB_(128); else LB_(64); }
+    const bool bf = kv->act_dtype == MI355_ACT_BF16;
+    MI355_CHECK_ARG(kv->act_dtype == MI355_ACT_F16 || bf, "paged_attn: act_dtype=%d", kv->act_dtype);
+    MI355_CHECK_ARG(int8 || (bf == (kv->kv_dtype == MI355_KV_BF16)), "paged_attn: a 16-bit cache has the dtype of the activations");
+#define LB_(HD_, I8_) do { if (NT == 1) hipLaunchKernelGGL((paged_attn_kernel<HD_, I8_, 1, 4, (I8_ ? 4 : 2), true>), grid, dim3(256), 0, st, p); \
+                           else         hipLaunchKernelGGL((paged_attn_kernel<HD_, I8_, 2, 4, 2, true>), grid, dim3(256), 0, st, p); } while (0)
+    if (bf)            { if (kv->hd == 128) { if (int8) LB_(128, true); else LB_(128, false); } else { if (int8) LB_(64, true); else LB_(64, false); } }
     else if (kv->hd == 128) { if (int8) L2_(128, true); else L2_(128, false); }
     else               { if (int8) L2_(64, true);  else L2_(64, false); }
 #undef LB_

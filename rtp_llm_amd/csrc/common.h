@@ -106,6 +106,19 @@ template <bool BF> __device__ __forceinline__ u32x4 act_pack8(const float (&o)[8
     return v;
 }
 
+// 8 unsigned bytes -> 8 bf16 holding the byte values exactly (8 significant bits suffice, but not under a fixed exponent as in
+// fp16): v_cvt_f32_ubyteN per byte, then the high halves of two floats packed by one v_perm -- 12 VALU per 8 bytes.  Used for the
+// offset-binary INT8 cache (byte = code + 128) and W8 weights (byte = q + 128) under bf16 activations.
+__device__ __forceinline__ u32x4 widen_u8_bf16(uint32_t lo, uint32_t hi) {
+    auto pk = [](float a, float b) { return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 0x07060302u); };
+    u32x4 r;
+    r[0] = pk((float)(lo & 0xFFu), (float)((lo >> 8) & 0xFFu));
+    r[1] = pk((float)((lo >> 16) & 0xFFu), (float)(lo >> 24));
+    r[2] = pk((float)(hi & 0xFFu), (float)((hi >> 8) & 0xFFu));
+    r[3] = pk((float)((hi >> 16) & 0xFFu), (float)(hi >> 24));
+    return r;
+}
+
 // 8 unsigned nibbles (native W4 order: nibble e at bit 4*(e/2)+16*(e&1)) -> 8 fp16
 // holding scale * (u - z) with zneg2 = {-(1024+z)} x2, s2 = {scale} x2.
 // (u | 0x6400) is the fp16 1024+u exactly; the add is exact; one rounding in the mul.

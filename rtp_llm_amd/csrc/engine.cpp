@@ -157,6 +157,7 @@ mi355_kv_layer_t kv_of(const mi355_decoder* d, int l) {
     kv.kv_base = d->layers[l].kv_base; kv.scale_base = d->layers[l].kv_scale_base;
     kv.kv_dtype = d->cfg.kv_dtype; kv.page = d->cfg.page; kv.nkv = d->cfg.nkv; kv.hd = d->cfg.hd;
     kv.num_blocks = d->cfg.num_blocks;
+    kv.act_dtype = d->cfg.act_dtype;
     return kv;
 }
 
@@ -186,14 +187,14 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     }
     {   // activation dtype: one for the whole step
         const bool bf = cfg->act_dtype == MI355_ACT_BF16;
-        bool ok = (cfg->act_dtype == MI355_ACT_F16 || bf) && (bf == (cfg->kv_dtype == MI355_KV_BF16));
-        auto lin_ok = [&](const mi355_weight_t& w) { return w.act_dtype == cfg->act_dtype && !(bf && w.wbits == 8); };   // W8: fp16 only
+        bool ok = (cfg->act_dtype == MI355_ACT_F16 || bf) && (cfg->kv_dtype == MI355_KV_INT8 || bf == (cfg->kv_dtype == MI355_KV_BF16));
+        auto lin_ok = [&](const mi355_weight_t& w) { return w.act_dtype == cfg->act_dtype; };
         ok = ok && lin_ok(model->lm_head);
         for (int l = 0; ok && l < cfg->num_layers; ++l)
             ok = lin_ok(layers[l].qkv) && lin_ok(layers[l].o) && lin_ok(layers[l].gate_up) && lin_ok(layers[l].down);
         if (!ok) {
             mi355_set_error("decoder_create: act_dtype=%d needs every linear in that dtype%s and a %s KV cache", cfg->act_dtype,
-                            bf ? " (W4 group-wise or 16-bit weights)" : "", bf ? "bf16" : "fp16 or INT8");
+                            "", bf ? "bf16 or INT8" : "fp16 or INT8");
             return nullptr;
         }
     }

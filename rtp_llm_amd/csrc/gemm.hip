@@ -61,7 +61,6 @@ namespace {
 // dequant); the reference's bf16 linear is f16_linear.py:100-112 with a bf16 tensor.
 template <int WBITS, int MB, int NBW, int GS, int D, int NWN, int KG, bool BF = false>
 __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams p) {
-    static_assert(!BF || WBITS != 8, "bf16 activations: W4 group-wise and 16-bit weights only");
     constexpr int LPC    = WBITS / 4;              // wave-loads per (tile, chunk)
     constexpr int NSUB   = (GS > 0) ? 4 / GS : 1;  // quantisation groups per chunk (per-channel: 1 pseudo group)
     constexpr int SPG    = 4 / NSUB;               // MFMA k-steps per group
@@ -258,7 +257,8 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
                             else    a = __builtin_bit_cast(u32x4, widen_w4(wr[d][nb][0][s], w4c));
                         } else {
                             const u32x4 w = wr[d][nb][(s >> 1) % LPC];
-                            a = __builtin_bit_cast(u32x4, widen_w8(w[(s & 1) * 2], w[(s & 1) * 2 + 1]));
+                            if (BF) a = widen_u8_bf16(w[(s & 1) * 2], w[(s & 1) * 2 + 1]);      // the stored byte itself: no code bias
+                            else    a = __builtin_bit_cast(u32x4, widen_w8(w[(s & 1) * 2], w[(s & 1) * 2 + 1]));
                         }
                     } else { // operand-side dequant: (code - z) [* scale] in fp16, exact subtract, one rounding
                         const uint32_t m = GROUPED ? mr[d][nb][gi] : mch[nb];
@@ -294,14 +294,15 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             // meta holds zneg = -(1024 + z); the bf16 codes are biased by 128
-                            const float t = __builtin_fmaf(BF ? (float)m4[r][0] + 896.f : (float)m4[r][0], XS[mb], ag[nb][mb][r]);
+                            // (W8 bytes enter the bf16 MFMA unbiased: + 1024)
+                            const float t = __builtin_fmaf(BF ? (float)m4[r][0] + (WBITS == 4 ? 896.f : 1024.f) : (float)m4[r][0], XS[mb], ag[nb][mb][r]);
                             acc[nb][mb][r] = __builtin_fmaf((float)m4[r][1], t, acc[nb][mb][r]);
                         }
                 } else { // per-channel int8: zero code 128 for every column, scale applied in the epilogue
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[nb][mb][r] += __builtin_fmaf(-1152.f, XS[mb], ag[nb][mb][r]);
+                        for (int r = 0; r < 4; ++r) acc[nb][mb][r] += __builtin_fmaf(BF ? -128.f : -1152.f, XS[mb], ag[nb][mb][r]);
                 }
             }
         }
@@ -559,7 +560,9 @@ int launch_gemm(const GemmParams& p, int wbits, int group_size, int cfg, hipStre
         if (wbits == 4 && group_size == 128) return launch_gemm_bf16_t<4, 4, 4, 4, 4>(p, cfg, st);
         if (wbits == 4 && group_size == 64) return launch_gemm_bf16_t<4, 2, 4, 4, 4>(p, cfg, st);
         if (wbits == 4 && group_size == 32) return launch_gemm_bf16_t<4, 1, 4, 4, 4>(p, cfg, st);
-        mi355_set_error("gemm: bf16 activations take W4 group-wise or 16-bit weights (wbits=%d group_size=%d)", wbits, group_size);
+        if (wbits == 8 && group_size == 0) return launch_gemm_bf16_t<8, 0, 4, 2, 2>(p, cfg, st);
+        if (wbits == 8 && group_size == 128) return launch_gemm_bf16_t<8, 4, 4, 2, 2>(p, cfg, st);
+        mi355_set_error("gemm: bf16 activations: unsupported wbits=%d group_size=%d", wbits, group_size);
         return MI355_ERR_UNSUPPORTED;
     }
     if (wbits == 16) return launch_gemm_t<16, 0, 2, 2, 2>(p, cfg, st);
@@ -589,10 +592,6 @@ int check_weight(const mi355_weight_t* w) {
     MI355_CHECK_ARG(w->wbits == 16 || w->meta, "linear: quantized weight needs meta");
     MI355_CHECK_ARG((uint64_t)w->K_pad * w->N_pad * w->wbits / 8 < 0xFFFFFFF0ull, "linear: weight image >= 4 GiB");
     MI355_CHECK_ARG(w->act_dtype == MI355_ACT_F16 || w->act_dtype == MI355_ACT_BF16, "linear: act_dtype=%d", w->act_dtype);
-    if (w->act_dtype == MI355_ACT_BF16 && !(w->wbits == 16 || (w->wbits == 4 && w->group_size > 0))) {
-        mi355_set_error("linear: bf16 activations take W4 group-wise or 16-bit (bf16) weights, not wbits=%d group_size=%d", w->wbits, w->group_size);
-        return MI355_ERR_UNSUPPORTED;
-    }
     return MI355_OK;
 }
 

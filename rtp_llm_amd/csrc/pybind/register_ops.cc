@@ -179,6 +179,7 @@ inline mi355_kv_layer_t kv_of(const AttentionConfigs& c, const LayerKVCache& kv)
     k.nkv        = (int)c.kv_head_num;
     k.hd         = (int)c.size_per_head;
     k.num_blocks = (int)(kv.kv_cache_base.numel() / (2 * c.kv_head_num * k.page * c.size_per_head));
+    k.act_dtype  = MI355_ACT_F16;
     return k;
 }
 

@@ -30,7 +30,7 @@ struct RopeParams {
     f16*           q_out;
 };
 
-// BF: qkv / bias / q_out and the (16-bit) cache are bf16 (kv_dtype MI355_KV_BF16); the INT8 cache pairs with fp16 activations only
+// BF: qkv / bias / q_out and a 16-bit cache are bf16 (kv_dtype MI355_KV_BF16); the INT8 cache is quantised from the same fp32 values either way
 template <bool BF>
 __global__ __launch_bounds__(256) void rope_kv_write_kernel(const RopeParams p) {
     using raw16 = uint16_t;
@@ -152,6 +152,9 @@ extern "C" int mi355_rope_kv_write_rows(const void* qkv_f16, const float* partia
                     "rope_kv_write: bad dims");
     MI355_CHECK_ARG(kv->kv_dtype == MI355_KV_FP16 || kv->kv_dtype == MI355_KV_BF16 || (kv->kv_dtype == MI355_KV_INT8 && kv->scale_base),
                     "rope_kv_write: int8 cache needs scale_base");
+    const bool bf = kv->act_dtype == MI355_ACT_BF16;
+    MI355_CHECK_ARG((kv->act_dtype == MI355_ACT_F16 || bf) && (kv->kv_dtype == MI355_KV_INT8 || bf == (kv->kv_dtype == MI355_KV_BF16)),
+                    "rope_kv_write: act_dtype=%d with kv_dtype=%d (a 16-bit cache has the dtype of the activations)", kv->act_dtype, kv->kv_dtype);
     const int nheads = nh + 2 * kv->nkv;
     MI355_CHECK_ARG(ld >= nheads * kv->hd, "rope_kv_write: ld=%d", ld);
     RopeParams p;
@@ -160,7 +163,7 @@ extern "C" int mi355_rope_kv_write_rows(const void* qkv_f16, const float* partia
     p.T = T; p.nh = nh; p.nkv = kv->nkv; p.hd = kv->hd; p.page = kv->page; p.kv_base = kv->kv_base;
     p.max_pos = max_pos; p.num_blocks = kv->num_blocks; p.oob_count = oob_count; p.q_len = q_len;
     p.scale_base = kv->scale_base; p.kv_int8 = kv->kv_dtype == MI355_KV_INT8; p.q_out = (f16*)q_out;
-    if (kv->kv_dtype == MI355_KV_BF16)
+    if (bf)
         hipLaunchKernelGGL(rope_kv_write_kernel<true>, dim3(T, cdiv(nheads, 4)), dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(rope_kv_write_kernel<false>, dim3(T, cdiv(nheads, 4)), dim3(256), 0, (hipStream_t)stream, p);

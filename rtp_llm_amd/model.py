@@ -367,12 +367,10 @@ class DecoderEngine:
                  max_seq_len: int, device, tp_size: int = 1, vocab_full: Optional[int] = None, dtype: torch.dtype = torch.float16):
         """dtype: activation dtype of the step (torch.float16 or torch.bfloat16; the reference runs either).  bf16: every 16-bit
         tensor of the model (embedding, norm weights, biases, a 16-bit lm_head / linear) is converted once here, the KV cache is
-        bf16, W4 weights are shared as they are; W8 weights and the INT8 cache are fp16-only."""
+        bf16 (or INT8), W4 / W8 weights are shared as they are."""
         if dtype not in (torch.float16, torch.bfloat16):
             raise ValueError(f"DecoderEngine: dtype {dtype}")
         bf = dtype == torch.bfloat16
-        if bf and kv_int8:
-            raise _C.Mi355Error("DecoderEngine: bf16 activations take a bf16 KV cache (the INT8 cache is fp16-only)")
         self.dtype = dtype
         cast = (lambda t: None if t is None else t.to(dtype)) if bf else (lambda t: t)
         self.cfg, self.device, self.tp_size = cfg, device, tp_size

@@ -47,13 +47,19 @@ def weight_struct(w: PackedWeight, act: torch.dtype = torch.float16) -> _C.Weigh
                      w.K_pad, w.N_pad, w.group_size, _C.ACT_BF16 if act == torch.bfloat16 else _C.ACT_F16)
 
 
-def kv_struct(kv_base: torch.Tensor, scale_base: Optional[torch.Tensor], page: int, nkv: int, hd: int) -> _C.KVLayer:
+def kv_struct(kv_base: torch.Tensor, scale_base: Optional[torch.Tensor], page: int, nkv: int, hd: int,
+              act: Optional[torch.dtype] = None) -> _C.KVLayer:
+    """act: dtype of the Q / K / V rows that go with this cache (default: the cache's own 16-bit dtype, fp16 for an INT8 cache)."""
     int8 = kv_base.dtype == torch.int8
     if int8 and scale_base is None:
         raise _C.Mi355Error("int8 KV cache requires the fp32 scale plane")
     nblk = kv_base.numel() // (2 * nkv * page * hd)
     kvd = _C.KV_INT8 if int8 else (_C.KV_BF16 if kv_base.dtype == torch.bfloat16 else _C.KV_FP16)
-    return _C.KVLayer(kv_base.data_ptr(), 0 if scale_base is None else scale_base.data_ptr(), kvd, page, nkv, hd, nblk)
+    act = _act_of_cache(kv_base) if act is None else act
+    if not int8 and act != kv_base.dtype:
+        raise _C.Mi355Error(f"a {kv_base.dtype} cache takes {kv_base.dtype} rows, got {act}")
+    return _C.KVLayer(kv_base.data_ptr(), 0 if scale_base is None else scale_base.data_ptr(), kvd, page, nkv, hd, nblk,
+                      _C.ACT_BF16 if act == torch.bfloat16 else _C.ACT_F16)
 
 
 def _act_of_cache(kv_base: torch.Tensor) -> torch.dtype:
@@ -351,13 +357,13 @@ def rope_kv_write(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], cos_sin: 
                   hd: int, page: int, oob_count: Optional[torch.Tensor] = None) -> torch.Tensor:
     """RoPE + bias + Q-extract + paged KV write for decode tokens; returns q [T, nh, hd].  Tokens with a position or
     block id out of range are not written; `oob_count` (int32 [1], device) counts them."""
-    _chk(qkv, _act_of_cache(kv_base), "rope_kv_write.qkv"); _chk(cos_sin, torch.float32, "rope_kv_write.cos_sin")
+    _chk_act(qkv, "rope_kv_write.qkv"); _chk(cos_sin, torch.float32, "rope_kv_write.cos_sin")
     _chk(positions, torch.int32, "rope_kv_write.positions"); _chk(block_table, torch.int32, "rope_kv_write.block_table")
     if qkv_bias is not None:
         _chk(qkv_bias, qkv.dtype, "rope_kv_write.qkv_bias")
     T = qkv.shape[0]
     q_out = torch.empty(T, nh, hd, dtype=qkv.dtype, device=qkv.device)
-    kv = kv_struct(kv_base, scale_base, page, nkv, hd)
+    kv = kv_struct(kv_base, scale_base, page, nkv, hd, qkv.dtype)
     _C.check(_C.lib().mi355_rope_kv_write(qkv.data_ptr(), None, 0, qkv.shape[1], _p(qkv_bias), cos_sin.data_ptr(), hd,
                                           cos_sin.shape[0], positions.data_ptr(), block_table.data_ptr(),
                                           block_table.shape[1], T, nh, C.byref(kv), q_out.data_ptr(), _p(oob_count), _stream()),
@@ -368,12 +374,12 @@ def rope_kv_write(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], cos_sin: 
 def rope_kv_write_rows(qkv: torch.Tensor, qkv_bias, cos_sin, positions, block_table, kv_base, scale_base, nh: int, nkv: int,
                        hd: int, page: int, q_len: int, oob_count: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q_len rows per sequence: qkv [B*q_len, ...], positions [B*q_len] (< 0 = padding row), block_table [B, M]."""
-    _chk(qkv, _act_of_cache(kv_base), "rope_kv_write_rows.qkv"); _chk(positions, torch.int32, "positions"); _chk(block_table, torch.int32, "block_table")
+    _chk_act(qkv, "rope_kv_write_rows.qkv"); _chk(positions, torch.int32, "positions"); _chk(block_table, torch.int32, "block_table")
     if qkv_bias is not None:
         _chk(qkv_bias, qkv.dtype, "rope_kv_write_rows.qkv_bias")
     T = qkv.shape[0]
     q_out = torch.empty(T, nh, hd, dtype=qkv.dtype, device=qkv.device)
-    kv = kv_struct(kv_base, scale_base, page, nkv, hd)
+    kv = kv_struct(kv_base, scale_base, page, nkv, hd, qkv.dtype)
     _C.check(_C.lib().mi355_rope_kv_write_rows(qkv.data_ptr(), None, 0, qkv.shape[1], _p(qkv_bias), cos_sin.data_ptr(), hd,
                                                cos_sin.shape[0], positions.data_ptr(), block_table.data_ptr(), block_table.shape[1],
                                                T, q_len, nh, C.byref(kv), q_out.data_ptr(), _p(oob_count), _stream()),
@@ -384,9 +390,9 @@ def rope_kv_write_rows(qkv: torch.Tensor, qkv_bias, cos_sin, positions, block_ta
 def paged_attention_rows(q: torch.Tensor, kv_base, scale_base, block_table: torch.Tensor, positions: torch.Tensor, nkv: int,
                          page: int, q_len: int, max_seq_len: int, scale: Optional[float] = None) -> torch.Tensor:
     """q [B*q_len, nh, hd]; row i of sequence b attends tokens 0..positions[b*q_len+i] (causal over the paged cache)."""
-    _chk(q, _act_of_cache(kv_base), "paged_attention_rows.q"); _chk(block_table, torch.int32, "block_table"); _chk(positions, torch.int32, "positions")
+    _chk_act(q, "paged_attention_rows.q"); _chk(block_table, torch.int32, "block_table"); _chk(positions, torch.int32, "positions")
     T, nh, hd = q.shape
-    kv = kv_struct(kv_base, scale_base, page, nkv, hd)
+    kv = kv_struct(kv_base, scale_base, page, nkv, hd, q.dtype)
     out = torch.empty(T, nh * hd, dtype=q.dtype, device=q.device)
     need = _C.lib().mi355_paged_attn_workspace_bytes(T, nh, hd, max_seq_len)
     ws = _workspace(need, q.device)
@@ -400,10 +406,10 @@ def paged_decode_attention(q: torch.Tensor, kv_base: torch.Tensor, scale_base: O
                            block_table: torch.Tensor, seq_lens: torch.Tensor, nkv: int, page: int,
                            max_seq_len: int, scale: Optional[float] = None) -> torch.Tensor:
     """q [B, nh, hd] -> out [B, nh*hd]; seq_lens = context length including the new token."""
-    _chk(q, _act_of_cache(kv_base), "paged_decode_attention.q"); _chk(block_table, torch.int32, "block_table")
+    _chk_act(q, "paged_decode_attention.q"); _chk(block_table, torch.int32, "block_table")
     _chk(seq_lens, torch.int32, "seq_lens")
     B, nh, hd = q.shape
-    kv = kv_struct(kv_base, scale_base, page, nkv, hd)
+    kv = kv_struct(kv_base, scale_base, page, nkv, hd, q.dtype)
     out = torch.empty(B, nh * hd, dtype=q.dtype, device=q.device)
     need = _C.lib().mi355_paged_attn_workspace_bytes(B, nh, hd, max_seq_len)
     ws = _workspace(need, q.device)

@@ -3,6 +3,7 @@ modules/base/rocm/test/rocm_norm_test.py): every kernel of the decode step in it
 (the oracle is dtype-generic: fp32 math, rounding to the input dtype at the points the reference's tensors have that dtype).
 Tolerance: bf16 keeps 8 significant bits (fp16: 11), so the 1e-2 of the fp16 tests becomes 2e-2 relative + 2e-2 absolute on O(1)
 values (one bf16 ulp at 2.0 is 1.6e-2); integer / copy results stay bit-exact."""
+import ctypes as C
 import math
 
 import pytest
@@ -26,10 +27,12 @@ def _x(M, K, seed, scale=0.5):
 
 
 def _dense(c):
+    if c.kind == "int8":
+        return oracle.dequant_int8(c.q, c.scales)
     return c.w.to(BF).float() if c.kind == "fp16" else oracle.dequant_groupwise(c.q, c.z_eff, c.scales, c.group_size)
 
 
-@pytest.mark.parametrize("kind,group", [("w4", 128), ("w4", 64), ("w4", 32), ("fp16", 0)])
+@pytest.mark.parametrize("kind,group", [("w4", 128), ("w4", 64), ("w4", 32), ("int8", 0), ("fp16", 0)])
 @pytest.mark.parametrize("M", [1, 7, 16, 33, 64, 83, 200])
 @pytest.mark.parametrize("K,N", [(256, 64), (1024, 4608), (3584, 512), (9472, 896)])
 def test_linear_bf16(kind, group, M, K, N):
@@ -53,9 +56,6 @@ def test_linear_bf16_silu_epilogue_and_refusals():
     y = ops.linear(x.to(DEV), c.pack(gate_up=True).to(DEV), None, _C.EPI_SILU_MUL)
     ref = oracle.silu_mul(oracle.linear(x, _dense(c)))
     assert y.dtype == BF and torch.allclose(y.cpu().float(), ref.float(), **TOL)
-    c8 = model.synth_linear(256, 64, "int8", "cpu", _gen(7))
-    with pytest.raises(_C.Mi355Error):            # W8 weights: fp16 activations only
-        ops.linear(_x(4, 256, 1).to(DEV), c8.pack().to(DEV))
     c16 = model.synth_linear(256, 64, "fp16", "cpu", _gen(8))
     with pytest.raises(_C.Mi355Error):            # a 16-bit weight image has the dtype it was packed with
         ops.linear(_x(4, 256, 1).to(DEV), c16.pack().to(DEV))
@@ -157,8 +157,8 @@ def _oracle_weights_bf16(w):
                         **{k: _dense(L[k]) for k in ("qkv", "o", "gate_up", "down")}} for L in w["layers"]]}
 
 
-@pytest.mark.parametrize("kind,B", [("w4", 3), ("fp16", 3), ("w4", 40)])
-def test_engine_bf16_greedy_decode_matches_oracle(kind, B):
+@pytest.mark.parametrize("kind,B,kv_int8", [("w4", 3, False), ("fp16", 3, False), ("w4", 40, False), ("int8", 3, False), ("w4", 3, True)])
+def test_engine_bf16_greedy_decode_matches_oracle(kind, B, kv_int8):
     """The whole decode step in bf16 (DecoderEngine(dtype=torch.bfloat16): bf16 embedding / norms / biases / KV cache, W4 or bf16
     linears through the bf16 MFMA kernels), hipGraph-replayed, against the oracle run on bf16 tensors; prompt fed token by token,
     then greedy generation with the oracle's tokens teacher-forced.  Logits within 3e-2 (three significant bits fewer than fp16
@@ -167,11 +167,15 @@ def test_engine_bf16_greedy_decode_matches_oracle(kind, B):
     w = model.synth_model(cfg, kind, "cpu", seed=3, zeros="centered")
     page, steps = 16, 10
     odec = oracle.OracleDecoder({**cfg.__dict__}, _oracle_weights_bf16(w))
-    eng = model.DecoderEngine(cfg, model.weights_to(w, DEV), kv_int8=False, page=page, num_blocks=4 * B, max_batch=B, max_seq_len=64,
+    eng = model.DecoderEngine(cfg, model.weights_to(w, DEV), kv_int8=kv_int8, page=page, num_blocks=4 * B, max_batch=B, max_seq_len=64,
                               device=DEV, dtype=BF)
-    assert eng.hidden.dtype == BF and eng.kv[0].dtype == BF
+    assert eng.hidden.dtype == BF and eng.kv[0].dtype == (torch.int8 if kv_int8 else BF)
     bt = torch.randperm(4 * B, generator=_gen(1)).reshape(B, 4).to(torch.int32)
-    okv = oracle.OracleKV(cfg.num_layers, B, False)
+
+    def kernel_codes(l, b, t):    # INT8 cache: the oracle attends over the codes the kernel wrote (tests/test_gpu_parity.py does the same)
+        K, V, ks, vs = kvcache.read_tokens(eng.kv[l], eng.kv_scale[l], bt[b], t + 1)
+        return K[t].cpu(), ks[t].cpu(), V[t].cpu(), vs[t].cpu()
+    okv = oracle.OracleKV(cfg.num_layers, B, kv_int8, forced=kernel_codes if kv_int8 else None)
     tok = torch.randint(0, cfg.vocab, (B,), generator=_gen(2), dtype=torch.int32)
     eng.set_inputs(tok.tolist(), [0] * B, bt)
     eng.capture(B)
@@ -194,7 +198,7 @@ def test_engine_bf16_greedy_decode_matches_oracle(kind, B):
         tok = ref_next
         eng.token_ids[:B].copy_(tok)
     assert eng.oob_count() == 0
-    print(f"bf16 {kind} B={B}: greedy ids {exact}/{n} identical to the oracle's argmax; max |logit error| {worst:.2e}")
+    print(f"bf16 {kind} B={B} kv_int8={kv_int8}: greedy ids {exact}/{n} identical to the oracle's argmax; max |logit error| {worst:.2e}")
 
 
 def test_engine_bf16_prefill_then_decode_matches_oracle():
@@ -227,11 +231,59 @@ def test_engine_bf16_prefill_then_decode_matches_oracle():
         eng.token_ids[:B].copy_(tok)
 
 
-def test_engine_bf16_refusals():
+def test_engine_dtype_mismatch_is_refused_at_creation():
+    """decoder_create checks that every linear and a 16-bit cache carry the step's activation dtype."""
     cfg = model.ModelConfig("tiny-qwen2", 1, 512, 8, 2, 64, 1024, 2048, max_pos=512)
     w = model.synth_model(cfg, "w4", "cpu", seed=6, zeros="centered")
-    with pytest.raises(_C.Mi355Error):
-        model.DecoderEngine(cfg, model.weights_to(w, DEV), kv_int8=True, page=16, num_blocks=8, max_batch=2, max_seq_len=64, device=DEV, dtype=BF)
-    w8 = model.synth_model(cfg, "int8", "cpu", seed=6)
-    with pytest.raises(_C.Mi355Error):
-        model.DecoderEngine(cfg, model.weights_to(w8, DEV), kv_int8=False, page=16, num_blocks=8, max_batch=2, max_seq_len=64, device=DEV, dtype=BF)
+    eng = model.DecoderEngine(cfg, model.weights_to(w, DEV), kv_int8=False, page=16, num_blocks=8, max_batch=2, max_seq_len=64, device=DEV, dtype=BF)
+    mc, mw, sb, lw = eng._structs
+    lw[0].o.act_dtype = _C.ACT_F16
+    assert not _C.lib().mi355_decoder_create(C.byref(mc), lw, C.byref(mw), C.byref(sb)) and b"act_dtype" in _C.lib().mi355_last_error()
+    lw[0].o.act_dtype = _C.ACT_BF16
+    mc.kv_dtype = _C.KV_FP16
+    assert not _C.lib().mi355_decoder_create(C.byref(mc), lw, C.byref(mw), C.byref(sb))
+
+
+@pytest.mark.parametrize("nh,nkv,hd,page", [(28, 4, 128, 16), (14, 2, 64, 64)])
+def test_int8_kv_cache_with_bf16_rows(nh, nkv, hd, page):
+    """The INT8 cache under bf16 activations: the writer quantises the bf16-rounded rotated K / V exactly like the oracle
+    (integer results bit-exact, K within one code), the attention widens cache bytes to bf16 exactly (v_cvt_f32_ubyte + pack,
+    bias 128 carried through both MFMAs) and matches the oracle on the SAME codes."""
+    T, max_blocks, nblk = 6, 8, 64
+    cs = oracle.rope_cos_sin(hd, 1e6, max_blocks * page)
+    qkv = _x(T, (nh + 2 * nkv) * hd, 11)
+    pos = torch.tensor([0, 1, 15, 16, 37, max_blocks * page - 1], dtype=torch.int32)
+    bt = torch.randperm(nblk, generator=_gen(2))[: T * max_blocks].reshape(T, max_blocks).to(torch.int32)
+    kv, sc = kvcache.alloc_layer_cache(nblk, nkv, page, hd, True, DEV)
+    q = ops.rope_kv_write(qkv.to(DEV), None, cs.to(DEV), pos.to(DEV), bt.to(DEV), kv, sc, nh, nkv, hd, page)
+    assert q.dtype == BF
+    kh = qkv[:, nh * hd: (nh + nkv) * hd].reshape(T, nkv, hd)
+    vh = qkv[:, (nh + nkv) * hd:].reshape(T, nkv, hd)
+    k_ref = oracle.apply_rope(kh, pos, cs)
+    for t in range(T):
+        K, V, ks, vs = kvcache.read_tokens(kv, sc, bt[t], int(pos[t]) + 1)
+        vq, vsc = oracle.quant_kv_int8(vh[t])
+        assert torch.equal(V[-1].cpu(), vq) and torch.equal(vs[-1].cpu(), vsc)
+        kq, ksc = oracle.quant_kv_int8(k_ref[t])
+        assert (K[-1].cpu().int() - kq.int()).abs().max() <= 1 and torch.allclose(ks[-1].cpu(), ksc, rtol=1e-2, atol=0)
+    # attention over a cache written by the host with the oracle's codes
+    ctx = [1, 8, 17, 33, 129, 500, 1024]
+    B = len(ctx)
+    g = _gen(21)
+    mb = (max(ctx) + page - 1) // page
+    nb2 = B * mb
+    bt2 = torch.randperm(nb2, generator=g).reshape(B, mb).to(torch.int32)
+    kv2, sc2 = kvcache.alloc_layer_cache(nb2, nkv, page, hd, True, DEV)
+    nat = []
+    for b in range(B):
+        K = torch.randn(ctx[b], nkv, hd, generator=g).to(BF); V = torch.randn(ctx[b], nkv, hd, generator=g).to(BF)
+        Kq, ks = oracle.quant_kv_int8(K); Vq, vs = oracle.quant_kv_int8(V)
+        kvcache.write_tokens(kv2, sc2, bt2[b], 0, Kq, Vq, ks, vs)
+        nat.append((Kq, Vq, ks, vs))
+    qq = torch.randn(B, nh, hd, generator=_gen(4)).to(BF)
+    out = ops.paged_decode_attention(qq.to(DEV), kv2, sc2, bt2.to(DEV), torch.tensor(ctx, dtype=torch.int32, device=DEV), nkv, page, max(ctx))
+    assert out.dtype == BF
+    for b in range(B):
+        Kq, Vq, ks, vs = nat[b]
+        ref = oracle.attention_decode(qq[b], Kq, Vq, 1 / math.sqrt(hd), ks, vs).reshape(-1)
+        assert torch.allclose(out[b].cpu().float(), ref.float(), **TOL), (b, ctx[b], float((out[b].cpu().float() - ref.float()).abs().max()))
