@@ -121,6 +121,14 @@ inline void need(const torch::Tensor& t, c10::ScalarType dt, const char* name) {
     TORCH_CHECK(t.is_contiguous(), name, ": tensor must be contiguous");
 }
 
+// activation tensors: fp16 or bf16 (the reference passes either through the same ops); returns the C-ABI dtype code
+inline int act_of(const torch::Tensor& t, const char* name) {
+    TORCH_CHECK(t.defined() && t.is_cuda(), name, ": tensor must live on the GPU (there is no CPU path)");
+    TORCH_CHECK(t.scalar_type() == torch::kFloat16 || t.scalar_type() == torch::kBFloat16, name, ": expected float16 or bfloat16, got ", t.scalar_type());
+    TORCH_CHECK(t.is_contiguous(), name, ": tensor must be contiguous");
+    return t.scalar_type() == torch::kBFloat16 ? MI355_ACT_BF16 : MI355_ACT_F16;
+}
+
 // ---- params object shared by the two attention ops (the role of CKAttn, FusedRopeKVCacheOp.cc:648-653) -------------
 #ifdef MI355_REFERENCE_TREE
 struct AttnParams: public rtp_llm::ParamsBase {   // ParamsBase.h:8-22: the framework refills recycled params through fillParams
@@ -166,20 +174,22 @@ inline AttnParamsPtr make_params(const PyAttentionInputs& in) {
     return p;
 }
 
-inline mi355_kv_layer_t kv_of(const AttentionConfigs& c, const LayerKVCache& kv) {
+inline mi355_kv_layer_t kv_of(const AttentionConfigs& c, const LayerKVCache& kv, int act = MI355_ACT_F16) {
     TORCH_CHECK(kv.kv_cache_base.defined() && kv.kv_cache_base.is_cuda(), "kv_cache.kv_cache_base must be a GPU tensor");
     const bool int8 = kv.kv_cache_base.scalar_type() == torch::kInt8;
-    TORCH_CHECK(int8 || kv.kv_cache_base.scalar_type() == torch::kFloat16, "kv cache dtype must be float16 or int8");
+    const bool bf_cache = kv.kv_cache_base.scalar_type() == torch::kBFloat16;
+    TORCH_CHECK(int8 || bf_cache || kv.kv_cache_base.scalar_type() == torch::kFloat16, "kv cache dtype must be float16, bfloat16 or int8");
+    TORCH_CHECK(int8 || bf_cache == (act == MI355_ACT_BF16), "a 16-bit kv cache has the dtype of the rows it serves");
     TORCH_CHECK(!int8 || kv.kv_scale_base.defined(), "int8 KV cache needs kv_scale_base (fp32 scale plane)");
     mi355_kv_layer_t k;
     k.kv_base    = kv.kv_cache_base.data_ptr();
     k.scale_base = int8 ? kv.kv_scale_base.data_ptr<float>() : nullptr;
-    k.kv_dtype   = int8 ? MI355_KV_INT8 : MI355_KV_FP16;
+    k.kv_dtype   = int8 ? MI355_KV_INT8 : (bf_cache ? MI355_KV_BF16 : MI355_KV_FP16);
     k.page       = kv.seq_size_per_block > 0 ? kv.seq_size_per_block : (int)c.tokens_per_block;
     k.nkv        = (int)c.kv_head_num;
     k.hd         = (int)c.size_per_head;
     k.num_blocks = (int)(kv.kv_cache_base.numel() / (2 * c.kv_head_num * k.page * c.size_per_head));
-    k.act_dtype  = MI355_ACT_F16;
+    k.act_dtype  = act;
     return k;
 }
 
@@ -198,14 +208,14 @@ public:
     AttnParamsPtr prepare(const PyAttentionInputs& in) { return make_params(in); }
 
     torch::Tensor forward(const torch::Tensor& qkv, std::optional<LayerKVCache> kv_cache, const AttnParamsPtr& params) {
-        need(qkv, torch::kFloat16, "qkv");
+        const int act = act_of(qkv, "qkv");
         TORCH_CHECK(kv_cache.has_value(), "Mi355RopeKVCacheDecodeOp.forward needs a LayerKVCache");
         TORCH_CHECK(params, "params is null: call prepare() first");
         const int T = (int)qkv.size(0);
         if (!cos_sin_.defined() || cos_sin_.device() != qkv.device()) cos_sin_ = cos_sin_host_.to(qkv.device());
         if (!oob_.defined() || oob_.device() != qkv.device()) oob_ = torch::zeros({1}, qkv.options().dtype(torch::kInt32));
         auto q = torch::empty({T, cfg_.head_num, cfg_.size_per_head}, qkv.options());   // FusedRopeKVCacheOp.cc:538-539
-        const mi355_kv_layer_t kv = kv_of(cfg_, *kv_cache);
+        const mi355_kv_layer_t kv = kv_of(cfg_, *kv_cache, act);
         check(mi355_rope_kv_write(qkv.data_ptr(), nullptr, 0, (int)qkv.size(1), nullptr, cos_sin_.data_ptr<float>(),
                                   (int)cfg_.size_per_head, (int)cos_sin_.size(0), params->positions.data_ptr<int32_t>(),
                                   params->block_table.data_ptr<int32_t>(), (int)params->block_table.size(1), T,
@@ -232,10 +242,10 @@ public:
     AttnParamsPtr prepare(const PyAttentionInputs& in) { return make_params(in); }
 
     torch::Tensor forward(const torch::Tensor& q, std::optional<LayerKVCache> kv_cache, const AttnParamsPtr& params) {
-        need(q, torch::kFloat16, "q");
+        const int act = act_of(q, "q");
         TORCH_CHECK(kv_cache.has_value() && params, "Mi355PagedAttnDecodeOp.forward needs a LayerKVCache and params");
         const int B = (int)q.size(0);
-        const mi355_kv_layer_t kv = kv_of(cfg_, *kv_cache);
+        const mi355_kv_layer_t kv = kv_of(cfg_, *kv_cache, act);
         const size_t need_ws = mi355_paged_attn_workspace_bytes(B, (int)cfg_.head_num, (int)cfg_.size_per_head, (int)cfg_.max_seq_len);
         if (!ws_.defined() || ws_.device() != q.device() || (size_t)ws_.numel() < need_ws)
             ws_ = torch::empty({(int64_t)std::max<size_t>(need_ws, 1)}, q.options().dtype(torch::kUInt8));   // address-stable after warm-up
@@ -264,15 +274,18 @@ public:
         w_.qweight = qweight_.data_ptr();
         w_.meta    = meta_.defined() ? meta_.data_ptr() : nullptr;
         w_.wbits = (int)wbits; w_.K = (int)K; w_.N = (int)N; w_.K_pad = (int)K_pad; w_.N_pad = (int)N_pad; w_.group_size = (int)group_size; w_.act_dtype = MI355_ACT_F16;
-        if (bias_.defined()) need(bias_, torch::kFloat16, "bias");
+        if (bias_.defined()) act_of(bias_, "bias");
     }
     torch::Tensor forward(const torch::Tensor& x, int64_t epilogue) {
-        need(x, torch::kFloat16, "x");
+        mi355_weight_t w_ = this->w_;                        // per call: the activation dtype of THIS x
+        w_.act_dtype = act_of(x, "x");
+        TORCH_CHECK(!bias_.defined() || bias_.scalar_type() == x.scalar_type(), "linear: bias dtype must match x");
+        TORCH_CHECK(w_.wbits != 16 || qweight_.scalar_type() == x.scalar_type(), "linear: a 16-bit weight image has the dtype it was packed with");
         TORCH_CHECK(x.size(-1) == w_.K, "linear: x last dim ", x.size(-1), " != K ", w_.K);
         const int M = (int)(x.numel() / w_.K);
         auto shape = x.sizes().vec();
         shape.back() = (epilogue & MI355_EPI_SILU_MUL) ? w_.N / 2 : w_.N;
-        auto y = torch::empty(shape, x.options().dtype((epilogue & MI355_EPI_OUT_F32) ? torch::kFloat32 : torch::kFloat16));
+        auto y = torch::empty(shape, x.options().dtype((epilogue & MI355_EPI_OUT_F32) ? torch::kFloat32 : x.scalar_type()));
         const size_t need_ws = mi355_linear_workspace_bytes(M, &w_);
         if (!ws_.defined() || ws_.device() != x.device() || (size_t)ws_.numel() < need_ws)
             ws_ = torch::empty({(int64_t)std::max<size_t>(need_ws, 1 << 20)}, x.options().dtype(torch::kUInt8));
@@ -289,27 +302,32 @@ private:
 
 // ---- free functions, reference argument convention: out-params first, optional raw stream --------------------------
 void rmsnorm(torch::Tensor& output, const torch::Tensor& input, const torch::Tensor& weight, double eps, int64_t hip_stream) {
-    need(input, torch::kFloat16, "input"); need(weight, torch::kFloat16, "weight"); need(output, torch::kFloat16, "output");
+    const int act = act_of(input, "input");
+    need(weight, input.scalar_type(), "weight"); need(output, input.scalar_type(), "output");
     const int H = (int)input.size(-1);
-    check(mi355_rmsnorm(input.data_ptr(), weight.data_ptr(), (float)eps, (int)(input.numel() / H), H, output.data_ptr(), cur_stream(hip_stream)),
+    check(mi355_rmsnorm_dt(input.data_ptr(), weight.data_ptr(), (float)eps, (int)(input.numel() / H), H, output.data_ptr(), act, cur_stream(hip_stream)),
           "mi355_rmsnorm");
 }
 // (normed, residual_out) <- (input (+bias) + residual): RMSResNorm (modules/base/rocm/norm.py:59-77)
 void fused_add_rmsnorm(torch::Tensor& output, torch::Tensor& residual_out, const torch::Tensor& input, const torch::Tensor& residual,
                        const torch::Tensor& weight, double eps, std::optional<torch::Tensor> bias, int64_t hip_stream) {
-    need(input, torch::kFloat16, "input"); need(residual, torch::kFloat16, "residual"); need(weight, torch::kFloat16, "weight");
+    const int act = act_of(input, "input");
+    need(residual, input.scalar_type(), "residual"); need(weight, input.scalar_type(), "weight");
+    need(output, input.scalar_type(), "output"); need(residual_out, input.scalar_type(), "residual_out");
+    if (bias) need(*bias, input.scalar_type(), "bias");
     const int H = (int)input.size(-1);
-    check(mi355_add_rmsnorm(input.data_ptr(), nullptr, 0, 0, bias ? bias->data_ptr() : nullptr, residual.data_ptr(), residual_out.data_ptr(),
-                            weight.data_ptr(), (float)eps, (int)(input.numel() / H), H, output.data_ptr(), cur_stream(hip_stream)),
+    check(mi355_add_rmsnorm_dt(input.data_ptr(), nullptr, 0, 0, bias ? bias->data_ptr() : nullptr, residual.data_ptr(), residual_out.data_ptr(),
+                               weight.data_ptr(), (float)eps, (int)(input.numel() / H), H, output.data_ptr(), act, cur_stream(hip_stream)),
           "mi355_add_rmsnorm");
 }
 void silu_and_mul(torch::Tensor& output, const torch::Tensor& gate_up, int64_t hip_stream) {   // aiter.silu_and_mul(out, x)
-    need(gate_up, torch::kFloat16, "gate_up"); need(output, torch::kFloat16, "output");
+    const int act = act_of(gate_up, "gate_up");
+    need(output, gate_up.scalar_type(), "output");
     const int I = (int)gate_up.size(-1) / 2;
-    check(mi355_silu_mul(gate_up.data_ptr(), (int)(gate_up.numel() / (2 * I)), I, output.data_ptr(), cur_stream(hip_stream)), "mi355_silu_mul");
+    check(mi355_silu_mul_dt(gate_up.data_ptr(), (int)(gate_up.numel() / (2 * I)), I, output.data_ptr(), act, cur_stream(hip_stream)), "mi355_silu_mul");
 }
 void embedding(torch::Tensor& output, const torch::Tensor& input, const torch::Tensor& weight) {   // RegisterBaseBindings.hpp:36-43
-    need(input, torch::kInt32, "input"); need(weight, torch::kFloat16, "weight"); need(output, torch::kFloat16, "output");
+    need(input, torch::kInt32, "input"); act_of(weight, "weight"); need(output, weight.scalar_type(), "output");
     check(mi355_embedding(input.data_ptr<int32_t>(), (int)input.numel(), weight.data_ptr(), (int)weight.size(1), (int)weight.size(0),
                           output.data_ptr(), cur_stream()),
           "mi355_embedding");

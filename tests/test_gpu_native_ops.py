@@ -105,3 +105,53 @@ def test_weight_only_linear_and_free_functions():
     assert torch.equal(ops.greedy_argmax(logits.to(DEV)).cpu(), oracle.greedy(logits))
     with pytest.raises(RuntimeError):
         lin.forward(x[:, :512].contiguous().to(DEV))            # K mismatch -> TORCH_CHECK
+
+
+def test_native_ops_take_bf16_tensors():
+    """The shim picks the activation dtype from the tensors (the reference passes fp16 or bf16 through the same ops): W4 linear,
+    norms, SiLU, RoPE + KV write and paged attention in bf16 through the op classes, bit-equal to the ctypes path (same kernels),
+    and mixed dtypes are a TORCH_CHECK error."""
+    BF = torch.bfloat16
+    ops = native_ops.load()
+    c = model.synth_linear(1024, 1536, "w4", "cpu", _g(41))
+    pw = c.pack().to(DEV)
+    lin = ops.Mi355WeightOnlyLinear(pw.qweight, pw.meta, pw.wbits, pw.K, pw.N, pw.K_pad, pw.N_pad, pw.group_size)
+    x = (torch.randn(9, 1024, generator=_g(1)) * 0.5).to(BF).to(DEV)
+    y = lin.forward(x)
+    assert y.dtype == BF and torch.equal(y, cops.linear(x, pw))
+    assert lin.forward(x.half()).dtype == torch.float16                      # the same object serves both dtypes (W4 image is dtype-free)
+    w = (1 + 0.1 * torch.randn(1024, generator=_g(2))).to(BF).to(DEV)
+    out = torch.empty_like(x)
+    ops.rmsnorm(out, x, w, 1e-6)
+    assert torch.equal(out, cops.rmsnorm(x, w, 1e-6))
+    res, out2 = torch.empty_like(x), torch.empty_like(x)
+    ops.fused_add_rmsnorm(out2, res, x, x, w, 1e-6)
+    y2, r2 = cops.add_rmsnorm(x, x, w, 1e-6)
+    assert torch.equal(out2, y2) and torch.equal(res, r2)
+    with pytest.raises(RuntimeError):
+        ops.rmsnorm(out, x, w.half(), 1e-6)
+    # attention op classes on a bf16 cache
+    nh, nkv, hd, page, B, nblk, M = 8, 2, 128, 16, 3, 16, 4
+    cfg = ops.AttentionConfigs()
+    cfg.head_num, cfg.kv_head_num, cfg.size_per_head, cfg.tokens_per_block, cfg.max_seq_len, cfg.rope_base = nh, nkv, hd, page, M * page, 1e6
+    rope_op, attn_op = ops.Mi355RopeKVCacheDecodeOp(cfg), ops.Mi355PagedAttnDecodeOp(cfg)
+    kv, sc = kvcache.alloc_layer_cache(nblk, nkv, page, hd, False, DEV, dtype=BF)
+    lk = ops.LayerKVCache()
+    lk.kv_cache_base, lk.seq_size_per_block, lk.layer_id = kv, page, 0
+    inp = ops.PyAttentionInputs()
+    pos = torch.tensor([0, 5, 17], dtype=torch.int32)
+    bt = torch.arange(B * M, dtype=torch.int32).reshape(B, M)
+    inp.is_prefill = False
+    inp.sequence_lengths, inp.kv_cache_kernel_block_id_device = pos, bt.to(DEV)
+    qkv = (torch.randn(B, (nh + 2 * nkv) * hd, generator=_g(3)) * 0.5).to(BF).to(DEV)
+    params = rope_op.prepare(inp)
+    q = rope_op.forward(qkv, lk, params)
+    kv2, _ = kvcache.alloc_layer_cache(nblk, nkv, page, hd, False, DEV, dtype=BF)
+    cs = oracle.rope_cos_sin(hd, 1e6, M * page).to(DEV)
+    q2 = cops.rope_kv_write(qkv, None, cs, pos.to(DEV), bt.to(DEV), kv2, None, nh, nkv, hd, page)
+    assert q.dtype == BF and torch.equal(q, q2) and torch.equal(kv, kv2)
+    o = attn_op.forward(q, lk, attn_op.prepare(inp))
+    o2 = cops.paged_decode_attention(q2, kv2, None, bt.to(DEV), (pos + 1).to(DEV), nkv, page, M * page)
+    assert o.dtype == BF and torch.equal(o, o2)
+    with pytest.raises(RuntimeError):
+        rope_op.forward(qkv.half(), lk, params)                                # fp16 rows against a bf16 cache
