@@ -213,6 +213,12 @@ def test_sampler_and_collective_entry_points_validate_on_the_host():
     assert l.mi355_ban_repeat_ngram(None, 0, 10, 10, None, 4, None, None, None) == 0
     assert l.mi355_allgather_hidden(None, 1, 1, 4, 64, None) == _C.ERR_ARG and b"not opened" in l.mi355_last_error()
     assert l.mi355_decoder_set_embedding_split(None, 1) == _C.ERR_ARG
+    # activation dtype codes are validated before anything is launched
+    assert l.mi355_rmsnorm_dt(1, 1, 1e-6, 2, 64, 1, 7, None) == _C.ERR_ARG and b"act_dtype" in l.mi355_last_error()
+    assert l.mi355_silu_mul_dt(1, 2, 64, 1, 5, None) == _C.ERR_ARG
+    assert l.mi355_allreduce_sum_dt(None, 1, 1, 2, 64, _C.ACT_BF16, None) == _C.ERR_ARG and b"not opened" in l.mi355_last_error()
+    wbad = _C.Weight(1, 1, 4, 256, 64, 256, 64, 128, 9)
+    assert l.mi355_linear_partial(1, 4, ctypes.byref(wbad), 1, 4, None) == _C.ERR_ARG and b"act_dtype" in l.mi355_last_error()
     assert l.mi355_decoder_attach_collective(None, None, 0) == _C.ERR_ARG
     assert l.mi355_rccl_unique_id_bytes() == 128
     assert l.mi355_rccl_unique_id(b"/nonexistent/librccl.so", ctypes.create_string_buffer(128)) < 0 and b"dlopen" in l.mi355_last_error()
