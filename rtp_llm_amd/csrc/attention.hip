@@ -138,6 +138,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
     }
     const int32_t* bt = p.block_table + (size_t)b * p.max_blocks;
     const size_t head_elems = (size_t)p.page * HD;
+    const uint64_t v_off = (uint64_t)p.nkv * head_elems;   // V heads sit nkv heads behind the K heads of a block
     const char* kvb = (const char*)p.kv_base;
     constexpr int ES = INT8 ? 1 : 2;
 
@@ -184,10 +185,13 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             const int wt = min(tb + 8 * a, lastw);
             const int ti = wt - page_of(wt) * p.page;
             const int blk = min(max(wn.raw[a], 0), p.num_blocks - 1);
-            const long hk = ((long)blk * 2 + 0) * p.nkv + kh, hv = hk + p.nkv;
-            kof[a] = hk * (long)head_elems + (long)ti * HD;
-            vof[a] = hv * (long)head_elems + ti;
-            sof[a] = (int)hk * p.page + ti;
+            // 32 x 32 -> 64-bit products (s_mul_i32 + s_mul_hi_u32): the head index fits 31 bits (host check on the scale plane), a
+            // head's elements 32; with `long` operands the scalar unit ran a 64 x 64 multiply chain per window (~40 instructions)
+            const uint32_t hk = (uint32_t)blk * (uint32_t)(2 * p.nkv) + (uint32_t)kh;
+            const uint64_t kbase = (uint64_t)hk * (uint64_t)(uint32_t)head_elems;
+            kof[a] = (long)(kbase + (uint32_t)(ti * HD));
+            vof[a] = (long)(kbase + v_off + (uint32_t)ti);
+            sof[a] = (int)(hk * (uint32_t)p.page) + ti;
         }
         long kb = kof[0]; kb = k1 ? kof[1] : kb; kb = k2 ? kof[2] : kb; kb = k3 ? kof[3] : kb;
         long vb = vof[0]; vb = v1 ? vof[1] : vb; vb = v2 ? vof[2] : vb; vb = v3 ? vof[3] : vb;
