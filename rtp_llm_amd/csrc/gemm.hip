@@ -722,7 +722,15 @@ extern "C" int mi355_linear_forward(const void* x, int32_t M, const mi355_weight
     // blocks without a K split: narrow outputs at moderate M (down_proj, N = 3584: 14 blocks per 128 rows) would leave
     // most CUs idle (measured M = 128: 246 us vs 2 x 21 us as 64-row slabs), so those stay on the decode kernels
     const bool bf = w->act_dtype == MI355_ACT_BF16;   // bf16 activations: 64-row slabs through the staged kernel at every M
-    if (!bf && M >= 128 && w->wbits != 16 && cdiv(w->N_pad / 16, 16) * cdiv(M, 128) >= 128) {
+    // compute-shaped kernel or 64-row slabs of the decode kernels?  A small time model (us), calibrated on MI355X at the Qwen2-7B
+    // shapes (profiles/r03_prefill_gemm_tiles_per_wave.txt): the prefill kernel takes ~2.2 us per 128-k chunk per round of 256
+    // column x row blocks, a 64-row slab ~(weight MB / 1.6 + 6) us.  Narrow outputs at moderate M stay on the slabs (down_proj
+    // at M = 512: 56 blocks, 280 vs 218 us), wider / deeper cases move over earlier than the old ">= 128 blocks" rule allowed
+    // (o_proj at M = 1024: 112 blocks, ~68 vs 204 us).
+    const long pf_blocks = (long)cdiv(w->N_pad / 16, 16) * cdiv(M, 128);
+    const double t_pf = (double)cdiv((int)pf_blocks, 256) * (w->K_pad / 128) * 2.2;
+    const double t_slab = (double)cdiv(M, 64) * ((double)w->K_pad * w->N_pad * w->wbits / 8 / 1.6e6 + 6.0);
+    if (!bf && M >= 128 && w->wbits != 16 && t_pf < t_slab) {
         GemmParams ps; fill_params(ps, x, M, w);
         ps.mode = mode; ps.bias = (const f16*)bias; ps.y = y; ps.ldy = ldy;
         const int rc = mi355_gemm_prefill(&ps, w->wbits, w->group_size, stream);

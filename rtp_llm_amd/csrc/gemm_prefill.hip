@@ -16,9 +16,12 @@
 
 namespace {
 
-template <int WBITS, int GS>
-__global__ __launch_bounds__(512, 2) void gemm_prefill_kernel(const GemmParams p) {
-    constexpr int BM = 128, MB = BM / 16, NW = 8, TPW = 2;   // rows, row blocks, waves, weight tiles per wave
+// TPW = weight tiles per wave: 2 (tile 128 x 256, two blocks per CU) or 4 (128 x 512, one block per CU).  One B-fragment read from
+// LDS feeds TPW MFMAs: at TPW = 2 the 8 waves of a block pull 256 KiB of fragments per 128-k chunk through the CU's LDS port for
+// 512 MFMAs -- 2048 cycles of each, neither hidden behind the other; TPW = 4 halves the LDS traffic per MFMA.
+template <int WBITS, int GS, int TPW>
+__global__ __launch_bounds__(512, TPW == 2 ? 2 : 1) void gemm_prefill_kernel(const GemmParams p) {
+    constexpr int BM = 128, MB = BM / 16, NW = 8;             // rows, row blocks, waves
     constexpr int LPC  = WBITS / 4;
     constexpr int NSUB = (GS > 0) ? 4 / GS : 1;
     constexpr int SPG  = 4 / NSUB;
@@ -111,30 +114,43 @@ __global__ __launch_bounds__(512, 2) void gemm_prefill_kernel(const GemmParams p
     load_w(1, 1);
     __syncthreads();
 
+    auto dq = [&](int d, int t, int s) -> f16x8 {
+        const uint32_t m = GROUPED ? mr[d][t][s / SPG] : mch[t];
+        const f16x2 zn = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u));
+        const f16x2 sc = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
+        if (WBITS == 4) return dequant_w4_vc(wr[d][t][0][s], zn, zn + c960, sc, w4c);
+        const u32x4 w = wr[d][t][(s >> 1) % LPC];   // per-channel int8: exact (u - z) operand, the column scale is applied in fp32 in the epilogue
+        return dequant_w8<GROUPED>(w[(s & 1) * 2], w[(s & 1) * 2 + 1], zn, sc);
+    };
     auto compute = [&](int d, int buf) {
-        f16x8 a[TPW][4];
+        if constexpr (TPW == 2) {            // all 8 operands of the chunk first, then 64 MFMAs
+            f16x8 a[TPW][4];
 #pragma unroll
-        for (int t = 0; t < TPW; ++t)
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a[t][s] = dq(d, t, s);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const f16x8 b = __builtin_bit_cast(f16x8, xs[buf][(s * 4 + q) * (16 * MB) + mb * 16 + (jj ^ q)]);
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) acc[t][mb] = mfma16x16x32(a[t][s], b, acc[t][mb]);
+                }
+        } else {                             // per k-step: TPW operands (16 registers), 8 fragment reads, 8 x TPW MFMAs
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const uint32_t m = GROUPED ? mr[d][t][s / SPG] : mch[t];
-                const f16x2 zn = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u));
-                const f16x2 sc = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
-                if (WBITS == 4) {
-                    a[t][s] = dequant_w4_vc(wr[d][t][0][s], zn, zn + c960, sc, w4c);
-                } else {   // per-channel int8: exact (u - z) operand, the column scale is applied in fp32 in the epilogue
-                    const u32x4 w = wr[d][t][(s >> 1) % LPC];
-                    a[t][s] = dequant_w8<GROUPED>(w[(s & 1) * 2], w[(s & 1) * 2 + 1], zn, sc);
+                f16x8 a[TPW];
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) a[t] = dq(d, t, s);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const f16x8 b = __builtin_bit_cast(f16x8, xs[buf][(s * 4 + q) * (16 * MB) + mb * 16 + (jj ^ q)]);
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) acc[t][mb] = mfma16x16x32(a[t], b, acc[t][mb]);
                 }
             }
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const f16x8 b = __builtin_bit_cast(f16x8, xs[buf][(s * 4 + q) * (16 * MB) + mb * 16 + (jj ^ q)]);
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) acc[t][mb] = mfma16x16x32(a[t][s], b, acc[t][mb]);
-            }
+        }
     };
 
     for (int c = 0; c < KC; c += 2) {
@@ -174,8 +190,15 @@ __global__ __launch_bounds__(512, 2) void gemm_prefill_kernel(const GemmParams p
 
 template <int WBITS, int GS>
 int launch_prefill_t(const GemmParams& p, hipStream_t st) {
-    dim3 grid(cdiv(p.NT, 16), cdiv(p.M, 128));
-    hipLaunchKernelGGL((gemm_prefill_kernel<WBITS, GS>), grid, dim3(512), 0, st, p);
+    // four tiles per wave (one block per CU) when its grid is one well-filled round of the 256 CUs or many rounds; in between
+    // (257..~560 blocks: a second round that is mostly empty) and for small grids the two-tile shape with two blocks per CU wins
+    // (profiles/r03_prefill_gemm_tiles_per_wave.txt: gate_up M = 4096 959 -> 1055 TFLOP/s, down 932 -> 1066, o 885 -> 1015;
+    // qkv M = 4096 with 288 blocks 755 vs 667, gate_up M = 512 with 296 blocks 776 vs 701)
+    const long b4 = (long)cdiv(p.NT, 32) * cdiv(p.M, 128);
+    const bool wide = TUNE(3) == 4 || (TUNE(3) != 2 && ((b4 >= 140 && b4 <= 256) || b4 >= 560));
+    dim3 grid(cdiv(p.NT, wide ? 32 : 16), cdiv(p.M, 128));
+    if (wide) hipLaunchKernelGGL((gemm_prefill_kernel<WBITS, GS, 4>), grid, dim3(512), 0, st, p);
+    else      hipLaunchKernelGGL((gemm_prefill_kernel<WBITS, GS, 2>), grid, dim3(512), 0, st, p);
     MI355_CHECK_LAUNCH("gemm_prefill_kernel");
     return MI355_OK;
 }
