@@ -653,6 +653,12 @@ GemmPlan plan_gemm(int M, const mi355_weight_t* w, int max_splits) {
         g.cfg = 8;
         g.bn  = kCfgBN[8];
     }
+    // 16-bit weights with a vocabulary-sized N (lm_head) at M > 32: 1188 blocks of BN = 128 fill the rounds over the CUs better
+    // than 594 of BN = 256 (measured M = 64, 152064 columns: 204.8 -> 187.9 us = 5.80 TB/s; profiles/r03_lmhead_block_shapes.txt)
+    if (MB >= 3 && TUNE(2) == 0 && w->wbits == 16 && NT >= 4096 && w->act_dtype == MI355_ACT_F16) {
+        g.cfg = 8;
+        g.bn  = kCfgBN[8];
+    }
     return g;
 }
 
