@@ -191,6 +191,65 @@ def gen_ref_layers():
     np.savez_compressed(os.path.join(OUT, "ref_layers.npz"), **out)
 
 
+def gen_ref_layers_bf16():
+    """The same reference implementations on bf16 tensors (the reference's second activation dtype) ->
+    tests/golden/ref_layers_bf16.npz; bf16 arrays are stored as their int16 bit patterns (numpy has no bf16)."""
+    _install_stubs()
+    MP = "rtp_llm/models_py/"
+    norm = _load("ref_norm", MP + "modules/base/common/norm.py")
+    real_props = torch.cuda.get_device_properties
+    torch.cuda.get_device_properties = lambda *a, **k: types.SimpleNamespace(gcnArchName="gfx950")
+    try:
+        fmha = _load("ref_fmha_test", MP + "modules/base/rocm/test/rocm_fmha_test.py")
+    finally:
+        torch.cuda.get_device_properties = real_props
+    rope = _load("ref_rope_test", MP + "modules/factory/attention/rocm_impl/test/test_fused_qkv_transpose_v3.py")
+    mlp = _load("ref_dense_mlp", MP + "modules/hybrid/test/dense_mlp_ref.py")
+    BF = torch.bfloat16
+    bits = lambda t: t.contiguous().view(torch.int16).numpy()
+    out = {}
+    g = torch.Generator().manual_seed(4321)
+    rn = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s)
+    for i, (T, H) in enumerate([(7, 896), (5, 3584), (2, 8199)]):
+        x, w = rn(T, H).to(BF), rn(H).to(BF)
+        y = norm.RMSNormTorch(w, 1e-6)(x)
+        assert y.dtype == BF
+        out[f"norm{i}_x"], out[f"norm{i}_w"], out[f"norm{i}_y"] = bits(x), bits(w), bits(y)
+    out["norm_count"] = np.array(3)
+    for i, (nh, nkv, hd, base, lens) in enumerate([(28, 4, 128, 1e6, [5, 11]), (8, 1, 128, 5e5, [3, 1, 9])]):
+        T = sum(lens)
+        qkv = rn(T, (nh + 2 * nkv) * hd).to(BF)
+        cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+        Q, K, V = rope._torch_reference(qkv, nh, nkv, hd, hd, base, 1.0, cu)
+        assert Q.dtype == BF
+        out[f"rope{i}_qkv"], out[f"rope{i}_cfg"], out[f"rope{i}_lens"] = bits(qkv), np.array([nh, nkv, hd, base]), np.array(lens)
+        out[f"rope{i}_q"], out[f"rope{i}_k"], out[f"rope{i}_v"] = bits(Q), bits(K), bits(V)
+    out["rope_count"] = np.array(2)
+    for i, (nh, nkv, hd, block, ctx) in enumerate([(28, 4, 128, 16, [1, 17, 70]), (8, 1, 128, 16, [5, 100])]):
+        B, x = len(ctx), 8
+        mb = (max(ctx) + block - 1) // block
+        nblk = B * mb
+        bt = torch.randperm(nblk, generator=g).reshape(B, mb).to(torch.int32)
+        q = rn(B, nh, hd).to(BF)
+        Kn, Vn = rn(nblk * block, nkv, hd).to(BF), rn(nblk * block, nkv, hd).to(BF)
+        k_cache = Kn.view(nblk, block, nkv, hd // x, x).permute(0, 2, 3, 1, 4).contiguous()
+        v_cache = Vn.view(nblk, block, nkv, hd).permute(0, 2, 3, 1).contiguous()
+        one = torch.tensor([1.0])
+        o = fmha.run_native(q, k_cache, v_cache, bt, torch.tensor(ctx), max(ctx), "auto", nkv, 1.0 / hd ** 0.5, None, one, one,
+                            nh // nkv, BF)
+        assert o.dtype == BF
+        out[f"attn{i}_cfg"] = np.array([nh, nkv, hd, block])
+        out[f"attn{i}_ctx"], out[f"attn{i}_bt"], out[f"attn{i}_q"] = np.array(ctx), bt.numpy(), bits(q)
+        out[f"attn{i}_k"], out[f"attn{i}_v"], out[f"attn{i}_out"] = bits(Kn), bits(Vn), bits(o)
+    out["attn_count"] = np.array(2)
+    H, I, T = 256, 640, 9
+    x, gate, up, down = rn(T, H, s=0.5).to(BF), rn(H, I, s=0.06).to(BF), rn(H, I, s=0.06).to(BF), rn(I, H, s=0.04).to(BF)
+    y = mlp.DenseMLP(gate, up, down, sys.modules["rtp_llm.ops"].ActivationType.Swiglu)(x)
+    out.update(mlp_x=bits(x), mlp_gate=bits(gate), mlp_up=bits(up), mlp_down=bits(down), mlp_y=bits(y))
+    np.savez_compressed(os.path.join(OUT, "ref_layers_bf16.npz"), **out)
+    print("wrote ref_layers_bf16.npz")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     mod = _import_reference_device_impl()
@@ -226,6 +285,7 @@ def main():
     q8, s8 = impl.apply_int8(W.clone(), "cpu")
     np.savez_compressed(os.path.join(OUT, "quant_int8.npz"), weight=W.numpy(), ref_q=q8.numpy(), ref_scale=s8.numpy())
     gen_ref_layers()
+    gen_ref_layers_bf16()
     print("golden vectors written to", os.path.abspath(OUT))
 
 

@@ -15,6 +15,10 @@ this path, each function citing the reference lines it follows.  Pinning status
     ref_masked_attention, DenseMLP -- the functions its ROCm unit tests compare the native kernels with at
     atol=rtol=1e-2), executed unmodified by oracle/gen_golden.py -> tests/golden/ref_layers.npz, checked by
     tests/test_oracle_pinned.py (bit-equal, or within one fp16 ulp where the fp32 contraction order differs).
+  * The same four in bf16 (the functions are dtype-generic: fp32 math, rounding to the input dtype where the reference's tensors
+    have that dtype): PINNED against the same reference implementations executed on bf16 tensors ->
+    tests/golden/ref_layers_bf16.npz (RMSNorm bit-equal; RoPE / attention within one bf16 ulp).
+  * Scaled RoPE styles (linear / llama3 / yarn): PINNED bit for bit, see rope_inv_freq and oracle/gen_rope_golden.py.
   * Chain rejection sampling (speculative verify): PINNED against the reference's own known-answer kernel tests
     (bindings/cuda/test/CudaSpeculativeSamplingTest.cc:36-366, transcribed in tests/spec_vectors.py).
   * W4A16 / W8A16 GEMM results and INT8 KV-cache numerics: PARITY UNPINNED — the reference

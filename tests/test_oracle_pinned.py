@@ -96,3 +96,52 @@ def test_mlp_reproduces_reference_dense_mlp(ref):
     gu = oracle.linear(x, torch.cat([gate, up], dim=1).float())
     got = oracle.linear(oracle.silu_mul(gu), down.float())
     assert torch.allclose(got.float(), y.float(), atol=2e-3, rtol=2e-3), float((got.float() - y.float()).abs().max())
+
+
+# ------------------------------------------------------------------ the same pins in bf16 (the reference's second activation dtype)
+@pytest.fixture(scope="module")
+def ref_bf16(golden_dir):
+    return np.load(os.path.join(golden_dir, "ref_layers_bf16.npz"))
+
+
+def _bf(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).view(torch.bfloat16)
+
+
+def test_bf16_oracle_reproduces_the_reference_torch_references(ref_bf16):
+    """tests/golden/ref_layers_bf16.npz: RMSNormTorch, _torch_reference (RoPE), run_native (paged attention) and DenseMLP of the
+    reference executed on bf16 tensors (oracle/gen_golden.py:gen_ref_layers_bf16; arrays stored as int16 bit patterns).  The
+    oracle run on the same bf16 tensors must reproduce them: this is what the bf16 HIP kernels are compared against."""
+    r = ref_bf16
+    for i in range(int(r["norm_count"])):
+        x, w, y = _bf(r[f"norm{i}_x"]), _bf(r[f"norm{i}_w"]), _bf(r[f"norm{i}_y"])
+        assert torch.equal(oracle.rmsnorm(x, w, 1e-6), y), f"norm case {i}"
+    for i in range(int(r["rope_count"])):
+        nh, nkv, hd, base = r[f"rope{i}_cfg"]
+        nh, nkv, hd = int(nh), int(nkv), int(hd)
+        qkv, lens = _bf(r[f"rope{i}_qkv"]), r[f"rope{i}_lens"].tolist()
+        pos = torch.cat([torch.arange(n, dtype=torch.int32) for n in lens])
+        T = qkv.shape[0]
+        cs = oracle.rope_cos_sin(hd, float(base), max(lens))
+        q = oracle.apply_rope(qkv[:, : nh * hd].reshape(T, nh, hd), pos, cs)
+        k = oracle.apply_rope(qkv[:, nh * hd: (nh + nkv) * hd].reshape(T, nkv, hd), pos, cs)
+        assert torch.equal(qkv[:, (nh + nkv) * hd:].reshape(T, nkv, hd), _bf(r[f"rope{i}_v"]))
+        for got, want in ((q, _bf(r[f"rope{i}_q"])), (k, _bf(r[f"rope{i}_k"]))):
+            d = (got.float() - want.float()).abs()
+            ulp = torch.exp2(torch.floor(torch.log2(torch.clamp(torch.maximum(want.float().abs(), got.float().abs()), min=2.0 ** -14))) - 7)
+            assert bool((d <= torch.clamp(ulp, min=1e-6)).all()), f"rope case {i}: max {d.max()}"      # last-bit angle differences: <= 1 bf16 ulp
+            assert (d > 0).float().mean() < 1e-3, f"rope case {i}: {(d > 0).float().mean():.4f} of the elements differ"
+    for i in range(int(r["attn_count"])):
+        nh, nkv, hd, block = (int(v) for v in r[f"attn{i}_cfg"])
+        ctx, bt, q = r[f"attn{i}_ctx"].tolist(), _t(r[f"attn{i}_bt"]), _bf(r[f"attn{i}_q"])
+        K, V, out = _bf(r[f"attn{i}_k"]), _bf(r[f"attn{i}_v"]), _bf(r[f"attn{i}_out"])
+        for b, n in enumerate(ctx):
+            idx = torch.tensor([int(bt[b, j // block]) * block + j % block for j in range(n)])
+            got = oracle.attention_decode(q[b], K[idx], V[idx], 1.0 / math.sqrt(hd))
+            d = (got.float() - out[b].float()).abs()
+            assert d.max() <= 2.0 ** -7 * max(1.0, float(out[b].float().abs().max())), (i, b, float(d.max()))   # <= one bf16 ulp
+            assert (d > 0).float().mean() < 0.01, (i, b)
+    x, gate, up, down, y = (_bf(r[k]) for k in ("mlp_x", "mlp_gate", "mlp_up", "mlp_down", "mlp_y"))
+    gu = oracle.linear(x, torch.cat([gate, up], dim=1).float())
+    got = oracle.linear(oracle.silu_mul(gu), down.float())
+    assert torch.allclose(got.float(), y.float(), atol=1.6e-2, rtol=1.6e-2), float((got.float() - y.float()).abs().max())
