@@ -8,11 +8,11 @@
 // (rtp_llm/cpp/models/PyWrappedModel.cc:938-1080, bindings/core/CudaSampleOp.cc:687-700)
 // and the per-batch-size graph capture of rtp_llm/cpp/cuda_graph/cuda_graph_runner.cc.
 //
-// Launches per layer (tp = 1), above 8 rows: QKV GEMM (split-K slabs) -> reduce+bias+RoPE+KV-write ->
+// Launches per layer (tp = 1), above 10 rows: QKV GEMM (split-K slabs) -> reduce+bias+RoPE+KV-write ->
 // paged attention (+ partition reduce) -> O GEMM (slabs) -> reduce+residual+RMSNorm ->
 // gate_up GEMM with fused SiLU-gate -> down GEMM (slabs) -> reduce+residual+RMSNorm
 // (already the next layer's input norm).  No standalone reduce / add / activation kernels.
-// Up to 8 rows every GEMM is a full-K launch with its consumer fused (gemm_fullk.hip), 6 launches:
+// Up to 10 rows every GEMM is a full-K launch with its consumer fused (gemm_fullk.hip), 6 launches:
 // [RMSNorm on load +] QKV + bias + RoPE + KV write -> attention -> partition reduce -> O + residual (leaves the
 // per-tile sums of squares) -> RMSNorm on load + gate_up + SiLU-gate -> down + residual.
 #include <hip/hip_runtime.h>
@@ -219,7 +219,7 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     d->pf_mask = 0; d->pf_pending = false;
     d->fuse_qkv = cfg->kv_dtype == MI355_KV_FP16 && cfg->rope_dim == cfg->hd;
     d->fuse_o = d->fuse_down = cfg->tp_size == 1;
-    d->fuse_rows = 8;
+    d->fuse_rows = 10;   // measured crossover (round 3): b = 9 2.23 vs 2.29 ms fused vs staged, b = 12 2.37 vs 2.35, b = 16 2.56 vs 2.38
     // W4 layers only: for small fp16 models (the 0.5B draft of speculative decoding: 36-56 blocks per launch) the fused
     // launches measured behind the staged kernels (draft step 1.11 vs 1.05 ms), although the kernels take fp16 weights
     auto w4ok = [](const mi355_weight_t* w) { return w->wbits == 4 && mi355_fullk_weight_ok(w); };
