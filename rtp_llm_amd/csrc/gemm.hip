@@ -649,7 +649,7 @@ GemmPlan plan_gemm(int M, const mi355_weight_t* w, int max_splits) {
     // Short-K / narrow-N shapes at M > 32 (qkv, o): BN = 256 leaves < 2/3 of the CUs with a block even after the
     // split; the BN = 128 shape (8 n-waves x 1 tile) doubles the block count at the same slab traffic
     // (measured M = 64: qkv 10.97 -> 9.45 us, o 10.91 -> 9.17 us; down stays on BN = 256, 21.0 vs 23.2 us).
-    if (MB >= 3 && TUNE(2) == 0 && w->wbits != 16 && blocks_n * g.nsplit <= 160) {
+    if (MB >= 3 && TUNE(2) == 0 && w->wbits != 16 && w->act_dtype == MI355_ACT_F16 && blocks_n * g.nsplit <= 160) {
         g.cfg = 8;
         g.bn  = kCfgBN[8];
     }

@@ -9,7 +9,8 @@ import sys
 
 import torch
 
-os.environ["MI355_TUNING_LIB"] = "1"   # experiment switches live in the tuning build only (python -m rtp_llm_amd.build --tuning)
+if "--product" not in sys.argv:
+    os.environ["MI355_TUNING_LIB"] = "1"   # experiment switches live in the tuning build only (python -m rtp_llm_amd.build --tuning)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rtp_llm_amd import _C, model, ops  # noqa: E402
 
@@ -30,14 +31,16 @@ def main():
     ap.add_argument("--nosmall", type=int, default=0, help="1: disable the persistent small-M kernel")
     ap.add_argument("--tune", default="", help="idx=val,... extra mi355_debug_set switches")
     ap.add_argument("--copies", type=int, default=0, help="weight copies rotated (0: enough to defeat the 256 MiB Infinity Cache; 1: cache-resident)")
+    ap.add_argument("--product", action="store_true", help="time the product library (no experiment switches) instead of the tuning build")
     ap.add_argument("--bf16", type=int, default=0, help="1: bf16 activations (staged kernel, accumulator-side dequant)")
     a = ap.parse_args()
     adt = torch.bfloat16 if a.bf16 else torch.float16
     lib = _C.lib()
-    lib.mi355_debug_set.argtypes = [C.c_int, C.c_int]
-    lib.mi355_debug_set(0, a.var); lib.mi355_debug_set(1, a.nsplit); lib.mi355_debug_set(2, a.nbw); lib.mi355_debug_set(4, a.nosmall); lib.mi355_debug_set(5, a.nowide)
-    for kv_ in filter(None, a.tune.split(",")):
-        lib.mi355_debug_set(int(kv_.split("=")[0]), int(kv_.split("=")[1]))
+    if not a.product:
+        lib.mi355_debug_set.argtypes = [C.c_int, C.c_int]
+        lib.mi355_debug_set(0, a.var); lib.mi355_debug_set(1, a.nsplit); lib.mi355_debug_set(2, a.nbw); lib.mi355_debug_set(4, a.nosmall); lib.mi355_debug_set(5, a.nowide)
+        for kv_ in filter(None, a.tune.split(",")):
+            lib.mi355_debug_set(int(kv_.split("=")[0]), int(kv_.split("=")[1]))
     dev = "cuda:0"
     gen = torch.Generator(device=dev).manual_seed(0)
     for kind in a.kinds.split(","):
