@@ -3,7 +3,8 @@
 usage: attn_bench.py [--batch 64 --ctx 1024 --int8 --ps N]"""
 import argparse, ctypes as C, os, sys
 import torch
-os.environ["MI355_TUNING_LIB"] = "1"   # experiment switches live in the tuning build only (python -m rtp_llm_amd.build --tuning)
+if "--product" not in sys.argv:
+    os.environ["MI355_TUNING_LIB"] = "1"   # experiment switches live in the tuning build only (python -m rtp_llm_amd.build --tuning)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rtp_llm_amd import _C, kvcache, ops  # noqa: E402
 
@@ -13,10 +14,13 @@ def main():
     ap.add_argument("--int8", action="store_true"); ap.add_argument("--ps", type=int, default=0)
     ap.add_argument("--page", type=int, default=16); ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--seq-bt", type=int, default=0, help="1: identity block table (contiguous pages) instead of a random permutation")
+    ap.add_argument("--product", action="store_true", help="time the product library instead of the tuning build")
     ap.add_argument("--tune", default="", help="idx=val,... forwarded to mi355_debug_set")
     a = ap.parse_args()
-    lib = _C.lib(); lib.mi355_debug_set_attn.argtypes = [C.c_int]; lib.mi355_debug_set_attn(a.ps)
-    lib.mi355_debug_set.argtypes = [C.c_int, C.c_int]
+    lib = _C.lib()
+    if not a.product:
+        lib.mi355_debug_set_attn.argtypes = [C.c_int]; lib.mi355_debug_set_attn(a.ps)
+        lib.mi355_debug_set.argtypes = [C.c_int, C.c_int]
     for kv_ in filter(None, a.tune.split(",")):
         lib.mi355_debug_set(int(kv_.split("=")[0]), int(kv_.split("=")[1]))
     dev = "cuda:0"; nh, nkv, hd = 28, 4, 128
