@@ -39,7 +39,8 @@ def _compile(name, force, tuning=False):
     obj = os.path.join(OBJ, os.path.splitext(name)[0] + ("_tuning.o" if tuning else ".o"))
     if not force and not _stale(src, obj):
         return obj, False
-    cmd = [HIPCC] + CFLAGS + (["-DMI355_TUNING"] if tuning else []) + ["-c", src, "-o", obj]
+    extra = os.environ.get("MI355_EXTRA_CFLAGS", "").split() if tuning else []   # tuning build only (e.g. -DMI355_FULLK_STAMPS)
+    cmd = [HIPCC] + CFLAGS + (["-DMI355_TUNING"] if tuning else []) + extra + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {name}:\n{r.stdout}\n{r.stderr}")

@@ -23,6 +23,12 @@
 #include <new>
 #include <vector>
 #include "internal.h"
+#ifdef MI355_TUNING
+extern int g_tune[8];   // gemm.hip: experiment switches of the tuning build
+#define TUNE(i) g_tune[i]
+#else
+#define TUNE(i) 0
+#endif
 
 void mi355_set_error(const char* fmt, ...);
 
@@ -219,7 +225,8 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     d->pf_mask = 0; d->pf_pending = false;
     d->fuse_qkv = cfg->kv_dtype == MI355_KV_FP16 && cfg->rope_dim == cfg->hd;
     d->fuse_o = d->fuse_down = cfg->tp_size == 1;
-    d->fuse_rows = 10;   // measured crossover (round 3): b = 9 2.23 vs 2.29 ms fused vs staged, b = 12 2.37 vs 2.35, b = 16 2.56 vs 2.38
+    d->fuse_rows = 12;   // measured crossover (round 3, after the full-K rework): b = 10 2.22 ms fused; b = 12 2.29 fused vs 2.38 staged; b = 16 2.49 vs 2.41
+    if (TUNE(6) > 0) d->fuse_rows = TUNE(6);   // tuning build: crossover experiments (tools/batch_sweep.py --tune 6=N)
     // W4 layers only: for small fp16 models (the 0.5B draft of speculative decoding: 36-56 blocks per launch) the fused
     // launches measured behind the staged kernels (draft step 1.11 vs 1.05 ms), although the kernels take fp16 weights
     auto w4ok = [](const mi355_weight_t* w) { return w->wbits == 4 && mi355_fullk_weight_ok(w); };

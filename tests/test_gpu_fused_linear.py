@@ -15,7 +15,7 @@ from rtp_llm_amd import _C, kvcache, model, ops
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL = dict(atol=1e-2, rtol=1e-2)
-MS = (1, 5, 16, 17, 32, 33, 48, 64)
+MS = (1, 2, 4, 5, 7, 8, 9, 16, 17, 32, 33, 48, 64)   # <= 4 / <= 8 rows: one / two dense activation loads per chunk (gemm_fullk.hip XL)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -80,7 +80,8 @@ def test_qkv_rope_kv_write_vs_oracle(nh, nkv, hd, hidden, page, q_len, gs):
     cfg = model.ModelConfig("t", 1, hidden, nh, nkv, hd, 64, 128, max_pos=max_blocks * page)
     cs = oracle.rope_cos_sin(hd, cfg.rope_theta, cfg.max_pos)
     bias = (torch.randn(N, generator=torch.Generator().manual_seed(4)) * 0.1).half()
-    for T in (q_len, 5 * q_len, 16 * q_len, (64 // q_len) * q_len):
+    for T in sorted({q_len, 2 * q_len, 4, 5 * q_len, 8, 16 * q_len, (64 // q_len) * q_len} - {0}):
+        if T % q_len: continue
         nseq = T // q_len
         g = torch.Generator().manual_seed(T)
         x = (torch.randn(T, hidden, generator=g) * 0.5).half()
@@ -131,7 +132,7 @@ def test_qkv_rope_kv_write_stale_rows_and_int8_refusal():
     assert ops.qkv_rope_kv_write(x, packed, None, cs, pos, bt, kv8, sc8, nh, nkv, hd, page, 1) is None
 
 
-@pytest.mark.parametrize("M", [1, 3, 8, 16])
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8, 9, 16])
 def test_fused_norm_chain_vs_oracle(M):
     """o_proj + residual (leaving per-tile sums of squares) -> RMSNorm on load + gate_up + SiLU-gate, and -> RMSNorm on load +
     QKV + RoPE + KV write: the launches of a small-batch layer without norm kernels, against oracle.rmsnorm + oracle.linear."""
