@@ -8,11 +8,11 @@
 // (rtp_llm/cpp/models/PyWrappedModel.cc:938-1080, bindings/core/CudaSampleOp.cc:687-700)
 // and the per-batch-size graph capture of rtp_llm/cpp/cuda_graph/cuda_graph_runner.cc.
 //
-// Launches per layer (tp = 1), above 10 rows: QKV GEMM (split-K slabs) -> reduce+bias+RoPE+KV-write ->
+// Launches per layer (tp = 1), above 12 rows: QKV GEMM (split-K slabs) -> reduce+bias+RoPE+KV-write ->
 // paged attention (+ partition reduce) -> O GEMM (slabs) -> reduce+residual+RMSNorm ->
 // gate_up GEMM with fused SiLU-gate -> down GEMM (slabs) -> reduce+residual+RMSNorm
 // (already the next layer's input norm).  No standalone reduce / add / activation kernels.
-// Up to 10 rows every GEMM is a full-K launch with its consumer fused (gemm_fullk.hip), 6 launches:
+// Up to 12 rows every GEMM is a full-K launch with its consumer fused (gemm_fullk.hip), 6 launches:
 // [RMSNorm on load +] QKV + bias + RoPE + KV write -> attention -> partition reduce -> O + residual (leaves the
 // per-tile sums of squares) -> RMSNorm on load + gate_up + SiLU-gate -> down + residual.
 #include <hip/hip_runtime.h>
