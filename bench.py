@@ -49,14 +49,18 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+TRAFFIC_KERNEL_SOURCES = ("common.h", "gemm_common.h", "gemm.hip", "gemm_wide.hip")
+
+
 def gemm_sources_sha():
-    """Hash of the sources of the dominant kernel family: a committed PMC traffic file is only quoted for the kernels it measured."""
+    """Hash of the sources of the kernels the committed PMC traffic file measured: the four quantised linears of the 64-row step are
+    gemm_wq_kernel (gemm.hip) and gemm_wide_kernel (gemm_wide.hip) over the shared headers.  The few-row full-K kernels
+    (gemm_fullk.hip, <= 12 rows) and the prefill GEMM are not launched by that workload, so edits there do not stale the file."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "rtp_llm_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.startswith("gemm") and (f.endswith(".hip") or f.endswith(".h")):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    for f in TRAFFIC_KERNEL_SOURCES:
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -312,7 +316,7 @@ def main():
                 if tj.get("gemm_sources_sha") == gemm_sources_sha():
                     traffic, traffic_src = int(tj["gemm_quant_bytes_per_launch"]), tj.get("source")
                 else:
-                    traffic_src = "stale: profiles/r03_traffic.json was collected for different gemm*.hip sources (re-run tools/engine_traffic.sh)"
+                    traffic_src = "stale: profiles/r03_traffic.json was collected for different sources of gemm.hip / gemm_wide.hip (re-run tools/engine_traffic.sh)"
         except Exception:  # noqa: BLE001
             traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": "gemm_wq_kernel / gemm_wide_kernel (the four quantised linears of a layer: qkv, o, gate_up, down)", "achieved": round(ach, 1),

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(MB >= 3 ? (TPB >= 2 ? 512 : 768) : 1024) void gemm_
     constexpr bool W16 = GS == 0;                    // GS: 4 -> W4 g128, 2 -> g64, 1 -> g32, 0 -> fp16 weights (no meta, 4 wave-loads per chunk)
     constexpr int LPC = W16 ? 4 : 1;
     constexpr int NSUB = W16 ? 1 : 4 / (W16 ? 1 : GS), SPG = 4 / NSUB;
-    constexpr int WD = (GS == 0 && TPB >= 2) ? 1 : 2; // weight ring, chunks (fp16 tiles are 4x the registers; four chunks for down_proj's long slices measured slower: 13.0 vs 11.3 us)
+    constexpr int WD = (GS == 0 && TPB >= 2) ? 1 : 2; // weight ring, chunks (fp16 tiles are 4x the registers).  Deeper rings for down_proj's ten-chunk
+                                                      // slices do not pay (3 / 4 / 5 chunks: 13.6 / 13.0 / 11.5 us against 11.3): its loop already streams at ~6 TB/s
     constexpr int HD = ((MB >= 3 && TPB < 2) || (MB == 2 && TPB >= 2) || NORM || TPB >= 4 || WD == 1) ? 2 : 4;   // activation ring, half chunks (2 k-steps x MB row blocks each); by register budget
     constexpr bool HELP = MB == 1 && (NORM || EPI == FK_ROPE);
     constexpr int RPL = 4 * XL, SPL = 4 / XL;        // XL < 4: rows per activation load, k-steps per load
