@@ -108,8 +108,8 @@ __global__ __launch_bounds__(MB >= 3 ? (TPB >= 2 ? 512 : 768) : 1024) void gemm_
                 hsq[r] = bload128<0>(rq, (r < p.M && lane < nv) ? (uint32_t)(r * fp.ssq_ld + lane * 4) * 4u : OOBX);
         }
         if (threadIdx.x < 16) rs_sh[threadIdx.x] = 0.f;
-        // the LDS stores above complete, then the barrier: NOT __syncthreads(), whose release fence would also make the helper
-        // wait for its requests to come back (vmcnt(0)) with every K wave parked behind it (measured: +2 to 3.5 us per launch)
+        // the LDS stores above complete, then the barrier, with the helper's requests still in flight across it (spelled out: this is
+        // what __syncthreads() compiles to on gfx950 -- lgkmcnt(0) + s_barrier, no vmcnt drain -- and nothing weaker or stronger will do)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 
