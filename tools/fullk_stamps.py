@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the time of one full-K launch goes at a few rows: per-wave wall_clock64 stamps (100 MHz) at entry / requests out
 (+ norm meet) / first half chunk computed (= first weights landed) / loop done / slices met / epilogue stores issued.
-Tuning build only (python -m rtp_llm_amd.build --tuning).  usage: fullk_stamps.py [--ms 1,8]"""
+Tuning build with MI355_EXTRA_CFLAGS=-DMI355_FULLK_STAMPS only.  usage: fullk_stamps.py [--ms 1,8]"""
 import argparse, ctypes as C, os, sys
 import torch
 os.environ["MI355_TUNING_LIB"] = "1"
@@ -22,6 +22,9 @@ gamma = torch.ones(H, dtype=torch.float16, device=dev)
 lib = _C.lib()
 for kv_ in [t for t in a.set.split(",") if t]:
     k_, v_ = kv_.split("="); lib.mi355_debug_set(int(k_), int(v_))
+if not hasattr(lib, "mi355_debug_fullk_stamps"):
+    sys.exit("the tuning library was built without the stamps: touch rtp_llm_amd/csrc/gemm_fullk.hip && "
+             "MI355_EXTRA_CFLAGS=-DMI355_FULLK_STAMPS python -m rtp_llm_amd.build --tuning  (the stamp stores change the schedule: rebuild without the flag afterwards)")
 lib.mi355_debug_fullk_stamps.argtypes = [C.c_void_p]
 NB = 4096
 st = torch.zeros(NB * 16 * 6, dtype=torch.int64, device=dev)
