@@ -251,6 +251,37 @@ int mi355_qkv_rope_kv_write(const void* x, int32_t M, const mi355_weight_t* wqkv
                             const mi355_fused_norm_t* norm, const float* cos_sin, int32_t rope_dim, int32_t max_pos,
                             const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq, int32_t q_len,
                             int32_t nh, const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count, mi355_stream_t stream);
+/*
+ * 17-64-row steps: the fused launches above with the activations handed over as an IMAGE (gemm_fullk64.hip).
+ * With K inside one block, every block pulls all M activation rows of its K range through its CU; gathered from the row-major tensor
+ * that is 16 runs of 64 B per MFMA fragment at the row stride, which the L2s serve at a fifth of the rate of dense 1 KB runs when the
+ * whole chip asks for the same rows (profiles/r04_fullk64_access_patterns.txt: QKV at 64 rows 19.8 vs 11.2 us).  The image stores
+ * x[M][K] (16-bit elements) fragment by fragment: element (row, col) at index
+ *   ((((col / 32) * ceil(M / 16) + row / 16) * 64 + ((col % 32) / 8) * 16 + row % 16) * 8) + col % 8
+ * i.e. 16-byte pieces of a row stay whole, so a producer's vector store only changes its address.  Rows past M inside the last row
+ * block are never read back as results.  Producers: mi355_add_rmsnorm_img (y), mi355_paged_attn_rows_img (out), or
+ * mi355_act_image_pack from a row-major tensor (direction 1: back).  Consumers: mi355_qkv_rope_kv_write_img,
+ * mi355_linear_residual_img: same arguments and results as the entry points without the suffix (no fused norm: the producer
+ * normed), W4 group-wise weights, 16 < M <= 64, K <= 5760, else MI355_ERR_UNSUPPORTED.
+ * Reference boundary these keep: modules/hybrid/causal_attention.py:75-93 (qkv_proj -> rope / kv write -> attention -> o_proj),
+ * model_desc/qwen3.py:57-79 (norm -> attention -> residual add).
+ */
+size_t mi355_act_image_bytes(int32_t M, int32_t K);
+int mi355_act_image_pack(const void* src, int32_t M, int32_t K, void* dst, int32_t direction, mi355_stream_t stream);
+int mi355_add_rmsnorm_img(const void* x, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
+                          const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M, int32_t H,
+                          void* y_img, int32_t act_dtype, mi355_stream_t stream);
+int mi355_paged_attn_rows_img(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_table,
+                              int32_t max_blocks_per_seq, const int32_t* positions, int32_t B, int32_t q_len, int32_t nh,
+                              float scale, int32_t max_seq_len, void* out_img, void* workspace, size_t workspace_bytes,
+                              mi355_stream_t stream);
+int mi355_linear_residual_img(const void* x_img, int32_t M, const mi355_weight_t* w, const void* bias, const void* residual_in,
+                              void* residual_out, float* tile_sumsq_out, int32_t tile_sumsq_ld, mi355_stream_t stream);
+int mi355_qkv_rope_kv_write_img(const void* x_img, int32_t M, const mi355_weight_t* wqkv, const void* qkv_bias,
+                                const float* cos_sin, int32_t rope_dim, int32_t max_pos, const int32_t* positions,
+                                const int32_t* block_table, int32_t max_blocks_per_seq, int32_t q_len, int32_t nh,
+                                const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count, mi355_stream_t stream);
+
 /* The same for q_len rows per sequence (speculative verify, chunked prefill): token t = row t % q_len of sequence t / q_len,
  * block_table is [T / q_len][max_blocks_per_seq]; positions[t] < 0 marks a padding row (q produced, nothing stored). */
 int mi355_rope_kv_write_rows(const void* qkv_f16, const float* partials, int32_t nsplit, int32_t ld,

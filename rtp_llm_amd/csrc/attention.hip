@@ -46,7 +46,12 @@ struct AttnParams {
     int q_len, R, ntile;   // rows per sequence, rows per 16-column tile (16 / G), row tiles per sequence
     uint32_t page_magic;   // 2^32 / page + 1: floor(t / page) == (t * magic) >> 32 for t * page < 2^32
     float scale_log2; // softmax scale * log2(e)
+    int img_mblk;     // > 0: out is an activation image of that many row blocks (common.h act_img_index) instead of [rows][nh * hd]
 };
+// element index of out[row][col], col = h * HD + d
+__device__ __forceinline__ size_t out_index(const AttnParams& p, int row, int col, int HD) {
+    return p.img_mblk > 0 ? act_img_index(row, col, p.img_mblk) : (size_t)row * p.nh * HD + col;
+}
 
 constexpr float NEG_BIG = -1e30f;
 
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
         if (part == 0)
             for (int idx = threadIdx.x; idx < nrows * p.G * HD; idx += NTHR) {
                 const int rl = idx / (p.G * HD), rem = idx - rl * (p.G * HD);
-                p.out[((size_t)(row0 + rl) * p.nh + kh * p.G) * HD + rem] = (f16)0.f;
+                p.out[out_index(p, row0 + rl, kh * p.G * HD + rem, HD)] = (f16)0.f;
             }
         return;
     }
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
                 const float inv = l > 0.f ? 1.f / l : 0.f;          // padding row / empty context: zeros, not NaN
                 u32x2 ov;
                 ov[0] = act_pack<BF>(acc[0] * inv, acc[1] * inv); ov[1] = act_pack<BF>(acc[2] * inv, acc[3] * inv);
-                *reinterpret_cast<u32x2*>(p.out + ((size_t)row * p.nh + h) * HD + d0) = ov;
+                *reinterpret_cast<u32x2*>(p.out + out_index(p, row, h * HD + d0, HD)) = ov;
             } else {
                 const size_t slot = ((size_t)row * p.nh + h) * p.P + part;
                 *reinterpret_cast<f32x4*>(p.tmp_out + slot * HD + d0) = acc;
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(256) void attn_reduce_kernel(const AttnParams p) {
         for (int c = 0; c < CPL; ++c) acc[c] += src[c] * f;
     }
     const float inv = l > 0.f ? 1.f / l : 0.f;
-    uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + (size_t)gid * HD + lane * CPL;
+    uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + out_index(p, row, (gid - row * p.nh) * HD + lane * CPL, HD);
 #pragma unroll
     for (int c = 0; c < CPL; ++c) dst[c] = act_to_bits<BF>(acc[c] * inv);
 }
@@ -551,7 +556,7 @@ extern "C" size_t mi355_paged_attn_workspace_bytes(int32_t B, int32_t nh, int32_
 namespace {
 int launch_attn(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_table, int32_t max_blocks_per_seq,
                 const int32_t* seq_lens, int32_t seq_lens_minus_one, int32_t B, int32_t q_len, int32_t nh, float scale,
-                int32_t max_seq_len, void* out, void* workspace, size_t workspace_bytes, mi355_stream_t stream) {
+                int32_t max_seq_len, void* out, void* workspace, size_t workspace_bytes, mi355_stream_t stream, int img_mblk = 0) {
     MI355_CHECK_ARG(q && kv && kv->kv_base && block_table && seq_lens && out, "paged_attn: null pointer");
     MI355_CHECK_ARG(kv->hd == 64 || kv->hd == 128, "paged_attn: hd=%d (64 or 128)", kv->hd);
     MI355_CHECK_ARG(kv->page >= 16 && kv->page % 8 == 0, "paged_attn: page=%d (>= 16, multiple of 8)", kv->page);
@@ -569,7 +574,7 @@ int launch_attn(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_
     p.seq_lens = seq_lens; p.out = (f16*)out; p.B = B; p.nh = nh; p.nkv = kv->nkv; p.G = nh / kv->nkv;
     p.page = kv->page; p.max_blocks = max_blocks_per_seq; p.seq_add = seq_lens_minus_one ? 1 : 0;
     p.max_seq = max_seq_len; p.num_blocks = kv->num_blocks;
-    p.q_len = q_len; p.R = 16 / p.G;
+    p.q_len = q_len; p.R = 16 / p.G; p.img_mblk = img_mblk;
     p.page_magic = (uint32_t)((1ull << 32) / (unsigned)kv->page + 1);
     const int NT = q_len > p.R ? 2 : 1;                 // column tiles per block: 2 x R rows share one pass over the KV
     p.ntile = cdiv(q_len, NT * p.R);
@@ -640,4 +645,15 @@ extern "C" int mi355_paged_attn_rows(const void* q, const mi355_kv_layer_t* kv, 
                                      mi355_stream_t stream) {
     return launch_attn(q, kv, block_table, max_blocks_per_seq, positions, 1, B, q_len, nh, scale, max_seq_len, out, workspace,
                        workspace_bytes, stream);
+}
+
+// the same with `out` written as an activation image (mi355_act_image_*: B * q_len <= 64 rows, K = nh * hd) for the O projection's
+// full-K launch (mi355_linear_residual_img)
+extern "C" int mi355_paged_attn_rows_img(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_table,
+                                         int32_t max_blocks_per_seq, const int32_t* positions, int32_t B, int32_t q_len, int32_t nh,
+                                         float scale, int32_t max_seq_len, void* out_img, void* workspace, size_t workspace_bytes,
+                                         mi355_stream_t stream) {
+    MI355_CHECK_ARG(B > 0 && q_len > 0 && B * q_len <= 64 && kv && (nh * kv->hd) % 32 == 0, "paged_attn_rows_img: %d x %d rows (<= 64)", B, q_len);
+    return launch_attn(q, kv, block_table, max_blocks_per_seq, positions, 1, B, q_len, nh, scale, max_seq_len, out_img, workspace,
+                       workspace_bytes, stream, cdiv(B * q_len, 16));
 }

@@ -192,6 +192,17 @@ __device__ __forceinline__ float xor32_sum(float v) { float a, b; swap32(v, a, b
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ---- activation image (mi355_act_image_*): the [M][K] 16-bit activations of a 17-64-row step in the order the full-K launches of
+// gemm_fullk64.hip read them -- one dense 1 KB run per MFMA B fragment (k-step of 32, row block of 16): lane (jj, q) of the
+// fragment owns the 16 bytes x[16 rb + jj][32 ks + 8 q .. + 7].  A fragment gathered from the row-major tensor instead is 16 runs
+// of 64 B at the row stride: with every CU of the chip asking for the same runs, the L2 serves them at ~7 TB/s against 35 for dense
+// runs (profiles/r04_fullk64_access_patterns.txt: 19.8 vs 11.2 us for the QKV launch at 64 rows).  The producers (RMSNorm,
+// attention) write this order directly: their 16-byte stores keep their size, only the address changes.
+// Element index of x[row][col]; mblk = row blocks of the image = ceil(M / 16).
+__host__ __device__ __forceinline__ size_t act_img_index(int row, int col, int mblk) {
+    return ((((size_t)(col >> 5) * mblk + (row >> 4)) * 64 + ((col & 31) >> 3) * 16 + (row & 15)) << 3) + (col & 7);
+}
+
 // compile-time loop: the body sees its index as a constant expression (std::integral_constant)
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {

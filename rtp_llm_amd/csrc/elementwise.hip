@@ -18,7 +18,7 @@ __global__ __launch_bounds__(512) void add_rmsnorm_kernel(const f16* __restrict_
                                                           int nsplit, int ld, int M, const f16* __restrict__ bias,
                                                           const f16* __restrict__ res_in, f16* __restrict__ res_out,
                                                           const f16* __restrict__ weight, float eps, int H,
-                                                          f16* __restrict__ y) {
+                                                          f16* __restrict__ y, int y_img_mblk) {
     constexpr int NTH = 512;
     const int row = blockIdx.x;
     const int tid = threadIdx.x;
@@ -132,7 +132,8 @@ __global__ __launch_bounds__(512) void add_rmsnorm_kernel(const f16* __restrict_
             act_unpack8<BF>(win[t], wv);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = wv[e] * act_round<BF>(v[t][e] * rs);   // product of two 16-bit tensors: rounded once by the pack
-            *reinterpret_cast<u32x4*>(y + (size_t)row * H + c0) = act_pack8<BF>(o);
+            // y_img_mblk > 0: y is an activation image (common.h act_img_index): the same 16 bytes at another address
+            *reinterpret_cast<u32x4*>(y + (y_img_mblk > 0 ? act_img_index(row, c0, y_img_mblk) : (size_t)row * H + c0)) = act_pack8<BF>(o);
         }
     }
 }
@@ -257,9 +258,9 @@ __global__ __launch_bounds__(64) void argmax_pick(const ArgPair* __restrict__ pa
 
 } // namespace
 
-extern "C" int mi355_add_rmsnorm_dt(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
-                                    const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M,
-                                    int32_t H, void* y, int32_t act_dtype, mi355_stream_t stream) {
+static int add_rmsnorm_launch(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
+                              const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M,
+                              int32_t H, void* y, int y_img_mblk, int32_t act_dtype, mi355_stream_t stream) {
     MI355_CHECK_ARG((x_f16 != nullptr) != (partials != nullptr), "add_rmsnorm: exactly one of x_f16 / partials");
     MI355_CHECK_ARG(M > 0 && H > 0 && H % 8 == 0 && H <= 8 * 512 * 2, "add_rmsnorm: M=%d H=%d (H %% 8 == 0, H <= 8192)", M, H);
     MI355_CHECK_ARG(!partials || (nsplit >= 1 && ld >= H && ld % 4 == 0), "add_rmsnorm: nsplit=%d ld=%d", nsplit, ld);
@@ -269,11 +270,50 @@ extern "C" int mi355_add_rmsnorm_dt(const void* x_f16, const float* partials, in
     const int vpt = cdiv(H / 8, 512);
 #define L_(V, B)                                                                                                        \
     hipLaunchKernelGGL((add_rmsnorm_kernel<V, B>), dim3(M), dim3(512), 0, st, (const f16*)x_f16, partials, nsplit, ld, M, \
-                       (const f16*)bias, (const f16*)residual_in, (f16*)residual_out, (const f16*)weight, eps, H, (f16*)y)
+                       (const f16*)bias, (const f16*)residual_in, (f16*)residual_out, (const f16*)weight, eps, H, (f16*)y, y_img_mblk)
     if (act_dtype == MI355_ACT_BF16) { if (vpt <= 1) L_(1, true); else L_(2, true); }
     else                             { if (vpt <= 1) L_(1, false); else L_(2, false); }
 #undef L_
     MI355_CHECK_LAUNCH("add_rmsnorm_kernel");
+    return MI355_OK;
+}
+
+extern "C" int mi355_add_rmsnorm_dt(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
+                                    const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M,
+                                    int32_t H, void* y, int32_t act_dtype, mi355_stream_t stream) {
+    return add_rmsnorm_launch(x_f16, partials, nsplit, ld, bias, residual_in, residual_out, weight, eps, M, H, y, 0, act_dtype, stream);
+}
+
+// the same with y written as an activation image (mi355_act_image_*) for the full-K launches of a 17-64-row step
+extern "C" int mi355_add_rmsnorm_img(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
+                                     const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M,
+                                     int32_t H, void* y_img, int32_t act_dtype, mi355_stream_t stream) {
+    MI355_CHECK_ARG(y_img && M <= 64 && H % 32 == 0, "add_rmsnorm_img: M=%d (<= 64) H=%d (%% 32 == 0), y_img required", M, H);
+    return add_rmsnorm_launch(x_f16, partials, nsplit, ld, bias, residual_in, residual_out, weight, eps, M, H, y_img, cdiv(M, 16), act_dtype, stream);
+}
+
+// ---------------------------------------------------------------- activation image
+namespace {
+__global__ __launch_bounds__(256) void act_image_pack_kernel(const u32x4* __restrict__ x, int M, int K, u32x4* __restrict__ img, int mblk, int unpack) {
+    const int nvec = K >> 3;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * nvec) return;
+    const int m = idx / nvec, c0 = (idx - m * nvec) * 8;
+    const size_t a = ((size_t)m * K + c0) >> 3, b = act_img_index(m, c0, mblk) >> 3;
+    if (unpack) img[a] = x[b]; else img[b] = x[a];
+}
+} // namespace
+
+extern "C" size_t mi355_act_image_bytes(int32_t M, int32_t K) {
+    return (M <= 0 || K <= 0) ? 0 : (size_t)cdiv(M, 16) * 16 * (size_t)((K + 31) & ~31) * 2;
+}
+
+// direction 0: row-major x [M][K] -> image; 1: image -> row-major (16-bit elements of either dtype)
+extern "C" int mi355_act_image_pack(const void* src, int32_t M, int32_t K, void* dst, int32_t direction, mi355_stream_t stream) {
+    MI355_CHECK_ARG(src && dst && M > 0 && M <= 64 && K > 0 && K % 32 == 0, "act_image_pack: M=%d (1..64) K=%d (%% 32 == 0)", M, K);
+    hipLaunchKernelGGL(act_image_pack_kernel, dim3(cdiv(M * (K / 8), 256)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, M, K,
+                       (u32x4*)dst, cdiv(M, 16), direction);
+    MI355_CHECK_LAUNCH("act_image_pack_kernel");
     return MI355_OK;
 }
 

@@ -45,6 +45,7 @@ struct mi355_decoder {
     mi355_step_buffers_t               bufs;
     // carved workspace
     void *resid, *xn, *q_buf, *attn_out, *act, *attn_ws, *argmax_ws;
+    void *xn_img, *attn_img;   // activation images (mi355_act_image_*) of the normed hidden rows / the attention output, 17-64-row steps
     int32_t* oob_count; // tokens refused by the KV writer (stale position / block id)
     mi355_allreduce_t* ar; // attached all-reduce context (tp_size > 1): the TP step runs entirely from C++
     int    vocab_offset;
@@ -78,6 +79,9 @@ struct mi355_decoder {
     // at 64 (measured M = 64: qkv+rope 20.8 vs 9.0 + 4.9 us, o 18.6 vs 9.7 + slab fold; M = 1: 6.8 vs 7.3 + 3.1 us)
     bool   fuse_qkv, fuse_o, fuse_down, fuse_norm;
     int    fuse_rows;
+    // 17-64 rows (tp = 1): QKV + bias + RoPE + KV write and O + residual as one full-K launch each (gemm_fullk64.hip), their
+    // activations handed over as images by the producing launches (RMSNorm fold, attention): 7 launches per layer instead of 8 + no slabs
+    bool   img_qkv, img_o;
     float* ssq;      // [16 rows][hidden / 16]: the producer GEMM's per-tile sums of h^2, consumed by the next GEMM's on-the-fly RMSNorm
     // graphs
     hipStream_t                    cap_stream;
@@ -123,11 +127,13 @@ size_t carve_all(mi355_decoder* d, const mi355_model_config_t& c, void* base) {
     void* argmax_ws = cv.take(gw);
     void* oob = cv.take(256);
     void* ssq = cv.take((size_t)16 * ((c.hidden / 16 + 3) & ~3) * 4);   // per-tile sums of squares of the residual rows (fused norm, <= 16 rows)
+    void* xn_img = cv.take(mi355_act_image_bytes(64, c.hidden));
+    void* attn_img = cv.take(mi355_act_image_bytes(64, qdim));
     const size_t wide_bytes = c.max_batch > 64 ? carve_prefill(c, c.max_batch, c.max_batch, nullptr, nullptr) : 0;
     void* wide_ws = cv.take(wide_bytes);
     void* iota = cv.take((size_t)c.max_batch * 4);
     if (d) {
-        d->ssq = (float*)ssq;
+        d->ssq = (float*)ssq; d->xn_img = xn_img; d->attn_img = attn_img;
         d->oob_count = (int32_t*)oob; d->wide_ws = wide_ws; d->wide_ws_bytes = wide_bytes; d->iota = (int32_t*)iota;
         d->resid = resid; d->xn = xn; d->q_buf = q_buf; d->attn_out = attn_out; d->act = act;
         d->partials = (float*)partials; d->partials_bytes = pbytes; d->attn_ws = attn_ws; d->attn_ws_bytes = aw;
@@ -239,6 +245,12 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     // per-tile sums of squares of the new residual rows, QKV / gate_up rebuild 1 / rms from them and normalise on load
     d->fuse_norm = d->fuse_qkv && d->fuse_o && d->fuse_down && cfg->hidden % 64 == 0;
     for (const auto& L : d->layers) d->fuse_norm = d->fuse_norm && w4ok(&L.gate_up);
+    // the 17-64-row full-K launches: W4 group-wise, K <= 5760 (gemm_fullk64.hip), single rank
+    auto w64ok = [&](const mi355_weight_t* w) { return w4ok(w) && w->K_pad / 128 <= 45 && w->K % 32 == 0; };
+    d->img_qkv = d->fuse_qkv && cfg->tp_size == 1 && cfg->act_dtype == MI355_ACT_F16;
+    d->img_o = d->fuse_o && cfg->act_dtype == MI355_ACT_F16;
+    for (const auto& L : d->layers) { d->img_qkv = d->img_qkv && w64ok(&L.qkv); d->img_o = d->img_o && w64ok(&L.o); }
+    if (TUNE(5) == 2) d->img_qkv = d->img_o = false;   // tuning build: A/B against the split-K + fold launches
     std::vector<int32_t> iota_h(cfg->max_batch);
     for (int i = 0; i < cfg->max_batch; ++i) iota_h[i] = i;
     if (hipMemset(d->oob_count, 0, 256) != hipSuccess ||
@@ -282,7 +294,11 @@ extern "C" int mi355_decoder_begin_rows(mi355_decoder_t* d, int32_t nseq, int32_
         RUN(MI355_KC_OTHER, mi355_embedding(d->bufs.token_ids, B, d->model.embedding, c.hidden, d->model.vocab_full, d->resid, st));
     }
     if (c.tp_size == 1 || d->ar) {
-        RUN(MI355_KC_NORM, mi355_rmsnorm_dt(d->resid, d->layers[0].input_norm, c.rms_eps, B, c.hidden, d->xn, ADT, st));
+        if (d->img_qkv && B > 16)
+            RUN(MI355_KC_NORM, mi355_add_rmsnorm_img(d->resid, nullptr, 0, 0, nullptr, nullptr, nullptr, d->layers[0].input_norm, c.rms_eps, B,
+                                                     c.hidden, d->xn_img, ADT, st));
+        else
+            RUN(MI355_KC_NORM, mi355_rmsnorm_dt(d->resid, d->layers[0].input_norm, c.rms_eps, B, c.hidden, d->xn, ADT, st));
     }
     return MI355_OK;
 }
@@ -436,7 +452,13 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
     const bool normed = small && d->fuse_norm;            // no norm launches in this step: see fuse_norm
     const int pf = c.tp_size == 1 ? d->pf_mask : 0;       // (tp > 1: the side stream belongs to comm_with_prefetch)
     if (int e = pf_join(d, st)) return e;                  // this layer's QKV weights, requested behind the previous down GEMM
-    if (d->fuse_qkv && small) {
+    const bool mid_qkv = d->img_qkv && B > 16, mid_o = d->img_o && B > 16;   // 17-64 rows: full-K launches on activation images
+    if (mid_qkv) {
+        RUN(MI355_KC_GEMM_QUANT, mi355_qkv_rope_kv_write_img(d->xn_img, B, &L.qkv, L.qkv_bias, d->model.cos_sin, c.rope_dim, c.max_pos,
+                                                             d->bufs.positions, d->bufs.block_table, c.max_blocks_per_seq, d->q_len, c.nh,
+                                                             &kv, d->q_buf, d->oob_count, st));
+        if (pf & (MI355_PF_O | MI355_PF_O_LATE)) if (int e = pf_issue(d, st, &L.o, kPfCap)) return e;
+    } else if (d->fuse_qkv && small) {
         // layer 0 reads the rows mi355_decoder_begin normed; later layers normalise the residual rows on load
         const mi355_fused_norm_t fn = {d->ssq, c.hidden / 16, (c.hidden / 16 + 3) & ~3, L.input_norm, c.rms_eps};
         const bool on_load = normed && l > 0;
@@ -454,6 +476,16 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
         if (pf & MI355_PF_O_LATE) if (int e = pf_issue(d, st, &L.o, kPfCap)) return e;     // under attention only
     }
     // q_len > 1: rows of one sequence share a pass over its KV, causal mask inside the page walk (is_target_verify)
+    if (mid_o) {   // the attention output as an image: what the O projection's full-K launch reads
+        RUN(MI355_KC_ATTN, mi355_paged_attn_rows_img(d->q_buf, &kv, d->bufs.block_table, c.max_blocks_per_seq, d->bufs.positions,
+                                                     B / d->q_len, d->q_len, c.nh, 1.0f / sqrtf((float)c.hd), c.max_seq_len, d->attn_img,
+                                                     d->attn_ws, d->attn_ws_bytes, st));
+        if (int e = pf_join(d, st)) return e;
+        RUN(MI355_KC_GEMM_QUANT, mi355_linear_residual_img(d->attn_img, B, &L.o, nullptr, d->resid, d->resid, nullptr, 0, st));
+        if (pf & MI355_PF_GATE_UP) if (int e = pf_issue(d, st, &L.gate_up, kPfCap)) return e;
+        RUN(MI355_KC_NORM, mi355_rmsnorm_dt(d->resid, L.post_norm, c.rms_eps, B, c.hidden, d->xn, ADT, st));
+        return MI355_OK;
+    }
     RUN(MI355_KC_ATTN, mi355_paged_attn_rows(d->q_buf, &kv, d->bufs.block_table, c.max_blocks_per_seq, d->bufs.positions,
                                              B / d->q_len, d->q_len, c.nh, 1.0f / sqrtf((float)c.hd), c.max_seq_len, d->attn_out,
                                              d->attn_ws, d->attn_ws_bytes, st));
@@ -515,8 +547,12 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
     RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->act, B, &L.down, d->partials, kMaxSplits, st));
     if (pf & MI355_PF_QKV_LATE) if (int e = pf_issue(d, st, next_qkv, kPfCap)) return e;    // under the reduce + norm launch only
     if (c.tp_size == 1) {
-        RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
-                                             c.rms_eps, B, c.hidden, d->xn, ADT, st));
+        if (d->img_qkv && B > 16 && l + 1 < c.num_layers)   // the next layer's QKV launch reads an image (the final norm feeds lm_head: row-major)
+            RUN(MI355_KC_NORM, mi355_add_rmsnorm_img(nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
+                                                     c.rms_eps, B, c.hidden, d->xn_img, ADT, st));
+        else
+            RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
+                                                 c.rms_eps, B, c.hidden, d->xn, ADT, st));
     } else if (d->ar) {
         const mi355_weight_t* next_w = (l + 1 < c.num_layers) ? &d->layers[l + 1].qkv : &d->model.lm_head;
         RUN(MI355_KC_COMM, comm_with_prefetch(d, st, next_w, [&]() {

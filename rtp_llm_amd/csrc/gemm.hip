@@ -31,6 +31,12 @@ extern "C" int mi355_gemm_prefill(const void* gp, int wbits, int group_size, mi3
 extern "C" int mi355_gemm_fullk(const void* gp, int wbits, int group_size, const void* norm, mi355_stream_t stream);
 extern "C" int mi355_gemm_fullk_residual(const void* gp, int wbits, int group_size, const void* residual_in, void* residual_out,
                                          float* ssq_out, int ssq_ld, mi355_stream_t stream);
+extern "C" int mi355_gemm_fullk_residual_img(const void* gp, int wbits, int group_size, const void* residual_in, void* residual_out,
+                                             float* ssq_out, int ssq_ld, mi355_stream_t stream);
+extern "C" int mi355_gemm_fullk_rope_img(const void* gp, int wbits, int group_size, const float* cos_sin, int32_t max_pos,
+                                         const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq,
+                                         int32_t q_len, int32_t nh, const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count,
+                                         mi355_stream_t stream);
 extern "C" int mi355_gemm_fullk_rope(const void* gp, int wbits, int group_size, const void* norm, const float* cos_sin, int32_t max_pos,
                                      const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq,
                                      int32_t q_len, int32_t nh, const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count,
@@ -875,4 +881,34 @@ extern "C" int mi355_qkv_rope_kv_write(const void* x, int32_t M, const mi355_wei
     p.mode = MODE_F16; p.bias = (const f16*)qkv_bias; p.ldy = wqkv->N;
     return mi355_gemm_fullk_rope(&p, wqkv->wbits, wqkv->group_size, norm, cos_sin, max_pos, positions, block_table, max_blocks_per_seq,
                                  q_len, nh, kv, q_out, oob_count, stream);
+}
+
+// ------------------------------------------------------------------ the same two launches for 17-64 rows, activations as an image
+// (gemm_fullk64.hip).  x_img: mi355_act_image_* of the [M][K] activations -- written directly by mi355_add_rmsnorm_img /
+// mi355_paged_attn_rows_img, or by mi355_act_image_pack from a row-major tensor.
+extern "C" int mi355_linear_residual_img(const void* x_img, int32_t M, const mi355_weight_t* w, const void* bias, const void* residual_in,
+                                         void* residual_out, float* tile_sumsq_out, int32_t tile_sumsq_ld, mi355_stream_t stream) {
+    if (int e = check_weight(w)) return e;
+    MI355_CHECK_ARG(x_img && residual_in && residual_out && M > 0, "linear_residual_img: bad args (M=%d)", M);
+    MI355_CHECK_ARG(!tile_sumsq_out || (tile_sumsq_ld >= w->N / 16 && tile_sumsq_ld % 4 == 0), "linear_residual_img: tile_sumsq_ld=%d (>= N/16 = %d, multiple of 4)", tile_sumsq_ld, w->N / 16);
+    if (M <= 16 || M > 64 || w->wbits != 4 || !mi355_fullk_weight_ok(w)) return MI355_ERR_UNSUPPORTED;
+    GemmParams p; fill_params(p, x_img, M, w);
+    p.mode = MODE_F16; p.bias = (const f16*)bias; p.ldy = w->N;
+    return mi355_gemm_fullk_residual_img(&p, w->wbits, w->group_size, residual_in, residual_out, tile_sumsq_out, tile_sumsq_ld, stream);
+}
+
+extern "C" int mi355_qkv_rope_kv_write_img(const void* x_img, int32_t M, const mi355_weight_t* wqkv, const void* qkv_bias,
+                                           const float* cos_sin, int32_t rope_dim, int32_t max_pos, const int32_t* positions,
+                                           const int32_t* block_table, int32_t max_blocks_per_seq, int32_t q_len, int32_t nh,
+                                           const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count, mi355_stream_t stream) {
+    if (int e = check_weight(wqkv)) return e;
+    MI355_CHECK_ARG(x_img && M > 0 && q_len >= 1 && M % q_len == 0, "qkv_rope_kv_write_img: M=%d q_len=%d", M, q_len);
+    MI355_CHECK_ARG(kv && kv->kv_base && cos_sin && positions && block_table && q_out, "qkv_rope_kv_write_img: null pointer");
+    MI355_CHECK_ARG(kv->page > 0 && nh > 0 && kv->nkv > 0 && max_pos > 0 && max_blocks_per_seq > 0 && kv->num_blocks > 0,
+                    "qkv_rope_kv_write_img: bad dims");
+    if (M <= 16 || M > 64 || wqkv->wbits != 4 || !mi355_fullk_weight_ok(wqkv) || rope_dim != kv->hd) return MI355_ERR_UNSUPPORTED;
+    GemmParams p; fill_params(p, x_img, M, wqkv);
+    p.mode = MODE_F16; p.bias = (const f16*)qkv_bias; p.ldy = wqkv->N;
+    return mi355_gemm_fullk_rope_img(&p, wqkv->wbits, wqkv->group_size, cos_sin, max_pos, positions, block_table, max_blocks_per_seq,
+                                     q_len, nh, kv, q_out, oob_count, stream);
 }

@@ -1,0 +1,41 @@
+// Parameter block, epilogue kinds and the per-wave stamps shared by the full-K launches: gemm_fullk.hip (<= 16 rows and the
+// generic shapes) and gemm_fullk64.hip (17-64 rows, W4 group-wise).
+#pragma once
+#include "gemm_common.h"
+
+namespace {
+
+struct RopeEpi {
+    const float*   cos_sin;
+    const int32_t* positions;
+    const int32_t* block_table;
+    int            max_blocks, nh, nkv, hd, page, max_pos, num_blocks, q_len;
+    int32_t*       oob_count;
+    void*          kv_base;
+    f16*           q_out;
+};
+struct FullKParams {
+    GemmParams g;
+    const f16* res_in;
+    f16*       res_out;
+    RopeEpi    r;
+    // NORM: x is the un-normed residual row h; the kernel applies RMSNorm on the fly, x_n = gamma * fp16(h * rs), with
+    // rs = rsqrt(sum_k h^2 / K + eps) rebuilt from the per-tile partial sums the producing launch left in ssq_in
+    const float* ssq_in;     // [rows][ssq_ld], ssq_ld >= ssq_tiles: sum over the 16 columns of tile t of h[row]^2
+    int          ssq_tiles, ssq_ld;
+    const f16*   gamma;
+    float        eps;
+    float*       ssq_out;    // FK_RESID: the same partial sums of the rows this launch produces ([M][ssq_ld]), or null
+    int          ilv;        // K slices of the waves interleaved chunk by chunk (see the kernel)
+#ifdef MI355_FULLK_STAMPS   // tuning build with MI355_EXTRA_CFLAGS=-DMI355_FULLK_STAMPS only: the stamp stores change the schedule
+    unsigned long long* stamps;   // tools/fullk_stamps.py: wall_clock64 per wave at entry / requests out (+ 1 / rms there) / first chunk done / loop done / slices met / exit
+#endif
+};
+#ifdef MI355_FULLK_STAMPS
+#define FK_STAMP(i) do { if (fp.stamps && lane == 0) fp.stamps[((size_t)blockIdx.x * 16 + wave) * 6 + (i)] = wall_clock64(); } while (0)
+#else
+#define FK_STAMP(i) do { } while (0)
+#endif
+enum { FK_PLAIN = 0, FK_RESID = 1, FK_ROPE = 2 };
+
+} // namespace

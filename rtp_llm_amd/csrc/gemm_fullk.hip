@@ -17,42 +17,10 @@
 //                                                                        as rope_kv.hip, which stays for INT8 caches)
 // Dequant is the operand-side sequence of gemm.hip (exact subtract of the biased code, one rounding, 13 VALU per 8
 // weights) for every M: at M <= 16 the kernel is latency-, not issue-bound.
-#include "gemm_common.h"
+#include "gemm_fullk.h"
 
 namespace {
 
-struct RopeEpi {
-    const float*   cos_sin;
-    const int32_t* positions;
-    const int32_t* block_table;
-    int            max_blocks, nh, nkv, hd, page, max_pos, num_blocks, q_len;
-    int32_t*       oob_count;
-    void*          kv_base;
-    f16*           q_out;
-};
-struct FullKParams {
-    GemmParams g;
-    const f16* res_in;
-    f16*       res_out;
-    RopeEpi    r;
-    // NORM: x is the un-normed residual row h; the kernel applies RMSNorm on the fly, x_n = gamma * fp16(h * rs), with
-    // rs = rsqrt(sum_k h^2 / K + eps) rebuilt from the per-tile partial sums the producing launch left in ssq_in
-    const float* ssq_in;     // [rows][ssq_ld], ssq_ld >= ssq_tiles: sum over the 16 columns of tile t of h[row]^2
-    int          ssq_tiles, ssq_ld;
-    const f16*   gamma;
-    float        eps;
-    float*       ssq_out;    // FK_RESID: the same partial sums of the rows this launch produces ([M][ssq_ld]), or null
-    int          ilv;        // K slices of the waves interleaved chunk by chunk (see the kernel)
-#ifdef MI355_FULLK_STAMPS   // tuning build with MI355_EXTRA_CFLAGS=-DMI355_FULLK_STAMPS only: the stamp stores change the schedule
-    unsigned long long* stamps;   // tools/fullk_stamps.py: wall_clock64 per wave at entry / requests out (+ 1 / rms there) / first chunk done / loop done / slices met / exit
-#endif
-};
-#ifdef MI355_FULLK_STAMPS
-#define FK_STAMP(i) do { if (fp.stamps && lane == 0) fp.stamps[((size_t)blockIdx.x * 16 + wave) * 6 + (i)] = wall_clock64(); } while (0)
-#else
-#define FK_STAMP(i) do { } while (0)
-#endif
-enum { FK_PLAIN = 0, FK_RESID = 1, FK_ROPE = 2 };
 
 // XL: activation wave-loads per chunk at <= 16 rows.  A B fragment of the 16x16x32 MFMA is 16 rows x 32 k; with M rows alive
 // a load in that shape is M / 16 dense, and at a few rows the launches were bound by the number of such loads (four per
@@ -579,12 +547,15 @@ bool fullk_shape_ok(const GemmParams& g, int wbits, int& group_size) {
 } // namespace
 
 #ifdef MI355_FULLK_STAMPS
-static unsigned long long* g_fullk_stamps = nullptr;
+unsigned long long* g_fullk_stamps = nullptr;   // also read by gemm_fullk64.hip
 extern "C" void mi355_debug_fullk_stamps(void* p) { g_fullk_stamps = (unsigned long long*)p; }
 #define FK_SET_STAMPS(fp) (fp).stamps = g_fullk_stamps
 #else
 #define FK_SET_STAMPS(fp) do { } while (0)
 #endif
+
+// 17-64 rows, W4 group-wise, K <= 5760, activations as an image (mi355_act_image_*): gemm_fullk64.hip
+extern "C" int mi355_gemm_fullk64(const void* fp, int epi, int group_size, mi355_stream_t stream);
 
 static void set_norm(FullKParams& fp, const mi355_fused_norm_t* n) {
     fp.ssq_in = n->tile_sumsq; fp.ssq_tiles = n->tiles; fp.ssq_ld = n->ld; fp.gamma = (const f16*)n->weight; fp.eps = n->eps;
@@ -643,4 +614,31 @@ extern "C" int mi355_gemm_fullk_rope(const void* gp, int wbits, int group_size, 
         return launch_fullk<2, FK_ROPE, true>(fp, group_size, nheads * (kv->hd / 32), (hipStream_t)stream);
     }
     return launch_fullk<2, FK_ROPE, false>(fp, group_size, nheads * (kv->hd / 32), (hipStream_t)stream);
+}
+
+// ---- the same two launches for 17-64 rows with the activations handed over as an image (gp->x: mi355_act_image_*), gemm_fullk64.hip
+extern "C" int mi355_gemm_fullk_residual_img(const void* gp, int wbits, int group_size, const void* residual_in, void* residual_out,
+                                             float* ssq_out, int ssq_ld, mi355_stream_t stream) {
+    FullKParams fp{};
+    fp.g = *reinterpret_cast<const GemmParams*>(gp);
+    if (wbits != 4 || !fullk_shape_ok(fp.g, wbits, group_size) || fp.g.N % 4 != 0) return MI355_ERR_UNSUPPORTED;
+    fp.res_in = (const f16*)residual_in; fp.res_out = (f16*)residual_out; fp.ssq_out = ssq_out; fp.ssq_ld = ssq_ld;
+    return mi355_gemm_fullk64(&fp, FK_RESID, group_size, stream);
+}
+
+extern "C" int mi355_gemm_fullk_rope_img(const void* gp, int wbits, int group_size, const float* cos_sin, int32_t max_pos,
+                                         const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq,
+                                         int32_t q_len, int32_t nh, const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count,
+                                         mi355_stream_t stream) {
+    FullKParams fp{};
+    fp.g = *reinterpret_cast<const GemmParams*>(gp);
+    if (wbits != 4 || !fullk_shape_ok(fp.g, wbits, group_size)) return MI355_ERR_UNSUPPORTED;
+    if (kv->kv_dtype != MI355_KV_FP16 || (kv->hd != 64 && kv->hd != 128)) return MI355_ERR_UNSUPPORTED;
+    const int nheads = nh + 2 * kv->nkv;
+    if (fp.g.N != nheads * kv->hd) return MI355_ERR_UNSUPPORTED;
+    RopeEpi& r = fp.r;
+    r.cos_sin = cos_sin; r.positions = positions; r.block_table = block_table; r.max_blocks = max_blocks_per_seq;
+    r.nh = nh; r.nkv = kv->nkv; r.hd = kv->hd; r.page = kv->page; r.max_pos = max_pos; r.num_blocks = kv->num_blocks;
+    r.q_len = q_len; r.oob_count = oob_count; r.kv_base = kv->kv_base; r.q_out = (f16*)q_out;
+    return mi355_gemm_fullk64(&fp, FK_ROPE, group_size, stream);
 }

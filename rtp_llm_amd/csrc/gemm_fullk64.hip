@@ -1,0 +1,342 @@
+// Full-K weight-only W4 GEMM for 17-64 rows with the consumer fused into the epilogue, gfx950: the QKV projection (+ bias + NeoX
+// RoPE + Q extract + paged fp16 KV write) and the O projection (+ bias + residual add, per-tile sums of squares of the new
+// residual rows) of a decode step as ONE launch each -- no split-K slabs, no fold launch.
+// Reference semantics: LinearBase.forward (models_py/modules/factory/linear/linear_base.py:75-85) followed by
+// FusedRopeKVCacheDecodeOp::forward (bindings/rocm/FusedRopeKVCacheOp.cc:519-646) resp. by the residual add of the decoder
+// layer (model_desc/qwen3.py:63-77); module boundary modules/hybrid/causal_attention.py:75-93.
+//
+// What bounds it.  At these shapes (Qwen2-7B: K = 3584, N = 4608 / 3584) the weights are 7-9 MB -- 1.5 us of HBM time -- and the
+// MFMA work is under a microsecond; what every block has to do is pull ALL 64 activation rows of its K range through its CU's
+// vector-memory path, because K stays inside the block: 64 x 3584 x 2 B = 458 KB at the ~137 GB/s a CU takes out of L2
+// (tools/probe/vmem_rate.hip: one 16-byte-per-lane wave-load per ~17 cycles) = 3.3 us, whatever the tile count of the block.  So:
+//   * a block owns a PAIR of 16-column tiles (the (d, d + hd/2) pair of a head for the RoPE epilogue, adjacent tiles otherwise):
+//     every activation fragment feeds two MFMAs, the grid is 144 / 112 blocks, and the XCDs' L2s serve 8 MB, not 13, each;
+//   * its <= 16 waves are K slices of CPW chunks (128 k each).  A wave asks for ALL weights of its slice before anything else
+//     (they come from HBM: longest latency, and vmcnt is an in-order queue -- a weight load issued between activation loads
+//     would drain the activation ring when it is waited for), then streams the activation fragments through a register ring
+//     of RING fragments in a fully static schedule: fragment f is consumed by TPB MFMAs and its slot re-requested at once, so
+//     RING - 1 loads per wave stay in flight all the time (the full-K kernel of the few-row path kept half a chunk per wave
+//     in flight and 7 waves per block: 20 us at 64 rows, profiles/r02_fullk_kernel_durations.txt);
+//   * the slices meet once in LDS; wave mb sums row block mb of both tiles in slice order and runs the epilogue, whose
+//     operands (bias / residual rows, position -> block id -> rotation row) were requested before the main loop.
+// Weight image, dequant (operand side: exact subtract of the biased code, one rounding) and epilogue arithmetic are those of
+// gemm_fullk.hip / rope_kv.hip, so the results are interchangeable with the composed launches.
+#include "gemm_fullk.h"
+
+namespace {
+
+// LDS behind the slices' partial sums: what the epilogue needs besides the sums, staged by the helper wave
+template <int EPI> struct Stage64 {};
+template <> struct Stage64<FK_RESID> { f16 res[64][32]; f16 bias[32]; };                       // residual rows / bias of the block's two tiles
+template <> struct Stage64<FK_ROPE>  { float cs[64][32]; int pos[64], blk[64]; f16 bias[32]; }; // rotation row of the block's 16 dims per token, position, block id
+
+template <int GS, int MB, int EPI, int CPW, int RING>
+__global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp) {
+    constexpr int TPB = 2;
+    constexpr int NSUB = 4 / GS, SPG = 4 / NSUB;     // GS: 4 -> g128, 2 -> g64, 1 -> g32: (zero, scale) words per chunk and column, k-steps per word
+    constexpr int NF = CPW * 4 * MB;                 // activation fragments of a wave: (chunk c, k-step s, row block mb), f = (c * 4 + s) * MB + mb
+    constexpr uint32_t FLAGS = 0x00020000u, OOBX = 0x80000000u, OOBS = 0x40000000u;   // out of range (lane / wave offsets)
+    static_assert(RING <= NF && RING >= MB, "ring: at least one k-step, at most the slice");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* red = reinterpret_cast<f32x4*>(smem);     // [NW][TPB * MB][64]
+    const GemmParams& p = fp.g;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int NW   = (int)(blockDim.x >> 6) - 1;     // K-slice waves; wave NW is the helper
+    const int jj = lane & 15, q = lane >> 4;
+    Stage64<EPI>& sg = *reinterpret_cast<Stage64<EPI>*>(smem + (size_t)NW * TPB * MB * 1024);
+    FK_STAMP(0);
+
+    int tile[TPB];
+    if constexpr (EPI == FK_ROPE) {
+        const int hh = fp.r.hd >> 5;                 // tiles per half head
+        const int h = blockIdx.x / hh, j = blockIdx.x % hh;
+        tile[0] = h * 2 * hh + j;
+        tile[1] = tile[0] + hh;
+    } else {
+        tile[0] = blockIdx.x * 2; tile[1] = tile[0] + 1;
+    }
+
+    if (wave == NW) {
+        // =============================================================== helper wave: no K slice.  It stages the epilogue's operands
+        // in LDS while the K waves stream: the chain position -> block id -> rotation row is two dependent round trips, and inside a
+        // K wave every one of its waits would also wait for the weights and the ring in flight (vmcnt is in order)
+        if constexpr (EPI == FK_RESID) {
+            // rows x 32 columns of the residual stream: lane = (row i * 16 + l / 4, 16-byte part l % 4); parts 0-1 tile 0, 2-3 tile 1
+            __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)fp.res_in, 0, (uint32_t)((size_t)p.M * p.N * 2), FLAGS);
+            const int part = lane & 3, n = tile[part >> 1] * 16 + (part & 1) * 8;
+            u32x4 rv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 16 + (lane >> 2);
+                rv[i] = bload128<0>(rr, (row < p.M && n < p.N) ? (uint32_t)(((size_t)row * p.N + n) * 2) : OOBX);
+            }
+            u32x4 bv = {0u, 0u, 0u, 0u};
+            if (p.bias && lane < 4 && n < p.N) bv = *reinterpret_cast<const u32x4*>(p.bias + n);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&sg.res[i * 16 + (lane >> 2)][part * 8]) = rv[i];
+            if (lane < 4) *reinterpret_cast<u32x4*>(&sg.bias[part * 8]) = bv;
+        } else {
+            const RopeEpi& R = fp.r;
+            const int half = R.hd >> 1, hh = R.hd >> 5;
+            const int h = tile[0] / (2 * hh), dj = (tile[0] % (2 * hh)) * 16;      // head, first of the block's 16 dims of the lower half
+            const int row = lane < p.M ? lane : p.M - 1;                             // lane = token
+            const int pos_in = R.positions[row];
+            u32x4 bv = {0u, 0u, 0u, 0u};                                             // bias: lanes 0-1 dims dj..dj+15, lanes 2-3 the same of the upper half
+            if (p.bias && lane < 4) bv = *reinterpret_cast<const u32x4*>(p.bias + h * R.hd + (lane >> 1) * half + dj + (lane & 1) * 8);
+            const int pos = min(max(pos_in, 0), min(R.max_pos, R.max_blocks * R.page) - 1);
+            const int blk = R.block_table[(size_t)(row / R.q_len) * R.max_blocks + pos / R.page];
+            sg.pos[lane] = pos_in;
+            if (lane < 4) *reinterpret_cast<u32x4*>(&sg.bias[lane * 8]) = bv;
+            // rotation rows: load i covers tokens 8 i + l / 8, 16-byte part l % 8 of the 128-byte run {cos, sin} x 16 dims
+            f32x4 cv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int pr = __shfl(pos, i * 8 + (lane >> 3));
+                cv[i] = *reinterpret_cast<const f32x4*>(R.cos_sin + ((size_t)pr * half + dj) * 2 + (lane & 7) * 4);
+            }
+            sg.blk[lane] = blk;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&sg.cs[i * 8 + (lane >> 3)][(lane & 7) * 4]) = cv[i];
+        }
+        FK_STAMP(1);
+    } else {
+    // =================================================================== K-slice waves: chunks [c0, c0 + n_ch), n_ch <= CPW
+    const uint32_t lane16 = lane * 16u, jj4 = jj * 4u;
+    const int c0 = wave * CPW;
+    const int n_ch = min(CPW, p.KC - c0);
+    __amdgpu_buffer_rsrc_t rw[TPB], rm[TPB];
+#pragma unroll
+    for (int t = 0; t < TPB; ++t) {
+        const bool ok = tile[t] < p.NT && !(fp.ilv & 2);
+        const char* wb = (const char*)p.qw + ((size_t)tile[t] * p.KC + c0) * 1024;
+        rw[t] = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, ok ? n_ch * 1024 : 0, FLAGS);
+        const char* mb_ = (const char*)p.meta + ((size_t)c0 * NSUB * p.N_pad + tile[t] * 16) * 4;
+        rm[t] = __builtin_amdgcn_make_buffer_rsrc((void*)mb_, 0, ok ? ((n_ch * NSUB - 1) * p.N_pad + 16) * 4 : 0, FLAGS);
+    }
+    // activations of the slice: the image's fragments (k-step 4 (c0 + c) + s, row block mb), 1 KB each (common.h act_img_index);
+    // fp.ilv: timing experiments of the tuning build (1: no activation traffic, 2: no weight traffic -- same instruction stream)
+    const int MBLK = (p.M + 15) >> 4;                // row blocks of the image (<= MB)
+    const char* xb = (const char*)p.x + (size_t)c0 * 4 * MBLK * 1024;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (fp.ilv & 1) ? 0u : (uint32_t)(n_ch * 4 * MBLK * 1024), FLAGS);
+
+    // ---- 1. all weights of the slice (HBM, non-temporal: read once by one CU)
+    u32x4    wr[CPW][TPB];
+    uint32_t mr[CPW][TPB][NSUB];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int t = 0; t < TPB; ++t) {
+            wr[c][t] = bload128<2 /*nt*/>(rw[t], lane16, (uint32_t)c * 1024u);
+#pragma unroll
+            for (int gi = 0; gi < NSUB; ++gi)
+                mr[c][t][gi] = __builtin_amdgcn_raw_buffer_load_b32(rm[t], jj4, (uint32_t)(c * NSUB + gi) * (uint32_t)p.N_pad * 4u, 0);
+        }
+
+    // ---- 2. activation ring, fully static: slot f % RING holds fragment f
+    u32x4 xr[RING];
+    auto load_frag = [&](int f) {                    // f compile-time at every call site (static_for)
+        const int c = f / (4 * MB), s = (f / MB) % 4, mb = f % MB;
+        // a row block the image does not have (M <= 48 in the 64-row instance) or a chunk past the slice: past the descriptor, zeros
+        xr[f % RING] = bload128<0>(rx, lane16, mb < MBLK ? (uint32_t)(((c * 4 + s) * MBLK + mb) * 1024) : OOBS);
+    };
+    static_for<0, RING>([&](auto f_) { load_frag(decltype(f_)::value); });
+    FK_STAMP(1);
+
+    f32x4 acc[TPB][MB];
+#pragma unroll
+    for (int t = 0; t < TPB; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[t][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const W4Consts w4c = w4_consts();
+    const f16x2 c960 = {(f16)960.f, (f16)960.f};
+    f16x8 a[TPB];
+    static_for<0, NF>([&](auto f_) {
+        constexpr int f = decltype(f_)::value, c = f / (4 * MB), s = (f / MB) % 4, mb = f % MB;
+        if constexpr (mb == 0) {                     // A fragments of k-step (c, s): one dequant per tile feeds MB MFMAs
+#pragma unroll
+            for (int t = 0; t < TPB; ++t) {
+                const uint32_t m = mr[c][t][s / SPG];
+                const f16x2 zn = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u)), sc = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
+                a[t] = dequant_w4_vc(wr[c][t][s], zn, zn + c960, sc, w4c);
+            }
+        }
+        const f16x8 b = __builtin_bit_cast(f16x8, xr[f % RING]);
+#pragma unroll
+        for (int t = 0; t < TPB; ++t) acc[t][mb] = mfma16x16x32(a[t], b, acc[t][mb]);
+        if constexpr (f + RING < NF) load_frag(f + RING);
+        // fence per fragment: left free, hipcc sinks the ring's re-requests to just in front of their use (vmcnt(0..2) in the ISA:
+        // one load in flight per wave instead of RING - 1)
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef MI355_FULLK_STAMPS
+        if constexpr (f == 0) { asm volatile("s_nop 0" ::: "memory"); FK_STAMP(2); }
+#endif
+    });
+    FK_STAMP(3);
+
+    // ---- 3. the K slices meet in LDS
+#pragma unroll
+    for (int t = 0; t < TPB; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) red[((size_t)wave * (TPB * MB) + t * MB + mb) * 64 + lane] = acc[t][mb];
+    }   // K-slice waves
+    __syncthreads();
+    FK_STAMP(4);
+    // wave mb sums row block mb of both tiles, in slice order, and finishes it (short K: fewer waves than row blocks, they take turns)
+    for (int mb = wave; mb < MB; mb += NW + 1) {
+    f32x4 v[TPB];
+#pragma unroll
+    for (int t = 0; t < TPB; ++t) {
+        v[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < NW; ++w) v[t] += red[((size_t)w * (TPB * MB) + t * MB + mb) * 64 + lane];
+    }
+    const int m = mb * 16 + jj;
+    if (m >= p.M) continue;
+
+    if constexpr (EPI == FK_RESID) {
+#pragma unroll
+        for (int t = 0; t < TPB; ++t) {
+            const int n0 = tile[t] * 16 + q * 4;
+            if (n0 >= p.N) continue;
+            const f16x4 bv = *reinterpret_cast<const f16x4*>(&sg.bias[t * 16 + q * 4]), rin = *reinterpret_cast<const f16x4*>(&sg.res[m][t * 16 + q * 4]);
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float y = (float)(f16)(v[t][r] + (float)bv[r]);    // the linear's output is an fp16 tensor in the reference
+                o[r] = (f16)(y + (float)rin[r]);
+            }
+            *reinterpret_cast<f16x4*>(fp.res_out + (size_t)m * p.N + n0) = o;
+            if (fp.ssq_out) {                         // this tile's share of sum h'^2 of the row, for the consumer's RMSNorm
+                float s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s2 += (float)o[r] * (float)o[r];
+                s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+                if (q == 0) fp.ssq_out[(size_t)m * fp.ssq_ld + tile[t]] = s2;
+            }
+        }
+        FK_STAMP(5);
+    } else if constexpr (EPI == FK_ROPE) {
+        // tile pair of one head: this lane holds dims d0..d0+3 (v[0]) and d0+half..+3 (v[1]) of row m = token m
+        const RopeEpi& R = fp.r;
+        const int half = R.hd >> 1, hh = R.hd >> 5;
+        const int h  = tile[0] / (2 * hh);
+        const int d0 = (tile[0] % (2 * hh)) * 16 + q * 4;
+        float x0[4], x1[4];
+        const f16x4 b0 = *reinterpret_cast<const f16x4*>(&sg.bias[q * 4]), b1 = *reinterpret_cast<const f16x4*>(&sg.bias[16 + q * 4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            x0[r] = (float)(f16)(v[0][r] + (float)b0[r]);
+            x1[r] = (float)(f16)(v[1][r] + (float)b1[r]);
+        }
+        const int pos_in  = sg.pos[m];
+        const int pos_lim = min(R.max_pos, R.max_blocks * R.page);
+        const int pos = min(max(pos_in, 0), pos_lim - 1);
+        const bool is_v = h >= R.nh + R.nkv;
+        if (!is_v) {
+            const f32x4 cs01 = *reinterpret_cast<const f32x4*>(&sg.cs[m][q * 8]), cs23 = *reinterpret_cast<const f32x4*>(&sg.cs[m][q * 8 + 4]);
+            const float cc[4] = {cs01[0], cs01[2], cs23[0], cs23[2]}, ss[4] = {cs01[1], cs01[3], cs23[1], cs23[3]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float r0 = cc[r] * x0[r] - ss[r] * x1[r];
+                const float r1 = cc[r] * x1[r] + ss[r] * x0[r];
+                x0[r] = (float)(f16)r0; x1[r] = (float)(f16)r1;
+            }
+        }
+        f16x4 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o0[r] = (f16)x0[r]; o1[r] = (f16)x1[r]; }
+        FK_STAMP(5);
+        if (h < R.nh) {
+            f16* dst = R.q_out + ((size_t)m * R.nh + h) * R.hd + d0;
+            *reinterpret_cast<f16x4*>(dst) = o0;
+            *reinterpret_cast<f16x4*>(dst + half) = o1;
+            continue;
+        }
+        const int kh = is_v ? h - R.nh - R.nkv : h - R.nh;
+        if (pos_in < 0) continue;                                  // padding row of a multi-row step
+        const int blk = sg.blk[m];
+        if (pos != pos_in || blk < 0 || blk >= R.num_blocks) {   // stale position / block id: never write somebody else's page
+            if (h == R.nh && d0 == 0 && R.oob_count) atomicAdd(R.oob_count, 1);
+            continue;
+        }
+        const int tok = pos % R.page;
+        const size_t head_elems = (size_t)R.page * R.hd;
+        const size_t blk_base   = ((size_t)blk * 2 + (is_v ? 1 : 0)) * R.nkv + kh;
+        f16* dst = (f16*)R.kv_base + blk_base * head_elems;
+        if (!is_v) {
+            *reinterpret_cast<f16x4*>(dst + tok * R.hd + d0) = o0;
+            *reinterpret_cast<f16x4*>(dst + tok * R.hd + d0 + half) = o1;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { dst[(d0 + r) * R.page + tok] = o0[r]; dst[(d0 + r + half) * R.page + tok] = o1[r]; }
+        }
+    }
+    }   // row blocks of this wave
+}
+
+template <int GS, int MB, int EPI, int CPW, int RING>
+int launch64_t(const FullKParams& fp, int blocks, hipStream_t st) {
+    auto k = gemm_fullk64_kernel<GS, MB, EPI, CPW, RING>;
+    const int NW = cdiv(fp.g.KC, CPW);
+    if (NW > 15) return MI355_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)NW * 2 * MB * 1024 + sizeof(Stage64<EPI>);
+    if (lds > 160 * 1024) return MI355_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024)
+        if (int e = raise_dynamic_lds((const void*)k, "gemm_fullk64")) return e;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * (NW + 1)), lds, st, fp);
+    MI355_CHECK_LAUNCH("gemm_fullk64_kernel");
+    return MI355_OK;
+}
+
+// slice depth by K: up to 30 chunks (K <= 3840) two chunks per wave, up to 45 (K <= 5760) three; <= 15 K waves + the helper
+template <int GS, int MB, int EPI>
+int launch64_k(const FullKParams& fp, int blocks, hipStream_t st) {
+    const int KC = fp.g.KC;
+#ifdef MI355_TUNING
+    if (TUNE(6) == 1 && KC <= 30) return launch64_t<GS, MB, EPI, 2, MB>(fp, blocks, st);         // experiment: one k-step in flight
+    if constexpr (GS == 4) if (TUNE(6) == 2 && KC <= 30) return launch64_t<GS, MB, EPI, 2, 3 * MB>(fp, blocks, st);     // experiment: three k-steps
+#endif
+    if (KC <= 30) return launch64_t<GS, MB, EPI, 2, 2 * MB>(fp, blocks, st);
+    if (KC <= 45) return launch64_t<GS, MB, EPI, 3, (GS == 1 && MB == 4) ? MB : 2 * MB>(fp, blocks, st);   // g32 at 64 rows: 24 (zero, scale) words per wave, one k-step in flight fits 128 registers
+    return MI355_ERR_UNSUPPORTED;
+}
+
+} // namespace
+
+#ifdef MI355_FULLK_STAMPS
+extern unsigned long long* g_fullk_stamps;   // gemm_fullk.hip
+#endif
+
+// fp_: a FullKParams filled by the entry points of gemm_fullk.hip (same layout in both translation units).  epi: FK_RESID or
+// FK_ROPE.  Takes W4 group-wise weights, 17-64 rows, K <= 5760; MI355_ERR_UNSUPPORTED otherwise (the caller goes on to the
+// generic full-K kernel).
+extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi355_stream_t stream) {
+    FullKParams fp = *reinterpret_cast<const FullKParams*>(fp_);
+#ifdef MI355_FULLK_STAMPS
+    fp.stamps = g_fullk_stamps;
+#endif
+    fp.ilv = TUNE(7);
+    const GemmParams& g = fp.g;
+    if (g.M <= 16 || g.M > 64 || g.KC < 4 || g.KC > 45 || g.K != g.KC * 128) return MI355_ERR_UNSUPPORTED;
+    if (group_size != 128 && group_size != 64 && group_size != 32) return MI355_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const bool mb2 = g.M <= 32;
+#define F64_(GS_, EPI_, BLOCKS_)                                                                        \
+    return mb2 ? launch64_k<GS_, 2, EPI_>(fp, BLOCKS_, st) : launch64_k<GS_, 4, EPI_>(fp, BLOCKS_, st)
+    if (epi == FK_ROPE) {
+        if (fp.r.hd != 64 && fp.r.hd != 128) return MI355_ERR_UNSUPPORTED;
+        const int blocks = (fp.r.nh + 2 * fp.r.nkv) * (fp.r.hd / 32);
+        if (group_size == 128) { F64_(4, FK_ROPE, blocks); }
+        if (group_size == 64)  { F64_(2, FK_ROPE, blocks); }
+        F64_(1, FK_ROPE, blocks);
+    }
+    if (epi == FK_RESID) {
+        const int blocks = cdiv(g.NT, 2);
+        if (group_size == 128) { F64_(4, FK_RESID, blocks); }
+        if (group_size == 64)  { F64_(2, FK_RESID, blocks); }
+        F64_(1, FK_RESID, blocks);
+    }
+#undef F64_
+    return MI355_ERR_UNSUPPORTED;
+}

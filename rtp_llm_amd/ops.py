@@ -181,6 +181,98 @@ def qkv_rope_kv_write(x: torch.Tensor, wqkv: PackedWeight, qkv_bias, cos_sin, po
 
 
 # ------------------------------------------------------------------ norms / elementwise
+# ---- activation images (17-64-row steps): see include/mi355_decode.h, mi355_act_image_*
+class ActImage:
+    """The [M][K] activations of a 17-64-row step in the order the full-K launches read them (one dense 1 KB run per MFMA fragment)."""
+    def __init__(self, data: torch.Tensor, M: int, K: int):
+        self.data, self.M, self.K = data, M, K
+
+    def unpack(self) -> torch.Tensor:
+        out = torch.empty(self.M, self.K, dtype=self.data.dtype, device=self.data.device)
+        _C.check(_C.lib().mi355_act_image_pack(self.data.data_ptr(), self.M, self.K, out.data_ptr(), 1, _stream()), "act_image_pack")
+        return out
+
+
+def _new_image(M: int, K: int, dtype, device) -> ActImage:
+    n = _C.lib().mi355_act_image_bytes(M, K) // 2
+    return ActImage(torch.zeros(n, dtype=dtype, device=device), M, K)
+
+
+def act_image_pack(x: torch.Tensor) -> ActImage:
+    _chk_act(x, "act_image_pack.x")
+    M, K = x.shape
+    img = _new_image(M, K, x.dtype, x.device)
+    _C.check(_C.lib().mi355_act_image_pack(x.data_ptr(), M, K, img.data.data_ptr(), 0, _stream()), "act_image_pack")
+    return img
+
+
+def add_rmsnorm_img(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, eps: float, bias: Optional[torch.Tensor] = None):
+    """(y_img, residual_out): add_rmsnorm (rmsnorm when residual is None) with y written as an activation image."""
+    _chk_act(x, "add_rmsnorm_img.x"); _chk_act(weight, "add_rmsnorm_img.weight", x)
+    M, H = x.shape
+    img = _new_image(M, H, x.dtype, x.device)
+    res_out = torch.empty_like(x) if residual is not None else None
+    _C.check(_C.lib().mi355_add_rmsnorm_img(x.data_ptr(), None, 0, 0, _p(bias), _p(residual), _p(res_out), weight.data_ptr(), eps, M, H,
+                                            img.data.data_ptr(), _dt(x), _stream()), "add_rmsnorm_img")
+    return img, res_out
+
+
+def paged_attention_rows_img(q: torch.Tensor, kv_base, scale_base, block_table: torch.Tensor, positions: torch.Tensor, nkv: int,
+                             page: int, q_len: int, max_seq_len: int, scale: Optional[float] = None) -> ActImage:
+    """paged_attention_rows with the output written as an activation image (<= 64 rows)."""
+    _chk_act(q, "paged_attention_rows_img.q"); _chk(block_table, torch.int32, "block_table"); _chk(positions, torch.int32, "positions")
+    T, nh, hd = q.shape
+    kv = kv_struct(kv_base, scale_base, page, nkv, hd, q.dtype)
+    img = _new_image(T, nh * hd, q.dtype, q.device)
+    need = _C.lib().mi355_paged_attn_workspace_bytes(T, nh, hd, max_seq_len)
+    ws = _workspace(need, q.device)
+    _C.check(_C.lib().mi355_paged_attn_rows_img(q.data_ptr(), C.byref(kv), block_table.data_ptr(), block_table.shape[1], positions.data_ptr(),
+                                                T // q_len, q_len, nh, scale if scale is not None else 1.0 / math.sqrt(hd), max_seq_len,
+                                                img.data.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "paged_attn_rows_img")
+    return img
+
+
+def linear_residual_img(x: ActImage, w: PackedWeight, residual: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                        out: Optional[torch.Tensor] = None, tile_sumsq: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """linear_residual for 17-64 rows with the activations as an image (gemm_fullk64.hip); None when the shape is not taken."""
+    _chk(x.data, torch.float16, "linear_residual_img.x"); _chk(residual, torch.float16, "linear_residual_img.residual")
+    M = x.M
+    if x.K != w.K or residual.shape[-1] != w.N or residual.numel() != M * w.N:
+        raise _C.Mi355Error(f"linear_residual_img: image {M} x {x.K} / residual {tuple(residual.shape)} against K={w.K} N={w.N}")
+    if tile_sumsq is not None:
+        _chk(tile_sumsq, torch.float32, "linear_residual_img.tile_sumsq")
+        if tile_sumsq.dim() != 2 or tile_sumsq.shape[0] < M or tile_sumsq.shape[1] < w.N // 16:
+            raise _C.Mi355Error(f"linear_residual_img: tile_sumsq {tuple(tile_sumsq.shape)} must be [>= {M}, >= N/16 = {w.N // 16}]")
+    if out is None:
+        out = torch.empty_like(residual)
+    ws_struct = weight_struct(w)
+    rc = _C.lib().mi355_linear_residual_img(x.data.data_ptr(), M, C.byref(ws_struct), _p(bias), residual.data_ptr(), out.data_ptr(),
+                                            _p(tile_sumsq), 0 if tile_sumsq is None else tile_sumsq.shape[1], _stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    _C.check(rc, "linear_residual_img")
+    return out
+
+
+def qkv_rope_kv_write_img(x: ActImage, wqkv: PackedWeight, qkv_bias, cos_sin, positions, block_table, kv_base, scale_base,
+                          nh: int, nkv: int, hd: int, page: int, q_len: int = 1, oob_count: Optional[torch.Tensor] = None):
+    """qkv_rope_kv_write for 17-64 rows with the activations as an image; None when the shape is not taken."""
+    _chk(x.data, torch.float16, "qkv_rope_kv_write_img.x"); _chk(positions, torch.int32, "positions"); _chk(block_table, torch.int32, "block_table")
+    T = x.M
+    if x.K != wqkv.K:
+        raise _C.Mi355Error(f"qkv_rope_kv_write_img: image K={x.K} against K={wqkv.K}")
+    q_out = torch.empty(T, nh, hd, dtype=torch.float16, device=x.data.device)
+    kv = kv_struct(kv_base, scale_base, page, nkv, hd)
+    ws_struct = weight_struct(wqkv)
+    rc = _C.lib().mi355_qkv_rope_kv_write_img(x.data.data_ptr(), T, C.byref(ws_struct), _p(qkv_bias), cos_sin.data_ptr(), hd, cos_sin.shape[0],
+                                              positions.data_ptr(), block_table.data_ptr(), block_table.shape[1], q_len, nh,
+                                              C.byref(kv), q_out.data_ptr(), _p(oob_count), _stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    _C.check(rc, "qkv_rope_kv_write_img")
+    return q_out
+
+
 def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
     _chk_act(x, "rmsnorm.x"); _chk_act(weight, "rmsnorm.weight", x)
     H = x.shape[-1]

@@ -184,3 +184,161 @@ def test_fused_norm_chain_vs_oracle(M):
     # more than 16 rows: not taken with a fused norm
     ssq2 = torch.zeros(32, H // 16, dtype=torch.float32, device=DEV)
     assert ops.norm_linear(torch.zeros(17, H, dtype=torch.float16, device=DEV), (ssq2, gamma.to(DEV), eps), wg) is None
+
+
+# ---------------------------------------------------------------------------------------------------------------- 17-64 rows
+# gemm_fullk64.hip: the same two fused launches with the activations handed over as an image (include/mi355_decode.h,
+# mi355_act_image_*), against the same oracle composition and tolerance as the row-major forms above.
+MS64 = (17, 31, 32, 33, 47, 48, 49, 63, 64)
+
+
+def _img_index(M, K):
+    """element index of x[m][k] in the image: the formula of include/mi355_decode.h, restated in torch"""
+    m = torch.arange(M)[:, None]; k = torch.arange(K)[None, :]
+    mblk = (M + 15) // 16
+    return ((((k // 32) * mblk + m // 16) * 64 + ((k % 32) // 8) * 16 + m % 16) * 8 + k % 8).reshape(-1)
+
+
+@pytest.mark.parametrize("M,K", [(17, 64), (64, 3584), (33, 512), (48, 3584)])
+def test_act_image_layout_and_round_trip(M, K):
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(M + K)).half().to(DEV)
+    img = ops.act_image_pack(x)
+    torch.cuda.synchronize()
+    assert img.data.numel() == ((M + 15) // 16) * 16 * K
+    assert torch.equal(img.data.cpu()[_img_index(M, K)].reshape(M, K), x.cpu())      # documented index formula
+    assert torch.equal(img.unpack(), x)
+
+
+@pytest.mark.parametrize("K,N,gs", [(3584, 3584, 128), (512, 272, 128), (1024, 256, 64), (512, 128, 32), (4096, 1024, 128), (5120, 512, 128)],
+                         ids=["o", "ragged-n", "g64", "g32", "k4096-three-chunk-slices", "k5120"])
+def test_linear_residual_img_vs_oracle(K, N, gs):
+    packed, W = _w4(K, N, K + N, gs)
+    x = (torch.randn(64, K, generator=torch.Generator().manual_seed(3)) * 0.5).half()
+    res = (torch.randn(64, N, generator=torch.Generator().manual_seed(5)) * 2.0).half()
+    bias = (torch.randn(N, generator=torch.Generator().manual_seed(4)) * 0.1).half()
+    ref = (oracle.linear(x, W, bias).float() + res.float()).half()
+    xd, rd, bd = x.to(DEV), res.to(DEV), bias.to(DEV)
+    for M in MS64:
+        ssq = torch.zeros(M, (N // 16 + 3) & ~3, dtype=torch.float32, device=DEV)
+        out = ops.linear_residual_img(ops.act_image_pack(xd[:M].contiguous()), packed, rd[:M].contiguous(), bd, tile_sumsq=ssq)
+        assert out is not None, "W4 group-wise, 17-64 rows, K <= 5760: the image kernel must take it"
+        torch.cuda.synchronize()
+        err = (out.cpu().float() - ref[:M].float()).abs().max()
+        assert torch.allclose(out.cpu().float(), ref[:M].float(), **TOL), f"M={M}: max err {err}"
+        assert torch.allclose(ssq[:, : N // 16].sum(1).cpu(), (out.cpu().float() ** 2).sum(1), rtol=1e-5)   # exact partial sums of what was stored
+        comp = ops.linear_residual(xd[:M].contiguous(), packed, rd[:M].contiguous(), bd)            # the row-major launch of the same contract
+        assert torch.allclose(out.float(), comp.float(), **TOL)
+    # in place on the residual stream, as the step driver calls it; no bias
+    r2 = rd.clone()
+    ops.linear_residual_img(ops.act_image_pack(xd), packed, r2, None, out=r2)
+    assert torch.equal(r2, ops.linear_residual_img(ops.act_image_pack(xd), packed, rd, None))
+
+
+def test_img_launches_refuse_other_shapes():
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    p = model.synth_linear(512, 256, "w4", DEV, gen).pack()
+    r = torch.zeros(16, 256, dtype=torch.float16, device=DEV)
+    assert ops.linear_residual_img(ops.act_image_pack(torch.zeros(16, 512, dtype=torch.float16, device=DEV)), p, r) is None     # <= 16 rows: gemm_fullk.hip's
+    p8 = model.synth_linear(512, 256, "int8", DEV, gen).pack()
+    r = torch.zeros(32, 256, dtype=torch.float16, device=DEV)
+    assert ops.linear_residual_img(ops.act_image_pack(torch.zeros(32, 512, dtype=torch.float16, device=DEV)), p8, r) is None
+    pk = model.synth_linear(5888, 256, "w4", DEV, gen).pack()                                                                    # 46 chunks: past the slices
+    assert ops.linear_residual_img(ops.act_image_pack(torch.zeros(32, 5888, dtype=torch.float16, device=DEV)), pk, r) is None
+
+
+@pytest.mark.parametrize("nh,nkv,hd,hidden,page,q_len,gs", [(28, 4, 128, 3584, 16, 1, 128), (28, 4, 128, 3584, 16, 4, 128), (4, 2, 64, 512, 8, 1, 128),
+                                                            (8, 1, 128, 1024, 16, 2, 64), (6, 2, 64, 512, 16, 1, 32)],
+                         ids=["qwen2-7b", "qwen2-7b-rows4", "hd64", "mqa-rows2-g64", "hd64-g32"])
+def test_qkv_rope_kv_write_img_vs_oracle(nh, nkv, hd, hidden, page, q_len, gs):
+    N = (nh + 2 * nkv) * hd
+    packed, W = _w4(hidden, N, hidden + N, gs)
+    max_blocks, nblk = 8, 1024
+    cfg = model.ModelConfig("t", 1, hidden, nh, nkv, hd, 64, 128, max_pos=max_blocks * page)
+    cs = oracle.rope_cos_sin(hd, cfg.rope_theta, cfg.max_pos)
+    bias = (torch.randn(N, generator=torch.Generator().manual_seed(4)) * 0.1).half()
+    for T in sorted({(t // q_len) * q_len for t in (17 + q_len - 1, 32, 33 + q_len - 1, 48, 64)}):
+        nseq = T // q_len
+        g = torch.Generator().manual_seed(T)
+        x = (torch.randn(T, hidden, generator=g) * 0.5).half()
+        start = torch.randint(0, max_blocks * page - q_len, (nseq,), generator=g)
+        pos = (start[:, None] + torch.arange(q_len)[None, :]).reshape(-1).to(torch.int32)
+        if q_len > 1:
+            pos[-1] = -1                                     # a padding row of a multi-row step: q produced, nothing stored
+        bt = torch.randperm(nblk, generator=g)[: nseq * max_blocks].reshape(nseq, max_blocks).to(torch.int32)
+        kv, sc = kvcache.alloc_layer_cache(nblk, nkv, page, hd, False, DEV)
+        before = kv.clone()
+        q = ops.qkv_rope_kv_write_img(ops.act_image_pack(x.to(DEV)), packed, bias.to(DEV), cs.to(DEV), pos.to(DEV), bt.to(DEV), kv, sc, nh, nkv, hd, page, q_len)
+        assert q is not None
+        torch.cuda.synchronize()
+        qkv = oracle.linear(x, W, bias)
+        qh = qkv[:, : nh * hd].reshape(T, nh, hd)
+        kh = qkv[:, nh * hd: (nh + nkv) * hd].reshape(T, nkv, hd)
+        vh = qkv[:, (nh + nkv) * hd:].reshape(T, nkv, hd)
+        pos_c = pos.clamp(min=0)
+        q_ref, k_ref = oracle.apply_rope(qh, pos_c, cs), oracle.apply_rope(kh, pos_c, cs)
+        assert torch.allclose(q.cpu().float(), q_ref.float(), **TOL), f"T={T}: q max err {(q.cpu().float() - q_ref.float()).abs().max()}"
+        for t in range(T):
+            if pos[t] < 0: continue
+            K, V, _, _ = kvcache.read_tokens(kv, sc, bt[t // q_len], int(pos[t]) + 1)
+            assert torch.allclose(K[-1].cpu().float(), k_ref[t].float(), **TOL)
+            assert torch.allclose(V[-1].cpu().float(), vh[t].float(), **TOL)
+        # the composed launches it replaces leave the same cache image (same tolerance) and touch the same pages only
+        kv2, sc2 = kvcache.alloc_layer_cache(nblk, nkv, page, hd, False, DEV)
+        y = ops.linear(x.to(DEV), packed, None)
+        q2 = ops.rope_kv_write_rows(y, bias.to(DEV), cs.to(DEV), pos.to(DEV), bt.to(DEV), kv2, sc2, nh, nkv, hd, page, q_len)
+        assert torch.allclose(q.float(), q2.float(), **TOL) and torch.allclose(kv.float(), kv2.float(), **TOL)
+        assert torch.equal((kv != before).reshape(nblk, -1).any(1), (kv2 != before).reshape(nblk, -1).any(1))
+
+
+def test_qkv_rope_kv_write_img_stale_rows_and_int8_refusal():
+    nh, nkv, hd, hidden, page = 4, 2, 64, 512, 8
+    N = (nh + 2 * nkv) * hd
+    packed, _ = _w4(hidden, N, 9)
+    max_blocks, nblk, T = 4, 256, 20
+    cfg = model.ModelConfig("t", 1, hidden, nh, nkv, hd, 64, 128, max_pos=max_blocks * page)
+    cs = oracle.rope_cos_sin(hd, cfg.rope_theta, cfg.max_pos).to(DEV)
+    x = ops.act_image_pack((torch.randn(T, hidden, generator=torch.Generator().manual_seed(1)) * 0.5).half().to(DEV))
+    pos = torch.full((T,), 3, dtype=torch.int32, device=DEV)
+    pos[1] = -1; pos[2] = max_blocks * page + 7                                            # padding row, past the table
+    bt = torch.arange(T * max_blocks, dtype=torch.int32, device=DEV).reshape(T, max_blocks)
+    bt[3, 0] = nblk + 5                                                                      # stale block id
+    kv, sc = kvcache.alloc_layer_cache(nblk, nkv, page, hd, False, DEV)
+    oob = torch.zeros(1, dtype=torch.int32, device=DEV)
+    before = kv.clone()
+    q = ops.qkv_rope_kv_write_img(x, packed, None, cs, pos, bt, kv, sc, nh, nkv, hd, page, 1, oob)
+    torch.cuda.synchronize()
+    assert q is not None and int(oob.item()) == 2            # rows 2 and 3 refused, row 1 is padding (not an error)
+    changed = (kv != before).reshape(nblk, -1).any(dim=1).nonzero().flatten().tolist()
+    assert changed == [t * max_blocks for t in range(T) if t not in (1, 2, 3)]
+    kv8, sc8 = kvcache.alloc_layer_cache(nblk, nkv, page, hd, True, DEV)
+    assert ops.qkv_rope_kv_write_img(x, packed, None, cs, pos, bt, kv8, sc8, nh, nkv, hd, page, 1) is None
+
+
+@pytest.mark.parametrize("M", [17, 40, 64])
+def test_image_producers_equal_the_row_major_launches(M):
+    """RMSNorm (+ residual add) and paged attention writing images: bit for bit the row-major results at the image's addresses."""
+    H = 3584
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, H, generator=g).half().to(DEV); res = torch.randn(M, H, generator=g).half().to(DEV)
+    gamma = (1.0 + 0.2 * torch.randn(H, generator=g)).half().to(DEV)
+    y, r = ops.add_rmsnorm(x, res, gamma, 1e-6)
+    yi, ri = ops.add_rmsnorm_img(x, res, gamma, 1e-6)
+    assert torch.equal(yi.unpack(), y) and torch.equal(ri, r)
+    yi, _ = ops.add_rmsnorm_img(x, None, gamma, 1e-6)
+    assert torch.equal(yi.unpack(), ops.rmsnorm(x, gamma, 1e-6))
+    nh, nkv, hd, page, max_blocks, nblk = 28, 4, 128, 16, 8, 1024
+    for int8, q_len in ((False, 1), (True, 1), (False, 4)):
+        T = (M // q_len) * q_len
+        nseq = T // q_len
+        kv, sc = kvcache.alloc_layer_cache(nblk, nkv, page, hd, int8, DEV)
+        if int8:
+            kv.copy_(torch.randint(0, 256, kv.shape, generator=g, dtype=torch.int32).to(kv.dtype)); sc.copy_(torch.rand(sc.shape, generator=g) * 0.02)
+        else:
+            kv.copy_(torch.randn(kv.shape, generator=g).half())
+        q = torch.randn(T, nh, hd, generator=g).half().to(DEV)
+        start = torch.randint(0, max_blocks * page - q_len, (nseq,), generator=g)
+        pos = (start[:, None] + torch.arange(q_len)[None, :]).reshape(-1).to(torch.int32).to(DEV)
+        bt = torch.randperm(nblk, generator=g)[: nseq * max_blocks].reshape(nseq, max_blocks).to(torch.int32).to(DEV)
+        a = ops.paged_attention_rows(q, kv, sc, bt, pos, nkv, page, q_len, max_blocks * page)
+        ai = ops.paged_attention_rows_img(q, kv, sc, bt, pos, nkv, page, q_len, max_blocks * page)
+        assert torch.equal(ai.unpack(), a)

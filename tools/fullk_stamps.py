@@ -58,6 +58,10 @@ for M in [int(m) for m in a.ms.split(",")]:
     bt = torch.arange(M * mbk, dtype=torch.int32, device=dev).reshape(M, mbk)
     ops.linear_residual(x, wo[0], res, tile_sumsq=ssq)
     norm = (ssq, gamma, 1e-6)
+    if M > 16:   # gemm_fullk64.hip (or, with --set 5=2, the generic kernel at these heights): no fused norm, QKV and O only
+        report("qkv (rope + kv write)", lambda i: ops.qkv_rope_kv_write(res, wq[i], None, cs, pos, bt, kv, sc, nh, nkv, hd, page))
+        report("o (residual)", lambda i: ops.linear_residual(x, wo[i], res))
+        continue
     report("qkv (norm + rope + kv write)", lambda i: ops.qkv_rope_kv_write(res, wq[i], None, cs, pos, bt, kv, sc, nh, nkv, hd, page, norm=norm))
     report("o (residual)", lambda i: ops.linear_residual(x, wo[i], res))
     report("gate_up (norm + silu)", lambda i: ops.norm_linear(res, norm, wg[i], None, _C.EPI_SILU_MUL))
