@@ -266,6 +266,18 @@ int mi355_qkv_rope_kv_write(const void* x, int32_t M, const mi355_weight_t* wqkv
  * Reference boundary these keep: modules/hybrid/causal_attention.py:75-93 (qkv_proj -> rope / kv write -> attention -> o_proj),
  * model_desc/qwen3.py:57-79 (norm -> attention -> residual add).
  */
+/* Deferred RMSNorm between the O projection and gate_up of a 17-64-row step (no norm launch): the producer stores, besides the new
+ * residual rows h, the image of g = fp16(weight * 2^-norm_exp * h) and the per-tile sums of h^2 (as mi355_linear_residual does);
+ * the consumer runs its GEMM on g and multiplies the accumulators by unscale * rsqrt(sum_k h^2 / K + eps), unscale = 2^norm_exp:
+ * (RMSNorm(h) W)[m][n] = rs[m] * sum_k weight[k] h[m][k] W[k][n].  norm_exp >= log2(max |weight|) keeps |g| <= |h|: no fp16
+ * overflow whatever the residual stream holds.  One rounding of the activations to fp16 instead of the reference's two
+ * (modules/base/common/norm.py:83-92: fp16(h * rs), then * weight), the row factor in fp32. */
+typedef struct {
+    const float* tile_sumsq; /* [rows][ld]: per-tile sums of h^2, tiles = K / 16 of them per row */
+    int32_t      tiles, ld;
+    float        eps;
+    float        unscale;    /* 2^norm_exp */
+} mi355_deferred_norm_t;
 size_t mi355_act_image_bytes(int32_t M, int32_t K);
 int mi355_act_image_pack(const void* src, int32_t M, int32_t K, void* dst, int32_t direction, mi355_stream_t stream);
 int mi355_add_rmsnorm_img(const void* x, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
@@ -277,6 +289,15 @@ int mi355_paged_attn_rows_img(const void* q, const mi355_kv_layer_t* kv, const i
                               mi355_stream_t stream);
 int mi355_linear_residual_img(const void* x_img, int32_t M, const mi355_weight_t* w, const void* bias, const void* residual_in,
                               void* residual_out, float* tile_sumsq_out, int32_t tile_sumsq_ld, mi355_stream_t stream);
+/* mi355_linear_residual_img that also leaves the deferred-norm operands of the rows it produces: xg_img_out = image of
+ * fp16(norm_weight * 2^-norm_exp * residual_out), tile_sumsq_out as above (both required) */
+int mi355_linear_residual_prenorm_img(const void* x_img, int32_t M, const mi355_weight_t* w, const void* bias, const void* residual_in,
+                                      void* residual_out, const void* norm_weight, int32_t norm_exp, void* xg_img_out,
+                                      float* tile_sumsq_out, int32_t tile_sumsq_ld, mi355_stream_t stream);
+/* y = epilogue(rs * (xg W) + bias): the wide GEMM (W4 group-wise, 16 < M <= 64, N wide enough to fill the chip: gate_up) on an
+ * activation image, with the deferred norm applied to the accumulators (dn may be null: a plain linear on an image) */
+int mi355_linear_deferred_norm_img(const void* xg_img, int32_t M, const mi355_deferred_norm_t* dn, const mi355_weight_t* w,
+                                   const void* bias, void* y, int32_t epilogue, mi355_stream_t stream);
 int mi355_qkv_rope_kv_write_img(const void* x_img, int32_t M, const mi355_weight_t* wqkv, const void* qkv_bias,
                                 const float* cos_sin, int32_t rope_dim, int32_t max_pos, const int32_t* positions,
                                 const int32_t* block_table, int32_t max_blocks_per_seq, int32_t q_len, int32_t nh,

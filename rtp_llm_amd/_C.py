@@ -39,6 +39,10 @@ class FusedNorm(C.Structure):  # mi355_fused_norm_t
     _fields_ = [("tile_sumsq", vp), ("tiles", i32), ("ld", i32), ("weight", vp), ("eps", f32)]
 
 
+class DeferredNorm(C.Structure):  # mi355_deferred_norm_t
+    _fields_ = [("tile_sumsq", vp), ("tiles", i32), ("ld", i32), ("eps", f32), ("unscale", f32)]
+
+
 class ModelConfig(C.Structure):  # mi355_model_config_t
     _fields_ = [(n, i32) for n in ("num_layers", "hidden", "nh", "nkv", "hd", "inter", "vocab", "rope_dim", "max_pos")] + \
                [("rms_eps", f32)] + \
@@ -92,6 +96,8 @@ SIGNATURES = {
     "mi355_add_rmsnorm_img": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, i32, vp]),
     "mi355_paged_attn_rows_img": (i32, [vp, C.POINTER(KVLayer), vp, i32, vp, i32, i32, i32, f32, i32, vp, vp, sz, vp]),
     "mi355_linear_residual_img": (i32, [vp, i32, C.POINTER(Weight), vp, vp, vp, vp, i32, vp]),
+    "mi355_linear_residual_prenorm_img": (i32, [vp, i32, C.POINTER(Weight), vp, vp, vp, vp, i32, vp, vp, i32, vp]),
+    "mi355_linear_deferred_norm_img": (i32, [vp, i32, C.POINTER(DeferredNorm), C.POINTER(Weight), vp, vp, i32, vp]),
     "mi355_qkv_rope_kv_write_img": (i32, [vp, i32, C.POINTER(Weight), vp, vp, i32, i32, vp, vp, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
     "mi355_qkv_rope_kv_write": (i32, [vp, i32, C.POINTER(Weight), vp, C.POINTER(FusedNorm), vp, i32, i32, vp, vp, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
     "mi355_paged_attn_workspace_bytes": (sz, [i32, i32, i32, i32]),

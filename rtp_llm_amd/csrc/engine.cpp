@@ -82,6 +82,12 @@ struct mi355_decoder {
     // 17-64 rows (tp = 1): QKV + bias + RoPE + KV write and O + residual as one full-K launch each (gemm_fullk64.hip), their
     // activations handed over as images by the producing launches (RMSNorm fold, attention): 7 launches per layer instead of 8 + no slabs
     bool   img_qkv, img_o;
+    // ... and the post-attention RMSNorm deferred into gate_up's accumulators (mi355_deferred_norm_t): the O launch leaves
+    // gamma 2^-e h' as an image + the per-tile sums of h'^2, the wide GEMM applies rsqrt(mean h'^2 + eps) 2^e: 6 launches per layer
+    bool   img_gate_up;
+    std::vector<int> post_norm_exp;   // per layer: e >= log2(max |post_norm weight|)
+    void*  xg_img;                    // image of gamma 2^-e h'
+    float* ssq64;                     // [64][hidden / 16 rounded up to 4]
     float* ssq;      // [16 rows][hidden / 16]: the producer GEMM's per-tile sums of h^2, consumed by the next GEMM's on-the-fly RMSNorm
     // graphs
     hipStream_t                    cap_stream;
@@ -128,12 +134,14 @@ size_t carve_all(mi355_decoder* d, const mi355_model_config_t& c, void* base) {
     void* oob = cv.take(256);
     void* ssq = cv.take((size_t)16 * ((c.hidden / 16 + 3) & ~3) * 4);   // per-tile sums of squares of the residual rows (fused norm, <= 16 rows)
     void* xn_img = cv.take(mi355_act_image_bytes(64, c.hidden));
+    void* xg_img = cv.take(mi355_act_image_bytes(64, c.hidden));
+    void* ssq64 = cv.take((size_t)64 * ((c.hidden / 16 + 3) & ~3) * 4);
     void* attn_img = cv.take(mi355_act_image_bytes(64, qdim));
     const size_t wide_bytes = c.max_batch > 64 ? carve_prefill(c, c.max_batch, c.max_batch, nullptr, nullptr) : 0;
     void* wide_ws = cv.take(wide_bytes);
     void* iota = cv.take((size_t)c.max_batch * 4);
     if (d) {
-        d->ssq = (float*)ssq; d->xn_img = xn_img; d->attn_img = attn_img;
+        d->ssq = (float*)ssq; d->xn_img = xn_img; d->attn_img = attn_img; d->xg_img = xg_img; d->ssq64 = (float*)ssq64;
         d->oob_count = (int32_t*)oob; d->wide_ws = wide_ws; d->wide_ws_bytes = wide_bytes; d->iota = (int32_t*)iota;
         d->resid = resid; d->xn = xn; d->q_buf = q_buf; d->attn_out = attn_out; d->act = act;
         d->partials = (float*)partials; d->partials_bytes = pbytes; d->attn_ws = attn_ws; d->attn_ws_bytes = aw;
@@ -251,6 +259,26 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     d->img_o = d->fuse_o && cfg->act_dtype == MI355_ACT_F16;
     for (const auto& L : d->layers) { d->img_qkv = d->img_qkv && w64ok(&L.qkv); d->img_o = d->img_o && w64ok(&L.o); }
     if (TUNE(5) == 2) d->img_qkv = d->img_o = false;   // tuning build: A/B against the split-K + fold launches
+    d->img_gate_up = d->img_o && cfg->hidden % 64 == 0 && TUNE(5) != 3;
+    for (const auto& L : d->layers) d->img_gate_up = d->img_gate_up && mi355_gemm_wide_direct_ok(&L.gate_up);
+    if (d->img_gate_up) {   // exponent of the deferred norm per layer: the largest |weight| of post_norm, read back once
+        std::vector<uint16_t> g(cfg->hidden);
+        for (const auto& L : d->layers) {
+            if (hipMemcpy(g.data(), L.post_norm, (size_t)cfg->hidden * 2, hipMemcpyDeviceToHost) != hipSuccess) {
+                mi355_set_error("decoder_create: cannot read the norm weights"); delete d; return nullptr;
+            }
+            float mx = 0.f;
+            for (uint16_t b : g) {   // fp16 bits -> float
+                const int e = (b >> 10) & 31, m = b & 1023;
+                const float v = e == 0 ? ldexpf((float)m, -24) : (e == 31 ? INFINITY : ldexpf((float)(m | 1024), e - 25));
+                if (v > mx) mx = v;
+            }
+            int ex = 0;
+            while (ex < 14 && ldexpf(1.f, ex) < mx) ++ex;
+            if (!(mx < INFINITY) || ldexpf(1.f, ex) < mx) { d->img_gate_up = false; break; }   // inf / nan / beyond 2^14 in a norm weight: keep the norm launch
+            d->post_norm_exp.push_back(ex);
+        }
+    }
     std::vector<int32_t> iota_h(cfg->max_batch);
     for (int i = 0; i < cfg->max_batch; ++i) iota_h[i] = i;
     if (hipMemset(d->oob_count, 0, 256) != hipSuccess ||
@@ -481,6 +509,11 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
                                                      B / d->q_len, d->q_len, c.nh, 1.0f / sqrtf((float)c.hd), c.max_seq_len, d->attn_img,
                                                      d->attn_ws, d->attn_ws_bytes, st));
         if (int e = pf_join(d, st)) return e;
+        if (d->img_gate_up) {   // no norm launch: gate_up finishes the RMSNorm on its accumulators
+            RUN(MI355_KC_GEMM_QUANT, mi355_linear_residual_prenorm_img(d->attn_img, B, &L.o, nullptr, d->resid, d->resid, L.post_norm,
+                                                                       d->post_norm_exp[l], d->xg_img, d->ssq64, (c.hidden / 16 + 3) & ~3, st));
+            return MI355_OK;
+        }
         RUN(MI355_KC_GEMM_QUANT, mi355_linear_residual_img(d->attn_img, B, &L.o, nullptr, d->resid, d->resid, nullptr, 0, st));
         if (pf & MI355_PF_GATE_UP) if (int e = pf_issue(d, st, &L.gate_up, kPfCap)) return e;
         RUN(MI355_KC_NORM, mi355_rmsnorm_dt(d->resid, L.post_norm, c.rms_eps, B, c.hidden, d->xn, ADT, st));
@@ -527,7 +560,10 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
     const bool normed = small && d->fuse_norm && d->fuse_o;
     const int pf = c.tp_size == 1 ? d->pf_mask : 0;
     if (int e = pf_join(d, st)) return e;
-    if (normed) {   // post-attention RMSNorm on load + gate_up + SiLU-gate in one launch
+    if (d->img_o && d->img_gate_up && B > 16) {   // the O launch left gamma 2^-e h' and the sums of h'^2: RMSNorm finished on gate_up's accumulators
+        const mi355_deferred_norm_t dn = {d->ssq64, c.hidden / 16, (c.hidden / 16 + 3) & ~3, c.rms_eps, ldexpf(1.f, d->post_norm_exp[l])};
+        RUN(MI355_KC_GEMM_QUANT, mi355_linear_deferred_norm_img(d->xg_img, B, &dn, &L.gate_up, nullptr, d->act, MI355_EPI_SILU_MUL, st));
+    } else if (normed) {   // post-attention RMSNorm on load + gate_up + SiLU-gate in one launch
         const mi355_fused_norm_t fn = {d->ssq, c.hidden / 16, (c.hidden / 16 + 3) & ~3, L.post_norm, c.rms_eps};
         RUN(MI355_KC_GEMM_QUANT, mi355_norm_linear(d->resid, B, &fn, &L.gate_up, nullptr, d->act, MI355_EPI_SILU_MUL, st));
     } else {

@@ -32,7 +32,9 @@ extern "C" int mi355_gemm_fullk(const void* gp, int wbits, int group_size, const
 extern "C" int mi355_gemm_fullk_residual(const void* gp, int wbits, int group_size, const void* residual_in, void* residual_out,
                                          float* ssq_out, int ssq_ld, mi355_stream_t stream);
 extern "C" int mi355_gemm_fullk_residual_img(const void* gp, int wbits, int group_size, const void* residual_in, void* residual_out,
-                                             float* ssq_out, int ssq_ld, mi355_stream_t stream);
+                                             float* ssq_out, int ssq_ld, const void* norm_weight, float xg_scale, void* xg_img,
+                                             mi355_stream_t stream);
+extern "C" int mi355_gemm_wide_img(const void* gp, int wbits, int group_size, const mi355_deferred_norm_t* dn, mi355_stream_t stream);
 extern "C" int mi355_gemm_fullk_rope_img(const void* gp, int wbits, int group_size, const float* cos_sin, int32_t max_pos,
                                          const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq,
                                          int32_t q_len, int32_t nh, const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count,
@@ -609,7 +611,7 @@ void fill_params(GemmParams& p, const void* x, int M, const mi355_weight_t* w) {
     p.meta_bytes = (uint32_t)((uint64_t)ngroups * w->N_pad * 4);
     p.x_bytes = (uint32_t)((uint64_t)M * w->K * 2);
     p.bias = nullptr; p.y = nullptr; p.partials = nullptr; p.ldy = 0;
-    p.bf16 = w->act_dtype == MI355_ACT_BF16;
+    p.bf16 = w->act_dtype == MI355_ACT_BF16; p.x_img = 0;
 #ifdef MI355_TUNING
     p.stamps = (TUNE(7) == 2) ? g_wide_stamps : nullptr;
 #endif
@@ -894,7 +896,35 @@ extern "C" int mi355_linear_residual_img(const void* x_img, int32_t M, const mi3
     if (M <= 16 || M > 64 || w->wbits != 4 || !mi355_fullk_weight_ok(w)) return MI355_ERR_UNSUPPORTED;
     GemmParams p; fill_params(p, x_img, M, w);
     p.mode = MODE_F16; p.bias = (const f16*)bias; p.ldy = w->N;
-    return mi355_gemm_fullk_residual_img(&p, w->wbits, w->group_size, residual_in, residual_out, tile_sumsq_out, tile_sumsq_ld, stream);
+    return mi355_gemm_fullk_residual_img(&p, w->wbits, w->group_size, residual_in, residual_out, tile_sumsq_out, tile_sumsq_ld, nullptr, 0.f, nullptr, stream);
+}
+
+extern "C" int mi355_linear_residual_prenorm_img(const void* x_img, int32_t M, const mi355_weight_t* w, const void* bias, const void* residual_in,
+                                                 void* residual_out, const void* norm_weight, int32_t norm_exp, void* xg_img_out,
+                                                 float* tile_sumsq_out, int32_t tile_sumsq_ld, mi355_stream_t stream) {
+    if (int e = check_weight(w)) return e;
+    MI355_CHECK_ARG(x_img && residual_in && residual_out && norm_weight && xg_img_out && tile_sumsq_out && M > 0, "linear_residual_prenorm_img: bad args (M=%d)", M);
+    MI355_CHECK_ARG(tile_sumsq_ld >= w->N / 16 && tile_sumsq_ld % 4 == 0 && w->N % 32 == 0 && norm_exp >= 0 && norm_exp <= 14,
+                    "linear_residual_prenorm_img: tile_sumsq_ld=%d (>= N/16 = %d, multiple of 4), N %% 32, norm_exp=%d (0..14)", tile_sumsq_ld, w->N / 16, norm_exp);
+    if (M <= 16 || M > 64 || w->wbits != 4 || !mi355_fullk_weight_ok(w)) return MI355_ERR_UNSUPPORTED;
+    GemmParams p; fill_params(p, x_img, M, w);
+    p.mode = MODE_F16; p.bias = (const f16*)bias; p.ldy = w->N;
+    return mi355_gemm_fullk_residual_img(&p, w->wbits, w->group_size, residual_in, residual_out, tile_sumsq_out, tile_sumsq_ld, norm_weight,
+                                         ldexpf(1.f, -norm_exp), xg_img_out, stream);
+}
+
+extern "C" int mi355_linear_deferred_norm_img(const void* xg_img, int32_t M, const mi355_deferred_norm_t* dn, const mi355_weight_t* w,
+                                              const void* bias, void* y, int32_t epilogue, mi355_stream_t stream) {
+    if (int e = check_weight(w)) return e;
+    MI355_CHECK_ARG(xg_img && y && M > 0, "linear_deferred_norm_img: bad args (M=%d)", M);
+    MI355_CHECK_ARG(!dn || (dn->tile_sumsq && dn->tiles == w->K / 16 && dn->tiles <= 512 && dn->tiles % 4 == 0 && dn->ld >= dn->tiles && dn->ld % 4 == 0 && dn->eps > 0.f && dn->unscale > 0.f),
+                    "linear_deferred_norm_img: needs tile_sumsq [M][ld >= K/16 = %d, multiple of 4], eps and unscale", w->K / 16);
+    if (M <= 16 || M > 64 || w->wbits != 4 || w->act_dtype != MI355_ACT_F16 || w->K % 128 != 0 || w->K_pad != w->K) return MI355_ERR_UNSUPPORTED;
+    GemmParams p; fill_params(p, xg_img, M, w);
+    p.mode = (epilogue & MI355_EPI_OUT_F32) ? MODE_F32 : (epilogue & MI355_EPI_SILU_MUL) ? MODE_SILU : MODE_F16;
+    p.bias = (const f16*)bias; p.y = y; p.ldy = (p.mode == MODE_SILU) ? w->N / 2 : w->N;
+    p.x_img = 1; p.x_bytes = (uint32_t)mi355_act_image_bytes(M, w->K);
+    return mi355_gemm_wide_img(&p, w->wbits, w->group_size, dn, stream);
 }
 
 extern "C" int mi355_qkv_rope_kv_write_img(const void* x_img, int32_t M, const mi355_weight_t* wqkv, const void* qkv_bias,

@@ -63,6 +63,7 @@ struct GemmParams {
     int mode;                 // 0 partial slabs, 1 fp16, 2 fp16 silu-mul, 3 fp32
     int ldy;
     int bf16;                 // activations (x, bias, y; W16 weights) are bf16: staged kernel only
+    int x_img;                // x is an activation image (common.h act_img_index) of ceil(M / 16) row blocks: wide kernel only
     uint32_t qw_bytes, meta_bytes, x_bytes;
 #ifdef MI355_TUNING
     unsigned long long* stamps;   // tools/wq_stamps.py: wall_clock64 of wave 0 at entry / prologue done / loop done / stores issued / exit, per block

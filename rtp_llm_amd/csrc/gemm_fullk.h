@@ -27,6 +27,11 @@ struct FullKParams {
     float        eps;
     float*       ssq_out;    // FK_RESID: the same partial sums of the rows this launch produces ([M][ssq_ld]), or null
     int          ilv;        // K slices of the waves interleaved chunk by chunk (see the kernel)
+    // FK_RESID of gemm_fullk64.hip, deferred RMSNorm of the rows it produces: besides h' it stores g = fp16(gamma 2^-e h') as an
+    // activation image for the next GEMM, which multiplies its accumulators by rsqrt(mean h'^2 + eps) 2^e (from ssq_out)
+    f16*         xg_img;     // image of g ([M][N]), or null
+    const f16*   xg_gamma;   // norm weight [N]
+    float        xg_scale;   // 2^-e with e >= log2(max |gamma|): |g| <= |h'|, no overflow whatever the residual stream holds
 #ifdef MI355_FULLK_STAMPS   // tuning build with MI355_EXTRA_CFLAGS=-DMI355_FULLK_STAMPS only: the stamp stores change the schedule
     unsigned long long* stamps;   // tools/fullk_stamps.py: wall_clock64 per wave at entry / requests out (+ 1 / rms there) / first chunk done / loop done / slices met / exit
 #endif

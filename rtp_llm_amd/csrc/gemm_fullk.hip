@@ -618,11 +618,13 @@ extern "C" int mi355_gemm_fullk_rope(const void* gp, int wbits, int group_size, 
 
 // ---- the same two launches for 17-64 rows with the activations handed over as an image (gp->x: mi355_act_image_*), gemm_fullk64.hip
 extern "C" int mi355_gemm_fullk_residual_img(const void* gp, int wbits, int group_size, const void* residual_in, void* residual_out,
-                                             float* ssq_out, int ssq_ld, mi355_stream_t stream) {
+                                             float* ssq_out, int ssq_ld, const void* norm_weight, float xg_scale, void* xg_img,
+                                             mi355_stream_t stream) {
     FullKParams fp{};
     fp.g = *reinterpret_cast<const GemmParams*>(gp);
     if (wbits != 4 || !fullk_shape_ok(fp.g, wbits, group_size) || fp.g.N % 4 != 0) return MI355_ERR_UNSUPPORTED;
     fp.res_in = (const f16*)residual_in; fp.res_out = (f16*)residual_out; fp.ssq_out = ssq_out; fp.ssq_ld = ssq_ld;
+    fp.xg_img = (f16*)xg_img; fp.xg_gamma = (const f16*)norm_weight; fp.xg_scale = xg_scale;   // deferred RMSNorm of the produced rows (or null)
     return mi355_gemm_fullk64(&fp, FK_RESID, group_size, stream);
 }
 

@@ -27,7 +27,7 @@ namespace {
 
 // LDS behind the slices' partial sums: what the epilogue needs besides the sums, staged by the helper wave
 template <int EPI> struct Stage64 {};
-template <> struct Stage64<FK_RESID> { f16 res[64][32]; f16 bias[32]; };                       // residual rows / bias of the block's two tiles
+template <> struct Stage64<FK_RESID> { f16 res[64][32]; f16 bias[32]; f16 gam[32]; };          // residual rows / bias / norm weight of the block's two tiles
 template <> struct Stage64<FK_ROPE>  { float cs[64][32]; int pos[64], blk[64]; f16 bias[32]; }; // rotation row of the block's 16 dims per token, position, block id
 
 template <int GS, int MB, int EPI, int CPW, int RING>
@@ -72,11 +72,12 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
                 const int row = i * 16 + (lane >> 2);
                 rv[i] = bload128<0>(rr, (row < p.M && n < p.N) ? (uint32_t)(((size_t)row * p.N + n) * 2) : OOBX);
             }
-            u32x4 bv = {0u, 0u, 0u, 0u};
+            u32x4 bv = {0u, 0u, 0u, 0u}, gv = bv;
             if (p.bias && lane < 4 && n < p.N) bv = *reinterpret_cast<const u32x4*>(p.bias + n);
+            if (fp.xg_img && lane < 4 && n < p.N) gv = *reinterpret_cast<const u32x4*>(fp.xg_gamma + n);
 #pragma unroll
             for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&sg.res[i * 16 + (lane >> 2)][part * 8]) = rv[i];
-            if (lane < 4) *reinterpret_cast<u32x4*>(&sg.bias[part * 8]) = bv;
+            if (lane < 4) { *reinterpret_cast<u32x4*>(&sg.bias[part * 8]) = bv; *reinterpret_cast<u32x4*>(&sg.gam[part * 8]) = gv; }
         } else {
             const RopeEpi& R = fp.r;
             const int half = R.hd >> 1, hh = R.hd >> 5;
@@ -207,6 +208,13 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
                 o[r] = (f16)(y + (float)rin[r]);
             }
             *reinterpret_cast<f16x4*>(fp.res_out + (size_t)m * p.N + n0) = o;
+            if (fp.xg_img) {                          // deferred RMSNorm: gamma 2^-e h' for the next GEMM (one rounding, from fp32)
+                const f16x4 gm = *reinterpret_cast<const f16x4*>(&sg.gam[t * 16 + q * 4]);
+                f16x4 g;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[r] = (f16)((float)gm[r] * fp.xg_scale * (float)o[r]);
+                *reinterpret_cast<f16x4*>(fp.xg_img + act_img_index(m, n0, (p.M + 15) >> 4)) = g;
+            }
             if (fp.ssq_out) {                         // this tile's share of sum h'^2 of the row, for the consumer's RMSNorm
                 float s2 = 0.f;
 #pragma unroll

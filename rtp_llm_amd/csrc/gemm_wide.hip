@@ -33,6 +33,11 @@ namespace {
 struct WideParams {
     GemmParams g;
     int G; // tile groups (grid.x)
+    // deferred RMSNorm (mi355_deferred_norm_t): x holds gamma 2^-e h; the accumulators are multiplied by rsqrt(mean h^2 + eps) 2^e,
+    // with sum h^2 of a row rebuilt from the producer's per-tile partial sums ssq[row * ssq_ld + t], t < ssq_tiles
+    const float* ssq;
+    int   ssq_tiles, ssq_ld;
+    float eps, unscale;
     unsigned long long* stamps; // DBG & 4: wall_clock64 at start / after prologue / after the main loop / at the end, per wave
 };
 
@@ -53,6 +58,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
     constexpr bool HAND = (WBITS == 4 && (MB == 4 || MB == 2)); // hand-ordered unit (WIDE_UNIT_W4 / _MB2)
     static_assert(XF <= NU - 8, "fragment writes, the barrier and the fragment reads must fit one phase");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr size_t RS_OFF = ((size_t)8 * 3 * MB * 1024 > (size_t)2 * 4 * 4 * MB * 1024) ? (size_t)8 * 3 * MB * 1024 : (size_t)2 * 4 * 4 * MB * 1024;   // behind the stage / merge regions: 64 floats
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -84,10 +90,14 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
     const uint32_t mvoff  = (uint32_t)((t0 + th * T) * 16 + i) * 4u;  // + t * 64: meta of column 16 (t0 + th T + t) + i
     const uint32_t mrow   = (uint32_t)p.N_pad * 4u;
     uint32_t xvoff[XF];                                  // fragment j = th XF + jj: rows 16 (j / 4) + i, k-step j % 4
+    const int MBLK = (p.M + 15) >> 4;                    // row blocks of an activation image
+    const uint32_t xchunk = p.x_img ? (uint32_t)(4 * MBLK * 1024) : 256u;   // bytes from chunk to chunk
 #pragma unroll
     for (int jj = 0; jj < XF; ++jj) {
         const int j = th * XF + jj;
         xvoff[jj] = (uint32_t)((((j / 4) * 16 + i) * p.K + q * 8) * 2 + (j % 4) * 64); // rows >= M: out of range
+        // image: fragment (k-step, row block) is one dense 1 KB run (see common.h: gathered from the row-major tensor, 16 runs of 64 B)
+        if (p.x_img) xvoff[jj] = (j / 4 < MBLK) ? (uint32_t)(((j % 4) * MBLK + j / 4) * 1024 + lane * 16) : INVX;
     }
 
     u32x4    wr[T][LPC];                                 // weight ring: tile t of the current chunk, refilled with the next
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
     // wave-uniform offsets of chunk `c` (or out of range when !valid); masks, not selects (see gemm_smallm.hip)
     auto w_soff = [&](int c, bool valid) { const uint32_t m = 0u - (uint32_t)valid; return (((uint32_t)c * (LPC * 1024u)) & m) | (INV & ~m); };
     auto m_soff = [&](int c, bool valid) { const uint32_t m = 0u - (uint32_t)valid; return (((uint32_t)c * NSUB * mrow) & m) | (INV & ~m); };
-    auto x_soff = [&](int c, bool valid) { const uint32_t m = 0u - (uint32_t)valid; return (((uint32_t)c * 256u) & m) | (INVX & ~m); };
+    auto x_soff = [&](int c, bool valid) { const uint32_t m = 0u - (uint32_t)valid; return (((uint32_t)c * xchunk) & m) | (INVX & ~m); };
 
     auto load_tile = [&](int t, uint32_t ws, uint32_t ms) {
 #pragma unroll
@@ -152,6 +162,27 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
         for (int jj = 0; jj < XF; ++jj) xt[jj] = bload128<0>(rx, xvoff[jj], xs1);
 #pragma unroll
         for (int jj = 0; jj < XF; ++jj) x0t[jj] = bload128<0>(rx, xvoff[jj], xs0);
+        // deferred norm: wave w sums the partial sums of rows 8 w .. 8 w + 7 (requested here, with the L2-resident fragments and in
+        // front of the HBM weight requests; reduced below, once the fragments are parked)
+        // (one batch of straight-line requests: a loop over rows or passes would wait for each load before asking for the next -- 8 round
+        // trips, +3 us on the launch)
+        f32x4 pq[8];
+        if (wp.ssq) {
+            __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)wp.ssq, 0, (uint32_t)((size_t)p.M * wp.ssq_ld * 4), FLAGS);
+            const uint32_t lim = (uint32_t)wp.ssq_tiles * 4u;                       // bytes of a row's partial sums
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t rowoff = (uint32_t)((wave * 8 + r) * wp.ssq_ld) * 4u;   // rows >= M: past the descriptor
+                pq[r] = __builtin_bit_cast(f32x4, bload128<0>(rq, lane * 16u < lim ? rowoff + lane * 16u : INVX));
+            }
+            if (lim > 1024u) {                                                       // K > 4096: tiles 256 .. 511 of every row
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const uint32_t rowoff = (uint32_t)((wave * 8 + r) * wp.ssq_ld) * 4u;
+                    pq[r] += __builtin_bit_cast(f32x4, bload128<0>(rq, 1024u + lane * 16u < lim ? rowoff + 1024u + lane * 16u : INVX));
+                }
+            }
+        }
         const uint32_t ws0 = w_soff(cw0, ncw > 0), ms0 = m_soff(cw0, ncw > 0);
 #pragma unroll
         for (int t = 0; t < T; ++t) load_tile(t, ws0, ms0);
@@ -161,6 +192,16 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
         block_sync();
 #pragma unroll
         for (int j = 0; j < NBL; ++j) bq[j / 4][j % 4] = __builtin_bit_cast(f16x8, x0[j * 64 + lane]);
+        if (wp.ssq) {
+            float* rs_sh = reinterpret_cast<float*>(smem + RS_OFF);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float a = (pq[r][0] + pq[r][1]) + (pq[r][2] + pq[r][3]);
+                a = dpp_add<0xB1>(a); a = dpp_add<0x4E>(a); a = dpp_add<0x141>(a); a = dpp_add<0x140>(a);   // 16-lane rows
+                a = xor16_sum(a); a = xor32_sum(a);
+                if (lane == 0) rs_sh[wave * 8 + r] = rsqrtf(a / (float)p.K + wp.eps) * wp.unscale;
+            }
+        }
     }
     f16x8 a_cur = dq(0, 0);
     if constexpr (DBG & 4) st1 = wall_clock64();
@@ -274,6 +315,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
                     v[r] *= (float)as_h2(mm)[1];
                 }
             }
+            if (wp.ssq && m < p.M) v *= reinterpret_cast<const float*>(smem + RS_OFF)[m];   // deferred RMSNorm of row m (see WideParams)
             if (m < p.M) gemm_store(p, v, m, n0, blockIdx.y);
         }
     }
@@ -289,7 +331,7 @@ template <int WBITS, int MB, int GS, int T, int DBG = 0>
 int launch_wide_t(const WideParams& wp, hipStream_t st) {
     auto k = gemm_wide_kernel<WBITS, MB, GS, T, DBG>;
     constexpr size_t red_b = (size_t)8 * 3 * MB * 1024, stage_b = (size_t)2 * 4 * 4 * MB * 1024;
-    constexpr size_t lds = red_b > stage_b ? red_b : stage_b;
+    constexpr size_t lds = (red_b > stage_b ? red_b : stage_b) + 256;   // + 1 / rms of the rows (deferred norm)
     if (int e = raise_dynamic_lds((const void*)k, "gemm_wide")) return e;
     hipLaunchKernelGGL(k, dim3(wp.G, wp.g.nsplit), dim3(512), lds, st, wp);
     MI355_CHECK_LAUNCH("gemm_wide_kernel");
@@ -311,8 +353,27 @@ extern "C" void mi355_debug_ptr(void* p) { g_wide_stamps = (unsigned long long*)
 
 // Plan + launch.  Returns the number of slabs written (partial mode), MI355_OK (direct mode), or
 // MI355_ERR_UNSUPPORTED when the shape does not fit this kernel (the caller falls back to gemm.hip).
+static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_partial, int max_splits, const mi355_deferred_norm_t* dn,
+                            mi355_stream_t stream);
+// does the direct (one launch, no slabs) form take this linear at 17-64 rows?  N alone has to fill the chip (gate_up)
+extern "C" int mi355_gemm_wide_direct_ok(const mi355_weight_t* w) {
+    if (!w || w->wbits != 4 || w->act_dtype != MI355_ACT_F16 || (w->group_size != 128 && w->group_size != 64 && w->group_size != 32)) return 0;
+    if (w->K % 128 != 0 || w->K_pad != w->K) return 0;
+    const int NT = w->N_pad / 16, TB = 10, CUS = 256;
+    int G = (NT + TB - 1) / TB;
+    if (G < CUS && NT >= CUS * (TB - 3)) G = CUS;
+    return G >= CUS * 3 / 4;
+}
 extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int want_partial, int max_splits,
                                mi355_stream_t stream) {
+    return gemm_wide_launch(gp, wbits, group_size, want_partial, max_splits, nullptr, stream);
+}
+// direct mode only, x an activation image (gp->x_img) and / or a deferred RMSNorm on the accumulators
+extern "C" int mi355_gemm_wide_img(const void* gp, int wbits, int group_size, const mi355_deferred_norm_t* dn, mi355_stream_t stream) {
+    return gemm_wide_launch(gp, wbits, group_size, 0, 1, dn, stream);
+}
+static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_partial, int max_splits, const mi355_deferred_norm_t* dn,
+                            mi355_stream_t stream) {
     GemmParams g = *reinterpret_cast<const GemmParams*>(gp);
     constexpr int T = 5, TB = 2 * T, CUS = 256;     // tiles per wave / per block
     if (g.M <= 16 || g.M > 64) return MI355_ERR_UNSUPPORTED;
@@ -338,6 +399,12 @@ extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int wa
     g.cps = (g.KC + nsplit - 1) / nsplit;
     g.nsplit = (g.KC + g.cps - 1) / g.cps;
     wp.g = g; wp.G = G; wp.stamps = WIDE_STAMPS;
+    wp.ssq = nullptr; wp.ssq_tiles = wp.ssq_ld = 0; wp.eps = 0.f; wp.unscale = 1.f;
+    if (dn) {
+        if (want_partial || (wbits == 8)) return MI355_ERR_UNSUPPORTED;   // the scale is applied at the K-slice merge of the W4 instances
+        wp.ssq = dn->tile_sumsq; wp.ssq_tiles = dn->tiles; wp.ssq_ld = dn->ld; wp.eps = dn->eps; wp.unscale = dn->unscale;
+    }
+    if (g.x_img && want_partial) return MI355_ERR_UNSUPPORTED;
     int rc;
     hipStream_t st = (hipStream_t)stream;
     const bool mb2 = g.M <= 32;

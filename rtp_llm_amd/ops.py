@@ -254,6 +254,60 @@ def linear_residual_img(x: ActImage, w: PackedWeight, residual: torch.Tensor, bi
     return out
 
 
+def norm_exponent(weight: torch.Tensor) -> int:
+    """e >= log2(max |weight|), e >= 0: the deferred RMSNorm stores weight * 2^-e * h, so that |stored| <= |h|."""
+    mx = float(weight.float().abs().max())
+    e = 0
+    while e < 14 and 2.0 ** e < mx:
+        e += 1
+    return e
+
+
+def linear_residual_prenorm_img(x: ActImage, w: PackedWeight, residual: torch.Tensor, norm_weight: torch.Tensor,
+                                bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """(residual_out, xg_img, tile_sumsq, norm_exp): linear_residual_img that also leaves the operands of the deferred RMSNorm of the
+    rows it produces (mi355_deferred_norm_t); None when the shape is not taken."""
+    _chk(x.data, torch.float16, "linear_residual_prenorm_img.x"); _chk(residual, torch.float16, "residual"); _chk(norm_weight, torch.float16, "norm_weight")
+    M = x.M
+    if x.K != w.K or residual.shape[-1] != w.N or residual.numel() != M * w.N or norm_weight.numel() != w.N:
+        raise _C.Mi355Error(f"linear_residual_prenorm_img: image {M} x {x.K} / residual {tuple(residual.shape)} against K={w.K} N={w.N}")
+    if out is None:
+        out = torch.empty_like(residual)
+    ld = (w.N // 16 + 3) & ~3
+    ssq = torch.zeros(M, ld, dtype=torch.float32, device=residual.device)
+    xg = _new_image(M, w.N, torch.float16, residual.device)
+    e = norm_exponent(norm_weight)
+    ws_struct = weight_struct(w)
+    rc = _C.lib().mi355_linear_residual_prenorm_img(x.data.data_ptr(), M, C.byref(ws_struct), _p(bias), residual.data_ptr(), out.data_ptr(),
+                                                    norm_weight.data_ptr(), e, xg.data.data_ptr(), ssq.data_ptr(), ld, _stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    _C.check(rc, "linear_residual_prenorm_img")
+    return out, xg, ssq, e
+
+
+def linear_deferred_norm_img(xg: ActImage, dn, w: PackedWeight, bias: Optional[torch.Tensor] = None, epilogue: int = _C.EPI_NONE):
+    """epilogue(rs * (xg @ W) + bias) on the wide GEMM; dn = (tile_sumsq, eps, norm_exp) as left by linear_residual_prenorm_img, or None
+    (plain linear on an image).  None when the shape is not taken (N too narrow to fill the chip in one launch)."""
+    _chk(xg.data, torch.float16, "linear_deferred_norm_img.x")
+    if xg.K != w.K:
+        raise _C.Mi355Error(f"linear_deferred_norm_img: image K={xg.K} against K={w.K}")
+    st = None
+    if dn is not None:
+        ssq, eps, e = dn
+        _chk(ssq, torch.float32, "linear_deferred_norm_img.tile_sumsq")
+        st = _C.DeferredNorm(ssq.data_ptr(), w.K // 16, ssq.shape[1], float(eps), float(2.0 ** e))
+    N_out = w.N // 2 if (epilogue & _C.EPI_SILU_MUL) else w.N
+    y = torch.empty(xg.M, N_out, dtype=torch.float32 if (epilogue & _C.EPI_OUT_F32) else torch.float16, device=xg.data.device)
+    ws_struct = weight_struct(w)
+    rc = _C.lib().mi355_linear_deferred_norm_img(xg.data.data_ptr(), xg.M, None if st is None else C.byref(st), C.byref(ws_struct), _p(bias),
+                                                 y.data_ptr(), epilogue, _stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    _C.check(rc, "linear_deferred_norm_img")
+    return y
+
+
 def qkv_rope_kv_write_img(x: ActImage, wqkv: PackedWeight, qkv_bias, cos_sin, positions, block_table, kv_base, scale_base,
                           nh: int, nkv: int, hd: int, page: int, q_len: int = 1, oob_count: Optional[torch.Tensor] = None):
     """qkv_rope_kv_write for 17-64 rows with the activations as an image; None when the shape is not taken."""

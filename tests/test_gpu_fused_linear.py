@@ -342,3 +342,45 @@ def test_image_producers_equal_the_row_major_launches(M):
         a = ops.paged_attention_rows(q, kv, sc, bt, pos, nkv, page, q_len, max_blocks * page)
         ai = ops.paged_attention_rows_img(q, kv, sc, bt, pos, nkv, page, q_len, max_blocks * page)
         assert torch.equal(ai.unpack(), a)
+
+
+@pytest.mark.parametrize("M,gmax,hscale", [(17, 1.2, 3.0), (32, 1.2, 3.0), (48, 30.0, 3.0), (64, 1.2, 3.0), (64, 30.0, 2000.0)],
+                         ids=["17", "32", "48-large-gamma", "64", "64-large-gamma-massive-residual"])
+def test_deferred_norm_chain_vs_oracle(M, gmax, hscale):
+    """o_proj + residual (leaving gamma 2^-e h' as an image and the per-tile sums of h'^2) -> gate_up + SiLU-gate with the RMSNorm
+    finished on the accumulators: the 17-64-row layer without its post-attention norm launch, against oracle.rmsnorm + oracle.linear.
+    The last case puts a norm weight of 30 on a residual stream of +-2000-8000: gamma h' would overflow fp16, gamma 2^-5 h' does not."""
+    cfg = model.QWEN2_7B
+    H, I = cfg.hidden, cfg.inter
+    wo, Wo = _w4(H, H, 1)
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    cg = model.synth_linear(H, 2 * I, "w4", DEV, gen, zeros="centered")
+    wg = cg.pack(gate_up=True)
+    cgc = model.weights_to({"w": cg}, "cpu")["w"]
+    Wg = oracle.dequant_groupwise(cgc.q, cgc.z_eff, cgc.scales, cgc.group_size)
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, H, generator=g) * 0.5).half()
+    res = (torch.randn(M, H, generator=g) * hscale).half()
+    gamma = (1.0 + 0.2 * torch.randn(H, generator=g)).half()
+    gamma[::97] = gmax                                   # a few large norm weights
+    eps = 1e-6
+    r = ops.linear_residual_prenorm_img(ops.act_image_pack(x.to(DEV)), wo, res.to(DEV), gamma.to(DEV))
+    assert r is not None
+    h, xg, ssq, e = r
+    torch.cuda.synchronize()
+    assert 2.0 ** e >= gmax and (e == 0 or 2.0 ** (e - 1) < max(gmax, float(gamma.float().abs().max())))
+    h_ref = (oracle.linear(x, Wo, None).float() + res.float()).half()
+    assert torch.allclose(h.cpu().float(), h_ref.float(), **TOL)
+    assert torch.allclose(ssq[:, : H // 16].sum(1).cpu(), (h.cpu().float() ** 2).sum(1), rtol=1e-5)
+    xg_ref = (gamma.float() * 2.0 ** -e * h.cpu().float()).half()                   # one rounding from fp32
+    assert torch.equal(xg.unpack().cpu(), xg_ref) and torch.isfinite(xg_ref.float()).all()
+    act = ops.linear_deferred_norm_img(xg, (ssq, eps, e), wg, None, _C.EPI_SILU_MUL)
+    assert act is not None
+    act_ref = oracle.silu_mul(oracle.linear(oracle.rmsnorm(h.cpu(), gamma, eps), Wg, None))
+    err = (act.cpu().float() - act_ref.float()).abs().max()
+    assert torch.allclose(act.cpu().float(), act_ref.float(), **TOL), err
+    # the plain linear on an image (no deferred norm) equals the row-major wide GEMM bit for bit: same instruction stream, other addresses
+    y_img = ops.linear_deferred_norm_img(ops.act_image_pack(h), None, wg, None, _C.EPI_SILU_MUL)
+    assert torch.equal(y_img, ops.linear(h, wg, None, _C.EPI_SILU_MUL))
+    # a narrow N cannot fill the chip in one launch: not taken
+    assert ops.linear_deferred_norm_img(ops.act_image_pack(h), None, wo) is None
