@@ -105,6 +105,7 @@ enum {
     MI355_EPI_NONE     = 0,
     MI355_EPI_SILU_MUL = 1, /* columns are interleaved (gate,up) pairs; y is [M, N/2] */
     MI355_EPI_OUT_F32  = 2, /* y is fp32 [M, N] (lm_head logits) */
+    MI355_EPI_OUT_IMAGE = 4, /* mi355_linear_deferred_norm_img only: the 16-bit y is written as an activation image (mi355_act_image_*) */
     /* kernel-family hints (per call, for A/B tests; results stay within the same tolerance): */
     MI355_HINT_STAGED        = 0x100, /* 16 < M <= 64: take the LDS-staged kernel instead of the register-resident one */
     MI355_HINT_NO_PERSISTENT = 0x200  /* M <= 8: skip the persistent x-resident kernel */
@@ -298,6 +299,11 @@ int mi355_linear_residual_prenorm_img(const void* x_img, int32_t M, const mi355_
  * activation image, with the deferred norm applied to the accumulators (dn may be null: a plain linear on an image) */
 int mi355_linear_deferred_norm_img(const void* xg_img, int32_t M, const mi355_deferred_norm_t* dn, const mi355_weight_t* w,
                                    const void* bias, void* y, int32_t epilogue, mi355_stream_t stream);
+/* fp32 split-K slabs [n][M][N_pad] of a deep-K linear (down_proj) from an activation image, for mi355_add_rmsnorm(_img) to fold:
+ * returns n (<= max_splits, <= 16), or MI355_ERR_UNSUPPORTED (not W4 group-wise / not 17-64 rows / K too short or too deep for
+ * 8 K-slice waves of <= 5 chunks per block: the caller uses mi355_linear_partial on the row-major tensor) */
+int mi355_linear_partial_img(const void* x_img, int32_t M, const mi355_weight_t* w, float* partials, int32_t max_splits,
+                             mi355_stream_t stream);
 int mi355_qkv_rope_kv_write_img(const void* x_img, int32_t M, const mi355_weight_t* wqkv, const void* qkv_bias,
                                 const float* cos_sin, int32_t rope_dim, int32_t max_pos, const int32_t* positions,
                                 const int32_t* block_table, int32_t max_blocks_per_seq, int32_t q_len, int32_t nh,

@@ -16,7 +16,7 @@ OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_WORKSPACE = 0, -1, -2, -3, -4
 W4, W8, W16 = 4, 8, 16
 KV_FP16, KV_INT8, KV_BF16 = 0, 1, 2
 ACT_F16, ACT_BF16 = 0, 1
-EPI_NONE, EPI_SILU_MUL, EPI_OUT_F32 = 0, 1, 2
+EPI_NONE, EPI_SILU_MUL, EPI_OUT_F32, EPI_OUT_IMAGE = 0, 1, 2, 4
 PF_QKV, PF_O, PF_GATE_UP, PF_QKV_LATE, PF_O_LATE, PF_TP_COMM = 1, 2, 4, 16, 32, 64   # mi355_decoder_set_weight_prefetch mask bits
 HINT_STAGED, HINT_NO_PERSISTENT = 0x100, 0x200
 ABI_VERSION = 3
@@ -98,6 +98,7 @@ SIGNATURES = {
     "mi355_linear_residual_img": (i32, [vp, i32, C.POINTER(Weight), vp, vp, vp, vp, i32, vp]),
     "mi355_linear_residual_prenorm_img": (i32, [vp, i32, C.POINTER(Weight), vp, vp, vp, vp, i32, vp, vp, i32, vp]),
     "mi355_linear_deferred_norm_img": (i32, [vp, i32, C.POINTER(DeferredNorm), C.POINTER(Weight), vp, vp, i32, vp]),
+    "mi355_linear_partial_img": (i32, [vp, i32, C.POINTER(Weight), vp, i32, vp]),
     "mi355_qkv_rope_kv_write_img": (i32, [vp, i32, C.POINTER(Weight), vp, vp, i32, i32, vp, vp, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
     "mi355_qkv_rope_kv_write": (i32, [vp, i32, C.POINTER(Weight), vp, C.POINTER(FusedNorm), vp, i32, i32, vp, vp, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
     "mi355_paged_attn_workspace_bytes": (sz, [i32, i32, i32, i32]),

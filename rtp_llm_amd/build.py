@@ -19,7 +19,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmi355_decode.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-SOURCES = ["gemm.hip", "gemm_smallm.hip", "gemm_wide.hip", "gemm_fullk.hip", "gemm_fullk64.hip", "gemm_prefill.hip", "attention.hip", "rope_kv.hip", "elementwise.hip", "sampling.hip", "allreduce.hip", "rccl_transport.cpp", "engine.cpp", "error.cpp"]
+SOURCES = ["gemm.hip", "gemm_smallm.hip", "gemm_wide.hip", "gemm_fullk.hip", "gemm_fullk64.hip", "gemm_splitk64.hip", "gemm_prefill.hip", "attention.hip", "rope_kv.hip", "elementwise.hip", "sampling.hip", "allreduce.hip", "rccl_transport.cpp", "engine.cpp", "error.cpp"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "gemm_fullk.h"), os.path.join(CSRC, "internal.h"), os.path.join(INCLUDE, "mi355_decode.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

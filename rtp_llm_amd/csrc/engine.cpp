@@ -85,6 +85,9 @@ struct mi355_decoder {
     // ... and the post-attention RMSNorm deferred into gate_up's accumulators (mi355_deferred_norm_t): the O launch leaves
     // gamma 2^-e h' as an image + the per-tile sums of h'^2, the wide GEMM applies rsqrt(mean h'^2 + eps) 2^e: 6 launches per layer
     bool   img_gate_up;
+    // ... and down_proj as 4 K-quarters from the image gate_up's SiLU epilogue writes (gemm_splitk64.hip) instead of 15 slabs
+    bool   img_down;
+    void*  act_img;
     std::vector<int> post_norm_exp;   // per layer: e >= log2(max |post_norm weight|)
     void*  xg_img;                    // image of gamma 2^-e h'
     float* ssq64;                     // [64][hidden / 16 rounded up to 4]
@@ -135,13 +138,14 @@ size_t carve_all(mi355_decoder* d, const mi355_model_config_t& c, void* base) {
     void* ssq = cv.take((size_t)16 * ((c.hidden / 16 + 3) & ~3) * 4);   // per-tile sums of squares of the residual rows (fused norm, <= 16 rows)
     void* xn_img = cv.take(mi355_act_image_bytes(64, c.hidden));
     void* xg_img = cv.take(mi355_act_image_bytes(64, c.hidden));
+    void* act_img = cv.take(mi355_act_image_bytes(64, c.inter));
     void* ssq64 = cv.take((size_t)64 * ((c.hidden / 16 + 3) & ~3) * 4);
     void* attn_img = cv.take(mi355_act_image_bytes(64, qdim));
     const size_t wide_bytes = c.max_batch > 64 ? carve_prefill(c, c.max_batch, c.max_batch, nullptr, nullptr) : 0;
     void* wide_ws = cv.take(wide_bytes);
     void* iota = cv.take((size_t)c.max_batch * 4);
     if (d) {
-        d->ssq = (float*)ssq; d->xn_img = xn_img; d->attn_img = attn_img; d->xg_img = xg_img; d->ssq64 = (float*)ssq64;
+        d->ssq = (float*)ssq; d->xn_img = xn_img; d->attn_img = attn_img; d->xg_img = xg_img; d->ssq64 = (float*)ssq64; d->act_img = act_img;
         d->oob_count = (int32_t*)oob; d->wide_ws = wide_ws; d->wide_ws_bytes = wide_bytes; d->iota = (int32_t*)iota;
         d->resid = resid; d->xn = xn; d->q_buf = q_buf; d->attn_out = attn_out; d->act = act;
         d->partials = (float*)partials; d->partials_bytes = pbytes; d->attn_ws = attn_ws; d->attn_ws_bytes = aw;
@@ -261,6 +265,10 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     if (TUNE(5) == 2) d->img_qkv = d->img_o = false;   // tuning build: A/B against the split-K + fold launches
     d->img_gate_up = d->img_o && cfg->hidden % 64 == 0 && TUNE(5) != 3;
     for (const auto& L : d->layers) d->img_gate_up = d->img_gate_up && mi355_gemm_wide_direct_ok(&L.gate_up);
+    d->img_down = d->img_gate_up && cfg->inter % 32 == 0 && TUNE(5) != 4;
+    for (const auto& L : d->layers)
+        d->img_down = d->img_down && L.down.K % 128 == 0 && L.down.K_pad == L.down.K &&
+                      mi355_gemm_splitk64_plan(64, L.down.N_pad / 16, L.down.K_pad / 128, L.down.wbits, L.down.group_size, kMaxSplits, nullptr) > 0;
     if (d->img_gate_up) {   // exponent of the deferred norm per layer: the largest |weight| of post_norm, read back once
         std::vector<uint16_t> g(cfg->hidden);
         for (const auto& L : d->layers) {
@@ -562,7 +570,9 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
     if (int e = pf_join(d, st)) return e;
     if (d->img_o && d->img_gate_up && B > 16) {   // the O launch left gamma 2^-e h' and the sums of h'^2: RMSNorm finished on gate_up's accumulators
         const mi355_deferred_norm_t dn = {d->ssq64, c.hidden / 16, (c.hidden / 16 + 3) & ~3, c.rms_eps, ldexpf(1.f, d->post_norm_exp[l])};
-        RUN(MI355_KC_GEMM_QUANT, mi355_linear_deferred_norm_img(d->xg_img, B, &dn, &L.gate_up, nullptr, d->act, MI355_EPI_SILU_MUL, st));
+        const bool down_img = d->img_down;                 // gate_up's SiLU epilogue writes the image down_proj's K-quarter launch reads
+        RUN(MI355_KC_GEMM_QUANT, mi355_linear_deferred_norm_img(d->xg_img, B, &dn, &L.gate_up, nullptr, down_img ? d->act_img : d->act,
+                                                                MI355_EPI_SILU_MUL | (down_img ? MI355_EPI_OUT_IMAGE : 0), st));
     } else if (normed) {   // post-attention RMSNorm on load + gate_up + SiLU-gate in one launch
         const mi355_fused_norm_t fn = {d->ssq, c.hidden / 16, (c.hidden / 16 + 3) & ~3, L.post_norm, c.rms_eps};
         RUN(MI355_KC_GEMM_QUANT, mi355_norm_linear(d->resid, B, &fn, &L.gate_up, nullptr, d->act, MI355_EPI_SILU_MUL, st));
@@ -580,7 +590,10 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
         if (!normed || last) RUN(MI355_KC_NORM, mi355_rmsnorm_dt(d->resid, next_norm, c.rms_eps, B, c.hidden, d->xn, ADT, st));
         return MI355_OK;
     }
-    RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->act, B, &L.down, d->partials, kMaxSplits, st));
+    if (d->img_o && d->img_gate_up && d->img_down && B > 16)
+        RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial_img(d->act_img, B, &L.down, d->partials, kMaxSplits, st));
+    else
+        RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->act, B, &L.down, d->partials, kMaxSplits, st));
     if (pf & MI355_PF_QKV_LATE) if (int e = pf_issue(d, st, next_qkv, kPfCap)) return e;    // under the reduce + norm launch only
     if (c.tp_size == 1) {
         if (d->img_qkv && B > 16 && l + 1 < c.num_layers)   // the next layer's QKV launch reads an image (the final norm feeds lm_head: row-major)

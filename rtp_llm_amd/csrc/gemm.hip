@@ -34,6 +34,7 @@ extern "C" int mi355_gemm_fullk_residual(const void* gp, int wbits, int group_si
 extern "C" int mi355_gemm_fullk_residual_img(const void* gp, int wbits, int group_size, const void* residual_in, void* residual_out,
                                              float* ssq_out, int ssq_ld, const void* norm_weight, float xg_scale, void* xg_img,
                                              mi355_stream_t stream);
+extern "C" int mi355_gemm_splitk64(const void* gp, int wbits, int group_size, int max_splits, mi355_stream_t stream);
 extern "C" int mi355_gemm_wide_img(const void* gp, int wbits, int group_size, const mi355_deferred_norm_t* dn, mi355_stream_t stream);
 extern "C" int mi355_gemm_fullk_rope_img(const void* gp, int wbits, int group_size, const float* cos_sin, int32_t max_pos,
                                          const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq,
@@ -611,7 +612,7 @@ void fill_params(GemmParams& p, const void* x, int M, const mi355_weight_t* w) {
     p.meta_bytes = (uint32_t)((uint64_t)ngroups * w->N_pad * 4);
     p.x_bytes = (uint32_t)((uint64_t)M * w->K * 2);
     p.bias = nullptr; p.y = nullptr; p.partials = nullptr; p.ldy = 0;
-    p.bf16 = w->act_dtype == MI355_ACT_BF16; p.x_img = 0;
+    p.bf16 = w->act_dtype == MI355_ACT_BF16; p.x_img = 0; p.y_img = 0;
 #ifdef MI355_TUNING
     p.stamps = (TUNE(7) == 2) ? g_wide_stamps : nullptr;
 #endif
@@ -924,7 +925,23 @@ extern "C" int mi355_linear_deferred_norm_img(const void* xg_img, int32_t M, con
     p.mode = (epilogue & MI355_EPI_OUT_F32) ? MODE_F32 : (epilogue & MI355_EPI_SILU_MUL) ? MODE_SILU : MODE_F16;
     p.bias = (const f16*)bias; p.y = y; p.ldy = (p.mode == MODE_SILU) ? w->N / 2 : w->N;
     p.x_img = 1; p.x_bytes = (uint32_t)mi355_act_image_bytes(M, w->K);
+    if (epilogue & MI355_EPI_OUT_IMAGE) {
+        MI355_CHECK_ARG(p.mode != MODE_F32 && p.ldy % 32 == 0, "linear_deferred_norm_img: an image output is a 16-bit tensor with a multiple of 32 columns");
+        p.y_img = 1;
+    }
     return mi355_gemm_wide_img(&p, w->wbits, w->group_size, dn, stream);
+}
+
+// Split-K slabs of a deep-K linear (down_proj) at 17-64 rows from an activation image (gemm_splitk64.hip): returns the number of
+// fp32 slabs [n][M][N_pad] written to `partials` (to be folded by mi355_add_rmsnorm / _img), or MI355_ERR_UNSUPPORTED
+extern "C" int mi355_linear_partial_img(const void* x_img, int32_t M, const mi355_weight_t* w, float* partials, int32_t max_splits,
+                                        mi355_stream_t stream) {
+    if (int e = check_weight(w)) return e;
+    MI355_CHECK_ARG(x_img && partials && M > 0 && max_splits >= 1, "linear_partial_img: bad args (M=%d)", M);
+    if (M <= 16 || M > 64 || w->wbits != 4 || w->act_dtype != MI355_ACT_F16 || w->K % 128 != 0 || w->K_pad != w->K) return MI355_ERR_UNSUPPORTED;
+    GemmParams p; fill_params(p, x_img, M, w);
+    p.x_img = 1; p.x_bytes = (uint32_t)mi355_act_image_bytes(M, w->K); p.partials = partials;
+    return mi355_gemm_splitk64(&p, w->wbits, w->group_size, max_splits > 16 ? 16 : max_splits, stream);
 }
 
 extern "C" int mi355_qkv_rope_kv_write_img(const void* x_img, int32_t M, const mi355_weight_t* wqkv, const void* qkv_bias,

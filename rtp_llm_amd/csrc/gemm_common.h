@@ -64,6 +64,7 @@ struct GemmParams {
     int ldy;
     int bf16;                 // activations (x, bias, y; W16 weights) are bf16: staged kernel only
     int x_img;                // x is an activation image (common.h act_img_index) of ceil(M / 16) row blocks: wide kernel only
+    int y_img;                // fp16 / SiLU-mul outputs are written as an activation image of ceil(M / 16) row blocks (gemm_store)
     uint32_t qw_bytes, meta_bytes, x_bytes;
 #ifdef MI355_TUNING
     unsigned long long* stamps;   // tools/wq_stamps.py: wall_clock64 of wave 0 at entry / prologue done / loop done / stores issued / exit, per block
@@ -174,7 +175,7 @@ __device__ __forceinline__ void gemm_store(const GemmParams& p, f32x4 v, int m, 
         f16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (f16)v[r];
-        *reinterpret_cast<f16x4*>((f16*)p.y + (size_t)m * p.ldy + n0) = o;
+        *reinterpret_cast<f16x4*>((f16*)p.y + (p.y_img ? act_img_index(m, n0, (p.M + 15) >> 4) : (size_t)m * p.ldy + n0)) = o;
     } else { // MODE_SILU: (gate, up) interleaved; round GEMM output to fp16 first
         f16x2 o;
 #pragma unroll
@@ -182,7 +183,8 @@ __device__ __forceinline__ void gemm_store(const GemmParams& p, f32x4 v, int m, 
             const float g = (float)(f16)v[2 * t], u = (float)(f16)v[2 * t + 1];
             o[t] = (f16)((g / (1.f + __expf(-g))) * u);
         }
-        *reinterpret_cast<f16x2*>((f16*)p.y + (size_t)m * p.ldy + (n0 >> 1)) = o;
+        // image: the 16 rows of a wave-store are 16 consecutive 16-byte pieces (row-major: 16 separate rows)
+        *reinterpret_cast<f16x2*>((f16*)p.y + (p.y_img ? act_img_index(m, n0 >> 1, (p.M + 15) >> 4) : (size_t)m * p.ldy + (n0 >> 1))) = o;
     }
 }
 

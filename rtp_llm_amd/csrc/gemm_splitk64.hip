@@ -1,0 +1,223 @@
+// Split-K weight-only W4 GEMM for 17-64 rows and DEEP K (down_proj: K = 18944, N = 3584), gfx950: fp32 slabs for the consumer's
+// fold launch (mi355_add_rmsnorm), activations read as an image (mi355_act_image_*).
+// Reference slot: LinearBase.forward of the W4A16 strategy (models_py/modules/factory/linear/linear_base.py:75-85,
+// factory.py:106-119) for DenseMLP.down_proj (modules/hybrid/dense_mlp.py:95-106); the slabs are an internal hand-over.
+//
+// Why another kernel.  The staged kernel of gemm.hip runs this shape as 14 x 15 blocks: 15 fp32 slabs (13.8 MB written and read
+// back for 36 MB of weights), a barrier and an LDS round trip per chunk, 19.6 us + a 6 us fold.  The bound of the shape at 64 rows is
+// the (4 MFMA + 13 VALU) unit per (tile, k-step): 224 x 592 units = ~7 us on 224 CUs at the ~50 ns a SIMD needs per unit with two
+// waves (tools/probe/unit_rate.hip, gemm_wide.hip), next to 6.5 us of HBM time.  So:
+//   * a block owns FOUR adjacent 16-column tiles and a quarter of K (grid 56 x 4 = 224 blocks): 4 slabs instead of 15;
+//   * its 8 waves (two per SIMD) are K slices of <= CPW chunks; a wave runs the units of ALL four tiles for its k-steps, so every
+//     activation fragment (one dense 1 KB load from the image, common.h) feeds 16 MFMAs and is loaded by exactly one wave of the
+//     block -- no LDS staging, no barrier in the main loop (vector-memory path per CU: 606 KB of activations + 151 KB of weights,
+//     5 us at the ~150 GB/s a CU takes, under the issue time);
+//   * weights stream through a two-chunk register ring per wave, activations through a ring of RING k-steps; the re-requests sit
+//     right behind the last reader of their registers (vmcnt is in order: every wait then leaves the younger requests in flight);
+//   * the unit is the fixed instruction stream of gemm_common.h (WIDE_UNIT_W4), operands carried in two fixed register tuples;
+//   * the K slices meet once in LDS, each wave sums two (tile, row block) sets in slice order and stores them write-through (sc1)
+//     into the slab of the block's K quarter.
+#include "gemm_common.h"
+
+namespace {
+
+struct SplitK64Params {
+    GemmParams g;     // x: activation image; partials: slabs [nsplit][M][N_pad]; cps: chunks per block
+};
+
+template <int GS, int MB, int T, int CPW, int RING>
+__global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params sp) {
+    const GemmParams& p = sp.g;
+    constexpr int NW = 8;
+    constexpr int NSUB = 4 / GS, SPG = 4 / NSUB;
+    constexpr int NKS = CPW * 4;                         // k-steps of a wave (static schedule; past the slice: zero weights, zero activations)
+    constexpr uint32_t FLAGS = 0x00020000u, OOBS = 0x40000000u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* red = reinterpret_cast<f32x4*>(smem);         // [NW][T * MB][64]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int jj = lane & 15, q = lane >> 4;
+    const int t0 = blockIdx.x * T;                       // first tile of the block
+    const int cb = blockIdx.y * p.cps, ncb = min(p.cps, p.KC - cb);
+    const int base = ncb / NW, rem = ncb - base * NW;    // waves 0 .. rem - 1 take one chunk more
+    const int c0 = cb + wave * base + min(wave, rem);
+    const int n_ch = base + (wave < rem ? 1 : 0);        // <= CPW (host)
+
+    __amdgpu_buffer_rsrc_t rw[T], rm[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const bool ok = t0 + t < p.NT && n_ch > 0;
+        const char* wb = (const char*)p.qw + ((size_t)(t0 + t) * p.KC + c0) * 1024;
+        rw[t] = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, ok ? n_ch * 1024 : 0, FLAGS);
+        const char* mb_ = (const char*)p.meta + ((size_t)c0 * NSUB * p.N_pad + (t0 + t) * 16) * 4;
+        rm[t] = __builtin_amdgcn_make_buffer_rsrc((void*)mb_, 0, ok ? ((n_ch * NSUB - 1) * p.N_pad + 16) * 4 : 0, FLAGS);
+    }
+    const int MBLK = (p.M + 15) >> 4;                    // row blocks of the image (<= MB)
+    const char* xb = (const char*)p.x + (size_t)c0 * 4 * MBLK * 1024;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (uint32_t)(n_ch * 4 * MBLK * 1024), FLAGS);
+    const uint32_t lane16 = lane * 16u, jj4 = jj * 4u;
+
+    u32x4    wr[2][T];                                   // weight ring: chunk c in slot c & 1
+    uint32_t mr[2][T][NSUB];
+    u32x4    xr[RING][MB];                               // activation ring: k-step ks in slot ks % RING
+    auto load_w = [&](int c) {                           // c compile-time at every call site
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            wr[c & 1][t] = bload128<2 /*nt*/>(rw[t], lane16, (uint32_t)c * 1024u);
+#pragma unroll
+            for (int gi = 0; gi < NSUB; ++gi)
+                mr[c & 1][t][gi] = __builtin_amdgcn_raw_buffer_load_b32(rm[t], jj4, (uint32_t)(c * NSUB + gi) * (uint32_t)p.N_pad * 4u, 0);
+        }
+    };
+    auto load_x = [&](int ks) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+            xr[ks % RING][mb] = bload128<0>(rx, lane16, mb < MBLK ? (uint32_t)((ks * MBLK + mb) * 1024) : OOBS);
+    };
+    // request order = need order (fenced: left free, hipcc sinks the 4-byte (zero, scale) loads behind the 16-byte ones and the first
+    // unit's wait for them drains the whole prologue)
+    load_w(0);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, RING>([&](auto k_) { load_x(decltype(k_)::value); });
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (CPW > 1) load_w(1);
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4 acc[T][MB];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[t][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const W4Consts w4c = w4_consts();
+    const f16x2 c960 = {(f16)960.f, (f16)960.f};
+    // (zero, scale) of the group in use PER TILE: consecutive units belong to different tiles (k-step-major order), so a tile's words
+    // live in its own registers and are refreshed when its next unit starts a new group
+    f16x2 zn[T], znb[T], scl[T];
+    auto meta_of = [&](int c, int t, int s) {
+        const uint32_t m = mr[c & 1][t][s / SPG];
+        zn[t]  = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u));
+        scl[t] = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
+        znb[t] = zn[t] + c960;
+    };
+    meta_of(0, 0, 0);
+    u32x4 aE = __builtin_bit_cast(u32x4, dequant_w4_vc(wr[0][0][0], zn[0], znb[0], scl[0], w4c)), aO = aE;   // operand of even / odd units (fixed register tuples)
+
+    // ---- units in k-step-major order: u = (ks * T + t), ks = 4 c + s
+    constexpr int NU = NKS * T;
+    static_for<0, NU>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int ks = u / T, t = u % T, c = ks / 4, s = ks % 4;
+        constexpr int un = u + 1, ksn = un / T, tn = un % T, cn = ksn / 4, sn = ksn % 4;   // the unit whose operand this one prepares
+        uint32_t wn = 0;
+        if constexpr (un < NU) {
+            if constexpr (sn % SPG == 0) meta_of(cn, tn, sn);
+            wn = wr[cn & 1][tn][sn];
+        }
+        uint32_t tmp;
+        if constexpr (MB == 4) {
+            if constexpr (u % 2 == 0) {
+                asm volatile(WIDE_UNIT_W4("v[100:103]", "v104", "v105", "v106", "v107")
+                             : [t] "=&v"(tmp), "=&{v[104:107]}"(aO), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1]),
+                               [c2] "+a"(acc[t][2]), [c3] "+a"(acc[t][3])
+                             : "{v[100:103]}"(aE), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
+                               [e1] "v"(w4c.e1), [zn] "v"(zn[tn % T]), [znb] "v"(znb[tn % T]), [sc] "v"(scl[tn % T]), [b0] "v"(xr[ks % RING][0]),
+                               [b1] "v"(xr[ks % RING][1]), [b2] "v"(xr[ks % RING][2]), [b3] "v"(xr[ks % RING][3]));
+            } else {
+                asm volatile(WIDE_UNIT_W4("v[104:107]", "v100", "v101", "v102", "v103")
+                             : [t] "=&v"(tmp), "=&{v[100:103]}"(aE), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1]),
+                               [c2] "+a"(acc[t][2]), [c3] "+a"(acc[t][3])
+                             : "{v[104:107]}"(aO), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
+                               [e1] "v"(w4c.e1), [zn] "v"(zn[tn % T]), [znb] "v"(znb[tn % T]), [sc] "v"(scl[tn % T]), [b0] "v"(xr[ks % RING][0]),
+                               [b1] "v"(xr[ks % RING][1]), [b2] "v"(xr[ks % RING][2]), [b3] "v"(xr[ks % RING][3]));
+            }
+        } else {
+            if constexpr (u % 2 == 0) {
+                asm volatile(WIDE_UNIT_W4_MB2("v[100:103]", "v104", "v105", "v106", "v107")
+                             : [t] "=&v"(tmp), "=&{v[104:107]}"(aO), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1])
+                             : "{v[100:103]}"(aE), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
+                               [e1] "v"(w4c.e1), [zn] "v"(zn[tn % T]), [znb] "v"(znb[tn % T]), [sc] "v"(scl[tn % T]), [b0] "v"(xr[ks % RING][0]),
+                               [b1] "v"(xr[ks % RING][1]));
+            } else {
+                asm volatile(WIDE_UNIT_W4_MB2("v[104:107]", "v100", "v101", "v102", "v103")
+                             : [t] "=&v"(tmp), "=&{v[100:103]}"(aE), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1])
+                             : "{v[104:107]}"(aO), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
+                               [e1] "v"(w4c.e1), [zn] "v"(zn[tn % T]), [znb] "v"(znb[tn % T]), [sc] "v"(scl[tn % T]), [b0] "v"(xr[ks % RING][0]),
+                               [b1] "v"(xr[ks % RING][1]));
+            }
+        }
+        // re-requests right behind the last reader of their registers: the k-step's fragments after its last tile; the chunk's
+        // weights after the unit that prepared the last operand taken from them
+        if constexpr (t == T - 1 && ks + RING < NKS) load_x(ks + RING);
+        if constexpr (s == 3 && t == T - 1 && c + 2 < CPW) load_w(c + 2);
+        __builtin_amdgcn_sched_barrier(0);               // fence per unit: keeps the requests where they were written
+    });
+    asm volatile("s_nop 15" ::: "memory");               // the last MFMAs' results are read by compiler code below
+
+    // ---- the K slices meet in LDS; wave w sums the sets e = w, w + 8, ... (set e = tile e / MB, row block e % MB) and stores them
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) red[((size_t)wave * (T * MB) + t * MB + mb) * 64 + lane] = acc[t][mb];
+    __syncthreads();
+    __amdgpu_buffer_rsrc_t rs = slab_rsrc(p, p.nsplit);
+    for (int e = wave; e < T * MB; e += NW) {
+        const int t = e / MB, mb = e % MB, m = mb * 16 + jj;
+        f32x4 v = red[((size_t)e) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += red[((size_t)w * (T * MB) + e) * 64 + lane];
+        if (m < p.M && t0 + t < p.NT)
+            st_slab(rs, (uint32_t)((((size_t)blockIdx.y * p.M + m) * p.N_pad + (t0 + t) * 16 + q * 4) * 4), v);
+    }
+}
+
+template <int GS, int MB, int T, int CPW, int RING>
+int launch_splitk64_t(const SplitK64Params& sp, int G, hipStream_t st) {
+    auto k = gemm_splitk64_kernel<GS, MB, T, CPW, RING>;
+    const size_t lds = (size_t)8 * T * MB * 1024;
+    if (lds > 64 * 1024)
+        if (int e = raise_dynamic_lds((const void*)k, "gemm_splitk64")) return e;
+    hipLaunchKernelGGL(k, dim3(G, sp.g.nsplit), dim3(512), lds, st, sp);
+    MI355_CHECK_LAUNCH("gemm_splitk64_kernel");
+    return MI355_OK;
+}
+
+} // namespace
+
+// Plan: four tiles per block; the fewest K splits that put a block on >= 3/4 of the CUs, each wave <= 5 chunks.
+// Returns the number of slabs, or MI355_ERR_UNSUPPORTED (shape not deep / wide enough: the caller stays on gemm.hip).
+extern "C" int mi355_gemm_splitk64_plan(int M, int NT, int KC, int wbits, int group_size, int max_splits, int* cps_out) {
+    if (M <= 16 || M > 64 || wbits != 4 || (group_size != 128 && group_size != 64 && group_size != 32)) return MI355_ERR_UNSUPPORTED;
+    const int G = (NT + 3) / 4;
+    int ns = (192 + G - 1) / G;                          // >= 192 blocks
+    if (ns < 2) return MI355_ERR_UNSUPPORTED;            // N alone fills the chip: the wide kernel's shape
+    if (ns > max_splits) ns = max_splits;
+    int cps = (KC + ns - 1) / ns;
+    while (ns < max_splits && (cps + 7) / 8 > 5) { ++ns; cps = (KC + ns - 1) / ns; }
+    ns = (KC + cps - 1) / cps;
+    if ((cps + 7) / 8 > 5 || cps < 8 || G * ns > 512) return MI355_ERR_UNSUPPORTED;   // every wave >= 1 chunk, <= 5
+    if (cps_out) *cps_out = cps;
+    return ns;
+}
+
+// gp: GemmParams with x = activation image, partials = slabs; returns the number of slabs written.
+extern "C" int mi355_gemm_splitk64(const void* gp, int wbits, int group_size, int max_splits, mi355_stream_t stream) {
+    SplitK64Params sp;
+    sp.g = *reinterpret_cast<const GemmParams*>(gp);
+    GemmParams& g = sp.g;
+    if (g.K != g.KC * 128 || !g.partials) return MI355_ERR_UNSUPPORTED;
+    int cps = 0;
+    const int ns = mi355_gemm_splitk64_plan(g.M, g.NT, g.KC, wbits, group_size, max_splits, &cps);
+    if (ns < 0) return ns;
+    g.nsplit = ns; g.cps = cps; g.mode = MODE_PARTIAL;
+    const int G = (g.NT + 3) / 4, cpw = (cps + 7) / 8;
+    hipStream_t st = (hipStream_t)stream;
+    const bool mb2 = g.M <= 32;
+    int rc;
+#define SK_(GS_)                                                                                                   \
+    rc = cpw <= 3 ? (mb2 ? launch_splitk64_t<GS_, 2, 4, 3, 3>(sp, G, st) : launch_splitk64_t<GS_, 4, 4, 3, 3>(sp, G, st))   \
+                  : (mb2 ? launch_splitk64_t<GS_, 2, 4, 5, 3>(sp, G, st) : launch_splitk64_t<GS_, 4, 4, 5, 3>(sp, G, st))
+    if (group_size == 128) { SK_(4); } else if (group_size == 64) { SK_(2); } else { SK_(1); }
+#undef SK_
+    return rc == MI355_OK ? ns : rc;
+}

@@ -298,14 +298,33 @@ def linear_deferred_norm_img(xg: ActImage, dn, w: PackedWeight, bias: Optional[t
         _chk(ssq, torch.float32, "linear_deferred_norm_img.tile_sumsq")
         st = _C.DeferredNorm(ssq.data_ptr(), w.K // 16, ssq.shape[1], float(eps), float(2.0 ** e))
     N_out = w.N // 2 if (epilogue & _C.EPI_SILU_MUL) else w.N
-    y = torch.empty(xg.M, N_out, dtype=torch.float32 if (epilogue & _C.EPI_OUT_F32) else torch.float16, device=xg.data.device)
+    if epilogue & _C.EPI_OUT_IMAGE:          # the output as an activation image (the input of linear_partial_img)
+        yi = _new_image(xg.M, N_out, torch.float16, xg.data.device)
+        y = yi.data
+    else:
+        yi = None
+        y = torch.empty(xg.M, N_out, dtype=torch.float32 if (epilogue & _C.EPI_OUT_F32) else torch.float16, device=xg.data.device)
     ws_struct = weight_struct(w)
     rc = _C.lib().mi355_linear_deferred_norm_img(xg.data.data_ptr(), xg.M, None if st is None else C.byref(st), C.byref(ws_struct), _p(bias),
                                                  y.data_ptr(), epilogue, _stream())
     if rc == ERR_UNSUPPORTED:
         return None
     _C.check(rc, "linear_deferred_norm_img")
-    return y
+    return yi if yi is not None else y
+
+
+def linear_partial_img(x: ActImage, w: PackedWeight, max_splits: int = 16):
+    """fp32 split-K slabs [n, M, N_pad] of a deep-K linear from an activation image (gemm_splitk64.hip); None when not taken."""
+    _chk(x.data, torch.float16, "linear_partial_img.x")
+    if x.K != w.K:
+        raise _C.Mi355Error(f"linear_partial_img: image K={x.K} against K={w.K}")
+    slabs = torch.empty(max_splits, x.M, w.N_pad, dtype=torch.float32, device=x.data.device)
+    ws_struct = weight_struct(w)
+    rc = _C.lib().mi355_linear_partial_img(x.data.data_ptr(), x.M, C.byref(ws_struct), slabs.data_ptr(), max_splits, _stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    _C.check(rc, "linear_partial_img")
+    return slabs[:rc]
 
 
 def qkv_rope_kv_write_img(x: ActImage, wqkv: PackedWeight, qkv_bias, cos_sin, positions, block_table, kv_base, scale_base,

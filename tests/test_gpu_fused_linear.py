@@ -384,3 +384,56 @@ def test_deferred_norm_chain_vs_oracle(M, gmax, hscale):
     assert torch.equal(y_img, ops.linear(h, wg, None, _C.EPI_SILU_MUL))
     # a narrow N cannot fill the chip in one launch: not taken
     assert ops.linear_deferred_norm_img(ops.act_image_pack(h), None, wo) is None
+
+
+@pytest.mark.parametrize("K,N,gs", [(18944, 3584, 128), (3584, 8192, 128), (4096, 3584, 64), (4096, 3584, 32), (3712, 8192, 128)],
+                         ids=["7b-down", "70b-tp8-down", "g64", "g32", "72b-tp8-down-29-chunks"])
+def test_linear_partial_img_vs_oracle(K, N, gs):
+    """gemm_splitk64.hip: the slabs of a deep-K linear from an activation image sum to oracle.linear (fp32 accumulation, so the sum
+    is compared before any fp16 rounding) and fold into the same residual + RMSNorm as the staged kernel's slabs."""
+    packed, W = _w4(K, N, K + N, gs)
+    x = (torch.randn(64, K, generator=torch.Generator().manual_seed(3)) * 0.5).half()
+    ref = x.float() @ W                                      # fp32 GEMM of the dequantised weights
+    for M in (17, 32, 33, 48, 64):
+        slabs = ops.linear_partial_img(ops.act_image_pack(x[:M].contiguous().to(DEV)), packed)
+        assert slabs is not None and 2 <= slabs.shape[0] <= 16
+        torch.cuda.synchronize()
+        y = slabs.sum(0)[:, :N].cpu()
+        err = (y - ref[:M]).abs().max()
+        assert torch.allclose(y, ref[:M], atol=1e-2, rtol=1e-2), f"M={M}: max err {err}"
+        y16 = ops.linear(x[:M].contiguous().to(DEV), packed, None)               # the composed path, rounded once to fp16
+        assert torch.allclose(y.half().float(), y16.cpu().float(), atol=1e-2, rtol=1e-2)
+    assert ops.linear_partial_img(ops.act_image_pack(x[:16].contiguous().to(DEV)), packed) is None      # <= 16 rows: not this kernel's
+
+
+def test_linear_partial_img_refuses_shapes_outside_its_plan():
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    x = ops.act_image_pack(torch.zeros(32, 512, dtype=torch.float16, device=DEV))
+    assert ops.linear_partial_img(x, model.synth_linear(512, 256, "w4", DEV, gen).pack()) is None          # 4 chunks: too short for 8 K slices
+    xw = ops.act_image_pack(torch.zeros(32, 3584, dtype=torch.float16, device=DEV))
+    assert ops.linear_partial_img(xw, model.synth_linear(3584, 37888, "w4", DEV, gen).pack(gate_up=True)) is None   # N alone fills the chip
+    assert ops.linear_partial_img(xw, model.synth_linear(3584, 3584, "int8", DEV, gen).pack()) is None
+
+
+@pytest.mark.parametrize("M", [17, 40, 64])
+def test_wide_gemm_writes_the_image_the_down_launch_reads(M):
+    """gate_up + SiLU-gate with the output as an image == the row-major output at the image's addresses (bit for bit), and the
+    whole MLP on images (gate_up -> down slabs) matches the oracle MLP."""
+    cfg = model.QWEN2_7B
+    H, I = cfg.hidden, cfg.inter
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    cg = model.synth_linear(H, 2 * I, "w4", DEV, gen, zeros="centered"); wg = cg.pack(gate_up=True)
+    cd = model.synth_linear(I, H, "w4", DEV, gen, zeros="centered"); wd = cd.pack()
+    x = (torch.randn(M, H, generator=torch.Generator().manual_seed(M)) * 0.5).half().to(DEV)
+    xi = ops.act_image_pack(x)
+    act = ops.linear_deferred_norm_img(xi, None, wg, None, _C.EPI_SILU_MUL)
+    act_img = ops.linear_deferred_norm_img(xi, None, wg, None, _C.EPI_SILU_MUL | _C.EPI_OUT_IMAGE)
+    assert isinstance(act_img, ops.ActImage) and torch.equal(act_img.unpack(), act)
+    slabs = ops.linear_partial_img(act_img, wd)
+    assert slabs is not None
+    cgc, cdc = model.weights_to({"w": cg}, "cpu")["w"], model.weights_to({"w": cd}, "cpu")["w"]
+    Wg = oracle.dequant_groupwise(cgc.q, cgc.z_eff, cgc.scales, cgc.group_size)
+    Wd = oracle.dequant_groupwise(cdc.q, cdc.z_eff, cdc.scales, cdc.group_size)
+    ref = oracle.linear(oracle.silu_mul(oracle.linear(x.cpu(), Wg, None)), Wd, None)
+    y = slabs.sum(0)[:, :H].half().cpu()
+    assert torch.allclose(y.float(), ref.float(), **TOL), (y.float() - ref.float()).abs().max()
