@@ -47,7 +47,15 @@ struct AttnParams {
     uint32_t page_magic;   // 2^32 / page + 1: floor(t / page) == (t * magic) >> 32 for t * page < 2^32
     float scale_log2; // softmax scale * log2(e)
     int img_mblk;     // > 0: out is an activation image of that many row blocks (common.h act_img_index) instead of [rows][nh * hd]
+#ifdef MI355_TUNING
+    unsigned long long* stamps;   // tools/attn_stamps.py: wall_clock64 per wave at entry / first requests out / first group computed / loop done / merged / exit
+#endif
 };
+#ifdef MI355_TUNING
+#define AT_STAMP(i) do { if (p.stamps && lane == 0) p.stamps[((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 6 + (i)] = wall_clock64(); } while (0)
+#else
+#define AT_STAMP(i) do { } while (0)
+#endif
 // element index of out[row][col], col = h * HD + d
 __device__ __forceinline__ size_t out_index(const AttnParams& p, int row, int col, int HD) {
     return p.img_mblk > 0 ? act_img_index(row, col, p.img_mblk) : (size_t)row * p.nh * HD + col;
@@ -103,6 +111,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, w = lane >> 4;
+    AT_STAMP(0);
 
     // column j of tile c = (row c*R + j/G, head kh*G + j%G); q fragments (B operand), zero for unused columns
     u32x4 qf[NT][NSTEP];
@@ -355,6 +364,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
         int tb = pstart + wave * 32;
         if constexpr (NG == 2) {
             if (tb < pend) { lookup(tb, w0); load_group(g0, tb, w0); }
+            AT_STAMP(1);
             if (tb + GS < pend) lookup(tb + GS, w1);
             // Steady state without a single condition: both groups of the round and both groups it prefetches lie inside the
             // partition and need no mask.  (Guards around the loads make hipcc's waitcnt pass assume a load may have been
@@ -363,6 +373,9 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
                 load_group(g1, tb + GS, w1);
                 lookup(tb + 2 * GS, w0);
                 compute_group(g0, tb, std::false_type{});
+#ifdef MI355_TUNING
+                if (tb == pstart + wave * 32) { asm volatile("s_nop 0" ::: "memory"); AT_STAMP(2); }
+#endif
                 load_group(g0, tb + 2 * GS, w0);
                 lookup(tb + 3 * GS, w1);
                 compute_group(g1, tb + GS, std::false_type{});
@@ -441,6 +454,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
         }
     }
 
+    AT_STAMP(3);
     // ---- merge the NW waves through LDS, one column tile at a time.  o[c][db][r] is O^T[d = db*16 + w*4 + r][j].
     __shared__ float s_o[NW][16][HD + 4];
     __shared__ float s_m[NW][16], s_l[NW][16], s_b[NW][16];   // s_b: INT8 bias term 1152 * sum p16 of the wave's tokens
@@ -456,6 +470,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
         if (INT8) l16 = xor32_sum(xor16_sum(l16));
         if (w == 0) { s_m[wave][j] = m_run[c]; s_l[wave][j] = lr; s_b[wave][j] = KVB * l16; }
         __syncthreads();
+        AT_STAMP(4);
         // thread -> (column jj, 4 channels); 16 columns * HD/4 vectors
         const int ncol = p.R * p.G;
         for (int idx = tid; idx < ncol * (HD / 4); idx += NTHR) {
@@ -488,6 +503,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             }
         }
     }
+    AT_STAMP(5);
 }
 
 // Merge partitions: one wave per (sequence, head); lane owns HD/64 channels.
@@ -545,6 +561,8 @@ int plan_partitions(int B, int nkv, int max_seq_len, int* ps_out) {
 
 #ifdef MI355_TUNING
 extern "C" void mi355_debug_set_attn(int ps) { g_attn_ps_override = ps; }
+static unsigned long long* g_attn_stamps = nullptr;
+extern "C" void mi355_debug_attn_stamps(void* p) { g_attn_stamps = (unsigned long long*)p; }
 #endif
 
 extern "C" size_t mi355_paged_attn_workspace_bytes(int32_t B, int32_t nh, int32_t hd, int32_t max_seq_len) {
@@ -575,6 +593,9 @@ int launch_attn(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_
     p.page = kv->page; p.max_blocks = max_blocks_per_seq; p.seq_add = seq_lens_minus_one ? 1 : 0;
     p.max_seq = max_seq_len; p.num_blocks = kv->num_blocks;
     p.q_len = q_len; p.R = 16 / p.G; p.img_mblk = img_mblk;
+#ifdef MI355_TUNING
+    p.stamps = g_attn_stamps;
+#endif
     p.page_magic = (uint32_t)((1ull << 32) / (unsigned)kv->page + 1);
     const int NT = q_len > p.R ? 2 : 1;                 // column tiles per block: 2 x R rows share one pass over the KV
     p.ntile = cdiv(q_len, NT * p.R);

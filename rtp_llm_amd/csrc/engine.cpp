@@ -243,8 +243,11 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     d->pf_mask = 0; d->pf_pending = false;
     d->fuse_qkv = cfg->kv_dtype == MI355_KV_FP16 && cfg->rope_dim == cfg->hd;
     d->fuse_o = d->fuse_down = cfg->tp_size == 1;
-    d->fuse_rows = 12;   // measured crossover (round 3, after the full-K rework): b = 10 2.22 ms fused; b = 12 2.29 fused vs 2.38 staged; b = 16 2.49 vs 2.41
-    if (TUNE(6) > 0) d->fuse_rows = TUNE(6);   // tuning build: crossover experiments (tools/batch_sweep.py --tune 6=N)
+    // crossover between the few-row full-K launches (gemm_fullk.hip, dense activation loads) and the launches on activation images
+    // (round 4, same box: b = 4 1.94 vs 2.05 ms, b = 5 2.16 vs 2.05, b = 8 2.28 vs 2.07, b = 12 2.64 vs 2.10; profiles/r04_batch_sweep_crossover.txt);
+    // without the image path (other weight formats, bf16, TP) the round-3 crossover to the staged kernels stays
+    d->fuse_rows = 12;
+   // tuning build: crossover experiments (tools/batch_sweep.py --tune 6=N)
     // W4 layers only: for small fp16 models (the 0.5B draft of speculative decoding: 36-56 blocks per launch) the fused
     // launches measured behind the staged kernels (draft step 1.11 vs 1.05 ms), although the kernels take fp16 weights
     auto w4ok = [](const mi355_weight_t* w) { return w->wbits == 4 && mi355_fullk_weight_ok(w); };
@@ -263,6 +266,8 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     d->img_o = d->fuse_o && cfg->act_dtype == MI355_ACT_F16;
     for (const auto& L : d->layers) { d->img_qkv = d->img_qkv && w64ok(&L.qkv); d->img_o = d->img_o && w64ok(&L.o); }
     if (TUNE(5) == 2) d->img_qkv = d->img_o = false;   // tuning build: A/B against the split-K + fold launches
+    if (d->img_qkv && d->img_o) d->fuse_rows = 4;
+    if (TUNE(6) > 0) d->fuse_rows = TUNE(6) == 99 ? 0 : TUNE(6);   // tuning build: crossover experiments (tools/batch_sweep.py --tune 6=N)
     d->img_gate_up = d->img_o && cfg->hidden % 64 == 0 && TUNE(5) != 3;
     for (const auto& L : d->layers) d->img_gate_up = d->img_gate_up && mi355_gemm_wide_direct_ok(&L.gate_up);
     d->img_down = d->img_gate_up && cfg->inter % 32 == 0 && TUNE(5) != 4;
@@ -330,7 +335,7 @@ extern "C" int mi355_decoder_begin_rows(mi355_decoder_t* d, int32_t nseq, int32_
         RUN(MI355_KC_OTHER, mi355_embedding(d->bufs.token_ids, B, d->model.embedding, c.hidden, d->model.vocab_full, d->resid, st));
     }
     if (c.tp_size == 1 || d->ar) {
-        if (d->img_qkv && B > 16)
+        if (d->img_qkv && B > d->fuse_rows)
             RUN(MI355_KC_NORM, mi355_add_rmsnorm_img(d->resid, nullptr, 0, 0, nullptr, nullptr, nullptr, d->layers[0].input_norm, c.rms_eps, B,
                                                      c.hidden, d->xn_img, ADT, st));
         else
@@ -488,7 +493,7 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
     const bool normed = small && d->fuse_norm;            // no norm launches in this step: see fuse_norm
     const int pf = c.tp_size == 1 ? d->pf_mask : 0;       // (tp > 1: the side stream belongs to comm_with_prefetch)
     if (int e = pf_join(d, st)) return e;                  // this layer's QKV weights, requested behind the previous down GEMM
-    const bool mid_qkv = d->img_qkv && B > 16, mid_o = d->img_o && B > 16;   // 17-64 rows: full-K launches on activation images
+    const bool mid_qkv = d->img_qkv && B > d->fuse_rows, mid_o = d->img_o && B > d->fuse_rows;   // 17-64 rows: full-K launches on activation images
     if (mid_qkv) {
         RUN(MI355_KC_GEMM_QUANT, mi355_qkv_rope_kv_write_img(d->xn_img, B, &L.qkv, L.qkv_bias, d->model.cos_sin, c.rope_dim, c.max_pos,
                                                              d->bufs.positions, d->bufs.block_table, c.max_blocks_per_seq, d->q_len, c.nh,
@@ -568,7 +573,7 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
     const bool normed = small && d->fuse_norm && d->fuse_o;
     const int pf = c.tp_size == 1 ? d->pf_mask : 0;
     if (int e = pf_join(d, st)) return e;
-    if (d->img_o && d->img_gate_up && B > 16) {   // the O launch left gamma 2^-e h' and the sums of h'^2: RMSNorm finished on gate_up's accumulators
+    if (d->img_o && d->img_gate_up && B > d->fuse_rows) {   // the O launch left gamma 2^-e h' and the sums of h'^2: RMSNorm finished on gate_up's accumulators
         const mi355_deferred_norm_t dn = {d->ssq64, c.hidden / 16, (c.hidden / 16 + 3) & ~3, c.rms_eps, ldexpf(1.f, d->post_norm_exp[l])};
         const bool down_img = d->img_down;                 // gate_up's SiLU epilogue writes the image down_proj's K-quarter launch reads
         RUN(MI355_KC_GEMM_QUANT, mi355_linear_deferred_norm_img(d->xg_img, B, &dn, &L.gate_up, nullptr, down_img ? d->act_img : d->act,
@@ -590,13 +595,13 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
         if (!normed || last) RUN(MI355_KC_NORM, mi355_rmsnorm_dt(d->resid, next_norm, c.rms_eps, B, c.hidden, d->xn, ADT, st));
         return MI355_OK;
     }
-    if (d->img_o && d->img_gate_up && d->img_down && B > 16)
+    if (d->img_o && d->img_gate_up && d->img_down && B > d->fuse_rows)
         RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial_img(d->act_img, B, &L.down, d->partials, kMaxSplits, st));
     else
         RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->act, B, &L.down, d->partials, kMaxSplits, st));
     if (pf & MI355_PF_QKV_LATE) if (int e = pf_issue(d, st, next_qkv, kPfCap)) return e;    // under the reduce + norm launch only
     if (c.tp_size == 1) {
-        if (d->img_qkv && B > 16 && l + 1 < c.num_layers)   // the next layer's QKV launch reads an image (the final norm feeds lm_head: row-major)
+        if (d->img_qkv && B > d->fuse_rows && l + 1 < c.num_layers)   // the next layer's QKV launch reads an image (the final norm feeds lm_head: row-major)
             RUN(MI355_KC_NORM, mi355_add_rmsnorm_img(nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
                                                      c.rms_eps, B, c.hidden, d->xn_img, ADT, st));
         else

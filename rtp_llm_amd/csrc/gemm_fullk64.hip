@@ -326,7 +326,7 @@ extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi35
 #endif
     fp.ilv = TUNE(7);
     const GemmParams& g = fp.g;
-    if (g.M <= 16 || g.M > 64 || g.KC < 4 || g.KC > 45 || g.K != g.KC * 128) return MI355_ERR_UNSUPPORTED;
+    if (g.M < 1 || g.M > 64 || g.KC < 4 || g.KC > 45 || g.K != g.KC * 128) return MI355_ERR_UNSUPPORTED;
     if (group_size != 128 && group_size != 64 && group_size != 32) return MI355_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const bool mb2 = g.M <= 32;

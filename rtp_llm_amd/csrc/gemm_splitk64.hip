@@ -187,7 +187,7 @@ int launch_splitk64_t(const SplitK64Params& sp, int G, hipStream_t st) {
 // Plan: four tiles per block; the fewest K splits that put a block on >= 3/4 of the CUs, each wave <= 5 chunks.
 // Returns the number of slabs, or MI355_ERR_UNSUPPORTED (shape not deep / wide enough: the caller stays on gemm.hip).
 extern "C" int mi355_gemm_splitk64_plan(int M, int NT, int KC, int wbits, int group_size, int max_splits, int* cps_out) {
-    if (M <= 16 || M > 64 || wbits != 4 || (group_size != 128 && group_size != 64 && group_size != 32)) return MI355_ERR_UNSUPPORTED;
+    if (M < 1 || M > 64 || wbits != 4 || (group_size != 128 && group_size != 64 && group_size != 32)) return MI355_ERR_UNSUPPORTED;
     const int G = (NT + 3) / 4;
     int ns = (192 + G - 1) / G;                          // >= 192 blocks
     if (ns < 2) return MI355_ERR_UNSUPPORTED;            // N alone fills the chip: the wide kernel's shape

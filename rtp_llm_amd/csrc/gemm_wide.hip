@@ -376,7 +376,7 @@ static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_
                             mi355_stream_t stream) {
     GemmParams g = *reinterpret_cast<const GemmParams*>(gp);
     constexpr int T = 5, TB = 2 * T, CUS = 256;     // tiles per wave / per block
-    if (g.M <= 16 || g.M > 64) return MI355_ERR_UNSUPPORTED;
+    if (g.M < 1 || g.M > 64) return MI355_ERR_UNSUPPORTED;   // row-major callers come with > 16 rows (gemm.hip); 13-16 rows: the image entries, on the two-row-block instances
     const bool w8 = wbits == 8 && group_size == 0;    // per-channel int8 (W8A16): compiler-scheduled unit, scale applied at the merge
     if (!w8 && !(wbits == 4 && (group_size == 128 || group_size == 64 || group_size == 32))) return MI355_ERR_UNSUPPORTED;
     if (g.K % 128 != 0 || g.qw_bytes > 0x40000000u || (!w8 && g.meta_bytes > 0x40000000u)) return MI355_ERR_UNSUPPORTED;

@@ -189,7 +189,7 @@ def test_fused_norm_chain_vs_oracle(M):
 # ---------------------------------------------------------------------------------------------------------------- 17-64 rows
 # gemm_fullk64.hip: the same two fused launches with the activations handed over as an image (include/mi355_decode.h,
 # mi355_act_image_*), against the same oracle composition and tolerance as the row-major forms above.
-MS64 = (17, 31, 32, 33, 47, 48, 49, 63, 64)
+MS64 = (1, 5, 13, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64)     # the engine takes these launches from 5 rows up; the kernels serve any 1..64
 
 
 def _img_index(M, K):
@@ -199,7 +199,7 @@ def _img_index(M, K):
     return ((((k // 32) * mblk + m // 16) * 64 + ((k % 32) // 8) * 16 + m % 16) * 8 + k % 8).reshape(-1)
 
 
-@pytest.mark.parametrize("M,K", [(17, 64), (64, 3584), (33, 512), (48, 3584)])
+@pytest.mark.parametrize("M,K", [(1, 64), (17, 64), (64, 3584), (33, 512), (48, 3584)])
 def test_act_image_layout_and_round_trip(M, K):
     x = torch.randn(M, K, generator=torch.Generator().manual_seed(M + K)).half().to(DEV)
     img = ops.act_image_pack(x)
@@ -237,8 +237,6 @@ def test_linear_residual_img_vs_oracle(K, N, gs):
 def test_img_launches_refuse_other_shapes():
     gen = torch.Generator(device=DEV).manual_seed(1)
     p = model.synth_linear(512, 256, "w4", DEV, gen).pack()
-    r = torch.zeros(16, 256, dtype=torch.float16, device=DEV)
-    assert ops.linear_residual_img(ops.act_image_pack(torch.zeros(16, 512, dtype=torch.float16, device=DEV)), p, r) is None     # <= 16 rows: gemm_fullk.hip's
     p8 = model.synth_linear(512, 256, "int8", DEV, gen).pack()
     r = torch.zeros(32, 256, dtype=torch.float16, device=DEV)
     assert ops.linear_residual_img(ops.act_image_pack(torch.zeros(32, 512, dtype=torch.float16, device=DEV)), p8, r) is None
@@ -256,7 +254,7 @@ def test_qkv_rope_kv_write_img_vs_oracle(nh, nkv, hd, hidden, page, q_len, gs):
     cfg = model.ModelConfig("t", 1, hidden, nh, nkv, hd, 64, 128, max_pos=max_blocks * page)
     cs = oracle.rope_cos_sin(hd, cfg.rope_theta, cfg.max_pos)
     bias = (torch.randn(N, generator=torch.Generator().manual_seed(4)) * 0.1).half()
-    for T in sorted({(t // q_len) * q_len for t in (17 + q_len - 1, 32, 33 + q_len - 1, 48, 64)}):
+    for T in sorted({(t // q_len) * q_len for t in (5 + q_len - 1, 16, 17 + q_len - 1, 32, 33 + q_len - 1, 48, 64)}):
         nseq = T // q_len
         g = torch.Generator().manual_seed(T)
         x = (torch.randn(T, hidden, generator=g) * 0.5).half()
@@ -314,7 +312,7 @@ def test_qkv_rope_kv_write_img_stale_rows_and_int8_refusal():
     assert ops.qkv_rope_kv_write_img(x, packed, None, cs, pos, bt, kv8, sc8, nh, nkv, hd, page, 1) is None
 
 
-@pytest.mark.parametrize("M", [17, 40, 64])
+@pytest.mark.parametrize("M", [5, 17, 40, 64])
 def test_image_producers_equal_the_row_major_launches(M):
     """RMSNorm (+ residual add) and paged attention writing images: bit for bit the row-major results at the image's addresses."""
     H = 3584
@@ -344,8 +342,8 @@ def test_image_producers_equal_the_row_major_launches(M):
         assert torch.equal(ai.unpack(), a)
 
 
-@pytest.mark.parametrize("M,gmax,hscale", [(17, 1.2, 3.0), (32, 1.2, 3.0), (48, 30.0, 3.0), (64, 1.2, 3.0), (64, 30.0, 2000.0)],
-                         ids=["17", "32", "48-large-gamma", "64", "64-large-gamma-massive-residual"])
+@pytest.mark.parametrize("M,gmax,hscale", [(5, 1.2, 3.0), (16, 1.2, 3.0), (17, 1.2, 3.0), (32, 1.2, 3.0), (48, 30.0, 3.0), (64, 1.2, 3.0), (64, 30.0, 2000.0)],
+                         ids=["5", "16", "17", "32", "48-large-gamma", "64", "64-large-gamma-massive-residual"])
 def test_deferred_norm_chain_vs_oracle(M, gmax, hscale):
     """o_proj + residual (leaving gamma 2^-e h' as an image and the per-tile sums of h'^2) -> gate_up + SiLU-gate with the RMSNorm
     finished on the accumulators: the 17-64-row layer without its post-attention norm launch, against oracle.rmsnorm + oracle.linear.
@@ -381,7 +379,11 @@ def test_deferred_norm_chain_vs_oracle(M, gmax, hscale):
     assert torch.allclose(act.cpu().float(), act_ref.float(), **TOL), err
     # the plain linear on an image (no deferred norm) equals the row-major wide GEMM bit for bit: same instruction stream, other addresses
     y_img = ops.linear_deferred_norm_img(ops.act_image_pack(h), None, wg, None, _C.EPI_SILU_MUL)
-    assert torch.equal(y_img, ops.linear(h, wg, None, _C.EPI_SILU_MUL))
+    y_row = ops.linear(h, wg, None, _C.EPI_SILU_MUL)
+    if M > 16:      # row-major callers reach the wide kernel above 16 rows only (the staged kernel below: other summation order)
+        assert torch.equal(y_img, y_row)
+    else:
+        assert torch.allclose(y_img.float(), y_row.float(), **TOL)
     # a narrow N cannot fill the chip in one launch: not taken
     assert ops.linear_deferred_norm_img(ops.act_image_pack(h), None, wo) is None
 
@@ -394,7 +396,7 @@ def test_linear_partial_img_vs_oracle(K, N, gs):
     packed, W = _w4(K, N, K + N, gs)
     x = (torch.randn(64, K, generator=torch.Generator().manual_seed(3)) * 0.5).half()
     ref = x.float() @ W                                      # fp32 GEMM of the dequantised weights
-    for M in (17, 32, 33, 48, 64):
+    for M in (1, 5, 16, 17, 32, 33, 48, 64):
         slabs = ops.linear_partial_img(ops.act_image_pack(x[:M].contiguous().to(DEV)), packed)
         assert slabs is not None and 2 <= slabs.shape[0] <= 16
         torch.cuda.synchronize()
@@ -403,7 +405,6 @@ def test_linear_partial_img_vs_oracle(K, N, gs):
         assert torch.allclose(y, ref[:M], atol=1e-2, rtol=1e-2), f"M={M}: max err {err}"
         y16 = ops.linear(x[:M].contiguous().to(DEV), packed, None)               # the composed path, rounded once to fp16
         assert torch.allclose(y.half().float(), y16.cpu().float(), atol=1e-2, rtol=1e-2)
-    assert ops.linear_partial_img(ops.act_image_pack(x[:16].contiguous().to(DEV)), packed) is None      # <= 16 rows: not this kernel's
 
 
 def test_linear_partial_img_refuses_shapes_outside_its_plan():
@@ -415,7 +416,7 @@ def test_linear_partial_img_refuses_shapes_outside_its_plan():
     assert ops.linear_partial_img(xw, model.synth_linear(3584, 3584, "int8", DEV, gen).pack()) is None
 
 
-@pytest.mark.parametrize("M", [17, 40, 64])
+@pytest.mark.parametrize("M", [5, 17, 40, 64])
 def test_wide_gemm_writes_the_image_the_down_launch_reads(M):
     """gate_up + SiLU-gate with the output as an image == the row-major output at the image's addresses (bit for bit), and the
     whole MLP on images (gate_up -> down slabs) matches the oracle MLP."""

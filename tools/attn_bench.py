@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--seq-bt", type=int, default=0, help="1: identity block table (contiguous pages) instead of a random permutation")
     ap.add_argument("--product", action="store_true", help="time the product library instead of the tuning build")
     ap.add_argument("--tune", default="", help="idx=val,... forwarded to mi355_debug_set")
+    ap.add_argument("--copies", type=int, default=0, help="KV copies rotated (default: enough to stay HBM-resident; 1 = one copy that may live in the Infinity Cache)")
     a = ap.parse_args()
     lib = _C.lib()
     if not a.product:
@@ -29,7 +30,7 @@ def main():
     nblk = B * mb
     g = torch.Generator(device=dev).manual_seed(0)
     bytes_kv = B * ctx * 2 * nkv * hd * (1 if a.int8 else 2)
-    ncopy = max(2, int(700e6 // bytes_kv) + 1)
+    ncopy = a.copies or max(2, int(700e6 // bytes_kv) + 1)
     caches = []
     for _ in range(ncopy):
         kv, sc = kvcache.alloc_layer_cache(nblk, nkv, page, hd, a.int8, dev)
