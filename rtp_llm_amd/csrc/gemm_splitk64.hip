@@ -14,6 +14,10 @@
 //     5 us at the ~150 GB/s a CU takes, under the issue time);
 //   * weights stream through a two-chunk register ring per wave, activations through a ring of RING k-steps; the re-requests sit
 //     right behind the last reader of their registers (vmcnt is in order: every wait then leaves the younger requests in flight);
+//     Measured at 64 rows (profiles/r04_splitk64_variants.txt): 17.3 us; same instruction stream without activation traffic 15.0,
+//     without weight traffic 12.5, without either 12.2 -- HBM-miss weight requests and L2-hit activation requests share the CU's
+//     in-order memory pipeline, and together they cost more than the sum.  Deeper rings (3 chunks of weights + 4 k-steps of
+//     activations, accumulators as VGPR operands so that hipcc allows 212 registers) measured the same (18.0 us);
 //   * the unit is the fixed instruction stream of gemm_common.h (WIDE_UNIT_W4), operands carried in two fixed register tuples;
 //   * the K slices meet once in LDS, each wave sums two (tile, row block) sets in slice order and stores them write-through (sc1)
 //     into the slab of the block's K quarter.
@@ -23,6 +27,7 @@ namespace {
 
 struct SplitK64Params {
     GemmParams g;     // x: activation image; partials: slabs [nsplit][M][N_pad]; cps: chunks per block
+    int dbg;          // tuning build, timing only (same instruction stream): 1 no activation traffic, 2 no weight traffic
 };
 
 template <int GS, int MB, int T, int CPW, int RING>
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
     __amdgpu_buffer_rsrc_t rw[T], rm[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        const bool ok = t0 + t < p.NT && n_ch > 0;
+        const bool ok = t0 + t < p.NT && n_ch > 0 && !(sp.dbg & 2);
         const char* wb = (const char*)p.qw + ((size_t)(t0 + t) * p.KC + c0) * 1024;
         rw[t] = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, ok ? n_ch * 1024 : 0, FLAGS);
         const char* mb_ = (const char*)p.meta + ((size_t)c0 * NSUB * p.N_pad + (t0 + t) * 16) * 4;
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
     }
     const int MBLK = (p.M + 15) >> 4;                    // row blocks of the image (<= MB)
     const char* xb = (const char*)p.x + (size_t)c0 * 4 * MBLK * 1024;
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (uint32_t)(n_ch * 4 * MBLK * 1024), FLAGS);
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (sp.dbg & 1) ? 0u : (uint32_t)(n_ch * 4 * MBLK * 1024), FLAGS);
     const uint32_t lane16 = lane * 16u, jj4 = jj * 4u;
 
     u32x4    wr[2][T];                                   // weight ring: chunk c in slot c & 1
@@ -204,6 +209,7 @@ extern "C" int mi355_gemm_splitk64_plan(int M, int NT, int KC, int wbits, int gr
 extern "C" int mi355_gemm_splitk64(const void* gp, int wbits, int group_size, int max_splits, mi355_stream_t stream) {
     SplitK64Params sp;
     sp.g = *reinterpret_cast<const GemmParams*>(gp);
+    sp.dbg = TUNE(7);
     GemmParams& g = sp.g;
     if (g.K != g.KC * 128 || !g.partials) return MI355_ERR_UNSUPPORTED;
     int cps = 0;

@@ -3,7 +3,9 @@
 (gemm.hip) + its fold, Qwen2-7B shape, weights rotating through HBM-resident copies, graph replay.  usage: splitk64_time.py [--ms 64,32]"""
 import argparse, ctypes as C, os, sys
 ap = argparse.ArgumentParser(); ap.add_argument("--ms", default="64,48,32,17"); ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--set", default="", help="k=v,... -> mi355_debug_set (tuning build): 7=1 no activation traffic, 7=2 no weight traffic, 7=3 neither")
 a = ap.parse_args()
+if a.set: os.environ["MI355_TUNING_LIB"] = "1"
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rtp_llm_amd import _C, model, ops
@@ -11,6 +13,8 @@ dev = "cuda:0"; gen = torch.Generator(device=dev).manual_seed(0)
 cfg = model.QWEN2_7B; H, I = cfg.hidden, cfg.inter
 wd = [model.synth_linear(I, H, "w4", dev, gen, zeros="centered").pack() for _ in range(10)]
 lib = _C.lib()
+for kv_ in [x for x in a.set.split(",") if x]:
+    lib.mi355_debug_set(int(kv_.split("=")[0]), int(kv_.split("=")[1]))
 
 def timed(fn, n):
     for i in range(n): fn(i)
