@@ -391,7 +391,7 @@ def main():
     if world > 1 and not args.no_tp:
         import threading
         replica = {"parallelism": out["config"]["parallelism"], "global_batch": B * dp, "tokens_per_s": out["value"],
-                   "ms_per_step": out["ms_per_step"], "p50_ms": out["p50_ms"], "scaling": "weak"}
+                   "ms_per_step": out["ms_per_step"], "p50_ms": out["p50_ms"], "ms_per_step_repeats": out["ms_per_step_repeats"], "scaling": "weak"}
 
         def _tp_timeout():
             if rank == 0:
@@ -437,6 +437,12 @@ def main():
                 teng.capture(B)
             trun = (lambda n: teng.replay(B, n)) if captured else (lambda n: [teng.step(B) for _ in range(n)])
             t_el, t_p50 = timed(trun, treset)
+            # the same three extra blocks of K steps as for the replica layout, so that `ms_per_step_repeats` of the line belongs to the
+            # layout `value` / `ms_per_step` are quoted on (max over ranks: a TP step ends when its slowest rank does)
+            t_repeats = []
+            for _ in range(3):
+                torch.cuda.synchronize(); barrier(); t0r = time.perf_counter(); trun(args.steps); torch.cuda.synchronize()
+                t_repeats.append(round(max_over_ranks(time.perf_counter() - t0r) / args.steps * 1e3, 4))
             st = ar.status() if ar is not None else 0
             if st != 0:
                 raise RuntimeError(f"all-reduce spin timed out (status {st})")
@@ -448,7 +454,7 @@ def main():
                                       ("RCCL fallback (IPC peer mapping unavailable): ncclAllReduce on the local split-K fold (2 per layer) + "
                                        "ncclAllGather of one (max, index) pair per row, all inside the captured step")}
             # headline := the TP layout
-            out.update(value=tp_info["tokens_per_s"], ms_per_step=tp_info["ms_per_step"], p50_ms=tp_info["p50_ms"],
+            out.update(value=tp_info["tokens_per_s"], ms_per_step=tp_info["ms_per_step"], p50_ms=tp_info["p50_ms"], ms_per_step_repeats=t_repeats,
                        scaling="strong" if dpn == 1 else "strong within a tp group, weak across the dp groups")
             out["config"].update(parallelism=tp_info["parallelism"], global_batch=B * dpn)
             out["tp_layout"], out["replica_layout"] = tp_info, replica

@@ -426,6 +426,9 @@ mi355_allreduce_t* mi355_allreduce_create(int32_t rank, int32_t world, size_t ma
 int                mi355_allreduce_open(mi355_allreduce_t* ar, const void* all_handles);
 void               mi355_allreduce_destroy(mi355_allreduce_t* ar);
 int                mi355_allreduce_status(mi355_allreduce_t* ar, mi355_stream_t stream); /* synchronises; 0 = healthy */
+/* bound of every in-kernel wait for a peer (default 2000 ms); ranks sharing ONE device (single-GPU validation runs) are time-sliced
+ * against each other and want a longer one.  Applies to launches enqueued or captured afterwards. */
+int                mi355_allreduce_set_spin_timeout_ms(mi355_allreduce_t* ar, int32_t ms);
 
 /* out[T, n * world] = the ranks' [T, n] column slices side by side, out[t][r n + j] = x_r[t][j]: the all-gather of the
  * reference's hidden-split embedding (modules/base/common/embedding.py:50-58: all_gather, then reshape(tp, m, n).transpose(0, 1)

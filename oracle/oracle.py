@@ -204,6 +204,7 @@ class OracleKV:
         self.int8 = int8
         self.forced = forced
         self.flips = self.codes = self.max_delta = 0
+        self.max_scale_rel = 0.0      # largest relative difference between a forced scale and this store's own
         self.k = [[[] for _ in range(batch)] for _ in range(num_layers)]
         self.v = [[[] for _ in range(batch)] for _ in range(num_layers)]
         self.ks = [[[] for _ in range(batch)] for _ in range(num_layers)]
@@ -218,6 +219,11 @@ class OracleKV:
                 for own, got in ((kq, fk), (vq, fv)):
                     d = (own.int() - got.int()).abs()
                     self.flips += int((d > 0).sum()); self.codes += d.numel(); self.max_delta = max(self.max_delta, int(d.max()))
+                # the scales the kernel wrote are compared with this store's own (amax / 127 of nearly the same fp16 row): a wrong scale
+                # plane would otherwise be read by both sides of the comparison and cancel out
+                for own, got in ((ksc, fks), (vsc, fvs)):
+                    rel = ((own.float() - got.float()).abs() / own.float().abs().clamp_min(1e-12)).max()
+                    self.max_scale_rel = max(self.max_scale_rel, float(rel))
                 kq, ksc, vq, vsc = fk.to(kq.dtype), fks.to(ksc.dtype), fv.to(vq.dtype), fvs.to(vsc.dtype)
             self.k[layer][b].append(kq); self.v[layer][b].append(vq)
             self.ks[layer][b].append(ksc); self.vs[layer][b].append(vsc)

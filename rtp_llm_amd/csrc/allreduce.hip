@@ -34,7 +34,7 @@ namespace {
 constexpr int kMaxWorld  = 8;
 constexpr int kMaxBlocks = 256;            // flag rows; grid of an all-reduce launch <= kMaxBlocks
 constexpr int kFlagRow   = 16;             // dwords per block row: slots 0..7 first barrier, 8..15 second barrier (two-shot); one 64-byte line per block
-constexpr unsigned long long kSpinTicks = 200000000ull;   // 2 s of the 100 MHz wall clock
+constexpr unsigned long long kSpinTicks = 200000000ull;   // default bound: 2 s of the 100 MHz wall clock (mi355_allreduce_set_spin_timeout_ms)
 constexpr int kOneShotRows = 64;          // tensors with more rows take the two-shot form (world > 2)
 constexpr size_t kAuxBytes = 32768;        // per parity, after the tensor region: 8-byte records of the argmax exchange.
 // Every location of a registered buffer has ONE owner block for all time, whatever the geometry (T, H) of the call: the tensor
@@ -56,6 +56,7 @@ struct ArDev {                             // device-visible part of the context
     size_t          slot_elems;            // elements of one block's slot (tensor and result regions: kMaxBlocks slots each)
     uint32_t        data_bytes;            // bytes of one peer buffer (both parities): buffer range of the remote loads
     int             rank, world;
+    unsigned long long spin_ticks;         // bound of every wait for a peer, in 100 MHz wall-clock ticks
 };
 
 struct FusedParams {
@@ -96,7 +97,7 @@ __device__ __forceinline__ void peer_barrier(const ArDev& ar, int b, uint32_t ep
         // monotonic epochs: a peer may already be one call ahead (its next call's flag), never behind once it arrived
         while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
             __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > kSpinTicks) { atomicExch(ar.status, 1 + t); break; }
+            if (wall_clock64() - t0 > ar.spin_ticks) { atomicExch(ar.status, 1 + t); break; }
         }
     }
     __syncthreads();
@@ -374,6 +375,7 @@ struct mi355_allreduce {
     uint32_t* epoch;
     int32_t*  status;
     bool    ready;
+    unsigned long long spin_ticks;
 };
 
 namespace {
@@ -417,7 +419,7 @@ ArDev dev_view(const mi355_allreduce* a) {
     d.res_elems = (region + kAuxBytes) / 2;
     d.slot_elems = a->slot_bytes / 2;
     d.data_bytes = (uint32_t)(2 * (2 * region + kAuxBytes));
-    d.rank = a->rank; d.world = a->world;
+    d.rank = a->rank; d.world = a->world; d.spin_ticks = a->spin_ticks;
     return d;
 }
 
@@ -435,7 +437,7 @@ extern "C" mi355_allreduce_t* mi355_allreduce_create(int32_t rank, int32_t world
     }
     mi355_allreduce* a = new (std::nothrow) mi355_allreduce();
     if (!a) return nullptr;
-    a->rank = rank; a->world = world; a->ready = false;
+    a->rank = rank; a->world = world; a->ready = false; a->spin_ticks = kSpinTicks;
     a->max_bytes = (max_bytes + 255) & ~(size_t)255;
     a->slot_bytes = slot_bytes;
     for (int r = 0; r < kMaxWorld; ++r) { a->peer_data[r] = a->peer_flags[r] = nullptr; a->opened[r] = false; }
@@ -487,6 +489,15 @@ extern "C" void mi355_allreduce_destroy(mi355_allreduce_t* a) {
     if (a->epoch) hipFree(a->epoch);
     (void)hipGetLastError();
     delete a;
+}
+
+// Bound of every in-kernel wait for a peer (default 2 s).  One process per GPU never comes near it; ranks that SHARE a device (the
+// single-GPU validation of the collectives, several test workers on one box) are time-sliced against each other and against whatever
+// else runs there, so their contexts ask for a longer bound.  Takes effect for launches enqueued (or captured) afterwards.
+extern "C" int mi355_allreduce_set_spin_timeout_ms(mi355_allreduce_t* a, int32_t ms) {
+    MI355_CHECK_ARG(a && ms >= 1 && ms <= 600000, "allreduce_set_spin_timeout_ms: ms=%d (1..600000)", ms);
+    a->spin_ticks = (unsigned long long)ms * 100000ull;
+    return MI355_OK;
 }
 
 extern "C" int mi355_allreduce_status(mi355_allreduce_t* a, mi355_stream_t stream) {

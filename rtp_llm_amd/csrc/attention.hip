@@ -79,8 +79,9 @@ __device__ __forceinline__ f16x8 widen_kv8(uint32_t lo, uint32_t hi) {
     return __builtin_bit_cast(f16x8, r);
 }
 
-// BF: Q, the 16-bit cache and the output are bf16 (kv_dtype MI355_KV_BF16): bf16 MFMAs for S = K q^T and O = V^T P, P rounded to
-// bf16; the INT8 cache pairs with fp16 activations only (its widening builds fp16 operands).
+// BF: Q, a 16-bit cache and the output are bf16 (kv_dtype MI355_KV_BF16): bf16 MFMAs for S = K q^T and O = V^T P, P rounded to
+// bf16.  The INT8 cache serves both activation dtypes: its bytes are widened to fp16 (widen_kv8, bias 1152) or to bf16
+// (widen_u8_bf16, bias 128).
 template <int HD, bool INT8, int NT, int NW, int NG, bool BF = false>
 __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p) {
     constexpr float KVB = BF ? 128.f : 1152.f;     // INT8: what a widened cache byte carries on top of its code (see widen_kv8 / _bf16)
@@ -94,9 +95,24 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
     const int nrows = min(RT, p.q_len - tile * RT);
     // context of a row = its position + 1 (seq_add = 1: positions hold tokens already cached) or seq_lens[row] itself;
     // a negative value marks a padding row.  The block walks up to the longest context of its rows.
+    const int pstart = part * p.PS;
+    // the block ids of every wave's first group are asked for TOGETHER with the context lengths (scalar loads, one round trip):
+    // their table slots depend on the partition only.  Slots past a short context hold whatever the table holds -- the ids are
+    // clamped where they are used and those tokens carry p = 0.  (They used to wait for seq_len: a second dependent round trip
+    // in front of the first K/V request; tools/attn_stamps.py.)
+    const int32_t* bt = p.block_table + (size_t)b * p.max_blocks;
+    const int wave_pre = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int first_ids[4];
+    {
+        const int tb0 = pstart + wave_pre * 32, tmax = p.max_blocks * p.page - 1;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int wt = min(tb0 + 8 * a, tmax);
+            first_ids[a] = bt[(int)__builtin_amdgcn_readfirstlane((int)(((unsigned long long)(unsigned)wt * p.page_magic) >> 32))];
+        }
+    }
     int seq_len = 0;
     for (int i = 0; i < nrows; ++i) seq_len = max(seq_len, min(p.seq_lens[row0 + i] + p.seq_add, p.max_seq));
-    const int pstart = part * p.PS;
     if (seq_len <= 0) {   // only padding rows here: their outputs are defined (zeros), nothing is read
         if (part == 0)
             for (int idx = threadIdx.x; idx < nrows * p.G * HD; idx += NTHR) {
@@ -150,7 +166,6 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             kq[c] = KVB * qs;
         }
     }
-    const int32_t* bt = p.block_table + (size_t)b * p.max_blocks;
     const size_t head_elems = (size_t)p.page * HD;
     const uint64_t v_off = (uint64_t)p.nkv * head_elems;   // V heads sit nkv heads behind the K heads of a block
     const char* kvb = (const char*)p.kv_base;
@@ -188,6 +203,13 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
     auto lookup = [&](int tb, Wins& wn) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) wn.raw[a] = bt[page_of(min(tb + 8 * a, lastw))];
+    };
+    // the first group's ids came with the prologue's scalar loads; a window past the context takes the id of the last window, as lookup does
+    auto first_wins = [&](Wins& wn) {
+        const int tb0 = pstart + wave * 32;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wn.raw[a] = first_ids[a];
+        if (tb0 + 24 > lastw) lookup(tb0, wn);           // the context ends inside this group (rare: the last group of a sequence)
     };
     // lane -> window selectors, loop invariant
     const bool k1 = (j >> 2) == 1, k2 = (j >> 2) == 2, k3 = (j >> 2) == 3;
@@ -363,7 +385,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
         Wins w0, w1, w2;
         int tb = pstart + wave * 32;
         if constexpr (NG == 2) {
-            if (tb < pend) { lookup(tb, w0); load_group(g0, tb, w0); }
+            if (tb < pend) { first_wins(w0); load_group(g0, tb, w0); }
             AT_STAMP(1);
             if (tb + GS < pend) lookup(tb + GS, w1);
             // Steady state without a single condition: both groups of the round and both groups it prefetches lie inside the
@@ -391,7 +413,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             }
         } else if constexpr (NG == 4) {
             Group g3; Wins w3;
-            if (tb < pend) { lookup(tb, w0); load_group(g0, tb, w0); }
+            if (tb < pend) { first_wins(w0); load_group(g0, tb, w0); }
             if (tb + GS < pend) { lookup(tb + GS, w1); load_group(g1, tb + GS, w1); }
             if (tb + 2 * GS < pend) { lookup(tb + 2 * GS, w2); load_group(g2, tb + 2 * GS, w2); }
             if (tb + 3 * GS < pend) lookup(tb + 3 * GS, w3);
@@ -425,7 +447,7 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
                 if (tb + 3 * GS < pend) compute(g3, tb + 3 * GS);
             }
         } else {
-            if (tb < pend) { lookup(tb, w0); load_group(g0, tb, w0); }
+            if (tb < pend) { first_wins(w0); load_group(g0, tb, w0); }
             if (tb + GS < pend) { lookup(tb + GS, w1); load_group(g1, tb + GS, w1); }
             if (tb + 2 * GS < pend) lookup(tb + 2 * GS, w2);
             while (tb + 5 * GS < pend && tb + 2 * GS + 32 <= full_end) {

@@ -474,6 +474,10 @@ extern "C" int mi355_decoder_set_weight_prefetch(mi355_decoder_t* d, int32_t mas
     if (!d || mask < 0) { mi355_set_error("decoder_set_weight_prefetch: bad argument"); return MI355_ERR_ARG; }
     for (auto& kv : d->graphs) hipGraphExecDestroy(kv.second);   // captured steps bake the fork / join edges in
     d->graphs.clear();
+    if (mask != 0 && !side_ready(d)) {   // the side stream and its events exist before any capture begins (not lazily inside one)
+        mi355_set_error("decoder_set_weight_prefetch: cannot create the prefetch stream: %s", hipGetErrorString(hipGetLastError()));
+        return MI355_ERR_HIP;
+    }
     d->pf_mask = mask;
     return MI355_OK;
 }
@@ -636,7 +640,7 @@ size_t linear_ws_bound(const mi355_model_config_t& c) {
     for (const auto& sh : shapes)
         for (int wbits : {4, 8, 16}) {
             mi355_weight_t w;
-            w.qweight = &need; w.meta = &need; w.wbits = wbits; w.K = sh[0]; w.N = sh[1]; w.act_dtype = MI355_ACT_F16;
+            w.qweight = &need; w.meta = &need; w.wbits = wbits; w.K = sh[0]; w.N = sh[1]; w.act_dtype = c.act_dtype;   // bf16 plans other block shapes (and splits) above 32 rows
             w.K_pad = (sh[0] + 127) & ~127; w.N_pad = (sh[1] + 15) & ~15; w.group_size = wbits == 4 ? 128 : 0;
             need = std::max(need, mi355_linear_workspace_bytes(64, &w));
         }

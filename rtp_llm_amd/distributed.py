@@ -62,7 +62,7 @@ class CustomAllReduce:
     """Host side of csrc/allreduce.hip (the role of TrtllmArFusionHandle + its Python wrapper, base/rocm/trt_allreduce.py:
     51-230): create the context, exchange the IPC handle blobs through the (CPU-capable) process group, open the peers."""
 
-    def __init__(self, max_bytes: int, group=None, rank: Optional[int] = None, world: Optional[int] = None):
+    def __init__(self, max_bytes: int, group=None, rank: Optional[int] = None, world: Optional[int] = None, spin_timeout_ms: Optional[int] = None):
         import ctypes as C
         from . import _C
         self._C, self.lib = _C, _C.lib()
@@ -86,6 +86,24 @@ class CustomAllReduce:
             self.close()
             raise _C.Mi355Error("; ".join(f"rank {r}: {e}" for r, e in enumerate(errs) if e))
         self.max_bytes = int(max_bytes)
+        # ranks that share ONE device (the single-GPU validation runs of the tests) are time-sliced against each other: their kernels
+        # wait for a peer whose kernel may not be resident yet, so the 2 s spin bound of a one-process-per-GPU deployment is raised
+        keys = [None] * self.world
+        dist.all_gather_object(keys, self._device_key(), group=group)
+        self.shared_device = len(set(keys)) < len(keys)
+        if self.shared_device if spin_timeout_ms is None else True:
+            self.set_spin_timeout_ms(30000 if spin_timeout_ms is None else spin_timeout_ms)
+
+    @staticmethod
+    def _device_key():
+        import socket
+        p = torch.cuda.get_device_properties(torch.cuda.current_device())
+        ident = getattr(p, "uuid", None) or (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", -1), getattr(p, "pci_device_id", -1))
+        return (socket.gethostname(), str(ident))
+
+    def set_spin_timeout_ms(self, ms: int) -> None:
+        """Bound of every in-kernel wait for a peer; applies to launches enqueued or captured afterwards."""
+        self._C.check(self.lib.mi355_allreduce_set_spin_timeout_ms(self.handle, int(ms)), "allreduce_set_spin_timeout_ms")
 
     def _st(self):
         return torch.cuda.current_stream().cuda_stream
@@ -156,16 +174,32 @@ class RcclTransport:
         path = lib_path.encode()
         n = self.lib.mi355_rccl_unique_id_bytes()
         blob = C.create_string_buffer(n)
+        # every rank learns about a failure of any rank before anyone raises (as CustomAllReduce does): rank 0 broadcasts the id OR its
+        # error, the open status is all-gathered -- a rank that raised alone would leave its peers blocked in the broadcast, or alone on
+        # another transport
+        err = None
         if self.rank == 0:
-            _C.check(self.lib.mi355_rccl_unique_id(path, blob), "rccl_unique_id")
+            rc = self.lib.mi355_rccl_unique_id(path, blob)
+            if rc < 0:
+                err = "rccl_unique_id failed: " + self.lib.mi355_last_error().decode(errors="replace")
         if self.world > 1:
-            box = [blob.raw]
+            box = [(blob.raw, err)]
             src = dist.get_global_rank(group, 0) if group is not None else 0
             dist.broadcast_object_list(box, src=src, group=group)
-            blob = C.create_string_buffer(box[0], n)
+            raw, err = box[0]
+            blob = C.create_string_buffer(raw, n)
+        if err is not None:
+            raise _C.Mi355Error(err)
         self.handle = self.lib.mi355_rccl_open(path, blob, self.rank, self.world)
-        if not self.handle:
-            raise _C.Mi355Error("rccl_open failed: " + self.lib.mi355_last_error().decode())
+        mine = None if self.handle else "rank %d: rccl_open failed: %s" % (self.rank, self.lib.mi355_last_error().decode(errors="replace"))
+        errs = [mine]
+        if self.world > 1:
+            errs = [None] * self.world
+            dist.all_gather_object(errs, mine, group=group)
+        bad = [e for e in errs if e]
+        if bad:
+            self.close()
+            raise _C.Mi355Error("; ".join(bad))
         self.collective = _C.Collective()
         _C.check(self.lib.mi355_rccl_collective(self.handle, C.byref(self.collective)), "rccl_collective")
 

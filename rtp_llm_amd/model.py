@@ -372,7 +372,17 @@ class DecoderEngine:
             raise ValueError(f"DecoderEngine: dtype {dtype}")
         bf = dtype == torch.bfloat16
         self.dtype = dtype
-        cast = (lambda t: None if t is None else t.to(dtype)) if bf else (lambda t: t)
+        def cast(t):
+            # every 16-bit tensor of the model takes the engine's activation dtype: bf16 checkpoint tensors handed to an fp16 engine (or
+            # the other way round) are converted, and an fp16 overflow raises instead of feeding inf / garbage bits to the kernels
+            if t is None or t.dtype == dtype:
+                return t
+            if t.dtype not in (torch.float16, torch.bfloat16):
+                raise ValueError(f"DecoderEngine: a {t.dtype} tensor where a 16-bit one of the model is expected")
+            out = t.to(dtype)
+            if not torch.isfinite(out.float()).all():
+                raise ValueError(f"DecoderEngine: converting a {t.dtype} tensor to {dtype} overflows; load the checkpoint in the engine's dtype")
+            return out
         self.cfg, self.device, self.tp_size = cfg, device, tp_size
         self.page, self.num_blocks, self.max_batch, self.max_seq_len = page, num_blocks, max_batch, max_seq_len
         self.max_blocks_per_seq = (max_seq_len + page - 1) // page

@@ -38,8 +38,11 @@ def _worker(rank, world, port, q, mode):
         from rtp_llm_amd import _C, distributed, model, ops
         dev = "cuda:0"
         torch.cuda.set_device(0)
+        torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // world)))    # `world` processes on one host: no oversubscription of the CPU side (weight synthesis, oracle)
         distributed.init_distributed("gloo")
-        ar = distributed.CustomAllReduce(max_bytes=300 * 8192 * 2)
+        # the ranks share one GPU: CustomAllReduce notices and raises the spin bound to 30 s (time-slicing); the timeout case keeps 2 s
+        ar = distributed.CustomAllReduce(max_bytes=300 * 8192 * 2, spin_timeout_ms=2000 if mode == "timeout" else None)
+        assert ar.shared_device
         g = torch.Generator().manual_seed(100 + rank)
         # All ranks share ONE GPU here: block b of a rank spins until block b of every peer has arrived, so every block of every
         # rank must be resident at once (on a real node each rank has its own 256 CUs).  Keep world x grid within what one GPU
@@ -408,6 +411,66 @@ def _worker(rank, world, port, q, mode):
                 tok = nxt
                 eng.token_ids[:B].copy_(tok)
             assert ar.status() == 0 and eng.oob_count() == 0
+        elif mode == "engine70full":
+            # BASELINE configs[3] at its real per-rank shapes: Llama-3-70B widths (hidden 8192, 64 q / 8 kv heads, FFN 28672, the
+            # whole 128256-token vocabulary), TP 8, batch 32 at context 2048 -- 2 of the 80 layers, every rank's shard
+            # (qkv 8192 x 1280, o 1024 x 8192, gate_up 8192 x 7168, down 3584 x 8192, lm_head 8192 x 16032) in one process each on
+            # ONE GPU, the step captured per rank, against the unsplit CPU oracle with the same 2047 cached tokens per sequence.
+            cfg = model.ModelConfig("llama3-70b-2l", 2, 8192, 64, 8, 128, 28672, 128256, rope_theta=5e5, max_pos=2048 + 16, qkv_bias=False)
+            w = model.synth_model(cfg, "w4", "cpu", seed=37, zeros="centered", method="awq")
+            V = cfg.vocab
+            layers = [model.split_layer_tp(L, cfg, world, rank) for L in w["layers"]]
+            head = w["lm_head"].cols(rank * (V // world), (rank + 1) * (V // world))
+            shard = {"layers": layers, "embedding": w["embedding"], "final_norm": w["final_norm"], "lm_head": head}
+            B, page, ctx = 32, 16, 2048
+            mbk = (ctx + 2 + page - 1) // page
+            eng = model.DecoderEngine(cfg.per_rank(world), model.weights_to(shard, dev), kv_int8=False, page=page, num_blocks=B * mbk,
+                                      max_batch=B, max_seq_len=ctx + 2, device=dev, tp_size=world, vocab_full=V)
+            eng.attach_allreduce(ar, rank * (V // world))
+            gk = torch.Generator().manual_seed(5)
+            bt = torch.randperm(B * mbk, generator=gk).reshape(B, mbk).to(torch.int32)
+            kh0 = cfg.kv_head_of_rank(world, rank) if hasattr(cfg, "kv_head_of_rank") else rank * cfg.nkv // world
+            nkr = cfg.per_rank(world).nkv
+            if rank == 0:
+                dense = lambda c: (c.w.float() if c.kind == "fp16" else oracle.dequant_groupwise(c.q, c.z_eff, c.scales, c.group_size))
+                ow = {"embedding": w["embedding"], "final_norm": w["final_norm"], "lm_head": dense(w["lm_head"]),
+                      "layers": [{"input_norm": L["input_norm"], "post_norm": L["post_norm"], "qkv_bias": L["qkv_bias"],
+                                  **{k: dense(L[k]) for k in ("qkv", "o", "gate_up", "down")}} for L in w["layers"]]}
+                odec = oracle.OracleDecoder({**cfg.__dict__}, ow)
+                okv = oracle.OracleKV(cfg.num_layers, B, False)
+            del w, shard, layers, head
+            for l in range(cfg.num_layers):      # the same ctx - 1 cached tokens on every rank (its kv head) and in the oracle
+                for b in range(B):
+                    K = torch.randn(ctx - 1, cfg.nkv, cfg.hd, generator=gk).half(); Vv = torch.randn(ctx - 1, cfg.nkv, cfg.hd, generator=gk).half()
+                    from rtp_llm_amd import kvcache
+                    kvcache.write_tokens(eng.kv[l], None, bt[b], 0, K[:, kh0:kh0 + nkr], Vv[:, kh0:kh0 + nkr])
+                    if rank == 0:
+                        okv.k[l][b], okv.v[l][b] = list(K), list(Vv)
+            tok = torch.randint(0, V, (B,), generator=torch.Generator().manual_seed(3), dtype=torch.int32)
+            eng.set_inputs(tok.tolist(), [ctx - 1] * B, bt)
+            dist.barrier()
+            eng.capture(B)
+            for step in range(2):
+                pos = torch.full((B,), ctx - 1 + step, dtype=torch.int32)
+                eng.replay(B, 1)
+                torch.cuda.synchronize()
+                full = torch.cat(_gather_cpu(eng.logits[:B].cpu(), world), dim=1)
+                mine = eng.token_ids[:B].cpu()
+                allids = _gather_cpu(mine, world)
+                assert all(torch.equal(allids[0], o) for o in allids[1:])
+                assert torch.equal(mine, torch.argmax(full, -1).int())
+                nxt = torch.zeros(B, dtype=torch.int32)
+                if rank == 0:
+                    _, ref = odec.forward_tokens(tok, pos, okv, list(range(B)))
+                    assert torch.allclose(full, ref, atol=1e-2, rtol=1e-2), (step, float((full - ref).abs().max()))
+                    nxt = oracle.greedy(ref).int()
+                    top2 = ref.topk(2, -1).values
+                    safe = (top2[:, 0] - top2[:, 1]) > 1e-2
+                    assert torch.equal(mine[safe], nxt[safe])
+                dist.broadcast(nxt, 0)
+                tok = nxt
+                eng.token_ids[:B].copy_(tok)
+            assert ar.status() == 0 and eng.oob_count() == 0
         elif mode == "timeout":
             x = torch.ones(4, 3584, dtype=torch.float16, device=dev)
             ar.all_reduce(x.clone()); torch.cuda.synchronize(); dist.barrier()
@@ -433,7 +496,7 @@ def _worker(rank, world, port, q, mode):
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("mode,world", [("kernels", 2), ("engine", 2), ("transport", 2), ("bf16", 2), ("bf16", 4), ("timeout", 2), ("twoshot", 3), ("mixed", 2), ("kernels", 4),
-                                        ("kernels", 8), ("twoshot", 4), ("twoshot", 8), ("engine70", 8)])
+                                        ("kernels", 8), ("twoshot", 4), ("twoshot", 8), ("engine70", 8), ("engine70full", 8)])
 def test_custom_allreduce_processes_on_one_gpu(mode, world):
     assert torch.cuda.is_available()
     port = _free_port()

@@ -64,6 +64,7 @@ def test_rope_kv_and_paged_attention_op_classes(int8):
         assert torch.allclose(out[b].cpu().float(), ref.float(), atol=1e-2, rtol=1e-2), b
     if int8:
         assert okv.max_delta <= 1 and okv.flips <= 0.10 * okv.codes, (okv.flips, okv.codes)
+        assert okv.max_scale_rel <= 2e-3, okv.max_scale_rel      # the scale plane the kernel wrote, against the oracle's own scales (1 fp16 ulp of the row's amax)
     # same kernels as the ctypes path: bit-equal
     q2 = cops.rope_kv_write(qkv.to(DEV), None, cs.to(DEV), pos.to(DEV), bt.to(DEV), kv, sc, nh, nkv, hd, page)
     out2 = cops.paged_decode_attention(q2, kv, sc, bt.to(DEV), (pos + 1).to(DEV), nkv, page, M * page)
