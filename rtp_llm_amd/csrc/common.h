@@ -192,13 +192,29 @@ __device__ __forceinline__ float xor32_sum(float v) { float a, b; swap32(v, a, b
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// the same with the dtype as a run-time flag: epilogues that run once per output element and are not worth a second kernel instance
+__device__ __forceinline__ float rt_from_bits(uint16_t b, bool bf) { return bf ? act_from_bits<true>(b) : act_from_bits<false>(b); }
+__device__ __forceinline__ uint16_t rt_to_bits(float v, bool bf) { return bf ? act_to_bits<true>(v) : act_to_bits<false>(v); }
+__device__ __forceinline__ float rt_round(float v, bool bf) { return bf ? act_round<true>(v) : act_round<false>(v); }
+
 // ---- activation image (mi355_act_image_*): the [M][K] 16-bit activations of a 17-64-row step in the order the full-K launches of
 // gemm_fullk64.hip read them -- one dense 1 KB run per MFMA B fragment (k-step of 32, row block of 16): lane (jj, q) of the
 // fragment owns the 16 bytes x[16 rb + jj][32 ks + 8 q .. + 7].  A fragment gathered from the row-major tensor instead is 16 runs
 // of 64 B at the row stride: with every CU of the chip asking for the same runs, the L2 serves them at ~7 TB/s against 35 for dense
 // runs (profiles/r04_fullk64_access_patterns.txt: 19.8 vs 11.2 us for the QKV launch at 64 rows).  The producers (RMSNorm,
 // attention) write this order directly: their 16-byte stores keep their size, only the address changes.
+// An image ALWAYS holds fp16: the GEMMs that read it run fp16 MFMAs on operand-side dequantised weights.  A bf16 step converts
+// on the way in (img_pack8 below) -- exact for every bf16 value inside the fp16 range (|x| < 65504; below 2^-14 it keeps fewer
+// bits, below 2^-24 it is zero: magnitudes that do not matter next to a row's typical element).
 // Element index of x[row][col]; mblk = row blocks of the image = ceil(M / 16).
+// 8 values of a BF-typed tensor (already rounded to it) -> the 16 bytes an image stores
+template <bool BF> __device__ __forceinline__ u32x4 img_pack8(const float (&o)[8]) {
+    if constexpr (!BF) return act_pack8<false>(o);
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = act_round<true>(o[i]);
+    return act_pack8<false>(r);
+}
 __host__ __device__ __forceinline__ size_t act_img_index(int row, int col, int mblk) {
     return ((((size_t)(col >> 5) * mblk + (row >> 4)) * 64 + ((col & 31) >> 3) * 16 + (row & 15)) << 3) + (col & 7);
 }

@@ -132,8 +132,9 @@ __global__ __launch_bounds__(512) void add_rmsnorm_kernel(const f16* __restrict_
             act_unpack8<BF>(win[t], wv);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = wv[e] * act_round<BF>(v[t][e] * rs);   // product of two 16-bit tensors: rounded once by the pack
-            // y_img_mblk > 0: y is an activation image (common.h act_img_index): the same 16 bytes at another address
-            *reinterpret_cast<u32x4*>(y + (y_img_mblk > 0 ? act_img_index(row, c0, y_img_mblk) : (size_t)row * H + c0)) = act_pack8<BF>(o);
+            // y_img_mblk > 0: y is an activation image (common.h act_img_index): the same 16 bytes at another address, always fp16
+            if (y_img_mblk > 0) *reinterpret_cast<u32x4*>(y + act_img_index(row, c0, y_img_mblk)) = img_pack8<BF>(o);
+            else                *reinterpret_cast<u32x4*>(y + (size_t)row * H + c0) = act_pack8<BF>(o);
         }
     }
 }

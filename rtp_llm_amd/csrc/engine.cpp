@@ -241,7 +241,9 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     d->has_ext = false; d->pairs_local = d->pairs_all = nullptr;
     d->side_stream = nullptr; d->ev_fork = d->ev_join = nullptr; d->overlap = false;
     d->pf_mask = 0; d->pf_pending = false;
-    d->fuse_qkv = cfg->kv_dtype == MI355_KV_FP16 && cfg->rope_dim == cfg->hd;
+    const bool bf_act = cfg->act_dtype == MI355_ACT_BF16;
+    // QKV + RoPE + KV write in one launch: a 16-bit cache of the activation dtype (INT8 caches keep the quantising writer of rope_kv.hip)
+    d->fuse_qkv = cfg->kv_dtype == (bf_act ? MI355_KV_BF16 : MI355_KV_FP16) && cfg->rope_dim == cfg->hd;
     d->fuse_o = d->fuse_down = cfg->tp_size == 1;
     // crossover between the few-row full-K launches (gemm_fullk.hip, dense activation loads) and the launches on activation images
     // (round 4, same box: b = 4 1.94 vs 2.05 ms, b = 5 2.16 vs 2.05, b = 8 2.28 vs 2.07, b = 12 2.64 vs 2.10; profiles/r04_batch_sweep_crossover.txt);
@@ -261,12 +263,17 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     d->fuse_norm = d->fuse_qkv && d->fuse_o && d->fuse_down && cfg->hidden % 64 == 0;
     for (const auto& L : d->layers) d->fuse_norm = d->fuse_norm && w4ok(&L.gate_up);
     // the 17-64-row full-K launches: W4 group-wise, K <= 5760 (gemm_fullk64.hip), single rank
-    auto w64ok = [&](const mi355_weight_t* w) { return w4ok(w) && w->K_pad / 128 <= 45 && w->K % 32 == 0; };
-    d->img_qkv = d->fuse_qkv && cfg->tp_size == 1 && cfg->act_dtype == MI355_ACT_F16;
-    d->img_o = d->fuse_o && cfg->act_dtype == MI355_ACT_F16;
+    // (either activation dtype: the images are fp16, the epilogues store the step's dtype -- the few-row launches above are fp16 only,
+    // mi355_fullk_weight_ok)
+    auto w64ok = [&](const mi355_weight_t* w) {
+        return w->qweight && w->meta && w->wbits == 4 && (w->group_size == 128 || w->group_size == 64 || w->group_size == 32) &&
+               w->K % 128 == 0 && w->K_pad == w->K && w->K_pad / 128 >= 4 && w->K_pad / 128 <= 45 && w->N % 16 == 0;
+    };
+    d->img_qkv = cfg->kv_dtype == (bf_act ? MI355_KV_BF16 : MI355_KV_FP16) && cfg->rope_dim == cfg->hd && cfg->tp_size == 1;
+    d->img_o = cfg->tp_size == 1;
     for (const auto& L : d->layers) { d->img_qkv = d->img_qkv && w64ok(&L.qkv); d->img_o = d->img_o && w64ok(&L.o); }
     if (TUNE(5) == 2) d->img_qkv = d->img_o = false;   // tuning build: A/B against the split-K + fold launches
-    if (d->img_qkv && d->img_o) d->fuse_rows = 4;
+    if (d->img_qkv && d->img_o) d->fuse_rows = bf_act ? 0 : 4;   // bf16: no few-row full-K launches to cross over to (the staged kernels lose at every height)
     if (TUNE(6) > 0) d->fuse_rows = TUNE(6) == 99 ? 0 : TUNE(6);   // tuning build: crossover experiments (tools/batch_sweep.py --tune 6=N)
     d->img_gate_up = d->img_o && cfg->hidden % 64 == 0 && TUNE(5) != 3;
     for (const auto& L : d->layers) d->img_gate_up = d->img_gate_up && mi355_gemm_wide_direct_ok(&L.gate_up);
@@ -281,15 +288,21 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
                 mi355_set_error("decoder_create: cannot read the norm weights"); delete d; return nullptr;
             }
             float mx = 0.f;
-            for (uint16_t b : g) {   // fp16 bits -> float
-                const int e = (b >> 10) & 31, m = b & 1023;
-                const float v = e == 0 ? ldexpf((float)m, -24) : (e == 31 ? INFINITY : ldexpf((float)(m | 1024), e - 25));
+            for (uint16_t b : g) {   // 16-bit pattern -> |value|
+                float v;
+                if (bf_act) { const uint32_t u = (uint32_t)(b & 0x7FFF) << 16; memcpy(&v, &u, 4); if (!(v == v)) v = INFINITY; }
+                else {
+                    const int e = (b >> 10) & 31, m = b & 1023;
+                    v = e == 0 ? ldexpf((float)m, -24) : (e == 31 ? INFINITY : ldexpf((float)(m | 1024), e - 25));
+                }
                 if (v > mx) mx = v;
             }
             int ex = 0;
             while (ex < 14 && ldexpf(1.f, ex) < mx) ++ex;
             if (!(mx < INFINITY) || ldexpf(1.f, ex) < mx) { d->img_gate_up = false; break; }   // inf / nan / beyond 2^14 in a norm weight: keep the norm launch
-            d->post_norm_exp.push_back(ex);
+            // a bf16 residual stream may exceed the fp16 range of the image: eight more binary orders of headroom (|h| < 1.6e7), paid for with
+            // precision only on elements below 2^-6 of a typical one
+            d->post_norm_exp.push_back(bf_act ? (ex + 8 > 14 ? 14 : ex + 8) : ex);
         }
     }
     std::vector<int32_t> iota_h(cfg->max_batch);

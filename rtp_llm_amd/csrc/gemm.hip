@@ -839,6 +839,13 @@ extern "C" int mi355_fullk_weight_ok(const mi355_weight_t* w) {
     return fmt && w->K % 128 == 0 && w->K_pad == w->K && w->K_pad / 128 >= 4 && w->N % 16 == 0;
 }
 
+// the launches on activation images (gemm_fullk64 / gemm_splitk64 / gemm_wide image entries): W4 group-wise weights in the native
+// image; the activation dtype of the surrounding tensors is free (the image itself is fp16, see common.h)
+static bool img_weight_ok(const mi355_weight_t* w) {
+    return w && w->qweight && w->meta && w->wbits == 4 && (w->group_size == 128 || w->group_size == 64 || w->group_size == 32) &&
+           w->K % 128 == 0 && w->K_pad == w->K && w->K_pad / 128 >= 4 && w->N % 16 == 0;
+}
+
 extern "C" int mi355_linear_residual(const void* x, int32_t M, const mi355_weight_t* w, const void* bias, const void* residual_in,
                                      void* residual_out, float* tile_sumsq_out, int32_t tile_sumsq_ld, mi355_stream_t stream) {
     if (int e = check_weight(w)) return e;
@@ -894,7 +901,7 @@ extern "C" int mi355_linear_residual_img(const void* x_img, int32_t M, const mi3
     if (int e = check_weight(w)) return e;
     MI355_CHECK_ARG(x_img && residual_in && residual_out && M > 0, "linear_residual_img: bad args (M=%d)", M);
     MI355_CHECK_ARG(!tile_sumsq_out || (tile_sumsq_ld >= w->N / 16 && tile_sumsq_ld % 4 == 0), "linear_residual_img: tile_sumsq_ld=%d (>= N/16 = %d, multiple of 4)", tile_sumsq_ld, w->N / 16);
-    if (M < 1 || M > 64 || w->wbits != 4 || !mi355_fullk_weight_ok(w)) return MI355_ERR_UNSUPPORTED;
+    if (M < 1 || M > 64 || !img_weight_ok(w)) return MI355_ERR_UNSUPPORTED;
     GemmParams p; fill_params(p, x_img, M, w);
     p.mode = MODE_F16; p.bias = (const f16*)bias; p.ldy = w->N;
     return mi355_gemm_fullk_residual_img(&p, w->wbits, w->group_size, residual_in, residual_out, tile_sumsq_out, tile_sumsq_ld, nullptr, 0.f, nullptr, stream);
@@ -907,7 +914,7 @@ extern "C" int mi355_linear_residual_prenorm_img(const void* x_img, int32_t M, c
     MI355_CHECK_ARG(x_img && residual_in && residual_out && norm_weight && xg_img_out && tile_sumsq_out && M > 0, "linear_residual_prenorm_img: bad args (M=%d)", M);
     MI355_CHECK_ARG(tile_sumsq_ld >= w->N / 16 && tile_sumsq_ld % 4 == 0 && w->N % 32 == 0 && norm_exp >= 0 && norm_exp <= 14,
                     "linear_residual_prenorm_img: tile_sumsq_ld=%d (>= N/16 = %d, multiple of 4), N %% 32, norm_exp=%d (0..14)", tile_sumsq_ld, w->N / 16, norm_exp);
-    if (M < 1 || M > 64 || w->wbits != 4 || !mi355_fullk_weight_ok(w)) return MI355_ERR_UNSUPPORTED;
+    if (M < 1 || M > 64 || !img_weight_ok(w)) return MI355_ERR_UNSUPPORTED;
     GemmParams p; fill_params(p, x_img, M, w);
     p.mode = MODE_F16; p.bias = (const f16*)bias; p.ldy = w->N;
     return mi355_gemm_fullk_residual_img(&p, w->wbits, w->group_size, residual_in, residual_out, tile_sumsq_out, tile_sumsq_ld, norm_weight,
@@ -920,7 +927,9 @@ extern "C" int mi355_linear_deferred_norm_img(const void* xg_img, int32_t M, con
     MI355_CHECK_ARG(xg_img && y && M > 0, "linear_deferred_norm_img: bad args (M=%d)", M);
     MI355_CHECK_ARG(!dn || (dn->tile_sumsq && dn->tiles == w->K / 16 && dn->tiles <= 512 && dn->tiles % 4 == 0 && dn->ld >= dn->tiles && dn->ld % 4 == 0 && dn->eps > 0.f && dn->unscale > 0.f),
                     "linear_deferred_norm_img: needs tile_sumsq [M][ld >= K/16 = %d, multiple of 4], eps and unscale", w->K / 16);
-    if (M < 1 || M > 64 || w->wbits != 4 || w->act_dtype != MI355_ACT_F16 || w->K % 128 != 0 || w->K_pad != w->K) return MI355_ERR_UNSUPPORTED;
+    if (M < 1 || M > 64 || !img_weight_ok(w)) return MI355_ERR_UNSUPPORTED;
+    // bf16 tensors around the GEMM: taken when the output is an image again (fp16 of the bf16-rounded values) and there is no bias
+    if (w->act_dtype == MI355_ACT_BF16 && (!(epilogue & MI355_EPI_OUT_IMAGE) || bias)) return MI355_ERR_UNSUPPORTED;
     GemmParams p; fill_params(p, xg_img, M, w);
     p.mode = (epilogue & MI355_EPI_OUT_F32) ? MODE_F32 : (epilogue & MI355_EPI_SILU_MUL) ? MODE_SILU : MODE_F16;
     p.bias = (const f16*)bias; p.y = y; p.ldy = (p.mode == MODE_SILU) ? w->N / 2 : w->N;
@@ -938,7 +947,7 @@ extern "C" int mi355_linear_partial_img(const void* x_img, int32_t M, const mi35
                                         mi355_stream_t stream) {
     if (int e = check_weight(w)) return e;
     MI355_CHECK_ARG(x_img && partials && M > 0 && max_splits >= 1, "linear_partial_img: bad args (M=%d)", M);
-    if (M < 1 || M > 64 || w->wbits != 4 || w->act_dtype != MI355_ACT_F16 || w->K % 128 != 0 || w->K_pad != w->K) return MI355_ERR_UNSUPPORTED;
+    if (M < 1 || M > 64 || !img_weight_ok(w)) return MI355_ERR_UNSUPPORTED;
     GemmParams p; fill_params(p, x_img, M, w);
     p.x_img = 1; p.x_bytes = (uint32_t)mi355_act_image_bytes(M, w->K); p.partials = partials;
     return mi355_gemm_splitk64(&p, w->wbits, w->group_size, max_splits > 16 ? 16 : max_splits, stream);
@@ -953,7 +962,7 @@ extern "C" int mi355_qkv_rope_kv_write_img(const void* x_img, int32_t M, const m
     MI355_CHECK_ARG(kv && kv->kv_base && cos_sin && positions && block_table && q_out, "qkv_rope_kv_write_img: null pointer");
     MI355_CHECK_ARG(kv->page > 0 && nh > 0 && kv->nkv > 0 && max_pos > 0 && max_blocks_per_seq > 0 && kv->num_blocks > 0,
                     "qkv_rope_kv_write_img: bad dims");
-    if (M < 1 || M > 64 || wqkv->wbits != 4 || !mi355_fullk_weight_ok(wqkv) || rope_dim != kv->hd) return MI355_ERR_UNSUPPORTED;
+    if (M < 1 || M > 64 || !img_weight_ok(wqkv) || rope_dim != kv->hd) return MI355_ERR_UNSUPPORTED;
     GemmParams p; fill_params(p, x_img, M, wqkv);
     p.mode = MODE_F16; p.bias = (const f16*)qkv_bias; p.ldy = wqkv->N;
     return mi355_gemm_fullk_rope_img(&p, wqkv->wbits, wqkv->group_size, cos_sin, max_pos, positions, block_table, max_blocks_per_seq,

@@ -625,6 +625,7 @@ extern "C" int mi355_gemm_fullk_residual_img(const void* gp, int wbits, int grou
     if (wbits != 4 || !fullk_shape_ok(fp.g, wbits, group_size) || fp.g.N % 4 != 0) return MI355_ERR_UNSUPPORTED;
     fp.res_in = (const f16*)residual_in; fp.res_out = (f16*)residual_out; fp.ssq_out = ssq_out; fp.ssq_ld = ssq_ld;
     fp.xg_img = (f16*)xg_img; fp.xg_gamma = (const f16*)norm_weight; fp.xg_scale = xg_scale;   // deferred RMSNorm of the produced rows (or null)
+    fp.bf16 = fp.g.bf16;                                                                      // dtype of bias / residual / norm weight
     return mi355_gemm_fullk64(&fp, FK_RESID, group_size, stream);
 }
 
@@ -635,7 +636,9 @@ extern "C" int mi355_gemm_fullk_rope_img(const void* gp, int wbits, int group_si
     FullKParams fp{};
     fp.g = *reinterpret_cast<const GemmParams*>(gp);
     if (wbits != 4 || !fullk_shape_ok(fp.g, wbits, group_size)) return MI355_ERR_UNSUPPORTED;
-    if (kv->kv_dtype != MI355_KV_FP16 || (kv->hd != 64 && kv->hd != 128)) return MI355_ERR_UNSUPPORTED;
+    // a 16-bit cache of the activation dtype (the epilogue stores the rotated K / V rows as they are; INT8 caches: rope_kv.hip)
+    if (kv->kv_dtype != (fp.g.bf16 ? MI355_KV_BF16 : MI355_KV_FP16) || (kv->hd != 64 && kv->hd != 128)) return MI355_ERR_UNSUPPORTED;
+    fp.bf16 = fp.g.bf16;
     const int nheads = nh + 2 * kv->nkv;
     if (fp.g.N != nheads * kv->hd) return MI355_ERR_UNSUPPORTED;
     RopeEpi& r = fp.r;

@@ -195,30 +195,34 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
     const int m = mb * 16 + jj;
     if (m >= p.M) continue;
 
+    const bool bf = fp.bf16 != 0;                   // dtype of everything 16-bit around the GEMM (the image and the weights' dequant are fp16)
     if constexpr (EPI == FK_RESID) {
 #pragma unroll
         for (int t = 0; t < TPB; ++t) {
             const int n0 = tile[t] * 16 + q * 4;
             if (n0 >= p.N) continue;
-            const f16x4 bv = *reinterpret_cast<const f16x4*>(&sg.bias[t * 16 + q * 4]), rin = *reinterpret_cast<const f16x4*>(&sg.res[m][t * 16 + q * 4]);
-            f16x4 o;
+            const uint16_t* bv = reinterpret_cast<const uint16_t*>(&sg.bias[t * 16 + q * 4]);
+            const uint16_t* rin = reinterpret_cast<const uint16_t*>(&sg.res[m][t * 16 + q * 4]);
+            float of[4];
+            uint16_t ob[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float y = (float)(f16)(v[t][r] + (float)bv[r]);    // the linear's output is an fp16 tensor in the reference
-                o[r] = (f16)(y + (float)rin[r]);
+                const float y = rt_round(v[t][r] + rt_from_bits(bv[r], bf), bf);    // the linear's output is a 16-bit tensor in the reference
+                of[r] = rt_round(y + rt_from_bits(rin[r], bf), bf);
+                ob[r] = rt_to_bits(of[r], bf);
             }
-            *reinterpret_cast<f16x4*>(fp.res_out + (size_t)m * p.N + n0) = o;
-            if (fp.xg_img) {                          // deferred RMSNorm: gamma 2^-e h' for the next GEMM (one rounding, from fp32)
-                const f16x4 gm = *reinterpret_cast<const f16x4*>(&sg.gam[t * 16 + q * 4]);
+            *reinterpret_cast<u32x2*>(fp.res_out + (size_t)m * p.N + n0) = (u32x2){(uint32_t)ob[0] | ((uint32_t)ob[1] << 16), (uint32_t)ob[2] | ((uint32_t)ob[3] << 16)};
+            if (fp.xg_img) {                          // deferred RMSNorm: gamma 2^-e h' for the next GEMM (one rounding, from fp32; fp16 image)
+                const uint16_t* gm = reinterpret_cast<const uint16_t*>(&sg.gam[t * 16 + q * 4]);
                 f16x4 g;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) g[r] = (f16)((float)gm[r] * fp.xg_scale * (float)o[r]);
+                for (int r = 0; r < 4; ++r) g[r] = (f16)(rt_from_bits(gm[r], bf) * fp.xg_scale * of[r]);
                 *reinterpret_cast<f16x4*>(fp.xg_img + act_img_index(m, n0, (p.M + 15) >> 4)) = g;
             }
             if (fp.ssq_out) {                         // this tile's share of sum h'^2 of the row, for the consumer's RMSNorm
                 float s2 = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s2 += (float)o[r] * (float)o[r];
+                for (int r = 0; r < 4; ++r) s2 += of[r] * of[r];
                 s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
                 if (q == 0) fp.ssq_out[(size_t)m * fp.ssq_ld + tile[t]] = s2;
             }
@@ -231,11 +235,12 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
         const int h  = tile[0] / (2 * hh);
         const int d0 = (tile[0] % (2 * hh)) * 16 + q * 4;
         float x0[4], x1[4];
-        const f16x4 b0 = *reinterpret_cast<const f16x4*>(&sg.bias[q * 4]), b1 = *reinterpret_cast<const f16x4*>(&sg.bias[16 + q * 4]);
+        const uint16_t* b0 = reinterpret_cast<const uint16_t*>(&sg.bias[q * 4]);
+        const uint16_t* b1 = reinterpret_cast<const uint16_t*>(&sg.bias[16 + q * 4]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            x0[r] = (float)(f16)(v[0][r] + (float)b0[r]);
-            x1[r] = (float)(f16)(v[1][r] + (float)b1[r]);
+            x0[r] = rt_round(v[0][r] + rt_from_bits(b0[r], bf), bf);
+            x1[r] = rt_round(v[1][r] + rt_from_bits(b1[r], bf), bf);
         }
         const int pos_in  = sg.pos[m];
         const int pos_lim = min(R.max_pos, R.max_blocks * R.page);
@@ -248,12 +253,14 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
             for (int r = 0; r < 4; ++r) {
                 const float r0 = cc[r] * x0[r] - ss[r] * x1[r];
                 const float r1 = cc[r] * x1[r] + ss[r] * x0[r];
-                x0[r] = (float)(f16)r0; x1[r] = (float)(f16)r1;
+                x0[r] = rt_round(r0, bf); x1[r] = rt_round(r1, bf);
             }
         }
-        f16x4 o0, o1;
+        f16x4 o0, o1;                                 // 16-bit patterns of the activation dtype (moved as f16-typed words)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { o0[r] = (f16)x0[r]; o1[r] = (f16)x1[r]; }
+        for (int r = 0; r < 4; ++r) {
+            o0[r] = __builtin_bit_cast(f16, rt_to_bits(x0[r], bf)); o1[r] = __builtin_bit_cast(f16, rt_to_bits(x1[r], bf));
+        }
         FK_STAMP(5);
         if (h < R.nh) {
             f16* dst = R.q_out + ((size_t)m * R.nh + h) * R.hd + d0;

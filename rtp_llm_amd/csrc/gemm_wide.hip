@@ -357,7 +357,7 @@ static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_
                             mi355_stream_t stream);
 // does the direct (one launch, no slabs) form take this linear at 17-64 rows?  N alone has to fill the chip (gate_up)
 extern "C" int mi355_gemm_wide_direct_ok(const mi355_weight_t* w) {
-    if (!w || w->wbits != 4 || w->act_dtype != MI355_ACT_F16 || (w->group_size != 128 && w->group_size != 64 && w->group_size != 32)) return 0;
+    if (!w || w->wbits != 4 || (w->group_size != 128 && w->group_size != 64 && w->group_size != 32)) return 0;   // either activation dtype: the image entry (gemm.hip) decides
     if (w->K % 128 != 0 || w->K_pad != w->K) return 0;
     const int NT = w->N_pad / 16, TB = 10, CUS = 256;
     int G = (NT + TB - 1) / TB;

@@ -199,9 +199,12 @@ def _new_image(M: int, K: int, dtype, device) -> ActImage:
 
 
 def act_image_pack(x: torch.Tensor) -> ActImage:
+    """Row-major [M, K] -> image.  Images hold fp16 (the GEMMs that read them run fp16 MFMAs): bf16 rows are converted, exactly
+    inside the fp16 range."""
     _chk_act(x, "act_image_pack.x")
+    x = x if x.dtype == torch.float16 else x.to(torch.float16)
     M, K = x.shape
-    img = _new_image(M, K, x.dtype, x.device)
+    img = _new_image(M, K, torch.float16, x.device)
     _C.check(_C.lib().mi355_act_image_pack(x.data_ptr(), M, K, img.data.data_ptr(), 0, _stream()), "act_image_pack")
     return img
 
@@ -210,7 +213,7 @@ def add_rmsnorm_img(x: torch.Tensor, residual: Optional[torch.Tensor], weight: t
     """(y_img, residual_out): add_rmsnorm (rmsnorm when residual is None) with y written as an activation image."""
     _chk_act(x, "add_rmsnorm_img.x"); _chk_act(weight, "add_rmsnorm_img.weight", x)
     M, H = x.shape
-    img = _new_image(M, H, x.dtype, x.device)
+    img = _new_image(M, H, torch.float16, x.device)          # fp16 whatever the dtype of x (a bf16 result is converted on the way in)
     res_out = torch.empty_like(x) if residual is not None else None
     _C.check(_C.lib().mi355_add_rmsnorm_img(x.data_ptr(), None, 0, 0, _p(bias), _p(residual), _p(res_out), weight.data_ptr(), eps, M, H,
                                             img.data.data_ptr(), _dt(x), _stream()), "add_rmsnorm_img")
@@ -223,7 +226,7 @@ def paged_attention_rows_img(q: torch.Tensor, kv_base, scale_base, block_table: 
     _chk_act(q, "paged_attention_rows_img.q"); _chk(block_table, torch.int32, "block_table"); _chk(positions, torch.int32, "positions")
     T, nh, hd = q.shape
     kv = kv_struct(kv_base, scale_base, page, nkv, hd, q.dtype)
-    img = _new_image(T, nh * hd, q.dtype, q.device)
+    img = _new_image(T, nh * hd, torch.float16, q.device)
     need = _C.lib().mi355_paged_attn_workspace_bytes(T, nh, hd, max_seq_len)
     ws = _workspace(need, q.device)
     _C.check(_C.lib().mi355_paged_attn_rows_img(q.data_ptr(), C.byref(kv), block_table.data_ptr(), block_table.shape[1], positions.data_ptr(),
@@ -235,7 +238,7 @@ def paged_attention_rows_img(q: torch.Tensor, kv_base, scale_base, block_table: 
 def linear_residual_img(x: ActImage, w: PackedWeight, residual: torch.Tensor, bias: Optional[torch.Tensor] = None,
                         out: Optional[torch.Tensor] = None, tile_sumsq: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """linear_residual for 17-64 rows with the activations as an image (gemm_fullk64.hip); None when the shape is not taken."""
-    _chk(x.data, torch.float16, "linear_residual_img.x"); _chk(residual, torch.float16, "linear_residual_img.residual")
+    _chk(x.data, torch.float16, "linear_residual_img.x"); _chk_act(residual, "linear_residual_img.residual")      # the image is fp16; residual / bias: fp16 or bf16
     M = x.M
     if x.K != w.K or residual.shape[-1] != w.N or residual.numel() != M * w.N:
         raise _C.Mi355Error(f"linear_residual_img: image {M} x {x.K} / residual {tuple(residual.shape)} against K={w.K} N={w.N}")
@@ -245,7 +248,7 @@ def linear_residual_img(x: ActImage, w: PackedWeight, residual: torch.Tensor, bi
             raise _C.Mi355Error(f"linear_residual_img: tile_sumsq {tuple(tile_sumsq.shape)} must be [>= {M}, >= N/16 = {w.N // 16}]")
     if out is None:
         out = torch.empty_like(residual)
-    ws_struct = weight_struct(w)
+    ws_struct = weight_struct(w, residual.dtype)
     rc = _C.lib().mi355_linear_residual_img(x.data.data_ptr(), M, C.byref(ws_struct), _p(bias), residual.data_ptr(), out.data_ptr(),
                                             _p(tile_sumsq), 0 if tile_sumsq is None else tile_sumsq.shape[1], _stream())
     if rc == ERR_UNSUPPORTED:
@@ -267,7 +270,7 @@ def linear_residual_prenorm_img(x: ActImage, w: PackedWeight, residual: torch.Te
                                 bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
     """(residual_out, xg_img, tile_sumsq, norm_exp): linear_residual_img that also leaves the operands of the deferred RMSNorm of the
     rows it produces (mi355_deferred_norm_t); None when the shape is not taken."""
-    _chk(x.data, torch.float16, "linear_residual_prenorm_img.x"); _chk(residual, torch.float16, "residual"); _chk(norm_weight, torch.float16, "norm_weight")
+    _chk(x.data, torch.float16, "linear_residual_prenorm_img.x"); _chk_act(residual, "residual"); _chk_act(norm_weight, "norm_weight", residual)
     M = x.M
     if x.K != w.K or residual.shape[-1] != w.N or residual.numel() != M * w.N or norm_weight.numel() != w.N:
         raise _C.Mi355Error(f"linear_residual_prenorm_img: image {M} x {x.K} / residual {tuple(residual.shape)} against K={w.K} N={w.N}")
@@ -276,8 +279,9 @@ def linear_residual_prenorm_img(x: ActImage, w: PackedWeight, residual: torch.Te
     ld = (w.N // 16 + 3) & ~3
     ssq = torch.zeros(M, ld, dtype=torch.float32, device=residual.device)
     xg = _new_image(M, w.N, torch.float16, residual.device)
-    e = norm_exponent(norm_weight)
-    ws_struct = weight_struct(w)
+    e = norm_exponent(norm_weight) + (8 if residual.dtype == torch.bfloat16 else 0)     # bf16 residual stream: headroom for the fp16 image
+    e = min(e, 14)
+    ws_struct = weight_struct(w, residual.dtype)
     rc = _C.lib().mi355_linear_residual_prenorm_img(x.data.data_ptr(), M, C.byref(ws_struct), _p(bias), residual.data_ptr(), out.data_ptr(),
                                                     norm_weight.data_ptr(), e, xg.data.data_ptr(), ssq.data_ptr(), ld, _stream())
     if rc == ERR_UNSUPPORTED:
@@ -286,7 +290,8 @@ def linear_residual_prenorm_img(x: ActImage, w: PackedWeight, residual: torch.Te
     return out, xg, ssq, e
 
 
-def linear_deferred_norm_img(xg: ActImage, dn, w: PackedWeight, bias: Optional[torch.Tensor] = None, epilogue: int = _C.EPI_NONE):
+def linear_deferred_norm_img(xg: ActImage, dn, w: PackedWeight, bias: Optional[torch.Tensor] = None, epilogue: int = _C.EPI_NONE,
+                             act: torch.dtype = torch.float16):
     """epilogue(rs * (xg @ W) + bias) on the wide GEMM; dn = (tile_sumsq, eps, norm_exp) as left by linear_residual_prenorm_img, or None
     (plain linear on an image).  None when the shape is not taken (N too narrow to fill the chip in one launch)."""
     _chk(xg.data, torch.float16, "linear_deferred_norm_img.x")
@@ -304,7 +309,7 @@ def linear_deferred_norm_img(xg: ActImage, dn, w: PackedWeight, bias: Optional[t
     else:
         yi = None
         y = torch.empty(xg.M, N_out, dtype=torch.float32 if (epilogue & _C.EPI_OUT_F32) else torch.float16, device=xg.data.device)
-    ws_struct = weight_struct(w)
+    ws_struct = weight_struct(w, act)          # act = bfloat16: the tensors around the GEMM are bf16 (image output only, see the header)
     rc = _C.lib().mi355_linear_deferred_norm_img(xg.data.data_ptr(), xg.M, None if st is None else C.byref(st), C.byref(ws_struct), _p(bias),
                                                  y.data_ptr(), epilogue, _stream())
     if rc == ERR_UNSUPPORTED:
@@ -334,9 +339,10 @@ def qkv_rope_kv_write_img(x: ActImage, wqkv: PackedWeight, qkv_bias, cos_sin, po
     T = x.M
     if x.K != wqkv.K:
         raise _C.Mi355Error(f"qkv_rope_kv_write_img: image K={x.K} against K={wqkv.K}")
-    q_out = torch.empty(T, nh, hd, dtype=torch.float16, device=x.data.device)
-    kv = kv_struct(kv_base, scale_base, page, nkv, hd)
-    ws_struct = weight_struct(wqkv)
+    act = _act_of_cache(kv_base) if kv_base.dtype != torch.int8 else torch.float16    # q / bias / cache share the step's 16-bit dtype
+    q_out = torch.empty(T, nh, hd, dtype=act, device=x.data.device)
+    kv = kv_struct(kv_base, scale_base, page, nkv, hd, act)
+    ws_struct = weight_struct(wqkv, act)
     rc = _C.lib().mi355_qkv_rope_kv_write_img(x.data.data_ptr(), T, C.byref(ws_struct), _p(qkv_bias), cos_sin.data_ptr(), hd, cos_sin.shape[0],
                                               positions.data_ptr(), block_table.data_ptr(), block_table.shape[1], q_len, nh,
                                               C.byref(kv), q_out.data_ptr(), _p(oob_count), _stream())

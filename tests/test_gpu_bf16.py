@@ -286,3 +286,61 @@ def test_int8_kv_cache_with_bf16_rows(nh, nkv, hd, page):
         Kq, Vq, ks, vs = nat[b]
         ref = oracle.attention_decode(qq[b], Kq, Vq, 1 / math.sqrt(hd), ks, vs).reshape(-1)
         assert torch.allclose(out[b].cpu().float(), ref.float(), **TOL), (b, ctx[b], float((out[b].cpu().float() - ref.float()).abs().max()))
+
+
+@pytest.mark.parametrize("M", [3, 17, 64])
+def test_image_path_layer_with_bf16_tensors_vs_oracle(M):
+    """The launches on activation images (gemm_fullk64 / gemm_wide image entry / gemm_splitk64) inside a bf16 step: the images hold
+    fp16 conversions of the bf16 values (exact), the GEMMs run fp16 MFMAs on the fp16 dequant, the epilogues round and store bf16
+    (q, KV cache, residual stream).  One attention-less layer chain against the oracle on bf16 tensors:
+      RMSNorm -> [image] QKV + bias + RoPE + KV write;  attn (random) -> [image] O + residual (+ deferred norm operands)
+      -> [image] gate_up + SiLU -> [image] down slabs -> fold (residual + RMSNorm) -> [image]."""
+    cfg = model.QWEN2_7B
+    H, I, nh, nkv, hd, page = cfg.hidden, cfg.inter, cfg.nh, cfg.nkv, cfg.hd, 16
+    g = _gen(M)
+    mk = lambda K, N, seed, **kw: model.synth_linear(K, N, "w4", "cpu", _gen(seed), zeros="centered")
+    cq, co, cg, cd = mk(H, (nh + 2 * nkv) * hd, 1), mk(H, H, 2), mk(H, 2 * I, 3), mk(I, H, 4)
+    wq, wo, wg, wd = cq.pack(dtype=BF).to(DEV), co.pack(dtype=BF).to(DEV), cg.pack(gate_up=True, dtype=BF).to(DEV), cd.pack(dtype=BF).to(DEV)
+    Wq, Wo, Wg, Wd = _dense(cq), _dense(co), _dense(cg), _dense(cd)
+    h0 = (torch.randn(M, H, generator=g) * 2.0).to(BF)
+    g_in = (1.0 + 0.2 * torch.randn(H, generator=g)).to(BF); g_post = (1.0 + 0.2 * torch.randn(H, generator=g)).to(BF)
+    bias = (torch.randn((nh + 2 * nkv) * hd, generator=g) * 0.1).to(BF)
+    eps = 1e-6
+    # ---- QKV on the image the norm writes
+    xn_img, _ = ops.add_rmsnorm_img(h0.to(DEV), None, g_in.to(DEV), eps)
+    assert xn_img.data.dtype == torch.float16
+    xn_ref = oracle.rmsnorm(h0, g_in, eps)
+    assert torch.equal(xn_img.unpack().cpu(), xn_ref.to(torch.float16))                  # the bf16 result, converted exactly
+    max_blocks, nblk = 8, 1024
+    c2 = model.ModelConfig("t", 1, H, nh, nkv, hd, 64, 128, max_pos=max_blocks * page)
+    cs = oracle.rope_cos_sin(hd, c2.rope_theta, c2.max_pos)
+    pos = torch.randint(0, max_blocks * page, (M,), generator=g).to(torch.int32)
+    bt = torch.randperm(nblk, generator=g)[: M * max_blocks].reshape(M, max_blocks).to(torch.int32)
+    kv, sc = kvcache.alloc_layer_cache(nblk, nkv, page, hd, False, DEV, dtype=BF)
+    q = ops.qkv_rope_kv_write_img(xn_img, wq, bias.to(DEV), cs.to(DEV), pos.to(DEV), bt.to(DEV), kv, sc, nh, nkv, hd, page)
+    assert q is not None and q.dtype == BF
+    qkv = oracle.linear(xn_ref, Wq, bias)
+    q_ref = oracle.apply_rope(qkv[:, : nh * hd].reshape(M, nh, hd), pos, cs)
+    k_ref = oracle.apply_rope(qkv[:, nh * hd: (nh + nkv) * hd].reshape(M, nkv, hd), pos, cs)
+    assert torch.allclose(q.cpu().float(), q_ref.float(), **TOL)
+    for t in range(M):
+        K, V, _, _ = kvcache.read_tokens(kv, sc, bt[t], int(pos[t]) + 1)
+        assert torch.allclose(K[-1].cpu().float(), k_ref[t].float(), **TOL)
+        assert torch.allclose(V[-1].cpu().float(), qkv[t, (nh + nkv) * hd:].reshape(nkv, hd).float(), **TOL)
+    # ---- O + residual with the deferred norm, gate_up + SiLU as an image, down slabs, fold
+    attn = (torch.randn(M, nh * hd, generator=g) * 0.5).to(BF)
+    r = ops.linear_residual_prenorm_img(ops.act_image_pack(attn.to(DEV)), wo, h0.to(DEV), g_post.to(DEV))
+    assert r is not None
+    h1, xg, ssq, e = r
+    h1_ref = (oracle.linear(attn, Wo, None).float() + h0.float()).to(BF)
+    assert h1.dtype == BF and torch.allclose(h1.cpu().float(), h1_ref.float(), **TOL)
+    act_img = ops.linear_deferred_norm_img(xg, (ssq, eps, e), wg, None, _C.EPI_SILU_MUL | _C.EPI_OUT_IMAGE, act=BF)
+    assert isinstance(act_img, ops.ActImage)
+    act_ref = oracle.silu_mul(oracle.linear(oracle.rmsnorm(h1.cpu(), g_post, eps), Wg, None))
+    act = act_img.unpack().cpu()
+    assert torch.equal(act, act.to(BF).to(torch.float16))                                 # bf16-representable values
+    assert torch.allclose(act.float(), act_ref.float(), **TOL), float((act.float() - act_ref.float()).abs().max())
+    slabs = ops.linear_partial_img(act_img, wd)
+    assert slabs is not None
+    down_ref = oracle.linear(act.to(BF), Wd, None)
+    assert torch.allclose(slabs.sum(0)[:, :H].cpu(), down_ref.float(), atol=4e-2, rtol=2e-2)
