@@ -49,13 +49,16 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-TRAFFIC_KERNEL_SOURCES = ("common.h", "gemm_common.h", "gemm.hip", "gemm_wide.hip")
+TRAFFIC_KERNEL_SOURCES = ("common.h", "gemm_common.h", "gemm.hip", "gemm_wide.hip", "gemm_fullk.h", "gemm_fullk64.hip", "gemm_splitk64.hip",
+                          "elementwise.hip")
 
 
 def gemm_sources_sha():
-    """Hash of the sources of the kernels the committed PMC traffic file measured: the four quantised linears of the 64-row step are
-    gemm_wq_kernel (gemm.hip) and gemm_wide_kernel (gemm_wide.hip) over the shared headers.  The few-row full-K kernels
-    (gemm_fullk.hip, <= 12 rows) and the prefill GEMM are not launched by that workload, so edits there do not stale the file."""
+    """Hash of the sources of the kernels the committed PMC traffic file measured: the four quantised linears of the 5-64-row step are
+    gemm_fullk64_kernel (qkv, o), gemm_wide_kernel (gate_up) and gemm_splitk64_kernel (down), and the launch that consumes their slabs /
+    writes their input images is add_rmsnorm_kernel (elementwise.hip); gemm.hip holds the entry points and planners.  The few-row
+    full-K kernels (gemm_fullk.hip, <= 4 rows) and the prefill GEMM are not launched by that workload, so edits there do not stale the
+    file."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "rtp_llm_amd", "csrc")
@@ -308,18 +311,18 @@ def main():
         ach = alg_bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_src = None, None
         try:  # HBM read + write bytes per launch of THESE launches (the engine's four linears per layer), from the committed
-            # rocprofv3 --pmc passes over `bench.py --no-graph` (tools/engine_traffic.sh -> profiles/r03_traffic.json); PMC
+            # rocprofv3 --pmc passes over `bench.py --no-graph` (tools/engine_traffic.sh -> profiles/r04_traffic.json); PMC
             # collection needs its own profiled runs, so it cannot happen inside this timed invocation: the value is static --
             # and only quoted while the GEMM sources still hash to what was measured (a stale file reports null)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json"))).get(args.workload)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json"))).get(args.workload)
             if tj and tj.get("batch") == B:
                 if tj.get("gemm_sources_sha") == gemm_sources_sha():
                     traffic, traffic_src = int(tj["gemm_quant_bytes_per_launch"]), tj.get("source")
                 else:
-                    traffic_src = "stale: profiles/r03_traffic.json was collected for different sources of gemm.hip / gemm_wide.hip (re-run tools/engine_traffic.sh)"
+                    traffic_src = "stale: profiles/r04_traffic.json was collected for different sources of the GEMM / fold kernels (re-run tools/engine_traffic.sh)"
         except Exception:  # noqa: BLE001
             traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "gemm_wq_kernel / gemm_wide_kernel (the four quantised linears of a layer: qkv, o, gate_up, down)", "achieved": round(ach, 1),
+        out["roofline"] = {"bound": "hbm", "kernel": "the four quantised linears of a layer: gemm_fullk64_kernel (qkv + RoPE + KV write, o + residual), gemm_wide_kernel (gate_up + SiLU), gemm_splitk64_kernel (down)", "achieved": round(ach, 1),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_ms * 1e3, 3),
                            "launches_timed": gq["launches"]}

@@ -6,7 +6,8 @@ usage: engine_traffic.py <fetch_dir> <write_dir>"""
 import collections, csv, glob, json, os, sys
 
 import re
-CLASSES = [(r"gemm_wide_kernel", "gemm_quant"), (r"gemm_wq_kernel(ILi|<)(4|8)[E,]", "gemm_quant"), (r"gemm_smallm", "gemm_quant"),
+CLASSES = [(r"gemm_wide_kernel", "gemm_quant"), (r"gemm_fullk64_kernel|gemm_splitk64_kernel|gemm_fullk_kernel", "gemm_quant"),
+           (r"gemm_wq_kernel(ILi|<)(4|8)[E,]", "gemm_quant"), (r"gemm_smallm", "gemm_quant"),
            (r"gemm_prefill", "gemm_quant"), (r"gemm_wq_kernel(ILi|<)16[E,]", "gemm_lmhead"), (r"paged_attn|attn_reduce", "attn"),
            (r"rope_kv", "rope_kv"), (r"add_rmsnorm", "norm"), (r"reduce_epilogue", "gemm_quant_reduce")]
 
@@ -41,7 +42,8 @@ g = out.get("gemm_quant")
 if g:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    js = {"qwen2-7b-w4a16": {"batch": 64, "gemm_sources_sha": bench.gemm_sources_sha(), "gemm_quant_read_bytes_per_launch": g["read_bytes_per_launch"],
+    js = {"qwen2-7b-w4a16": {"batch": 64, "gemm_sources_sha": bench.gemm_sources_sha(), "gemm_sources_sha_over": list(bench.TRAFFIC_KERNEL_SOURCES),
+                             "gemm_quant_read_bytes_per_launch": g["read_bytes_per_launch"],
                              "gemm_quant_write_bytes_per_launch": g["write_bytes_per_launch"],
                              "gemm_quant_bytes_per_launch": g["read_bytes_per_launch"] + g["write_bytes_per_launch"],
                              "per_class": out,

@@ -3,7 +3,7 @@
 # only) over `bench.py --no-graph` (eager launches of the C++ step: hipGraph replays are not broken down per kernel by the
 # counter tool), summarised per kernel class by tools/engine_traffic.py.
 # usage (on the GPU box): bash tools/engine_traffic.sh   -> gpurun_out/$ROUND/{pmc_engine_*.txt, traffic.json}
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND:-r03}; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND:-r04}; mkdir -p $O
 export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
   ( cd $R && timeout 240 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_engine_$ctr -o run -- \
