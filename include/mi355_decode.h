@@ -253,7 +253,7 @@ int mi355_qkv_rope_kv_write(const void* x, int32_t M, const mi355_weight_t* wqkv
                             const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq, int32_t q_len,
                             int32_t nh, const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count, mi355_stream_t stream);
 /*
- * 17-64-row steps: the fused launches above with the activations handed over as an IMAGE (gemm_fullk64.hip).
+ * 5-64-row steps: the fused launches above with the activations handed over as an IMAGE (gemm_fullk64.hip).
  * With K inside one block, every block pulls all M activation rows of its K range through its CU; gathered from the row-major tensor
  * that is 16 runs of 64 B per MFMA fragment at the row stride, which the L2s serve at a fifth of the rate of dense 1 KB runs when the
  * whole chip asks for the same rows (profiles/r04_fullk64_access_patterns.txt: QKV at 64 rows 19.8 vs 11.2 us).  The image stores
@@ -263,11 +263,11 @@ int mi355_qkv_rope_kv_write(const void* x, int32_t M, const mi355_weight_t* wqkv
  * block are never read back as results.  Producers: mi355_add_rmsnorm_img (y), mi355_paged_attn_rows_img (out), or
  * mi355_act_image_pack from a row-major tensor (direction 1: back).  Consumers: mi355_qkv_rope_kv_write_img,
  * mi355_linear_residual_img: same arguments and results as the entry points without the suffix (no fused norm: the producer
- * normed), W4 group-wise weights, 16 < M <= 64, K <= 5760, else MI355_ERR_UNSUPPORTED.
+ * normed), W4 group-wise weights, 1 <= M <= 64 (two- / four-row-block instances; the step driver takes them from 5 rows), K <= 5760, else MI355_ERR_UNSUPPORTED.
  * Reference boundary these keep: modules/hybrid/causal_attention.py:75-93 (qkv_proj -> rope / kv write -> attention -> o_proj),
  * model_desc/qwen3.py:57-79 (norm -> attention -> residual add).
  */
-/* Deferred RMSNorm between the O projection and gate_up of a 17-64-row step (no norm launch): the producer stores, besides the new
+/* Deferred RMSNorm between the O projection and gate_up of a 5-64-row step (no norm launch): the producer stores, besides the new
  * residual rows h, the image of g = fp16(weight * 2^-norm_exp * h) and the per-tile sums of h^2 (as mi355_linear_residual does);
  * the consumer runs its GEMM on g and multiplies the accumulators by unscale * rsqrt(sum_k h^2 / K + eps), unscale = 2^norm_exp:
  * (RMSNorm(h) W)[m][n] = rs[m] * sum_k weight[k] h[m][k] W[k][n].  norm_exp >= log2(max |weight|) keeps |g| <= |h|: no fp16
@@ -295,12 +295,12 @@ int mi355_linear_residual_img(const void* x_img, int32_t M, const mi355_weight_t
 int mi355_linear_residual_prenorm_img(const void* x_img, int32_t M, const mi355_weight_t* w, const void* bias, const void* residual_in,
                                       void* residual_out, const void* norm_weight, int32_t norm_exp, void* xg_img_out,
                                       float* tile_sumsq_out, int32_t tile_sumsq_ld, mi355_stream_t stream);
-/* y = epilogue(rs * (xg W) + bias): the wide GEMM (W4 group-wise, 16 < M <= 64, N wide enough to fill the chip: gate_up) on an
+/* y = epilogue(rs * (xg W) + bias): the wide GEMM (W4 group-wise, 1 <= M <= 64, N wide enough to fill the chip: gate_up) on an
  * activation image, with the deferred norm applied to the accumulators (dn may be null: a plain linear on an image) */
 int mi355_linear_deferred_norm_img(const void* xg_img, int32_t M, const mi355_deferred_norm_t* dn, const mi355_weight_t* w,
                                    const void* bias, void* y, int32_t epilogue, mi355_stream_t stream);
 /* fp32 split-K slabs [n][M][N_pad] of a deep-K linear (down_proj) from an activation image, for mi355_add_rmsnorm(_img) to fold:
- * returns n (<= max_splits, <= 16), or MI355_ERR_UNSUPPORTED (not W4 group-wise / not 17-64 rows / K too short or too deep for
+ * returns n (<= max_splits, <= 16), or MI355_ERR_UNSUPPORTED (not W4 group-wise / more than 64 rows / K too short or too deep for
  * 8 K-slice waves of <= 5 chunks per block: the caller uses mi355_linear_partial on the row-major tensor) */
 int mi355_linear_partial_img(const void* x_img, int32_t M, const mi355_weight_t* w, float* partials, int32_t max_splits,
                              mi355_stream_t stream);

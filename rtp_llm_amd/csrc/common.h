@@ -197,7 +197,7 @@ __device__ __forceinline__ float rt_from_bits(uint16_t b, bool bf) { return bf ?
 __device__ __forceinline__ uint16_t rt_to_bits(float v, bool bf) { return bf ? act_to_bits<true>(v) : act_to_bits<false>(v); }
 __device__ __forceinline__ float rt_round(float v, bool bf) { return bf ? act_round<true>(v) : act_round<false>(v); }
 
-// ---- activation image (mi355_act_image_*): the [M][K] 16-bit activations of a 17-64-row step in the order the full-K launches of
+// ---- activation image (mi355_act_image_*): the [M][K] 16-bit activations of a 5-64-row step in the order the full-K launches of
 // gemm_fullk64.hip read them -- one dense 1 KB run per MFMA B fragment (k-step of 32, row block of 16): lane (jj, q) of the
 // fragment owns the 16 bytes x[16 rb + jj][32 ks + 8 q .. + 7].  A fragment gathered from the row-major tensor instead is 16 runs
 // of 64 B at the row stride: with every CU of the chip asking for the same runs, the L2 serves them at ~7 TB/s against 35 for dense

@@ -285,7 +285,7 @@ extern "C" int mi355_add_rmsnorm_dt(const void* x_f16, const float* partials, in
     return add_rmsnorm_launch(x_f16, partials, nsplit, ld, bias, residual_in, residual_out, weight, eps, M, H, y, 0, act_dtype, stream);
 }
 
-// the same with y written as an activation image (mi355_act_image_*) for the full-K launches of a 17-64-row step
+// the same with y written as an activation image (mi355_act_image_*) for the full-K launches of a 5-64-row step
 extern "C" int mi355_add_rmsnorm_img(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
                                      const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M,
                                      int32_t H, void* y_img, int32_t act_dtype, mi355_stream_t stream) {

@@ -8,13 +8,17 @@
 // (rtp_llm/cpp/models/PyWrappedModel.cc:938-1080, bindings/core/CudaSampleOp.cc:687-700)
 // and the per-batch-size graph capture of rtp_llm/cpp/cuda_graph/cuda_graph_runner.cc.
 //
-// Launches per layer (tp = 1), above 12 rows: QKV GEMM (split-K slabs) -> reduce+bias+RoPE+KV-write ->
-// paged attention (+ partition reduce) -> O GEMM (slabs) -> reduce+residual+RMSNorm ->
-// gate_up GEMM with fused SiLU-gate -> down GEMM (slabs) -> reduce+residual+RMSNorm
-// (already the next layer's input norm).  No standalone reduce / add / activation kernels.
-// Up to 12 rows every GEMM is a full-K launch with its consumer fused (gemm_fullk.hip), 6 launches:
-// [RMSNorm on load +] QKV + bias + RoPE + KV write -> attention -> partition reduce -> O + residual (leaves the
-// per-tile sums of squares) -> RMSNorm on load + gate_up + SiLU-gate -> down + residual.
+// Launches per layer (tp = 1):
+//   * 5-64 rows, W4 group-wise weights, 16-bit cache (round 4): SIX launches, activations handed over as fragment-ordered images
+//     (common.h act_img_index): QKV + bias + RoPE + KV write (gemm_fullk64.hip) -> paged attention (+ partition reduce) ->
+//     O + residual, leaving gamma 2^-e h' as an image and the sums of squares -> gate_up + SiLU with the RMSNorm finished on its
+//     accumulators (gemm_wide.hip) -> down as 4 K-quarters (gemm_splitk64.hip) -> fold: slabs + residual + RMSNorm -> image;
+//   * up to 4 rows every GEMM is a full-K launch with its consumer fused (gemm_fullk.hip), 6 launches:
+//     [RMSNorm on load +] QKV + bias + RoPE + KV write -> attention -> partition reduce -> O + residual (leaves the
+//     per-tile sums of squares) -> RMSNorm on load + gate_up + SiLU-gate -> down + residual;
+//   * other formats / TP (above 12 rows): QKV GEMM (split-K slabs) -> reduce+bias+RoPE+KV-write -> paged attention (+ partition
+//     reduce) -> O GEMM (slabs) -> reduce+residual+RMSNorm -> gate_up GEMM with fused SiLU-gate -> down GEMM (slabs) ->
+//     reduce+residual+RMSNorm (already the next layer's input norm).  No standalone reduce / add / activation kernels.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <algorithm>
@@ -45,7 +49,7 @@ struct mi355_decoder {
     mi355_step_buffers_t               bufs;
     // carved workspace
     void *resid, *xn, *q_buf, *attn_out, *act, *attn_ws, *argmax_ws;
-    void *xn_img, *attn_img;   // activation images (mi355_act_image_*) of the normed hidden rows / the attention output, 17-64-row steps
+    void *xn_img, *attn_img;   // activation images (mi355_act_image_*) of the normed hidden rows / the attention output, 5-64-row steps
     int32_t* oob_count; // tokens refused by the KV writer (stale position / block id)
     mi355_allreduce_t* ar; // attached all-reduce context (tp_size > 1): the TP step runs entirely from C++
     int    vocab_offset;
@@ -79,7 +83,7 @@ struct mi355_decoder {
     // at 64 (measured M = 64: qkv+rope 20.8 vs 9.0 + 4.9 us, o 18.6 vs 9.7 + slab fold; M = 1: 6.8 vs 7.3 + 3.1 us)
     bool   fuse_qkv, fuse_o, fuse_down, fuse_norm;
     int    fuse_rows;
-    // 17-64 rows (tp = 1): QKV + bias + RoPE + KV write and O + residual as one full-K launch each (gemm_fullk64.hip), their
+    // 1-64 rows (tp = 1): QKV + bias + RoPE + KV write and O + residual as one full-K launch each (gemm_fullk64.hip), their
     // activations handed over as images by the producing launches (RMSNorm fold, attention): 7 launches per layer instead of 8 + no slabs
     bool   img_qkv, img_o;
     // ... and the post-attention RMSNorm deferred into gate_up's accumulators (mi355_deferred_norm_t): the O launch leaves
@@ -510,7 +514,7 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
     const bool normed = small && d->fuse_norm;            // no norm launches in this step: see fuse_norm
     const int pf = c.tp_size == 1 ? d->pf_mask : 0;       // (tp > 1: the side stream belongs to comm_with_prefetch)
     if (int e = pf_join(d, st)) return e;                  // this layer's QKV weights, requested behind the previous down GEMM
-    const bool mid_qkv = d->img_qkv && B > d->fuse_rows, mid_o = d->img_o && B > d->fuse_rows;   // 17-64 rows: full-K launches on activation images
+    const bool mid_qkv = d->img_qkv && B > d->fuse_rows, mid_o = d->img_o && B > d->fuse_rows;   // 1-64 rows: full-K launches on activation images
     if (mid_qkv) {
         RUN(MI355_KC_GEMM_QUANT, mi355_qkv_rope_kv_write_img(d->xn_img, B, &L.qkv, L.qkv_bias, d->model.cos_sin, c.rope_dim, c.max_pos,
                                                              d->bufs.positions, d->bufs.block_table, c.max_blocks_per_seq, d->q_len, c.nh,

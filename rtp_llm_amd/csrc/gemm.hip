@@ -893,7 +893,7 @@ extern "C" int mi355_qkv_rope_kv_write(const void* x, int32_t M, const mi355_wei
                                  q_len, nh, kv, q_out, oob_count, stream);
 }
 
-// ------------------------------------------------------------------ the same two launches for 17-64 rows, activations as an image
+// ------------------------------------------------------------------ the same two launches for 1-64 rows (the step driver: from 5), activations as an image
 // (gemm_fullk64.hip).  x_img: mi355_act_image_* of the [M][K] activations -- written directly by mi355_add_rmsnorm_img /
 // mi355_paged_attn_rows_img, or by mi355_act_image_pack from a row-major tensor.
 extern "C" int mi355_linear_residual_img(const void* x_img, int32_t M, const mi355_weight_t* w, const void* bias, const void* residual_in,
@@ -941,7 +941,7 @@ extern "C" int mi355_linear_deferred_norm_img(const void* xg_img, int32_t M, con
     return mi355_gemm_wide_img(&p, w->wbits, w->group_size, dn, stream);
 }
 
-// Split-K slabs of a deep-K linear (down_proj) at 17-64 rows from an activation image (gemm_splitk64.hip): returns the number of
+// Split-K slabs of a deep-K linear (down_proj) at 1-64 rows from an activation image (gemm_splitk64.hip): returns the number of
 // fp32 slabs [n][M][N_pad] written to `partials` (to be folded by mi355_add_rmsnorm / _img), or MI355_ERR_UNSUPPORTED
 extern "C" int mi355_linear_partial_img(const void* x_img, int32_t M, const mi355_weight_t* w, float* partials, int32_t max_splits,
                                         mi355_stream_t stream) {

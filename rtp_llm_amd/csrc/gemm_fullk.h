@@ -1,5 +1,5 @@
 // Parameter block, epilogue kinds and the per-wave stamps shared by the full-K launches: gemm_fullk.hip (<= 16 rows and the
-// generic shapes) and gemm_fullk64.hip (17-64 rows, W4 group-wise).
+// generic shapes) and gemm_fullk64.hip (1-64 rows, W4 group-wise).
 #pragma once
 #include "gemm_common.h"
 

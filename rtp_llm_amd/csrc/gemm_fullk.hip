@@ -554,7 +554,7 @@ extern "C" void mi355_debug_fullk_stamps(void* p) { g_fullk_stamps = (unsigned l
 #define FK_SET_STAMPS(fp) do { } while (0)
 #endif
 
-// 17-64 rows, W4 group-wise, K <= 5760, activations as an image (mi355_act_image_*): gemm_fullk64.hip
+// 1-64 rows, W4 group-wise, K <= 5760, activations as an image (mi355_act_image_*): gemm_fullk64.hip
 extern "C" int mi355_gemm_fullk64(const void* fp, int epi, int group_size, mi355_stream_t stream);
 
 static void set_norm(FullKParams& fp, const mi355_fused_norm_t* n) {
@@ -616,7 +616,7 @@ extern "C" int mi355_gemm_fullk_rope(const void* gp, int wbits, int group_size, 
     return launch_fullk<2, FK_ROPE, false>(fp, group_size, nheads * (kv->hd / 32), (hipStream_t)stream);
 }
 
-// ---- the same two launches for 17-64 rows with the activations handed over as an image (gp->x: mi355_act_image_*), gemm_fullk64.hip
+// ---- the same two launches for 1-64 rows (the step driver: from 5) with the activations handed over as an image (gp->x: mi355_act_image_*), gemm_fullk64.hip
 extern "C" int mi355_gemm_fullk_residual_img(const void* gp, int wbits, int group_size, const void* residual_in, void* residual_out,
                                              float* ssq_out, int ssq_ld, const void* norm_weight, float xg_scale, void* xg_img,
                                              mi355_stream_t stream) {

@@ -1,4 +1,4 @@
-// Full-K weight-only W4 GEMM for 17-64 rows with the consumer fused into the epilogue, gfx950: the QKV projection (+ bias + NeoX
+// Full-K weight-only W4 GEMM for 1-64 rows (the step driver: from 5) with the consumer fused into the epilogue, gfx950: the QKV projection (+ bias + NeoX
 // RoPE + Q extract + paged fp16 KV write) and the O projection (+ bias + residual add, per-tile sums of squares of the new
 // residual rows) of a decode step as ONE launch each -- no split-K slabs, no fold launch.
 // Reference semantics: LinearBase.forward (models_py/modules/factory/linear/linear_base.py:75-85) followed by
@@ -324,7 +324,7 @@ extern unsigned long long* g_fullk_stamps;   // gemm_fullk.hip
 #endif
 
 // fp_: a FullKParams filled by the entry points of gemm_fullk.hip (same layout in both translation units).  epi: FK_RESID or
-// FK_ROPE.  Takes W4 group-wise weights, 17-64 rows, K <= 5760; MI355_ERR_UNSUPPORTED otherwise (the caller goes on to the
+// FK_ROPE.  Takes W4 group-wise weights, 1-64 rows, K <= 5760; MI355_ERR_UNSUPPORTED otherwise (the caller goes on to the
 // generic full-K kernel).
 extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi355_stream_t stream) {
     FullKParams fp = *reinterpret_cast<const FullKParams*>(fp_);

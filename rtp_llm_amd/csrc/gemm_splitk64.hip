@@ -1,4 +1,4 @@
-// Split-K weight-only W4 GEMM for 17-64 rows and DEEP K (down_proj: K = 18944, N = 3584), gfx950: fp32 slabs for the consumer's
+// Split-K weight-only W4 GEMM for 1-64 rows (the step driver: from 5) and DEEP K (down_proj: K = 18944, N = 3584), gfx950: fp32 slabs for the consumer's
 // fold launch (mi355_add_rmsnorm), activations read as an image (mi355_act_image_*).
 // Reference slot: LinearBase.forward of the W4A16 strategy (models_py/modules/factory/linear/linear_base.py:75-85,
 // factory.py:106-119) for DenseMLP.down_proj (modules/hybrid/dense_mlp.py:95-106); the slabs are an internal hand-over.

@@ -355,7 +355,7 @@ extern "C" void mi355_debug_ptr(void* p) { g_wide_stamps = (unsigned long long*)
 // MI355_ERR_UNSUPPORTED when the shape does not fit this kernel (the caller falls back to gemm.hip).
 static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_partial, int max_splits, const mi355_deferred_norm_t* dn,
                             mi355_stream_t stream);
-// does the direct (one launch, no slabs) form take this linear at 17-64 rows?  N alone has to fill the chip (gate_up)
+// does the direct (one launch, no slabs) form take this linear at 1-64 rows?  N alone has to fill the chip (gate_up)
 extern "C" int mi355_gemm_wide_direct_ok(const mi355_weight_t* w) {
     if (!w || w->wbits != 4 || (w->group_size != 128 && w->group_size != 64 && w->group_size != 32)) return 0;   // either activation dtype: the image entry (gemm.hip) decides
     if (w->K % 128 != 0 || w->K_pad != w->K) return 0;
@@ -376,7 +376,7 @@ static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_
                             mi355_stream_t stream) {
     GemmParams g = *reinterpret_cast<const GemmParams*>(gp);
     constexpr int T = 5, TB = 2 * T, CUS = 256;     // tiles per wave / per block
-    if (g.M < 1 || g.M > 64) return MI355_ERR_UNSUPPORTED;   // row-major callers come with > 16 rows (gemm.hip); 13-16 rows: the image entries, on the two-row-block instances
+    if (g.M < 1 || g.M > 64) return MI355_ERR_UNSUPPORTED;   // row-major callers come with > 16 rows (gemm.hip); fewer: the image entries only, on the two-row-block instances
     const bool w8 = wbits == 8 && group_size == 0;    // per-channel int8 (W8A16): compiler-scheduled unit, scale applied at the merge
     if (!w8 && !(wbits == 4 && (group_size == 128 || group_size == 64 || group_size == 32))) return MI355_ERR_UNSUPPORTED;
     if (g.K % 128 != 0 || g.qw_bytes > 0x40000000u || (!w8 && g.meta_bytes > 0x40000000u)) return MI355_ERR_UNSUPPORTED;

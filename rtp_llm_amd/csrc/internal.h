@@ -16,8 +16,8 @@ int mi355_paged_decode_attn_ex(const void* q, const mi355_kv_layer_t* kv, const 
                                int32_t nh, float scale, int32_t max_seq_len, void* out, void* workspace,
                                size_t workspace_bytes, mi355_stream_t stream);
 int mi355_fullk_weight_ok(const mi355_weight_t* w);
-int mi355_gemm_wide_direct_ok(const mi355_weight_t* w);
-int mi355_gemm_splitk64_plan(int M, int NT, int KC, int wbits, int group_size, int max_splits, int* cps_out);   /* gemm_splitk64.hip: slabs, or < 0 */   /* gemm_wide.hip: one-launch form at 17-64 rows (N fills the chip) */
+int mi355_gemm_wide_direct_ok(const mi355_weight_t* w);   /* gemm_wide.hip: the one-launch form takes this linear (N fills the chip) */
+int mi355_gemm_splitk64_plan(int M, int NT, int KC, int wbits, int group_size, int max_splits, int* cps_out);   /* gemm_splitk64.hip: slabs, or < 0 */
 int mi355_prefetch(const void* ptr, size_t bytes, void* sink, mi355_stream_t stream);
 int mi355_argmax_candidates(const float* logits, int32_t B, int32_t V, int32_t ld, void* workspace, size_t workspace_bytes,
                             mi355_stream_t stream);

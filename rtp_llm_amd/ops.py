@@ -181,9 +181,9 @@ def qkv_rope_kv_write(x: torch.Tensor, wqkv: PackedWeight, qkv_bias, cos_sin, po
 
 
 # ------------------------------------------------------------------ norms / elementwise
-# ---- activation images (17-64-row steps): see include/mi355_decode.h, mi355_act_image_*
+# ---- activation images (5-64-row steps): see include/mi355_decode.h, mi355_act_image_*
 class ActImage:
-    """The [M][K] activations of a 17-64-row step in the order the full-K launches read them (one dense 1 KB run per MFMA fragment)."""
+    """The [M][K] activations of a 5-64-row step in the order the full-K launches read them (one dense 1 KB run per MFMA fragment)."""
     def __init__(self, data: torch.Tensor, M: int, K: int):
         self.data, self.M, self.K = data, M, K
 
@@ -237,7 +237,7 @@ def paged_attention_rows_img(q: torch.Tensor, kv_base, scale_base, block_table: 
 
 def linear_residual_img(x: ActImage, w: PackedWeight, residual: torch.Tensor, bias: Optional[torch.Tensor] = None,
                         out: Optional[torch.Tensor] = None, tile_sumsq: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
-    """linear_residual for 17-64 rows with the activations as an image (gemm_fullk64.hip); None when the shape is not taken."""
+    """linear_residual for 1-64 rows (the step driver: from 5) with the activations as an image (gemm_fullk64.hip); None when the shape is not taken."""
     _chk(x.data, torch.float16, "linear_residual_img.x"); _chk_act(residual, "linear_residual_img.residual")      # the image is fp16; residual / bias: fp16 or bf16
     M = x.M
     if x.K != w.K or residual.shape[-1] != w.N or residual.numel() != M * w.N:
@@ -334,7 +334,7 @@ def linear_partial_img(x: ActImage, w: PackedWeight, max_splits: int = 16):
 
 def qkv_rope_kv_write_img(x: ActImage, wqkv: PackedWeight, qkv_bias, cos_sin, positions, block_table, kv_base, scale_base,
                           nh: int, nkv: int, hd: int, page: int, q_len: int = 1, oob_count: Optional[torch.Tensor] = None):
-    """qkv_rope_kv_write for 17-64 rows with the activations as an image; None when the shape is not taken."""
+    """qkv_rope_kv_write for 1-64 rows (the step driver: from 5) with the activations as an image; None when the shape is not taken."""
     _chk(x.data, torch.float16, "qkv_rope_kv_write_img.x"); _chk(positions, torch.int32, "positions"); _chk(block_table, torch.int32, "block_table")
     T = x.M
     if x.K != wqkv.K:
