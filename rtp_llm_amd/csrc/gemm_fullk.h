@@ -32,6 +32,7 @@ struct FullKParams {
     f16*         xg_img;     // image of g ([M][N]), or null
     const f16*   xg_gamma;   // norm weight [N]
     float        xg_scale;   // 2^-e with e >= log2(max |gamma|): |g| <= |h'|, no overflow whatever the residual stream holds
+    int          rowsplit;   // gemm_fullk64.hip: two blocks per tile pair, 32 rows each (block b: pair b / 2, row blocks 2 (b & 1) .. + 1)
     int          bf16;       // gemm_fullk64.hip: bias / residual / norm weight / q / KV cache are bf16 (the activation image and the MFMAs stay fp16)
 #ifdef MI355_FULLK_STAMPS   // tuning build with MI355_EXTRA_CFLAGS=-DMI355_FULLK_STAMPS only: the stamp stores change the schedule
     unsigned long long* stamps;   // tools/fullk_stamps.py: wall_clock64 per wave at entry / requests out (+ 1 / rms there) / first chunk done / loop done / slices met / exit

@@ -48,14 +48,19 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
     Stage64<EPI>& sg = *reinterpret_cast<Stage64<EPI>*>(smem + (size_t)NW * TPB * MB * 1024);
     FK_STAMP(0);
 
+    // rowsplit (O projection above 32 rows): the block's activation loads are what bounds the launch, and they are per ROW -- two
+    // blocks per tile pair take 32 rows each (224 blocks for Qwen2-7B's O instead of 112; the weights of a pair are then read twice,
+    // 56 KB more per CU pair).  Not for QKV: 144 pairs x 2 = 288 blocks, and the CUs with two of them would set the time.
+    const int pair = fp.rowsplit ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int rb0  = fp.rowsplit ? (int)(blockIdx.x & 1) * MB : 0;      // first row block of this block
     int tile[TPB];
     if constexpr (EPI == FK_ROPE) {
         const int hh = fp.r.hd >> 5;                 // tiles per half head
-        const int h = blockIdx.x / hh, j = blockIdx.x % hh;
+        const int h = pair / hh, j = pair % hh;
         tile[0] = h * 2 * hh + j;
         tile[1] = tile[0] + hh;
     } else {
-        tile[0] = blockIdx.x * 2; tile[1] = tile[0] + 1;
+        tile[0] = pair * 2; tile[1] = tile[0] + 1;
     }
 
     if (wave == NW) {
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
     auto load_frag = [&](int f) {                    // f compile-time at every call site (static_for)
         const int c = f / (4 * MB), s = (f / MB) % 4, mb = f % MB;
         // a row block the image does not have (M <= 48 in the 64-row instance) or a chunk past the slice: past the descriptor, zeros
-        xr[f % RING] = bload128<0>(rx, lane16, mb < MBLK ? (uint32_t)(((c * 4 + s) * MBLK + mb) * 1024) : OOBS);
+        xr[f % RING] = bload128<0>(rx, lane16, rb0 + mb < MBLK ? (uint32_t)(((c * 4 + s) * MBLK + rb0 + mb) * 1024) : OOBS);
     };
     static_for<0, RING>([&](auto f_) { load_frag(decltype(f_)::value); });
     FK_STAMP(1);
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
         v[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int w = 0; w < NW; ++w) v[t] += red[((size_t)w * (TPB * MB) + t * MB + mb) * 64 + lane];
     }
-    const int m = mb * 16 + jj;
+    const int m = (rb0 + mb) * 16 + jj;
     if (m >= p.M) continue;
 
     const bool bf = fp.bf16 != 0;                   // dtype of everything 16-bit around the GEMM (the image and the weights' dequant are fp16)
@@ -331,7 +336,7 @@ extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi35
 #ifdef MI355_FULLK_STAMPS
     fp.stamps = g_fullk_stamps;
 #endif
-    fp.ilv = TUNE(7);
+    fp.ilv = TUNE(7); fp.rowsplit = 0;
     const GemmParams& g = fp.g;
     if (g.M < 1 || g.M > 64 || g.KC < 4 || g.KC > 45 || g.K != g.KC * 128) return MI355_ERR_UNSUPPORTED;
     if (group_size != 128 && group_size != 64 && group_size != 32) return MI355_ERR_UNSUPPORTED;
@@ -348,6 +353,12 @@ extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi35
     }
     if (epi == FK_RESID) {
         const int blocks = cdiv(g.NT, 2);
+        if (g.M > 32 && 2 * blocks <= 256 && !(TUNE(4) == 3)) {       // two blocks per tile pair, 32 rows each (see the kernel)
+            fp.rowsplit = 1;
+            if (group_size == 128) return launch64_k<4, 2, FK_RESID>(fp, 2 * blocks, st);
+            if (group_size == 64)  return launch64_k<2, 2, FK_RESID>(fp, 2 * blocks, st);
+            return launch64_k<1, 2, FK_RESID>(fp, 2 * blocks, st);
+        }
         if (group_size == 128) { F64_(4, FK_RESID, blocks); }
         if (group_size == 64)  { F64_(2, FK_RESID, blocks); }
         F64_(1, FK_RESID, blocks);

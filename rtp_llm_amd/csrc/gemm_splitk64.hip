@@ -110,7 +110,7 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
 
     // ---- units in k-step-major order: u = (ks * T + t), ks = 4 c + s
     constexpr int NU = NKS * T;
-    static_for<0, NU>([&](auto uc) {
+    auto unit = [&](auto uc) {
         constexpr int u = decltype(uc)::value;
         constexpr int ks = u / T, t = u % T, c = ks / 4, s = ks % 4;
         constexpr int un = u + 1, ksn = un / T, tn = un % T, cn = ksn / 4, sn = ksn % 4;   // the unit whose operand this one prepares
@@ -156,7 +156,12 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
         if constexpr (t == T - 1 && ks + RING < NKS) load_x(ks + RING);
         if constexpr (s == 3 && t == T - 1 && c + 2 < CPW) load_w(c + 2);
         __builtin_amdgcn_sched_barrier(0);               // fence per unit: keeps the requests where they were written
-    });
+    };
+    // the slices of a block differ by at most one chunk (base / base + 1): the waves without the last chunk skip its units (zero
+    // weights otherwise: 48 of a block's 640 units at K = 18944)
+    constexpr int NU_HEAD = (CPW - 1) * 4 * T;
+    static_for<0, NU_HEAD>(unit);
+    if (n_ch == CPW) static_for<NU_HEAD, NU>(unit);
     asm volatile("s_nop 15" ::: "memory");               // the last MFMAs' results are read by compiler code below
 
     // ---- the K slices meet in LDS; wave w sums the sets e = w, w + 8, ... (set e = tile e / MB, row block e % MB) and stores them
