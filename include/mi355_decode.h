@@ -280,7 +280,9 @@ typedef struct {
     float        unscale;    /* 2^norm_exp */
 } mi355_deferred_norm_t;
 size_t mi355_act_image_bytes(int32_t M, int32_t K);
-int mi355_act_image_pack(const void* src, int32_t M, int32_t K, void* dst, int32_t direction, mi355_stream_t stream);
+/* direction 0: row-major [M][K] tensor of act_dtype -> image; 1: image -> row-major tensor of act_dtype.  An image always holds fp16
+ * (the GEMMs that read it run fp16 MFMAs): bf16 rows are converted, exactly inside the fp16 range. */
+int mi355_act_image_pack(const void* src, int32_t M, int32_t K, void* dst, int32_t direction, int32_t act_dtype, mi355_stream_t stream);
 int mi355_add_rmsnorm_img(const void* x, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
                           const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M, int32_t H,
                           void* y_img, int32_t act_dtype, mi355_stream_t stream);

@@ -92,7 +92,7 @@ SIGNATURES = {
     "mi355_linear_residual": (i32, [vp, i32, C.POINTER(Weight), vp, vp, vp, vp, i32, vp]),
     "mi355_norm_linear": (i32, [vp, i32, C.POINTER(FusedNorm), C.POINTER(Weight), vp, vp, i32, vp]),
     "mi355_act_image_bytes": (sz, [i32, i32]),
-    "mi355_act_image_pack": (i32, [vp, i32, i32, vp, i32, vp]),
+    "mi355_act_image_pack": (i32, [vp, i32, i32, vp, i32, i32, vp]),
     "mi355_add_rmsnorm_img": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, i32, vp]),
     "mi355_paged_attn_rows_img": (i32, [vp, C.POINTER(KVLayer), vp, i32, vp, i32, i32, i32, f32, i32, vp, vp, sz, vp]),
     "mi355_linear_residual_img": (i32, [vp, i32, C.POINTER(Weight), vp, vp, vp, vp, i32, vp]),

@@ -187,9 +187,10 @@ class ActImage:
     def __init__(self, data: torch.Tensor, M: int, K: int):
         self.data, self.M, self.K = data, M, K
 
-    def unpack(self) -> torch.Tensor:
-        out = torch.empty(self.M, self.K, dtype=self.data.dtype, device=self.data.device)
-        _C.check(_C.lib().mi355_act_image_pack(self.data.data_ptr(), self.M, self.K, out.data_ptr(), 1, _stream()), "act_image_pack")
+    def unpack(self, dtype: torch.dtype = torch.float16) -> torch.Tensor:
+        """The row-major [M, K] tensor (fp16, or the image's values rounded to bf16)."""
+        out = torch.empty(self.M, self.K, dtype=dtype, device=self.data.device)
+        _C.check(_C.lib().mi355_act_image_pack(self.data.data_ptr(), self.M, self.K, out.data_ptr(), 1, _dt(out), _stream()), "act_image_pack")
         return out
 
 
@@ -202,10 +203,9 @@ def act_image_pack(x: torch.Tensor) -> ActImage:
     """Row-major [M, K] -> image.  Images hold fp16 (the GEMMs that read them run fp16 MFMAs): bf16 rows are converted, exactly
     inside the fp16 range."""
     _chk_act(x, "act_image_pack.x")
-    x = x if x.dtype == torch.float16 else x.to(torch.float16)
     M, K = x.shape
     img = _new_image(M, K, torch.float16, x.device)
-    _C.check(_C.lib().mi355_act_image_pack(x.data_ptr(), M, K, img.data.data_ptr(), 0, _stream()), "act_image_pack")
+    _C.check(_C.lib().mi355_act_image_pack(x.data_ptr(), M, K, img.data.data_ptr(), 0, _dt(x), _stream()), "act_image_pack")
     return img
 
 
