@@ -326,3 +326,106 @@ extern "C" int mi355_act_image_pack(const void* src, int32_t M, int32_t K, void*
     MI355_CHECK_LAUNCH("act_image_pack_kernel");
     return MI355_OK;
 }
+
+extern "C" int mi355_add_rmsnorm(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
+                                 const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M,
+                                 int32_t H, void* y, mi355_stream_t stream) {
+    return mi355_add_rmsnorm_dt(x_f16, partials, nsplit, ld, bias, residual_in, residual_out, weight, eps, M, H, y, MI355_ACT_F16, stream);
+}
+
+extern "C" int mi355_rmsnorm_dt(const void* x, const void* weight, float eps, int32_t M, int32_t H, void* y, int32_t act_dtype,
+                                mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && weight && y, "rmsnorm: null pointer");
+    return mi355_add_rmsnorm_dt(x, nullptr, 0, 0, nullptr, nullptr, nullptr, weight, eps, M, H, y, act_dtype, stream);
+}
+
+extern "C" int mi355_rmsnorm(const void* x, const void* weight, float eps, int32_t M, int32_t H, void* y,
+                             mi355_stream_t stream) {
+    return mi355_rmsnorm_dt(x, weight, eps, M, H, y, MI355_ACT_F16, stream);
+}
+
+extern "C" int mi355_silu_mul_dt(const void* gate_up, int32_t M, int32_t I, void* out, int32_t act_dtype, mi355_stream_t stream) {
+    MI355_CHECK_ARG(gate_up && out && M > 0 && I > 0 && I % 8 == 0, "silu_mul: M=%d I=%d", M, I);
+    MI355_CHECK_ARG(act_dtype == MI355_ACT_F16 || act_dtype == MI355_ACT_BF16, "silu_mul: act_dtype=%d", act_dtype);
+    const int total = M * (I / 8);
+    if (act_dtype == MI355_ACT_BF16)
+        hipLaunchKernelGGL(silu_mul_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)gate_up, M, I, (f16*)out);
+    else
+        hipLaunchKernelGGL(silu_mul_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)gate_up, M, I, (f16*)out);
+    MI355_CHECK_LAUNCH("silu_mul_kernel");
+    return MI355_OK;
+}
+
+extern "C" int mi355_silu_mul(const void* gate_up, int32_t M, int32_t I, void* out, mi355_stream_t stream) {
+    return mi355_silu_mul_dt(gate_up, M, I, out, MI355_ACT_F16, stream);
+}
+
+extern "C" int mi355_embedding(const int32_t* ids, int32_t T, const void* table, int32_t H, int32_t vocab, void* out,
+                               mi355_stream_t stream) {
+    MI355_CHECK_ARG(ids && table && out && T > 0 && H > 0 && H % 8 == 0 && vocab > 0, "embedding: T=%d H=%d", T, H);
+    const int total = T * (H / 8);
+    hipLaunchKernelGGL(embedding_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, ids, T, (const f16*)table,
+                       H, vocab, (f16*)out);
+    MI355_CHECK_LAUNCH("embedding_kernel");
+    return MI355_OK;
+}
+
+extern "C" int mi355_argmax_ex(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t* ids, int32_t* positions,
+                               void* workspace, size_t workspace_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(logits && ids && workspace && B > 0 && V > 0 && ld >= V && ld % 4 == 0, "argmax: B=%d V=%d ld=%d", B, V, ld);
+    const int nparts = 64;
+    if (workspace_bytes < (size_t)B * nparts * 8) { mi355_set_error("argmax: workspace too small"); return MI355_ERR_WORKSPACE; }
+    float* cv = (float*)workspace; int* ci = (int*)(cv + (size_t)B * nparts);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(argmax_stage1, dim3(B, nparts), dim3(256), 0, st, logits, V, ld, cv, ci);
+    hipLaunchKernelGGL(argmax_stage2, dim3(B), dim3(64), 0, st, (const float*)cv, (const int*)ci, nparts, ids, positions);
+    MI355_CHECK_LAUNCH("argmax");
+    return MI355_OK;
+}
+
+extern "C" int mi355_prefetch(const void* ptr, size_t bytes, void* sink, mi355_stream_t stream) {
+    if (!ptr || bytes < 16) return MI355_OK;
+    const size_t nvec = bytes / 16;
+    const int grid = (int)(nvec / 256 < 512 ? (nvec + 255) / 256 : 512);
+    hipLaunchKernelGGL(prefetch_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u32x4*)ptr, nvec, (uint32_t*)sink);
+    MI355_CHECK_LAUNCH("prefetch_kernel");
+    return MI355_OK;
+}
+
+// stage 1 only: per-row candidates (value, local index) x 64 into `workspace` (consumed by mi355_allreduce_argmax)
+extern "C" int mi355_argmax_candidates(const float* logits, int32_t B, int32_t V, int32_t ld, void* workspace,
+                                       size_t workspace_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(logits && workspace && B > 0 && V > 0 && ld >= V && ld % 4 == 0, "argmax: B=%d V=%d ld=%d", B, V, ld);
+    const int nparts = 64;
+    if (workspace_bytes < (size_t)B * nparts * 8) { mi355_set_error("argmax: workspace too small"); return MI355_ERR_WORKSPACE; }
+    float* cv = (float*)workspace; int* ci = (int*)(cv + (size_t)B * nparts);
+    hipLaunchKernelGGL(argmax_stage1, dim3(B, nparts), dim3(256), 0, (hipStream_t)stream, logits, V, ld, cv, ci);
+    MI355_CHECK_LAUNCH("argmax_stage1");
+    return MI355_OK;
+}
+
+extern "C" int mi355_argmax(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t* ids, void* workspace,
+                            size_t workspace_bytes, mi355_stream_t stream) {
+    return mi355_argmax_ex(logits, B, V, ld, ids, nullptr, workspace, workspace_bytes, stream);
+}
+
+// vocab-split greedy, local half: one (max, global index) pair per row -> pairs_out [B] (8 bytes each)
+extern "C" int mi355_argmax_pairs(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t vocab_offset, void* pairs_out,
+                                  void* workspace, size_t workspace_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(pairs_out && vocab_offset >= 0, "argmax_pairs: bad argument");
+    if (int e = mi355_argmax_candidates(logits, B, V, ld, workspace, workspace_bytes, stream)) return e;
+    const float* cv = (const float*)workspace; const int* ci = (const int*)(cv + (size_t)B * 64);
+    hipLaunchKernelGGL(argmax_pair, dim3(B), dim3(64), 0, (hipStream_t)stream, cv, ci, 64, vocab_offset, (ArgPair*)pairs_out);
+    MI355_CHECK_LAUNCH("argmax_pair");
+    return MI355_OK;
+}
+
+// global half: pairs_all [world][B] (all-gathered) -> ids [B], positions[b] += 1
+extern "C" int mi355_argmax_pick(const void* pairs_all, int32_t world, int32_t B, int32_t* ids, int32_t* positions,
+                                 mi355_stream_t stream) {
+    MI355_CHECK_ARG(pairs_all && ids && world > 0 && B > 0, "argmax_pick: world=%d B=%d", world, B);
+    hipLaunchKernelGGL(argmax_pick, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, (const ArgPair*)pairs_all, world, B, ids,
+                       positions);
+    MI355_CHECK_LAUNCH("argmax_pick");
+    return MI355_OK;
+}
