@@ -51,8 +51,12 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
     // rowsplit (O projection above 32 rows): the block's activation loads are what bounds the launch, and they are per ROW -- two
     // blocks per tile pair take 32 rows each (224 blocks for Qwen2-7B's O instead of 112; the weights of a pair are then read twice,
     // 56 KB more per CU pair).  Not for QKV: 144 pairs x 2 = 288 blocks, and the CUs with two of them would set the time.
-    const int pair = fp.rowsplit ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
-    const int rb0  = fp.rowsplit ? (int)(blockIdx.x & 1) * MB : 0;      // first row block of this block
+    // The two blocks of a pair read the same weights: placed on the SAME XCD (block b runs on XCD b % 8 -- observed, used for speed
+    // only) the second read comes out of that XCD's L2 instead of crossing the fabric again (rowsplit = 2: pairs a multiple of 8).
+    int pair = (int)blockIdx.x, half = 0;
+    if (fp.rowsplit == 2) { const int slot = (int)blockIdx.x >> 3; pair = (slot >> 1) * 8 + ((int)blockIdx.x & 7); half = slot & 1; }
+    else if (fp.rowsplit) { pair = (int)blockIdx.x >> 1; half = (int)blockIdx.x & 1; }
+    const int rb0 = half * MB;                       // first row block of this block (0 without a row split)
     int tile[TPB];
     if constexpr (EPI == FK_ROPE) {
         const int hh = fp.r.hd >> 5;                 // tiles per half head
@@ -354,7 +358,7 @@ extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi35
     if (epi == FK_RESID) {
         const int blocks = cdiv(g.NT, 2);
         if (g.M > 32 && 2 * blocks <= 256 && !(TUNE(4) == 3)) {       // two blocks per tile pair, 32 rows each (see the kernel)
-            fp.rowsplit = 1;
+            fp.rowsplit = (blocks % 8 == 0) ? 2 : 1;
             if (group_size == 128) return launch64_k<4, 2, FK_RESID>(fp, 2 * blocks, st);
             if (group_size == 64)  return launch64_k<2, 2, FK_RESID>(fp, 2 * blocks, st);
             return launch64_k<1, 2, FK_RESID>(fp, 2 * blocks, st);

@@ -307,4 +307,5 @@ def test_committed_bench_line_and_traffic_file_follow_the_contract():
     if tj["gemm_sources_sha"] == bench.gemm_sources_sha():          # else bench.py reports traffic: null ("stale")
         assert rf["traffic"] == int(tj["gemm_quant_bytes_per_launch"]) and rf["traffic"] >= 0.9 * rf["bytes_per_launch"]
     pj = json.load(open(os.path.join(root, "profiles", "r04_parity_greedy_ids.json")))    # tests/conftest.py: the full-width end-to-end record
-    assert pj["summary"]["rows"] >= 400 and pj["summary"]["exact"] >= pj["summary"]["safe"] and pj["summary"]["max_abs_logit_err"] < 1e-2
+    assert pj["summary"]["rows"] >= 400 and pj["summary"]["exact"] >= pj["summary"]["safe"]
+    assert all(r["max_abs_logit_err"] <= r["tol"] and (r["exact"] == r["rows"] or r["safe"] < r["rows"]) for r in pj["records"])

@@ -204,7 +204,7 @@ def test_engine_full_width_step_vs_oracle(kind, kv_int8, B, ctx, parity):
 def test_engine_full_width_step_bf16_vs_oracle(parity):
     """The metric's shapes (Qwen2-7B widths, 2 layers, B = 64, ctx 1024) with bf16 activations and a bf16 KV cache: the staged
     bf16 kernels at their real sizes (gate_up 3584 x 37888 at 64 rows on the 16-wave shape, split-K slabs of qkv / o / down,
-    152064-column bf16 lm_head) against the oracle run on bf16 tensors.  Tolerance 3e-2 as in tests/test_gpu_bf16.py."""
+    152064-column bf16 lm_head) against the oracle run on bf16 tensors.  Tolerance 1e-2 (see the assert)."""
     BF = torch.bfloat16
     B, ctx = 64, 1024
     cfg = model.ModelConfig("qwen2-7b-2l", 2, 3584, 28, 4, 128, 18944, 152064, max_pos=ctx + 16)
@@ -238,10 +238,13 @@ def test_engine_full_width_step_bf16_vs_oracle(parity):
         eng.replay(B, 1)
         torch.cuda.synchronize()
         got = eng.logits[:B].cpu()
-        assert torch.allclose(got, ref_logits, atol=3e-2, rtol=3e-2), (step, float((got - ref_logits).abs().max()))
+        # north_star's 1e-2, as for fp16: at full width the bf16 step on the image launches (fp16 MFMAs on exact conversions of the bf16
+        # activations, fp16 dequant, bf16 stores) measures 5.6e-3 (profiles/r04_parity_greedy_ids.json); the 3e-2 of tests/test_gpu_bf16.py
+        # is for its toy widths
+        assert torch.allclose(got, ref_logits, atol=1e-2, rtol=1e-2), (step, float((got - ref_logits).abs().max()))
         ref_next = oracle.greedy(ref_logits)
         got_next = eng.token_ids[:B].cpu()
-        parity.step(got_ids=got_next, ref_ids=ref_next, ref_logits=ref_logits, got_logits=got, tol=3e-2, label=f"bf16 step {step}")
+        parity.step(got_ids=got_next, ref_ids=ref_next, ref_logits=ref_logits, got_logits=got, tol=1e-2, label=f"bf16 step {step}")
         tok = ref_next
         eng.token_ids[:B].copy_(tok)
 
