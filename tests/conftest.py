@@ -57,7 +57,16 @@ def pytest_sessionfinish(session, exitstatus):
     import json
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    tot = {"steps": len(_PARITY_RECORDS), "rows": sum(r["rows"] for r in _PARITY_RECORDS), "exact": sum(r["exact"] for r in _PARITY_RECORDS),
-           "safe": sum(r["safe"] for r in _PARITY_RECORDS), "max_abs_logit_err": max(r["max_abs_logit_err"] for r in _PARITY_RECORDS)}
     with open(os.path.join(out, "parity_greedy_ids.json"), "w") as f:
-        json.dump({"summary": tot, "records": _PARITY_RECORDS}, f, indent=1)
+        json.dump(parity_summary(_PARITY_RECORDS), f, indent=1)
+
+
+def parity_summary(records):
+    """Totals over all steps and per logits tolerance (1e-2: the fp16 steps and the full-width bf16 step; 3e-2: bf16 at toy widths)."""
+    def tot(rs):
+        return {"steps": len(rs), "rows": sum(r["rows"] for r in rs), "exact": sum(r["exact"] for r in rs), "safe": sum(r["safe"] for r in rs),
+                "max_abs_logit_err": max(r["max_abs_logit_err"] for r in rs)}
+    by_tol = {}
+    for r in records:
+        by_tol.setdefault(str(r["tol"]), []).append(r)
+    return {"summary": tot(records), "summary_by_tol": {k: tot(v) for k, v in sorted(by_tol.items())}, "records": records}
