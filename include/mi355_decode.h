@@ -450,6 +450,13 @@ int mi355_allreduce_fused(mi355_allreduce_t* ar, const void* x_f16, const float*
                           const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
                           int32_t T, int32_t H, void* y, mi355_stream_t stream);
 
+/* In-launch prefetch for the NEXT mi355_allreduce_fused[_dt] launch of this context (cleared by that launch): while a block waits
+ * for its peers' flags its other waves touch one dword per 128-byte line of [ptr, ptr + bytes) -- normally the weight shard of the
+ * GEMM that consumes the all-reduce -- so the HBM fetch runs under the xGMI exchange without a side stream (the reference's
+ * enable_comm_overlap hook, ConfigModules.h:275-282, at kernel granularity).  A launch of T <= 256 blocks covers at most
+ * T * 448 * 8 lines.  ptr NULL or bytes 0: off.  No effect on the results. */
+int mi355_allreduce_set_prefetch(mi355_allreduce_t* ar, const void* ptr, size_t bytes);
+
 /* the same two calls with the tensors in act_dtype (MI355_ACT_BF16: bf16 copies are exchanged, sums stay fp32 in rank order);
  * mi355_allgather_hidden copies 16-bit elements and mi355_allreduce_argmax works on fp32 logits: both serve either dtype */
 int mi355_allreduce_sum_dt(mi355_allreduce_t* ar, const void* x, void* out, int32_t T, int32_t H, int32_t act_dtype,
@@ -608,8 +615,13 @@ enum {
     MI355_PF_GATE_UP  = 4,   /* gate_up (first 48 MB), requested behind the O GEMM (runs under reduce + RMSNorm) */
     MI355_PF_QKV_LATE = 16,  /* next layer's QKV, requested behind the down GEMM (runs under reduce + RMSNorm only) */
     MI355_PF_O_LATE   = 32,  /* O, requested behind the RoPE / KV-write launch (runs under attention only) */
-    MI355_PF_TP_COMM  = 64   /* tp_size > 1: the next linear's shard while the fused all-reduce launch runs (round 2's default; off since
+    MI355_PF_TP_COMM  = 64,  /* tp_size > 1: the next linear's shard while the fused all-reduce launch runs (round 2's default; off since
                               * the round-3 A/B: a fork / join pair inside the step graph costs more than the prefetch saves) */
+    MI355_PF_TP_INLAUNCH = 128 /* tp_size > 1, attached all-reduce context: the same overlap WITHOUT a second stream or a graph edge -- the
+                              * waves of the fused all-reduce launch that only wait for the peers' flags request the first 8 MB of the
+                              * next linear's shard (mi355_allreduce_set_prefetch).  Off by default until an 8-GPU A/B exists: the
+                              * peer reads of the reduction queue behind the requests (vmcnt returns in order), which costs on one
+                              * node what it may save on a loaded fabric; results are identical either way. */
 };
 int mi355_decoder_set_weight_prefetch(mi355_decoder_t* d, int32_t mask);
 

@@ -71,6 +71,9 @@ struct FusedParams {
     f16*         y;            // normed output
     float        eps;
     int          T, H;
+    const uint32_t* pf;        // in-launch prefetch (mi355_allreduce_set_prefetch): the waves that only wait at the flag barrier touch
+    uint32_t     pf_lines;     //   one dword of each of these 128-byte lines (null: off)
+    uint32_t*    pf_sink;
 };
 
 // element offset (inside a region) of row `row` of a [T][H] tensor handled by a grid of `grid` blocks: slot row % grid, rows of
@@ -86,10 +89,30 @@ __device__ __forceinline__ u32x4 load_sys(__amdgpu_buffer_rsrc_t r, uint32_t off
 
 // Raise this block's flag at every peer, then wait for every peer's flag of the same epoch.  Executed by the whole block.
 // slot0: 0 = the call's first barrier, 8 = the second barrier of a two-shot call (its own flag slots, same epoch value).
-__device__ __forceinline__ void peer_barrier(const ArDev& ar, int b, uint32_t epoch, int slot0 = 0) {
+// pf: while thread t < world polls, waves 1.. of the block (which would only sit at the closing barrier) request the next GEMM's
+// weight shard (mi355_allreduce_set_prefetch): kPfIters 128-byte lines per thread, issued AFTER the release fence so nothing is
+// added in front of this block's flags; the words come back in pfv and are folded at the END of the kernel (pf_fold), never at
+// the barrier.  vmcnt returns in order, so the peer reads of stage 1 queue behind these requests: the caller sizes the range.
+constexpr int kPfIters = 8;
+struct PfRegs { uint32_t v[kPfIters]; };
+__device__ __forceinline__ void pf_fold(const PfRegs& r, uint32_t* sink) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < kPfIters; ++i) acc ^= r.v[i];
+    if (acc == 0x9E3779B9u && sink) *sink = acc;           // practically never: keeps the loads alive without a store per thread
+}
+__device__ __forceinline__ void peer_barrier(const ArDev& ar, int b, uint32_t epoch, int slot0 = 0, const uint32_t* pf = nullptr,
+                                             uint32_t pf_lines = 0, PfRegs* pfv = nullptr) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: this block's published rows first
     __syncthreads();
     const int t = threadIdx.x;
+    if (pfv) {
+        const uint32_t per = gridDim.x * (blockDim.x - 64);
+        const uint32_t line = b * (blockDim.x - 64) + (t - 64);
+#pragma unroll
+        for (int i = 0; i < kPfIters; ++i)
+            pfv->v[i] = (pf && t >= 64 && line + i * per < pf_lines) ? __builtin_nontemporal_load(pf + (size_t)(line + i * per) * 32) : 0u;
+    }
     if (t < ar.world) {
         __hip_atomic_store(ar.peer_flags[t] + b * kFlagRow + slot0 + ar.rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const uint32_t* mine = ar.peer_flags[ar.rank] + b * kFlagRow + slot0 + t;
@@ -162,7 +185,8 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
             *reinterpret_cast<u32x4*>(ar.my_data + par + row_off(ar, row, gridDim.x, p.H) + c0) = o;
         }
     }
-    peer_barrier(ar, b, epoch);
+    PfRegs pfv;
+    peer_barrier(ar, b, epoch, 0, p.pf, p.pf_lines, &pfv);
     // ---- stage 1: rank-ordered fp32 sum of the N copies, residual add, RMSNorm
     __amdgpu_buffer_rsrc_t rp[kMaxWorld];
 #pragma unroll
@@ -271,6 +295,7 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
     }
     __syncthreads();
     if (tid == 0) ar.epoch[b] = epoch;
+    pf_fold(pfv, p.pf_sink);
 }
 
 // All-gather along the hidden dimension over the same transport: every rank publishes its [T][n] column slice, then copies
@@ -376,6 +401,8 @@ struct mi355_allreduce {
     int32_t*  status;
     bool    ready;
     unsigned long long spin_ticks;
+    const void* pf_ptr = nullptr;      // mi355_allreduce_set_prefetch: range the next fused launch touches while it waits
+    size_t      pf_bytes = 0;
 };
 
 namespace {
@@ -500,6 +527,18 @@ extern "C" int mi355_allreduce_set_spin_timeout_ms(mi355_allreduce_t* a, int32_t
     return MI355_OK;
 }
 
+// In-launch prefetch for the NEXT mi355_allreduce_fused[_dt] launch of this context (then cleared): while a block waits for its
+// peers' flags, its otherwise idle waves touch one dword per 128-byte line of [ptr, ptr + bytes) -- the shard of the GEMM that
+// consumes the all-reduce -- so the fetch from HBM runs under the xGMI exchange without a second stream or a graph edge
+// (profiles/r03_prefetch_sidestream_ab.txt: every fork / join pair costs ~17 us of a step).  A launch of `grid` blocks covers at most
+// grid * 448 * 8 lines (28 MB at 64 rows); the rest of the range is simply not touched.  ptr == NULL or bytes == 0: off.
+extern "C" int mi355_allreduce_set_prefetch(mi355_allreduce_t* a, const void* ptr, size_t bytes) {
+    MI355_CHECK_ARG(a && ((uintptr_t)ptr & 3) == 0, "allreduce_set_prefetch: null context or unaligned pointer");
+    a->pf_ptr = bytes ? ptr : nullptr;
+    a->pf_bytes = ptr ? (bytes < ((size_t)1 << 38) ? bytes : ((size_t)1 << 38)) : 0;
+    return MI355_OK;
+}
+
 extern "C" int mi355_allreduce_status(mi355_allreduce_t* a, mi355_stream_t stream) {
     MI355_CHECK_ARG(a, "allreduce_status: null");
     int32_t v = 0;
@@ -532,6 +571,8 @@ extern "C" int mi355_allreduce_fused_dt(mi355_allreduce_t* a, const void* x_f16,
     p.x = (const f16*)x_f16; p.partials = partials; p.nsplit = nsplit; p.ld = ld; p.bias = (const f16*)bias;
     p.res_in = (const f16*)residual_in; p.res_out = (f16*)residual_out; p.weight = (const f16*)weight; p.y = (f16*)y;
     p.eps = eps; p.T = T; p.H = H;
+    p.pf = (const uint32_t*)a->pf_ptr; p.pf_lines = (uint32_t)(a->pf_bytes >> 7); p.pf_sink = (uint32_t*)a->status + 32;
+    a->pf_ptr = nullptr; a->pf_bytes = 0;                    // one launch only
     const int grid = T < kMaxBlocks ? T : kMaxBlocks;
     MI355_CHECK_ARG((size_t)cdiv(T, grid) * H * 2 <= a->slot_bytes, "allreduce: %d rows of %d per block exceed the %zu-byte slot", cdiv(T, grid), H, a->slot_bytes);
     hipStream_t st = (hipStream_t)stream;

@@ -422,11 +422,19 @@ extern "C" int mi355_decoder_set_embedding_split(mi355_decoder_t* d, int32_t on)
 }
 
 namespace {
+constexpr size_t kPfInLaunchCap = (size_t)8 << 20;   // MI355_PF_TP_INLAUNCH: bytes of the next shard one all-reduce launch requests (the
+                                                     // peer reads of its reduction queue behind them: vmcnt returns in order)
 // all-reduce on `st`, prefetch of the next GEMM's weights on the side stream, joined before the GEMM (fork / join are
 // plain event edges, so the pair is captured into the step graph like everything else)
 template <class F>
 int comm_with_prefetch(mi355_decoder* d, hipStream_t st, const mi355_weight_t* next_w, F&& comm) {
     const bool ov = d->overlap && (d->pf_mask & MI355_PF_TP_COMM) && next_w && next_w->qweight;
+    if ((d->pf_mask & MI355_PF_TP_INLAUNCH) && d->ar && next_w && next_w->qweight) {
+        // no second stream: the waves of the fused all-reduce launch that only wait for the peers' flags request the shard
+        const size_t bytes = (size_t)next_w->K_pad * next_w->N_pad * next_w->wbits / 8;
+        const int rc = mi355_allreduce_set_prefetch(d->ar, next_w->qweight, bytes < kPfInLaunchCap ? bytes : kPfInLaunchCap);
+        if (rc < 0) return rc;
+    }
     if (ov) {
         const size_t bytes = (size_t)next_w->K_pad * next_w->N_pad * next_w->wbits / 8;
         if (hipEventRecord(d->ev_fork, st) != hipSuccess || hipStreamWaitEvent(d->side_stream, d->ev_fork, 0) != hipSuccess) {
@@ -491,7 +499,7 @@ extern "C" int mi355_decoder_set_weight_prefetch(mi355_decoder_t* d, int32_t mas
     if (!d || mask < 0) { mi355_set_error("decoder_set_weight_prefetch: bad argument"); return MI355_ERR_ARG; }
     for (auto& kv : d->graphs) hipGraphExecDestroy(kv.second);   // captured steps bake the fork / join edges in
     d->graphs.clear();
-    if (mask != 0 && !side_ready(d)) {   // the side stream and its events exist before any capture begins (not lazily inside one)
+    if ((mask & ~MI355_PF_TP_INLAUNCH) != 0 && !side_ready(d)) {   // the side stream and its events exist before any capture begins (not lazily inside one)
         mi355_set_error("decoder_set_weight_prefetch: cannot create the prefetch stream: %s", hipGetErrorString(hipGetLastError()));
         return MI355_ERR_HIP;
     }

@@ -41,8 +41,10 @@ struct WideParams {
     unsigned long long* stamps; // DBG & 4: wall_clock64 at start / after prologue / after the main loop / at the end, per wave
 };
 
-// T = tiles per wave; a block owns 2T tiles.
-template <int WBITS, int MB, int GS, int T, int DBG = 0>
+// T = tiles per wave; a block owns 2T tiles.  RING = chunks of weights a wave keeps requested ahead of the one it multiplies: 1 at 64 rows
+// (a phase of 20 four-MFMA units outlasts the HBM latency; the registers are the B fragments'), 2 at <= 32 rows, where a phase is
+// short, half the fragment registers are free and one chunk ahead (5 KB per wave, 40 KB per CU) left the loop waiting on memory.
+template <int WBITS, int MB, int GS, int T, int DBG = 0, int RING = 1>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
     const GemmParams& p = wp.g;
     constexpr int NKS  = 4, NW = 8;                      // K slices, waves
@@ -57,6 +59,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
     constexpr uint32_t INVX = 0x80000000u;
     constexpr bool HAND = (WBITS == 4 && (MB == 4 || MB == 2)); // hand-ordered unit (WIDE_UNIT_W4 / _MB2)
     static_assert(XF <= NU - 8, "fragment writes, the barrier and the fragment reads must fit one phase");
+    static_assert(RING == 1 || (RING == 2 && GS > 0), "two chunks ahead: group-wise instances only (per-channel meta lives in slot 0)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr size_t RS_OFF = ((size_t)8 * 3 * MB * 1024 > (size_t)2 * 4 * 4 * MB * 1024) ? (size_t)8 * 3 * MB * 1024 : (size_t)2 * 4 * 4 * MB * 1024;   // behind the stage / merge regions: 64 floats
 
@@ -100,8 +103,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
         if (p.x_img) xvoff[jj] = (j / 4 < MBLK) ? (uint32_t)(((j % 4) * MBLK + j / 4) * 1024 + lane * 16) : INVX;
     }
 
-    u32x4    wr[T][LPC];                                 // weight ring: tile t of the current chunk, refilled with the next
-    uint32_t mr[T][NSUB];
+    u32x4    wr[RING][T][LPC];                           // weight ring: slot k % RING holds tile t of chunk k, refilled with chunk k + RING
+    uint32_t mr[RING][T][NSUB];
     f16x8    bq[MB][4];                                  // B fragments of the current chunk: [row block][k-step]
     u32x4    xt[XF];                                     // this wave's half of the fragments of chunk k + 2, in flight
     f32x4    acc[T][MB];
@@ -117,34 +120,38 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
     auto m_soff = [&](int c, bool valid) { const uint32_t m = 0u - (uint32_t)valid; return (((uint32_t)c * NSUB * mrow) & m) | (INV & ~m); };
     auto x_soff = [&](int c, bool valid) { const uint32_t m = 0u - (uint32_t)valid; return (((uint32_t)c * xchunk) & m) | (INVX & ~m); };
 
-    auto load_tile = [&](int t, uint32_t ws, uint32_t ms) {
+    auto load_tile = [&](auto slot_c, int t, uint32_t ws, uint32_t ms) {
+        constexpr int SL = decltype(slot_c)::value;
 #pragma unroll
-        for (int lp = 0; lp < LPC; ++lp) wr[t][lp] = bload128<2 /*nt*/>(rw, lane16 + lp * 1024u, toff[t] + ws);
+        for (int lp = 0; lp < LPC; ++lp) wr[SL][t][lp] = bload128<2 /*nt*/>(rw, lane16 + lp * 1024u, toff[t] + ws);
         if (GROUPED) {
 #pragma unroll
             for (int gi = 0; gi < NSUB; ++gi)
-                mr[t][gi] = __builtin_amdgcn_raw_buffer_load_b32(rm, mvoff + t * 64u, ms + gi * mrow, 0);
+                mr[SL][t][gi] = __builtin_amdgcn_raw_buffer_load_b32(rm, mvoff + t * 64u, ms + gi * mrow, 0);
         }
     };
+    using Slot0 = std::integral_constant<int, 0>;
+    using Slot1 = std::integral_constant<int, RING - 1>;
 
     // operand-side dequant of unit (t, s): column i of tile t, k = 32 s + 8 q .. + 7
     f16x2 zn, znb, scl;
-    auto meta_of = [&](int t, int s) {
-        const uint32_t m = mr[t][GROUPED ? s / SPG : 0];
+    auto meta_of = [&](auto slot_c, int t, int s) {
+        const uint32_t m = mr[GROUPED ? decltype(slot_c)::value : 0][t][GROUPED ? s / SPG : 0];
         zn  = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u));
         scl = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
         if (WBITS == 4) znb = zn + c960;
     };
-    auto dq = [&](int t, int s) -> f16x8 {
-        if (s % SPG == 0) meta_of(t, s);
-        if (WBITS == 4) return dequant_w4_vc(wr[t][0][s], zn, znb, scl, w4c);
-        const u32x4 w = wr[t][(s >> 1) % LPC];
+    auto dq = [&](auto slot_c, int t, int s) -> f16x8 {
+        constexpr int SL = decltype(slot_c)::value;
+        if (s % SPG == 0) meta_of(slot_c, t, s);
+        if (WBITS == 4) return dequant_w4_vc(wr[SL][t][0][s], zn, znb, scl, w4c);
+        const u32x4 w = wr[SL][t][(s >> 1) % LPC];
         return dequant_w8<GROUPED>(w[(s & 1) * 2], w[(s & 1) * 2 + 1], zn, scl);
     };
 
     if (!GROUPED) { // per-channel: the meta row is constant along K
 #pragma unroll
-        for (int t = 0; t < T; ++t) mr[t][0] = __builtin_amdgcn_raw_buffer_load_b32(rm, mvoff + t * 64u, 0, 0);
+        for (int t = 0; t < T; ++t) mr[0][t][0] = __builtin_amdgcn_raw_buffer_load_b32(rm, mvoff + t * 64u, 0, 0);
     }
 
     // LDS: fragments of chunk c of K slice ks live in xbuf[c & 1][ks][fragment][lane]
@@ -185,7 +192,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
         }
         const uint32_t ws0 = w_soff(cw0, ncw > 0), ms0 = m_soff(cw0, ncw > 0);
 #pragma unroll
-        for (int t = 0; t < T; ++t) load_tile(t, ws0, ms0);
+        for (int t = 0; t < T; ++t) load_tile(Slot0{}, t, ws0, ms0);
+        if constexpr (RING == 2) {
+            const uint32_t ws1 = w_soff(cw0 + 1, !(DBG & 2) && ncw > 1), ms1 = m_soff(cw0 + 1, !(DBG & 2) && ncw > 1);
+#pragma unroll
+            for (int t = 0; t < T; ++t) load_tile(Slot1{}, t, ws1, ms1);
+        }
         u32x4* x0 = xregion(0);
 #pragma unroll
         for (int jj = 0; jj < XF; ++jj) x0[(th * XF + jj) * 64 + lane] = x0t[jj];
@@ -203,16 +215,18 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
             }
         }
     }
-    f16x8 a_cur = dq(0, 0);
+    f16x8 a_cur = dq(Slot0{}, 0, 0);
     if constexpr (DBG & 4) st1 = wall_clock64();
     u32x4 aE = __builtin_bit_cast(u32x4, a_cur), aO = aE;   // HAND: operand of even / odd units (fixed register tuples)
 
     // ---- phase k: chunk k of the K slice.  Units 0..XF-1 park the fragments of chunk k+1 (loaded one phase ago) in LDS
     // and fetch those of chunk k+2; the barrier follows; the last tile's units read chunk k+1 back into bq[..][s].
-    for (int k = 0; k < per; ++k) {
+    auto phase = [&](auto slot_c, const int k) {
+        constexpr int SL = decltype(slot_c)::value;                          // ring slot of chunk k
+        using SlotN = std::integral_constant<int, (SL + 1) % RING>;          // ... of chunk k + 1 (the last unit dequantises its first dword)
         // DBG (timing experiments only): out-of-range offsets keep the instruction stream but remove the memory traffic
-        const bool v1 = !(DBG & 2) && k + 1 < ncw, v2 = !(DBG & 1) && k + 2 < ncw;
-        const uint32_t ws = w_soff(cw0 + k + 1, v1), ms = m_soff(cw0 + k + 1, v1), xs = x_soff(cw0 + k + 2, v2);
+        const bool v1 = !(DBG & 2) && k + RING < ncw, v2 = !(DBG & 1) && k + 2 < ncw;
+        const uint32_t ws = w_soff(cw0 + k + RING, v1), ms = m_soff(cw0 + k + RING, v1), xs = x_soff(cw0 + k + 2, v2);
         u32x4* xn = xregion((k + 1) & 1);
         static_for<0, NU>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
@@ -222,11 +236,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
                 xt[u] = bload128<0>(rx, xvoff[u], xs);
             }
             if constexpr (u == XF) block_sync();
-            if constexpr (s == 3) load_tile(t, ws, ms);                     // dq(t, 3) was issued in unit (t, 2)
+            if constexpr (s == 3) load_tile(slot_c, t, ws, ms);             // dq(t, 3) was issued in unit (t, 2)
             constexpr int un = (u + 1) % NU, tn = un / 4, sn = un % 4;
+            using SlotU = std::conditional_t<un == 0, SlotN, std::integral_constant<int, SL>>;
             if constexpr (HAND) {
-                if constexpr (sn % SPG == 0) meta_of(tn, sn);
-                const uint32_t wn = wr[tn][0][sn];
+                if constexpr (sn % SPG == 0) meta_of(SlotU{}, tn, sn);
+                const uint32_t wn = wr[SlotU::value][tn][0][sn];
                 uint32_t tmp;
                 if constexpr (MB == 4) {
                     if constexpr (u % 2 == 0) {
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
                     }
                 }
             } else {
-                const f16x8 a_next = dq(tn, sn);
+                const f16x8 a_next = dq(SlotU{}, tn, sn);
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) acc[t][mb] = mfma16x16x32(a_cur, bq[mb][s], acc[t][mb]);
                 a_cur = a_next;
@@ -283,6 +298,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
             if constexpr (t == T - 1) __builtin_amdgcn_sched_group_barrier(0x100, MB, 0);
             __builtin_amdgcn_sched_barrier(0);   // fence per unit: the groups above only order what is inside it
         });
+    };
+    for (int k = 0; k < per; k += RING) {
+        phase(Slot0{}, k);
+        if constexpr (RING == 2) if (k + 1 < per) phase(Slot1{}, k + 1);     // per is uniform over the block: its barriers stay matched
     }
     if constexpr (DBG & 4) st2 = wall_clock64();
     if constexpr (HAND) asm volatile("s_nop 15" ::: "memory"); // the last MFMAs' results are read by compiler code below
@@ -327,9 +346,9 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
     }
 }
 
-template <int WBITS, int MB, int GS, int T, int DBG = 0>
+template <int WBITS, int MB, int GS, int T, int DBG = 0, int RING = 1>
 int launch_wide_t(const WideParams& wp, hipStream_t st) {
-    auto k = gemm_wide_kernel<WBITS, MB, GS, T, DBG>;
+    auto k = gemm_wide_kernel<WBITS, MB, GS, T, DBG, RING>;
     constexpr size_t red_b = (size_t)8 * 3 * MB * 1024, stage_b = (size_t)2 * 4 * 4 * MB * 1024;
     constexpr size_t lds = (red_b > stage_b ? red_b : stage_b) + 256;   // + 1 / rms of the rows (deferred norm)
     if (int e = raise_dynamic_lds((const void*)k, "gemm_wide")) return e;
@@ -409,9 +428,14 @@ static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_
     hipStream_t st = (hipStream_t)stream;
     const bool mb2 = g.M <= 32;
     if (w8)                    rc = mb2 ? launch_wide_t<8, 2, 0, T>(wp, st) : launch_wide_t<8, 4, 0, T>(wp, st);
-    else if (group_size == 64) rc = mb2 ? launch_wide_t<4, 2, 2, T>(wp, st) : launch_wide_t<4, 4, 2, T>(wp, st);
-    else if (group_size == 32) rc = mb2 ? launch_wide_t<4, 2, 1, T>(wp, st) : launch_wide_t<4, 4, 1, T>(wp, st);
-    else if (mb2 && (WIDE_DBG & 7) == 0) rc = launch_wide_t<4, 2, 4, T>(wp, st);
+    else if (group_size == 64) rc = mb2 ? launch_wide_t<4, 2, 2, T, 0, 2>(wp, st) : launch_wide_t<4, 4, 2, T>(wp, st);
+    else if (group_size == 32) rc = mb2 ? launch_wide_t<4, 2, 1, T, 0, 2>(wp, st) : launch_wide_t<4, 4, 1, T>(wp, st);
+#ifdef MI355_TUNING
+    else if (mb2 && WIDE_DBG == 16) rc = launch_wide_t<4, 2, 4, T, 0, 1>(wp, st);   // one chunk ahead (the round-2..4 instance)
+    else if (mb2 && WIDE_DBG == 2)  rc = launch_wide_t<4, 2, 4, T, 2, 2>(wp, st);   // instruction stream without weight traffic
+    else if (mb2 && WIDE_DBG == 3)  rc = launch_wide_t<4, 2, 4, T, 3, 2>(wp, st);   // ... without any main-loop traffic
+#endif
+    else if (mb2) rc = launch_wide_t<4, 2, 4, T, 0, 2>(wp, st);
     else
         switch (WIDE_DBG & 7) {
 #ifdef MI355_TUNING

@@ -129,6 +129,12 @@ class CustomAllReduce:
                       "allreduce_fused")
         return y, res
 
+    def set_prefetch(self, t: torch.Tensor = None):
+        """The NEXT fused all-reduce launch touches the bytes of `t` (normally the next GEMM's weight shard) with the waves that only
+        wait for the peers' flags (mi355_allreduce_set_prefetch); None: off.  No effect on results."""
+        self._C.check(self.lib.mi355_allreduce_set_prefetch(self.handle, t.data_ptr() if t is not None else None,
+                                                            t.numel() * t.element_size() if t is not None else 0), "allreduce_set_prefetch")
+
     def all_gather_hidden(self, t: torch.Tensor) -> torch.Tensor:
         """[T, n] column slice per rank -> [T, n * world], slices side by side in rank order (the all_gather + transpose of the
         reference's hidden-split embedding, modules/base/common/embedding.py:50-58)."""

@@ -69,6 +69,12 @@ def _worker(rank, world, port, q, mode):
             s = ar.all_reduce(x.clone())
             y2, r2 = ops.add_rmsnorm(s, res, w, 1e-6)
             assert torch.equal(y, y2) and torch.equal(r_out, r2)
+            # in-launch prefetch: the waiting waves touch a 6 MB range; one launch only; numbers unchanged
+            junk = torch.randint(0, 2 ** 31 - 1, (6 << 18,), dtype=torch.int32, device=dev)
+            ar.set_prefetch(junk)
+            y3, r3 = ar.all_reduce_add_rmsnorm(x, res, w, 1e-6)
+            y4, r4 = ar.all_reduce_add_rmsnorm(x, res, w, 1e-6)
+            assert torch.equal(y3, y2) and torch.equal(r3, r2) and torch.equal(y4, y2) and torch.equal(r4, r2)
             # graph capture + replay: epochs advance on the device
             xs = (torch.randn(16, 3584, generator=g)).half().to(dev)
             out = torch.empty_like(xs)
@@ -182,15 +188,22 @@ def _worker(rank, world, port, q, mode):
             eng3 = model.DecoderEngine(cfg.per_rank(world), model.weights_to(shard, dev), kv_int8=False, page=page, num_blocks=B * 2,
                                        max_batch=B, max_seq_len=32, device=dev, tp_size=world, vocab_full=V)
             eng3.attach_allreduce(ar, rank * (V // world))
+            # in-launch prefetch (MI355_PF_TP_INLAUNCH: the waiting waves of each fused all-reduce launch request the next shard):
+            # off by default, no effect on the numbers
+            eng4 = model.DecoderEngine(cfg.per_rank(world), model.weights_to(shard, dev), kv_int8=False, page=page, num_blocks=B * 2,
+                                       max_batch=B, max_seq_len=32, device=dev, tp_size=world, vocab_full=V)
+            eng4.attach_allreduce(ar, rank * (V // world))
+            eng4.set_weight_prefetch(_C.PF_TP_INLAUNCH)
             tok0 = torch.randint(0, V, (B,), generator=torch.Generator().manual_seed(4), dtype=torch.int32)
-            for e in (eng2, eng3):
+            for e in (eng2, eng3, eng4):
                 e.set_inputs(tok0.tolist(), [0] * B, bt)
             dist.barrier()
-            eng2.capture(B); eng3.capture(B)
+            eng2.capture(B); eng3.capture(B); eng4.capture(B)
             for step in range(4):
-                eng2.replay(B, 1); eng3.replay(B, 1)
+                eng2.replay(B, 1); eng3.replay(B, 1); eng4.replay(B, 1)
                 torch.cuda.synchronize()
                 assert torch.equal(eng2.logits[:B], eng3.logits[:B]) and torch.equal(eng2.token_ids[:B], eng3.token_ids[:B]), step
+                assert torch.equal(eng4.logits[:B], eng3.logits[:B]) and torch.equal(eng4.token_ids[:B], eng3.token_ids[:B]), step
             assert ar.status() == 0
         elif mode == "transport":
             # the external-transport form of the TP step (mi355_decoder_attach_collective: the RCCL fallback).  RCCL cannot

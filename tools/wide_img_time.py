@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """gate_up at 17-64 rows on the wide GEMM: row-major activations vs an activation image vs image + deferred RMSNorm (gemm_wide.hip),
-Qwen2-7B shape, weights rotating through HBM-resident copies, graph replay.  usage: wide_img_time.py [--ms 64,32] [--tuning]"""
+Qwen2-7B shape, weights rotating through HBM-resident copies, graph replay.  usage: wide_img_time.py [--ms 64,32] [--tuning [--dbg 0,16,2,3]]
+--dbg (tuning build, <= 32 rows): 0 = shipped (two chunks of weights requested ahead), 16 = one chunk ahead (rounds 2-4), 2 = the instruction
+stream without weight traffic, 3 = without any main-loop traffic."""
 import argparse, os, sys
-ap = argparse.ArgumentParser(); ap.add_argument("--ms", default="64,32"); ap.add_argument("--iters", type=int, default=30); ap.add_argument("--tuning", action="store_true")
+ap = argparse.ArgumentParser(); ap.add_argument("--ms", default="64,32"); ap.add_argument("--iters", type=int, default=30); ap.add_argument("--tuning", action="store_true"); ap.add_argument("--dbg", default="")
 a = ap.parse_args()
 if a.tuning:
     os.environ["MI355_TUNING_LIB"] = "1"
@@ -31,4 +33,12 @@ for M in [int(m) for m in a.ms.split(",")]:
     t = [timed(lambda i: ops.linear(x, wg[i % 8], None, _C.EPI_SILU_MUL), 8),
          timed(lambda i: ops.linear_deferred_norm_img(xi, None, wg[i % 8], None, _C.EPI_SILU_MUL), 8),
          timed(lambda i: ops.linear_deferred_norm_img(xi, (ssq, 1e-6, 1), wg[i % 8], None, _C.EPI_SILU_MUL), 8)]
+    if a.tuning and a.dbg:
+        import ctypes as C
+        lib = _C.lib(); lib.mi355_debug_set.argtypes = [C.c_int, C.c_int]; lib.mi355_debug_set.restype = None
+        for v in [int(v) for v in a.dbg.split(",")]:
+            lib.mi355_debug_set(0, v)
+            tv = timed(lambda i: ops.linear_deferred_norm_img(xi, (ssq, 1e-6, 1), wg[i % 8], None, _C.EPI_SILU_MUL), 8)
+            print(f"M={M:3d}  image + deferred norm, switch {v:2d}: {tv:6.2f} us", flush=True)
+        lib.mi355_debug_set(0, 0)
     print(f"M={M:3d}  gate_up + SiLU: row-major {t[0]:6.2f}   image {t[1]:6.2f}   image + deferred norm {t[2]:6.2f} us (graph replay, gaps included)", flush=True)
