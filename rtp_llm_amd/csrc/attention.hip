@@ -540,21 +540,53 @@ __global__ __launch_bounds__(256) void attn_reduce_kernel(const AttnParams p) {
     const int gid = blockIdx.x * 4 + (threadIdx.x >> 6); // (row, h)
     if (gid >= p.B * p.q_len * p.nh) return;
     const int row = gid / p.nh;
-    const int np = (min(max(p.seq_lens[row] + p.seq_add, 0), p.max_seq) + p.PS - 1) / p.PS;   // partitions that saw this row
-    const float* ml = p.tmp_ml + (size_t)gid * p.P * 2;
-    float mstar = NEG_BIG;
-    for (int i = 0; i < np; ++i) mstar = fmaxf(mstar, ml[i * 2]);
-    constexpr int CPL = HD / 64;
+    // ONE memory round trip: the row's length, the (max, sum) pairs (partition i in lane i) and the first 16 partial rows are requested
+    // together; only the masks depend on the length.  (A loop bounded by the length waited for it, then walked the pairs one load at a
+    // time: 5.6 us for this launch at one sequence.)  Partitions >= np were not written by this step: masked by select, never multiplied.
+    const int sl = p.seq_lens[row];
+    const float* __restrict__ ml = p.tmp_ml + (size_t)gid * p.P * 2;
+    const float* __restrict__ po = p.tmp_out + (size_t)gid * p.P * HD + lane * (HD / 64);
+    constexpr int CPL = HD / 64, UB = 16;
     float acc[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
-    float l = 0.f;
-    for (int i = 0; i < np; ++i) {
-        const float f = __builtin_amdgcn_exp2f(ml[i * 2] - mstar);
-        l += ml[i * 2 + 1] * f;
-        const float* src = p.tmp_out + ((size_t)gid * p.P + i) * HD + lane * CPL;
+    float l = 0.f, mstar = NEG_BIG;
+    for (int i0 = 0; i0 < p.P; i0 += 64) {                                  // 64 partitions per pass (one pass up to 8192 tokens)
+        float2 mlv = make_float2(NEG_BIG, 0.f);
+        if (i0 + lane < p.P) mlv = *reinterpret_cast<const float2*>(ml + (size_t)(i0 + lane) * 2);
+        float v[UB][CPL];
+        const int nfirst = min(UB, p.P - i0);
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) acc[c] += src[c] * f;
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) v[u][c] = u < nfirst ? po[(size_t)(i0 + u) * HD + c] : 0.f;
+        const int np = (min(max(sl + p.seq_add, 0), p.max_seq) + p.PS - 1) / p.PS;   // partitions that saw this row
+        const bool mine = i0 + lane < np;
+        const float m_i = mine ? mlv.x : NEG_BIG;
+        const float mnew = fmaxf(mstar, wave_max(m_i));
+        const float resc = __builtin_amdgcn_exp2f(mstar - mnew);            // earlier passes (1 on the first: NEG_BIG - NEG_BIG = 0)
+        const float f_i = mine ? __builtin_amdgcn_exp2f(m_i - mnew) : 0.f;
+        l *= resc;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[c] *= resc;
+        mstar = mnew;
+        const int nhere = min(max(np - i0, 0), 64);
+        auto lane_of = [&](float x, int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), i)); };
+        // sums in partition order, as one thread walking the partitions would form them
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const bool on = u < nhere;
+            const float f = lane_of(f_i, u), ly = on ? lane_of(mlv.y, u) : 0.f;
+            l += ly * f;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[c] += (on ? v[u][c] : 0.f) * f;
+        }
+        for (int i = UB; i < nhere; ++i) {                                   // long sequences at few rows: the rest
+            const float f = lane_of(f_i, i);
+            l += lane_of(mlv.y, i) * f;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[c] += po[(size_t)(i0 + i) * HD + c] * f;
+        }
     }
     const float inv = l > 0.f ? 1.f / l : 0.f;
     uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + out_index(p, row, (gid - row * p.nh) * HD + lane * CPL, HD);

@@ -235,6 +235,20 @@ def test_paged_attention_long_context_and_spike():
         assert torch.allclose(out[b].cpu().float(), ref.float(), **TOL)
 
 
+def test_paged_attention_more_than_64_partitions():
+    """One sequence of 9000 tokens and one kv head: 71 partitions of 128 tokens -- the merge launch takes them 64 per pass (lane i holds
+    partition i's (max, sum)) and rescales between passes; the first 16 partial rows come with the same round trip."""
+    nh, nkv, hd, page, ctx = 4, 1, 64, 16, 9000
+    kv, sc, bt, nat = _fill_cache(1, [ctx], nkv, hd, page, False, 600, 15)
+    q = torch.randn(1, nh, hd, generator=_gen(16)).half()
+    K, V, _, _ = nat[0]
+    K[8800, 0] = (q[0, 2] * 0.9).half()                      # the largest logit sits in the second pass (partition 68)
+    kvcache.write_tokens(kv, sc, bt[0], 0, K, V)
+    out = ops.paged_decode_attention(q.to(DEV), kv, sc, bt.to(DEV), torch.tensor([ctx], dtype=torch.int32, device=DEV), nkv, page, ctx)
+    ref = oracle.attention_decode(q[0], K, V, 1 / math.sqrt(hd)).reshape(-1)
+    assert torch.allclose(out[0].cpu().float(), ref.float(), **TOL)
+
+
 # ------------------------------------------------------------------ whole decode step: engine vs module graph vs oracle
 def _tiny_cfg():
     return model.ModelConfig("tiny-qwen2", 3, 512, 8, 2, 64, 1024, 2048, max_pos=512)
