@@ -48,6 +48,42 @@
     "v_pk_mul_f16 " N2 ", " N2 ", %[sc]\n\t"                                \
     "v_pk_mul_f16 " N3 ", " N3 ", %[sc]"
 
+// 48 rows (3 MFMAs per unit): as the 64-row unit without its last MFMA.
+#define WIDE_UNIT_W4_MB3(AIN, N0, N1, N2, N3)                               \
+    "v_lshrrev_b32 %[t], 8, %[w]\n\t"                                       \
+    "v_and_or_b32 " N0 ", %[w], %[m0], %[e0]\n\t"                           \
+    "v_mfma_f32_16x16x32_f16 %[c0], " AIN ", %[b0], %[c0]\n\t"              \
+    "v_and_or_b32 " N1 ", %[w], %[m1], %[e1]\n\t"                           \
+    "v_and_or_b32 " N2 ", %[t], %[m0], %[e0]\n\t"                           \
+    "v_and_or_b32 " N3 ", %[t], %[m1], %[e1]\n\t"                           \
+    "v_pk_add_f16 " N0 ", " N0 ", %[zn]\n\t"                                \
+    "v_mfma_f32_16x16x32_f16 %[c1], " AIN ", %[b1], %[c1]\n\t"              \
+    "v_pk_add_f16 " N1 ", " N1 ", %[znb]\n\t"                               \
+    "v_pk_add_f16 " N2 ", " N2 ", %[zn]\n\t"                                \
+    "v_pk_add_f16 " N3 ", " N3 ", %[znb]\n\t"                               \
+    "v_pk_mul_f16 " N0 ", " N0 ", %[sc]\n\t"                                \
+    "v_mfma_f32_16x16x32_f16 %[c2], " AIN ", %[b2], %[c2]\n\t"              \
+    "v_pk_mul_f16 " N1 ", " N1 ", %[sc]\n\t"                                \
+    "v_pk_mul_f16 " N2 ", " N2 ", %[sc]\n\t"                                \
+    "v_pk_mul_f16 " N3 ", " N3 ", %[sc]"
+
+// 16 rows (1 MFMA per unit): VALU-issue bound; the MFMA sits behind the two leading VALU (the wait states of its VALU-written operand).
+#define WIDE_UNIT_W4_MB1(AIN, N0, N1, N2, N3)                               \
+    "v_lshrrev_b32 %[t], 8, %[w]\n\t"                                       \
+    "v_and_or_b32 " N0 ", %[w], %[m0], %[e0]\n\t"                           \
+    "v_mfma_f32_16x16x32_f16 %[c0], " AIN ", %[b0], %[c0]\n\t"              \
+    "v_and_or_b32 " N1 ", %[w], %[m1], %[e1]\n\t"                           \
+    "v_and_or_b32 " N2 ", %[t], %[m0], %[e0]\n\t"                           \
+    "v_and_or_b32 " N3 ", %[t], %[m1], %[e1]\n\t"                           \
+    "v_pk_add_f16 " N0 ", " N0 ", %[zn]\n\t"                                \
+    "v_pk_add_f16 " N1 ", " N1 ", %[znb]\n\t"                               \
+    "v_pk_add_f16 " N2 ", " N2 ", %[zn]\n\t"                                \
+    "v_pk_add_f16 " N3 ", " N3 ", %[znb]\n\t"                               \
+    "v_pk_mul_f16 " N0 ", " N0 ", %[sc]\n\t"                                \
+    "v_pk_mul_f16 " N1 ", " N1 ", %[sc]\n\t"                                \
+    "v_pk_mul_f16 " N2 ", " N2 ", %[sc]\n\t"                                \
+    "v_pk_mul_f16 " N3 ", " N3 ", %[sc]"
+
 namespace {
 
 struct GemmParams {
@@ -92,6 +128,42 @@ __device__ __forceinline__ W4Consts w4_consts() {
     W4Consts c = {0x000F000Fu, 0x00F000F0u, 0x64006400u, 0x54005400u};
     asm volatile("" : "+v"(c.m0), "+v"(c.m1), "+v"(c.e0), "+v"(c.e1)); // keep them in VGPRs
     return c;
+}
+// One hand-ordered (tile, k-step) unit for MB row blocks (WIDE_UNIT_W4*): the operand of THIS unit sits in the fixed tuple of its
+// parity (even units v[100:103] = aE, odd ones v[104:107] = aO) and the dword `wn` is dequantised into the other tuple for the next
+// unit.  c0..c3 / b0..b3: accumulators (AGPRs) and B fragments of the unit's row blocks; those >= MB are not touched.
+template <int MB, bool EVEN, class BT>
+__device__ __forceinline__ void wide_unit_w4(u32x4& aE, u32x4& aO, uint32_t wn, const W4Consts& k, f16x2 zn, f16x2 znb, f16x2 sc,
+                                             f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3, const BT& b0, const BT& b1, const BT& b2, const BT& b3) {
+    uint32_t tmp;
+#define WU_IN_  [w] "v"(wn), [m0] "v"(k.m0), [m1] "v"(k.m1), [e0] "v"(k.e0), [e1] "v"(k.e1), [zn] "v"(zn), [znb] "v"(znb), [sc] "v"(sc)
+#define WU_EVEN_(MACRO, ACCS, ...) asm volatile(MACRO("v[100:103]", "v104", "v105", "v106", "v107") : [t] "=&v"(tmp), "=&{v[104:107]}"(aO), ACCS : "{v[100:103]}"(aE), WU_IN_, __VA_ARGS__)
+#define WU_ODD_(MACRO, ACCS, ...)  asm volatile(MACRO("v[104:107]", "v100", "v101", "v102", "v103") : [t] "=&v"(tmp), "=&{v[100:103]}"(aE), ACCS : "{v[104:107]}"(aO), WU_IN_, __VA_ARGS__)
+#define WU_ACC1_ [c0] "+a"(c0)
+#define WU_ACC2_ [c0] "+a"(c0), [c1] "+a"(c1)
+#define WU_ACC3_ [c0] "+a"(c0), [c1] "+a"(c1), [c2] "+a"(c2)
+#define WU_ACC4_ [c0] "+a"(c0), [c1] "+a"(c1), [c2] "+a"(c2), [c3] "+a"(c3)
+    if constexpr (MB == 4) {
+        if constexpr (EVEN) WU_EVEN_(WIDE_UNIT_W4, WU_ACC4_, [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3));
+        else                WU_ODD_(WIDE_UNIT_W4, WU_ACC4_, [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3));
+    } else if constexpr (MB == 3) {
+        if constexpr (EVEN) WU_EVEN_(WIDE_UNIT_W4_MB3, WU_ACC3_, [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2));
+        else                WU_ODD_(WIDE_UNIT_W4_MB3, WU_ACC3_, [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2));
+    } else if constexpr (MB == 2) {
+        if constexpr (EVEN) WU_EVEN_(WIDE_UNIT_W4_MB2, WU_ACC2_, [b0] "v"(b0), [b1] "v"(b1));
+        else                WU_ODD_(WIDE_UNIT_W4_MB2, WU_ACC2_, [b0] "v"(b0), [b1] "v"(b1));
+    } else {
+        static_assert(MB == 1, "row blocks: 1..4");
+        if constexpr (EVEN) WU_EVEN_(WIDE_UNIT_W4_MB1, WU_ACC1_, [b0] "v"(b0));
+        else                WU_ODD_(WIDE_UNIT_W4_MB1, WU_ACC1_, [b0] "v"(b0));
+    }
+#undef WU_IN_
+#undef WU_EVEN_
+#undef WU_ODD_
+#undef WU_ACC1_
+#undef WU_ACC2_
+#undef WU_ACC3_
+#undef WU_ACC4_
 }
 __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t m, uint32_t o) {
     return (a & m) | o; // selected as v_and_or_b32 once the constants are opaque VGPRs (no inline asm: its result

@@ -345,9 +345,10 @@ extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi35
     if (g.M < 1 || g.M > 64 || g.KC < 4 || g.KC > 45 || g.K != g.KC * 128) return MI355_ERR_UNSUPPORTED;
     if (group_size != 128 && group_size != 64 && group_size != 32) return MI355_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const bool mb2 = g.M <= 32;
+    const int mblk = (g.M + 15) >> 4;                // an instance per row-block count: the activation loads of a block are per row block
 #define F64_(GS_, EPI_, BLOCKS_)                                                                        \
-    return mb2 ? launch64_k<GS_, 2, EPI_>(fp, BLOCKS_, st) : launch64_k<GS_, 4, EPI_>(fp, BLOCKS_, st)
+    return mblk == 1 ? launch64_k<GS_, 1, EPI_>(fp, BLOCKS_, st) : mblk == 2 ? launch64_k<GS_, 2, EPI_>(fp, BLOCKS_, st) \
+         : mblk == 3 ? launch64_k<GS_, 3, EPI_>(fp, BLOCKS_, st) : launch64_k<GS_, 4, EPI_>(fp, BLOCKS_, st)
     if (epi == FK_ROPE) {
         if (fp.r.hd != 64 && fp.r.hd != 128) return MI355_ERR_UNSUPPORTED;
         const int blocks = (fp.r.nh + 2 * fp.r.nkv) * (fp.r.hd / 32);

@@ -125,38 +125,9 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
             if constexpr (sn % SPG == 0) meta_of(cn, tn, sn);
             wn = wr[cn & 1][tn][sn];
         }
-        uint32_t tmp;
-        if constexpr (MB == 4) {
-            if constexpr (u % 2 == 0) {
-                asm volatile(WIDE_UNIT_W4("v[100:103]", "v104", "v105", "v106", "v107")
-                             : [t] "=&v"(tmp), "=&{v[104:107]}"(aO), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1]),
-                               [c2] "+a"(acc[t][2]), [c3] "+a"(acc[t][3])
-                             : "{v[100:103]}"(aE), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
-                               [e1] "v"(w4c.e1), [zn] "v"(zn[tn % T]), [znb] "v"(znb[tn % T]), [sc] "v"(scl[tn % T]), [b0] "v"(xr[ks % RING][0]),
-                               [b1] "v"(xr[ks % RING][1]), [b2] "v"(xr[ks % RING][2]), [b3] "v"(xr[ks % RING][3]));
-            } else {
-                asm volatile(WIDE_UNIT_W4("v[104:107]", "v100", "v101", "v102", "v103")
-                             : [t] "=&v"(tmp), "=&{v[100:103]}"(aE), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1]),
-                               [c2] "+a"(acc[t][2]), [c3] "+a"(acc[t][3])
-                             : "{v[104:107]}"(aO), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
-                               [e1] "v"(w4c.e1), [zn] "v"(zn[tn % T]), [znb] "v"(znb[tn % T]), [sc] "v"(scl[tn % T]), [b0] "v"(xr[ks % RING][0]),
-                               [b1] "v"(xr[ks % RING][1]), [b2] "v"(xr[ks % RING][2]), [b3] "v"(xr[ks % RING][3]));
-            }
-        } else {
-            if constexpr (u % 2 == 0) {
-                asm volatile(WIDE_UNIT_W4_MB2("v[100:103]", "v104", "v105", "v106", "v107")
-                             : [t] "=&v"(tmp), "=&{v[104:107]}"(aO), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1])
-                             : "{v[100:103]}"(aE), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
-                               [e1] "v"(w4c.e1), [zn] "v"(zn[tn % T]), [znb] "v"(znb[tn % T]), [sc] "v"(scl[tn % T]), [b0] "v"(xr[ks % RING][0]),
-                               [b1] "v"(xr[ks % RING][1]));
-            } else {
-                asm volatile(WIDE_UNIT_W4_MB2("v[104:107]", "v100", "v101", "v102", "v103")
-                             : [t] "=&v"(tmp), "=&{v[100:103]}"(aE), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1])
-                             : "{v[104:107]}"(aO), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
-                               [e1] "v"(w4c.e1), [zn] "v"(zn[tn % T]), [znb] "v"(znb[tn % T]), [sc] "v"(scl[tn % T]), [b0] "v"(xr[ks % RING][0]),
-                               [b1] "v"(xr[ks % RING][1]));
-            }
-        }
+        wide_unit_w4<MB, u % 2 == 0>(aE, aO, wn, w4c, zn[tn % T], znb[tn % T], scl[tn % T], acc[t][0], acc[t][MB > 1 ? 1 : 0], acc[t][MB > 2 ? 2 : 0],
+                                     acc[t][MB > 3 ? 3 : 0], xr[ks % RING][0], xr[ks % RING][MB > 1 ? 1 : 0], xr[ks % RING][MB > 2 ? 2 : 0],
+                                     xr[ks % RING][MB > 3 ? 3 : 0]);
         // re-requests right behind the last reader of their registers: the k-step's fragments after its last tile; the chunk's
         // weights after the unit that prepared the last operand taken from them
         if constexpr (t == T - 1 && ks + RING < NKS) load_x(ks + RING);
@@ -231,12 +202,12 @@ extern "C" int mi355_gemm_splitk64(const void* gp, int wbits, int group_size, in
     const int G = (g.NT + 3) / 4, cpw = (cps + 7) / 8;
     sp.xmap = (8 % ns == 0 && G % (8 / ns) == 0 && (G * ns) % 8 == 0) ? 8 / ns : 0;   // K splits over whole XCDs when the counts divide
     hipStream_t st = (hipStream_t)stream;
-    const bool mb2 = g.M <= 32;
+    const int mblk = (g.M + 15) >> 4;                    // row blocks: an instance per count (1 MFMA per unit at <= 16 rows ... 4 at 49-64)
     int rc;
-#define SK_(GS_)                                                                                                   \
-    rc = cpw <= 3 ? (mb2 ? launch_splitk64_t<GS_, 2, 4, 3, 3>(sp, G, st) : launch_splitk64_t<GS_, 4, 4, 3, 3>(sp, G, st))   \
-                  : (mb2 ? launch_splitk64_t<GS_, 2, 4, 5, 3>(sp, G, st) : launch_splitk64_t<GS_, 4, 4, 5, 3>(sp, G, st))
+#define SK_MB_(GS_, MB_) (cpw <= 3 ? launch_splitk64_t<GS_, MB_, 4, 3, 3>(sp, G, st) : launch_splitk64_t<GS_, MB_, 4, 5, 3>(sp, G, st))
+#define SK_(GS_) rc = mblk == 1 ? SK_MB_(GS_, 1) : mblk == 2 ? SK_MB_(GS_, 2) : mblk == 3 ? SK_MB_(GS_, 3) : SK_MB_(GS_, 4)
     if (group_size == 128) { SK_(4); } else if (group_size == 64) { SK_(2); } else { SK_(1); }
+#undef SK_MB_
 #undef SK_
     return rc == MI355_OK ? ns : rc;
 }

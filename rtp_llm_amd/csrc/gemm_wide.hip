@@ -57,7 +57,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
     constexpr int NU   = 4 * T;                          // (tile, k-step) units per chunk
     constexpr uint32_t INV  = 0x40000000u;               // images are <= 1 GiB: any sum with INV is out of range, no wrap
     constexpr uint32_t INVX = 0x80000000u;
-    constexpr bool HAND = (WBITS == 4 && (MB == 4 || MB == 2)); // hand-ordered unit (WIDE_UNIT_W4 / _MB2)
+    constexpr bool HAND = WBITS == 4;                   // hand-ordered unit (wide_unit_w4: WIDE_UNIT_W4 / _MB3 / _MB2 / _MB1)
     static_assert(XF <= NU - 8, "fragment writes, the barrier and the fragment reads must fit one phase");
     static_assert(RING == 1 || (RING == 2 && GS > 0), "two chunks ahead: group-wise instances only (per-channel meta lives in slot 0)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -242,38 +242,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
             if constexpr (HAND) {
                 if constexpr (sn % SPG == 0) meta_of(SlotU{}, tn, sn);
                 const uint32_t wn = wr[SlotU::value][tn][0][sn];
-                uint32_t tmp;
-                if constexpr (MB == 4) {
-                    if constexpr (u % 2 == 0) {
-                        asm volatile(WIDE_UNIT_W4("v[100:103]", "v104", "v105", "v106", "v107")
-                                     : [t] "=&v"(tmp), "=&{v[104:107]}"(aO), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1]),
-                                       [c2] "+a"(acc[t][2]), [c3] "+a"(acc[t][3])
-                                     : "{v[100:103]}"(aE), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
-                                       [e1] "v"(w4c.e1), [zn] "v"(zn), [znb] "v"(znb), [sc] "v"(scl), [b0] "v"(bq[0][s]),
-                                       [b1] "v"(bq[1][s]), [b2] "v"(bq[2][s]), [b3] "v"(bq[3][s]));
-                    } else {
-                        asm volatile(WIDE_UNIT_W4("v[104:107]", "v100", "v101", "v102", "v103")
-                                     : [t] "=&v"(tmp), "=&{v[100:103]}"(aE), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1]),
-                                       [c2] "+a"(acc[t][2]), [c3] "+a"(acc[t][3])
-                                     : "{v[104:107]}"(aO), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
-                                       [e1] "v"(w4c.e1), [zn] "v"(zn), [znb] "v"(znb), [sc] "v"(scl), [b0] "v"(bq[0][s]),
-                                       [b1] "v"(bq[1][s]), [b2] "v"(bq[2][s]), [b3] "v"(bq[3][s]));
-                    }
-                } else {
-                    if constexpr (u % 2 == 0) {
-                        asm volatile(WIDE_UNIT_W4_MB2("v[100:103]", "v104", "v105", "v106", "v107")
-                                     : [t] "=&v"(tmp), "=&{v[104:107]}"(aO), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1])
-                                     : "{v[100:103]}"(aE), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
-                                       [e1] "v"(w4c.e1), [zn] "v"(zn), [znb] "v"(znb), [sc] "v"(scl), [b0] "v"(bq[0][s]),
-                                       [b1] "v"(bq[1][s]));
-                    } else {
-                        asm volatile(WIDE_UNIT_W4_MB2("v[104:107]", "v100", "v101", "v102", "v103")
-                                     : [t] "=&v"(tmp), "=&{v[100:103]}"(aE), [c0] "+a"(acc[t][0]), [c1] "+a"(acc[t][1])
-                                     : "{v[104:107]}"(aO), [w] "v"(wn), [m0] "v"(w4c.m0), [m1] "v"(w4c.m1), [e0] "v"(w4c.e0),
-                                       [e1] "v"(w4c.e1), [zn] "v"(zn), [znb] "v"(znb), [sc] "v"(scl), [b0] "v"(bq[0][s]),
-                                       [b1] "v"(bq[1][s]));
-                    }
-                }
+                wide_unit_w4<MB, u % 2 == 0>(aE, aO, wn, w4c, zn, znb, scl, acc[t][0], acc[t][MB > 1 ? 1 : 0], acc[t][MB > 2 ? 2 : 0],
+                                             acc[t][MB > 3 ? 3 : 0], bq[0][s], bq[MB > 1 ? 1 : 0][s], bq[MB > 2 ? 2 : 0][s], bq[MB > 3 ? 3 : 0][s]);
             } else {
                 const f16x8 a_next = dq(SlotU{}, tn, sn);
 #pragma unroll
@@ -427,26 +397,30 @@ static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_
     int rc;
     hipStream_t st = (hipStream_t)stream;
     const bool mb2 = g.M <= 32;
+    const int mblk = (g.M + 15) >> 4;               // W4: an instance per row-block count (1 MFMA per unit at <= 16 rows ... 4 at 49-64); two
+                                                    // chunks of weights ahead up to 32 rows (see the kernel)
+#define WIDE_W4_(GS_) (mblk == 1 ? launch_wide_t<4, 1, GS_, T, 0, 2>(wp, st) : mblk == 2 ? launch_wide_t<4, 2, GS_, T, 0, 2>(wp, st) \
+                       : mblk == 3 ? launch_wide_t<4, 3, GS_, T>(wp, st) : launch_wide_t<4, 4, GS_, T>(wp, st))
     if (w8)                    rc = mb2 ? launch_wide_t<8, 2, 0, T>(wp, st) : launch_wide_t<8, 4, 0, T>(wp, st);
-    else if (group_size == 64) rc = mb2 ? launch_wide_t<4, 2, 2, T, 0, 2>(wp, st) : launch_wide_t<4, 4, 2, T>(wp, st);
-    else if (group_size == 32) rc = mb2 ? launch_wide_t<4, 2, 1, T, 0, 2>(wp, st) : launch_wide_t<4, 4, 1, T>(wp, st);
+    else if (group_size == 64) rc = WIDE_W4_(2);
+    else if (group_size == 32) rc = WIDE_W4_(1);
 #ifdef MI355_TUNING
     else if (mb2 && WIDE_DBG == 16) rc = launch_wide_t<4, 2, 4, T, 0, 1>(wp, st);   // one chunk ahead (the round-2..4 instance)
+    else if (mb2 && WIDE_DBG == 17) rc = launch_wide_t<4, 2, 4, T, 0, 2>(wp, st);   // two row blocks whatever the row count
     else if (mb2 && WIDE_DBG == 2)  rc = launch_wide_t<4, 2, 4, T, 2, 2>(wp, st);   // instruction stream without weight traffic
     else if (mb2 && WIDE_DBG == 3)  rc = launch_wide_t<4, 2, 4, T, 3, 2>(wp, st);   // ... without any main-loop traffic
-#endif
-    else if (mb2) rc = launch_wide_t<4, 2, 4, T, 0, 2>(wp, st);
-    else
+    else if ((WIDE_DBG & 7) != 0 && WIDE_DBG < 8)
         switch (WIDE_DBG & 7) {
-#ifdef MI355_TUNING
             case 1: rc = launch_wide_t<4, 4, 4, T, 1>(wp, st); break;
             case 2: rc = launch_wide_t<4, 4, 4, T, 2>(wp, st); break;
             case 3: rc = launch_wide_t<4, 4, 4, T, 3>(wp, st); break;
             case 4: rc = launch_wide_t<4, 4, 4, T, 4>(wp, st); break;
             case 7: rc = launch_wide_t<4, 4, 4, T, 7>(wp, st); break;   // stamps of the traffic-free instruction stream
-#endif
             default: rc = launch_wide_t<4, 4, 4, T>(wp, st);
         }
+#endif
+    else rc = WIDE_W4_(4);
+#undef WIDE_W4_
     if (rc != MI355_OK) return rc;
     return want_partial ? g.nsplit : MI355_OK;
 }
