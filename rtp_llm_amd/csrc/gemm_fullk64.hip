@@ -48,9 +48,9 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
     Stage64<EPI>& sg = *reinterpret_cast<Stage64<EPI>*>(smem + (size_t)NW * TPB * MB * 1024);
     FK_STAMP(0);
 
-    // rowsplit (O projection above 32 rows): the block's activation loads are what bounds the launch, and they are per ROW -- two
-    // blocks per tile pair take 32 rows each (224 blocks for Qwen2-7B's O instead of 112; the weights of a pair are then read twice,
-    // 56 KB more per CU pair).  Not for QKV: 144 pairs x 2 = 288 blocks, and the CUs with two of them would set the time.
+    // rowsplit (O projection above 16 rows): the block's activation loads are what bounds the launch, and they are per ROW -- two
+    // blocks per tile pair take MB row blocks each (16 rows up to 32, 32 above: 224 blocks for Qwen2-7B's O instead of 112; the weights
+    // of a pair are then read twice, 56 KB more per CU pair).  Not for QKV: 144 pairs x 2 = 288 blocks, and the CUs with two of them would set the time.
     // The two blocks of a pair read the same weights: placed on the SAME XCD (block b runs on XCD b % 8 -- observed, used for speed
     // only) the second read comes out of that XCD's L2 instead of crossing the fabric again (rowsplit = 2: pairs a multiple of 8).
     int pair = (int)blockIdx.x, half = 0;
@@ -358,11 +358,13 @@ extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi35
     }
     if (epi == FK_RESID) {
         const int blocks = cdiv(g.NT, 2);
-        if (g.M > 32 && 2 * blocks <= 256 && !(TUNE(4) == 3)) {       // two blocks per tile pair, 32 rows each (see the kernel)
+        if (g.M > 16 && 2 * blocks <= 256 && !(TUNE(4) == 3)) {       // two blocks per tile pair, half of the row blocks each (see the kernel)
             fp.rowsplit = (blocks % 8 == 0) ? 2 : 1;
-            if (group_size == 128) return launch64_k<4, 2, FK_RESID>(fp, 2 * blocks, st);
-            if (group_size == 64)  return launch64_k<2, 2, FK_RESID>(fp, 2 * blocks, st);
-            return launch64_k<1, 2, FK_RESID>(fp, 2 * blocks, st);
+#define F64H_(GS_) return mblk <= 2 ? launch64_k<GS_, 1, FK_RESID>(fp, 2 * blocks, st) : launch64_k<GS_, 2, FK_RESID>(fp, 2 * blocks, st)
+            if (group_size == 128) { F64H_(4); }
+            if (group_size == 64)  { F64H_(2); }
+            F64H_(1);
+#undef F64H_
         }
         if (group_size == 128) { F64_(4, FK_RESID, blocks); }
         if (group_size == 64)  { F64_(2, FK_RESID, blocks); }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # end-of-round evidence for the sources as committed: full GPU suite, smoke(), then tools/collect_profiles_r04.sh (kernel traces, PMC traffic, sweeps, bench line)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r04
-( timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -5 ) | tee gpurun_out/r04/full_gpu_suite.txt
+( timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | grep -E "passed|failed|error" | tail -5 ) | tee gpurun_out/r04/full_gpu_suite.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04/smoke.txt
 bash tools/collect_profiles_r04.sh > gpurun_out/r04/collect.log 2>&1
 tail -1 gpurun_out/r04/bench_default.json | python -c "
