@@ -41,6 +41,9 @@ struct WideParams {
     unsigned long long* stamps; // DBG & 4: wall_clock64 at start / after prologue / after the main loop / at the end, per wave
 };
 
+// tiles per round of the K-slice merge: all of them where the 8 x T x MB KB fit the LDS (<= 32 rows: one round, one barrier pair), 3 above
+constexpr int wide_merge_tiles(int MB, int T) { return MB <= 2 ? T : 3; }
+
 // T = tiles per wave; a block owns 2T tiles.  RING = chunks of weights a wave keeps requested ahead of the one it multiplies: 1 at 64 rows
 // (a phase of 20 four-MFMA units outlasts the HBM latency; the registers are the B fragments'), 2 at <= 32 rows, where a phase is
 // short, half the fragment registers are free and one chunk ahead (5 KB per wave, 40 KB per CU) left the loop waiting on memory.
@@ -61,7 +64,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
     static_assert(XF <= NU - 8, "fragment writes, the barrier and the fragment reads must fit one phase");
     static_assert(RING == 1 || (RING == 2 && GS > 0), "two chunks ahead: group-wise instances only (per-channel meta lives in slot 0)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr size_t RS_OFF = ((size_t)8 * 3 * MB * 1024 > (size_t)2 * 4 * 4 * MB * 1024) ? (size_t)8 * 3 * MB * 1024 : (size_t)2 * 4 * 4 * MB * 1024;   // behind the stage / merge regions: 64 floats
+    constexpr int TR = wide_merge_tiles(MB, T);          // tiles per round of the K-slice merge
+    constexpr size_t RS_OFF = ((size_t)8 * TR * MB * 1024 > (size_t)2 * 4 * 4 * MB * 1024) ? (size_t)8 * TR * MB * 1024 : (size_t)2 * 4 * 4 * MB * 1024;   // behind the stage / merge regions: 64 floats
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -174,7 +178,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
         // (one batch of straight-line requests: a loop over rows or passes would wait for each load before asking for the next -- 8 round
         // trips, +3 us on the launch)
         f32x4 pq[8];
-        if (wp.ssq) {
+        const bool pq_on = wp.ssq && wave * 8 < p.M;                                // few rows: the waves past them ask for nothing
+        if (pq_on) {
             __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)wp.ssq, 0, (uint32_t)((size_t)p.M * wp.ssq_ld * 4), FLAGS);
             const uint32_t lim = (uint32_t)wp.ssq_tiles * 4u;                       // bytes of a row's partial sums
 #pragma unroll
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
         block_sync();
 #pragma unroll
         for (int j = 0; j < NBL; ++j) bq[j / 4][j % 4] = __builtin_bit_cast(f16x8, x0[j * 64 + lane]);
-        if (wp.ssq) {
+        if (pq_on) {
             float* rs_sh = reinterpret_cast<float*>(smem + RS_OFF);
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -278,7 +283,6 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
     __syncthreads(); // fragment regions are reused by the merge below
 
     // ---- merge the four K slices through LDS (TR tiles per round), epilogue
-    constexpr int TR = 3;
     f32x4* red = reinterpret_cast<f32x4*>(smem);
 #pragma unroll
     for (int r0 = 0; r0 < T; r0 += TR) {
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
 template <int WBITS, int MB, int GS, int T, int DBG = 0, int RING = 1>
 int launch_wide_t(const WideParams& wp, hipStream_t st) {
     auto k = gemm_wide_kernel<WBITS, MB, GS, T, DBG, RING>;
-    constexpr size_t red_b = (size_t)8 * 3 * MB * 1024, stage_b = (size_t)2 * 4 * 4 * MB * 1024;
+    constexpr size_t red_b = (size_t)8 * wide_merge_tiles(MB, T) * MB * 1024, stage_b = (size_t)2 * 4 * 4 * MB * 1024;
     constexpr size_t lds = (red_b > stage_b ? red_b : stage_b) + 256;   // + 1 / rms of the rows (deferred norm)
     if (int e = raise_dynamic_lds((const void*)k, "gemm_wide")) return e;
     hipLaunchKernelGGL(k, dim3(wp.G, wp.g.nsplit), dim3(512), lds, st, wp);
