@@ -607,8 +607,8 @@ int mi355_decoder_set_embedding_split(mi355_decoder_t* d, int32_t on);
  * mi355_decoder_attach_allreduce): while a latency-bound launch runs, a side stream pulls the weights of a later linear into
  * the 256 MB Infinity Cache, joined (event edge, captured into the step graph) right before that linear.  The hook the
  * reference keeps for this is DeviceResourceConfig{enable_comm_overlap, overlap_comm_type} (rtp_llm/cpp/config/ConfigModules.h:275-282).
- * mask: MI355_PF_* bits, 0 = off (default: profiles/r03_prefetch_sidestream_ab.txt -- every fork / join pair costs ~17 us of
- * step time inside a hipGraph on this stack).  Invalidates captured graphs. */
+ * mask: MI355_PF_* bits, 0 = off.  Default: MI355_PF_QKV_IN_FOLD only -- the side-stream bits stay off (profiles/r03_prefetch_sidestream_ab.txt:
+ * every fork / join pair costs ~17 us of step time inside a hipGraph on this stack).  Invalidates captured graphs. */
 enum {
     MI355_PF_QKV      = 1,   /* next layer's QKV, requested before the down GEMM is launched */
     MI355_PF_O        = 2,   /* O, requested behind the QKV GEMM (runs under RoPE / KV write and attention) */
@@ -617,6 +617,9 @@ enum {
     MI355_PF_O_LATE   = 32,  /* O, requested behind the RoPE / KV-write launch (runs under attention only) */
     MI355_PF_TP_COMM  = 64,  /* tp_size > 1: the next linear's shard while the fused all-reduce launch runs (round 2's default; off since
                               * the round-3 A/B: a fork / join pair inside the step graph costs more than the prefetch saves) */
+    MI355_PF_QKV_IN_FOLD = 256, /* tp_size == 1, 5-64-row steps: the slab-fold launch behind down_proj runs on B of the 256 CUs; its spare blocks
+                              * read one dword per 128-byte line of the NEXT layer's QKV weights (unit u on the XCD that will run the QKV
+                              * launch's block u), so that launch finds them in the Infinity Cache / L2.  No stream, no graph edge. */
     MI355_PF_TP_INLAUNCH = 128 /* tp_size > 1, attached all-reduce context: the same overlap WITHOUT a second stream or a graph edge -- the
                               * waves of the fused all-reduce launch that only wait for the peers' flags request the first 8 MB of the
                               * next linear's shard (mi355_allreduce_set_prefetch).  Off by default until an 8-GPU A/B exists: the

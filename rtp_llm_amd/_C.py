@@ -17,7 +17,7 @@ W4, W8, W16 = 4, 8, 16
 KV_FP16, KV_INT8, KV_BF16 = 0, 1, 2
 ACT_F16, ACT_BF16 = 0, 1
 EPI_NONE, EPI_SILU_MUL, EPI_OUT_F32, EPI_OUT_IMAGE = 0, 1, 2, 4
-PF_QKV, PF_O, PF_GATE_UP, PF_QKV_LATE, PF_O_LATE, PF_TP_COMM, PF_TP_INLAUNCH = 1, 2, 4, 16, 32, 64, 128   # mi355_decoder_set_weight_prefetch mask bits
+PF_QKV, PF_O, PF_GATE_UP, PF_QKV_LATE, PF_O_LATE, PF_TP_COMM, PF_TP_INLAUNCH, PF_QKV_IN_FOLD = 1, 2, 4, 16, 32, 64, 128, 256   # mi355_decoder_set_weight_prefetch mask bits
 HINT_STAGED, HINT_NO_PERSISTENT = 0x100, 0x200
 ABI_VERSION = 3
 KC_NAMES = ["gemm_quant", "gemm_lmhead", "attn", "rope_kv", "norm", "other", "comm"]

@@ -18,10 +18,30 @@ __global__ __launch_bounds__(512) void add_rmsnorm_kernel(const f16* __restrict_
                                                           int nsplit, int ld, int M, const f16* __restrict__ bias,
                                                           const f16* __restrict__ res_in, f16* __restrict__ res_out,
                                                           const f16* __restrict__ weight, float eps, int H,
-                                                          f16* __restrict__ y, int y_img_mblk) {
+                                                          f16* __restrict__ y, int y_img_mblk, const mi355_touch_t tc) {
     constexpr int NTH = 512;
     const int row = blockIdx.x;
     const int tid = threadIdx.x;
+    if (row >= M) {   // spare blocks (internal.h, mi355_touch_t): unit u of the next launch, from a block on the XCD that will run it
+        const int q = row - M, u = (row & 7) + 8 * (q >> 3);
+        if (u < tc.n_units) {
+            for (int i = 0; i < tc.delay; ++i) __builtin_amdgcn_s_sleep(8);
+            const uint32_t* qw = (const uint32_t*)tc.qw; const uint32_t* meta = (const uint32_t*)tc.meta;
+            const int t0 = (u / tc.hh) * 2 * tc.hh + u % tc.hh;
+            const uint32_t lines = tc.run_bytes >> 7, run_dw = tc.run_bytes >> 2;
+            uint32_t acc = 0;
+            for (uint32_t l = tid; l < 2 * lines; l += NTH) {
+                const uint32_t r = l >= lines ? 1u : 0u;
+                acc ^= qw[(size_t)(t0 + r * tc.hh) * run_dw + (l - r * lines) * 32];
+            }
+            for (uint32_t g = tid; g < 2 * tc.meta_groups; g += NTH) {
+                const uint32_t r = g >= tc.meta_groups ? 1u : 0u;
+                acc ^= meta[(size_t)(g - r * tc.meta_groups) * tc.meta_stride + (t0 + r * tc.hh) * 16];
+            }
+            if (acc == 0x9E3779B9u) *(uint32_t*)tc.sink = acc;   // practically never: keeps the loads alive
+        }
+        return;
+    }
     const int nvec = H >> 3;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     float v[VPT][8];
@@ -261,7 +281,7 @@ __global__ __launch_bounds__(64) void argmax_pick(const ArgPair* __restrict__ pa
 
 static int add_rmsnorm_launch(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
                               const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M,
-                              int32_t H, void* y, int y_img_mblk, int32_t act_dtype, mi355_stream_t stream) {
+                              int32_t H, void* y, int y_img_mblk, int32_t act_dtype, mi355_stream_t stream, const mi355_touch_t* touch = nullptr) {
     MI355_CHECK_ARG((x_f16 != nullptr) != (partials != nullptr), "add_rmsnorm: exactly one of x_f16 / partials");
     MI355_CHECK_ARG(M > 0 && H > 0 && H % 8 == 0 && H <= 8 * 512 * 2, "add_rmsnorm: M=%d H=%d (H %% 8 == 0, H <= 8192)", M, H);
     MI355_CHECK_ARG(!partials || (nsplit >= 1 && ld >= H && ld % 4 == 0), "add_rmsnorm: nsplit=%d ld=%d", nsplit, ld);
@@ -269,9 +289,12 @@ static int add_rmsnorm_launch(const void* x_f16, const float* partials, int32_t 
     MI355_CHECK_ARG(act_dtype == MI355_ACT_F16 || act_dtype == MI355_ACT_BF16, "add_rmsnorm: act_dtype=%d", act_dtype);
     hipStream_t st = (hipStream_t)stream;
     const int vpt = cdiv(H / 8, 512);
+    mi355_touch_t tc = {};
+    int spare = 0;                                   // blocks past the rows: 8 per 8 units (see the kernel), only while the launch stays inside one round of the CUs
+    if (touch && touch->qw && touch->n_units > 0 && touch->hh > 0 && M + cdiv(touch->n_units, 8) * 8 <= 256) { tc = *touch; spare = cdiv(touch->n_units, 8) * 8; if (TUNE(3) > 0) tc.delay = TUNE(3); }
 #define L_(V, B)                                                                                                        \
-    hipLaunchKernelGGL((add_rmsnorm_kernel<V, B>), dim3(M), dim3(512), 0, st, (const f16*)x_f16, partials, nsplit, ld, M, \
-                       (const f16*)bias, (const f16*)residual_in, (f16*)residual_out, (const f16*)weight, eps, H, (f16*)y, y_img_mblk)
+    hipLaunchKernelGGL((add_rmsnorm_kernel<V, B>), dim3(M + spare), dim3(512), 0, st, (const f16*)x_f16, partials, nsplit, ld, M, \
+                       (const f16*)bias, (const f16*)residual_in, (f16*)residual_out, (const f16*)weight, eps, H, (f16*)y, y_img_mblk, tc)
     if (act_dtype == MI355_ACT_BF16) { if (vpt <= 1) L_(1, true); else L_(2, true); }
     else                             { if (vpt <= 1) L_(1, false); else L_(2, false); }
 #undef L_
@@ -291,6 +314,14 @@ extern "C" int mi355_add_rmsnorm_img(const void* x_f16, const float* partials, i
                                      int32_t H, void* y_img, int32_t act_dtype, mi355_stream_t stream) {
     MI355_CHECK_ARG(y_img && M <= 64 && H % 32 == 0, "add_rmsnorm_img: M=%d (<= 64) H=%d (%% 32 == 0), y_img required", M, H);
     return add_rmsnorm_launch(x_f16, partials, nsplit, ld, bias, residual_in, residual_out, weight, eps, M, H, y_img, cdiv(M, 16), act_dtype, stream);
+}
+
+// the same launch with its spare blocks touching the weights of the launch that follows (internal.h: mi355_touch_t)
+extern "C" int mi355_add_rmsnorm_img_touch(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
+                                           const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M,
+                                           int32_t H, void* y_img, int32_t act_dtype, const mi355_touch_t* touch, mi355_stream_t stream) {
+    MI355_CHECK_ARG(y_img && M <= 64 && H % 32 == 0, "add_rmsnorm_img: M=%d (<= 64) H=%d (%% 32 == 0), y_img required", M, H);
+    return add_rmsnorm_launch(x_f16, partials, nsplit, ld, bias, residual_in, residual_out, weight, eps, M, H, y_img, cdiv(M, 16), act_dtype, stream, touch);
 }
 
 // ---------------------------------------------------------------- activation image

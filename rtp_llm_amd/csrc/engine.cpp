@@ -244,7 +244,7 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     d->B = 0; d->q_len = 1; d->cap_stream = nullptr; d->prof_on = false; d->ev_used = 0; d->ar = nullptr; d->vocab_offset = 0;
     d->has_ext = false; d->pairs_local = d->pairs_all = nullptr;
     d->side_stream = nullptr; d->ev_fork = d->ev_join = nullptr; d->overlap = false;
-    d->pf_mask = 0; d->pf_pending = false;
+    d->pf_mask = MI355_PF_QKV_IN_FOLD; d->pf_pending = false;   // the one prefetch that needs no stream and measured positive (profiles/r04_touch_prefetch.txt)
     const bool bf_act = cfg->act_dtype == MI355_ACT_BF16;
     // QKV + RoPE + KV write in one launch: a 16-bit cache of the activation dtype (INT8 caches keep the quantising writer of rope_kv.hip)
     d->fuse_qkv = cfg->kv_dtype == (bf_act ? MI355_KV_BF16 : MI355_KV_FP16) && cfg->rope_dim == cfg->hd;
@@ -499,7 +499,7 @@ extern "C" int mi355_decoder_set_weight_prefetch(mi355_decoder_t* d, int32_t mas
     if (!d || mask < 0) { mi355_set_error("decoder_set_weight_prefetch: bad argument"); return MI355_ERR_ARG; }
     for (auto& kv : d->graphs) hipGraphExecDestroy(kv.second);   // captured steps bake the fork / join edges in
     d->graphs.clear();
-    if ((mask & ~MI355_PF_TP_INLAUNCH) != 0 && !side_ready(d)) {   // the side stream and its events exist before any capture begins (not lazily inside one)
+    if ((mask & ~(MI355_PF_TP_INLAUNCH | MI355_PF_QKV_IN_FOLD)) != 0 && !side_ready(d)) {   // the side stream and its events exist before any capture begins (not lazily inside one)
         mi355_set_error("decoder_set_weight_prefetch: cannot create the prefetch stream: %s", hipGetErrorString(hipGetLastError()));
         return MI355_ERR_HIP;
     }
@@ -631,8 +631,13 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
     if (pf & MI355_PF_QKV_LATE) if (int e = pf_issue(d, st, next_qkv, kPfCap)) return e;    // under the reduce + norm launch only
     if (c.tp_size == 1) {
         if (d->img_qkv && B > d->fuse_rows && l + 1 < c.num_layers)   // the next layer's QKV launch reads an image (the final norm feeds lm_head: row-major)
-            RUN(MI355_KC_NORM, mi355_add_rmsnorm_img(nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
-                                                     c.rms_eps, B, c.hidden, d->xn_img, ADT, st));
+        {   // the fold runs on B of the 256 CUs: its spare blocks touch the NEXT layer's QKV weights (MI355_PF_QKV_IN_FOLD, internal.h mi355_touch_t)
+            mi355_touch_t tc; const mi355_touch_t* touch = nullptr;
+            if ((d->pf_mask & MI355_PF_QKV_IN_FOLD) && l + 1 < c.num_layers &&
+                mi355_qkv_touch_plan(&d->layers[l + 1].qkv, c.hd, d->oob_count + 32, &tc) == MI355_OK) touch = &tc;
+            RUN(MI355_KC_NORM, mi355_add_rmsnorm_img_touch(nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
+                                                           c.rms_eps, B, c.hidden, d->xn_img, ADT, touch, st));
+        }
         else
             RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
                                                  c.rms_eps, B, c.hidden, d->xn, ADT, st));

@@ -846,6 +846,17 @@ static bool img_weight_ok(const mi355_weight_t* w) {
            w->K % 128 == 0 && w->K_pad == w->K && w->K_pad / 128 >= 4 && w->N % 16 == 0;
 }
 
+// what block u of gemm_fullk64's QKV launch reads (internal.h: mi355_touch_t), for the spare blocks of the launch in front of it
+extern "C" int mi355_qkv_touch_plan(const mi355_weight_t* wqkv, int32_t hd, void* sink, mi355_touch_t* out) {
+    if (!out || !sink || !img_weight_ok(wqkv) || (hd != 64 && hd != 128) || wqkv->N % hd != 0) return MI355_ERR_UNSUPPORTED;
+    const int KC = wqkv->K_pad / 128;
+    out->qw = wqkv->qweight; out->meta = wqkv->meta;
+    out->run_bytes = (uint32_t)KC * 1024u;                               // W4: 1 KB per (tile, chunk), a tile's chunks back to back
+    out->meta_groups = (uint32_t)(wqkv->K_pad / wqkv->group_size); out->meta_stride = (uint32_t)wqkv->N_pad;
+    out->n_units = wqkv->N / 32; out->hh = hd / 32; out->sink = sink; out->delay = 0;
+    return MI355_OK;
+}
+
 extern "C" int mi355_linear_residual(const void* x, int32_t M, const mi355_weight_t* w, const void* bias, const void* residual_in,
                                      void* residual_out, float* tile_sumsq_out, int32_t tile_sumsq_ld, mi355_stream_t stream) {
     if (int e = check_weight(w)) return e;

@@ -19,6 +19,23 @@ int mi355_fullk_weight_ok(const mi355_weight_t* w);
 int mi355_gemm_wide_direct_ok(const mi355_weight_t* w);   /* gemm_wide.hip: the one-launch form takes this linear (N fills the chip) */
 int mi355_gemm_splitk64_plan(int M, int NT, int KC, int wbits, int group_size, int max_splits, int* cps_out);   /* gemm_splitk64.hip: slabs, or < 0 */
 int mi355_prefetch(const void* ptr, size_t bytes, void* sink, mi355_stream_t stream);
+/* Touch plan: the blocks a latency-bound launch has to spare (the slab fold in front of a QKV launch: 64 blocks on 256 CUs) read one dword per
+ * 128-byte line of the weights the NEXT launch streams, so that its first requests are served by the Infinity Cache (or the XCD's L2)
+ * instead of HBM under the launch burst.  Unit u = what block u of the next launch reads, touched by a block on the same XCD (block b runs
+ * on XCD b % 8 -- observed, speed only).  For gemm_fullk64's QKV launch unit u is the (d, d + hd/2) tile pair u: two runs of run_bytes at
+ * tiles (u / hh) 2 hh + u % hh and + hh, and the (zero, scale) words of those tiles.  No effect on any result. */
+typedef struct {
+    const void* qw; const void* meta;     /* weight image, (zero, scale) words [groups][N_pad] */
+    uint32_t run_bytes;                   /* bytes of one tile's weights (contiguous) */
+    uint32_t meta_groups, meta_stride;    /* groups along K, dwords from group to group */
+    int32_t  n_units, hh;                 /* tile pairs, tiles per half head */
+    void*    sink;                        /* a dword nobody reads */
+    int32_t  delay;                       /* the spare blocks wait delay x 512 cycles first (the launch's own requests go out ahead) */
+} mi355_touch_t;
+int mi355_qkv_touch_plan(const mi355_weight_t* wqkv, int32_t hd, void* sink, mi355_touch_t* out);   /* gemm.hip: MI355_OK, or MI355_ERR_UNSUPPORTED */
+int mi355_add_rmsnorm_img_touch(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld, const void* bias, const void* residual_in,
+                                void* residual_out, const void* weight, float eps, int32_t M, int32_t H, void* y_img, int32_t act_dtype,
+                                const mi355_touch_t* touch, mi355_stream_t stream);
 int mi355_argmax_candidates(const float* logits, int32_t B, int32_t V, int32_t ld, void* workspace, size_t workspace_bytes,
                             mi355_stream_t stream);
 int mi355_argmax_pairs(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t vocab_offset, void* pairs_out,

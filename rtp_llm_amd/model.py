@@ -653,7 +653,8 @@ class DecoderEngine:
         self._transport = transport
 
     def set_weight_prefetch(self, mask: int):
-        """Weight prefetch one launch ahead on a side stream (mi355_decoder_set_weight_prefetch, _C.PF_* bits; 0 = off).
+        """Weight prefetch one launch ahead (mi355_decoder_set_weight_prefetch, _C.PF_* bits; 0 = off; the engine's default is
+        _C.PF_QKV_IN_FOLD, the spare blocks of the slab fold reading the next QKV weights -- the side-stream bits are off).
         Captured graphs are dropped: capture again."""
         _C.check(self.lib.mi355_decoder_set_weight_prefetch(self.handle, int(mask)), "decoder_set_weight_prefetch")
 

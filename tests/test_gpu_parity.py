@@ -355,6 +355,33 @@ def test_engine_wide_hidden_mid_batch_matches_oracle():
         eng.token_ids[:B].copy_(tok)
 
 
+def test_engine_fold_touch_prefetch_changes_nothing():
+    """MI355_PF_QKV_IN_FOLD: the spare blocks of the slab-fold launch read the next layer's QKV weights -- a cache warm-up for the launch
+    that follows.  Same logits and ids bit for bit with and without, eager and replayed, at row counts on the image path."""
+    cfg = _tiny_cfg()
+    w = model.synth_model(cfg, "w4", "cpu", seed=23, zeros="centered")
+    for B in (8, 33, 64):
+        engs = []
+        for mask in (0, _C.PF_QKV_IN_FOLD):
+            eng = model.DecoderEngine(cfg, model.weights_to(w, DEV), kv_int8=False, page=16, num_blocks=B * 2, max_batch=B, max_seq_len=32, device=DEV)
+            eng.set_weight_prefetch(mask)
+            eng.set_inputs(torch.randint(0, cfg.vocab, (B,), generator=_gen(5), dtype=torch.int32).tolist(), [0] * B,
+                           torch.arange(B * 2, dtype=torch.int32).reshape(B, 2))
+            engs.append(eng)
+        for e in engs:
+            e.step(B)                                   # eager
+        torch.cuda.synchronize()
+        assert torch.equal(engs[0].logits[:B], engs[1].logits[:B]) and torch.equal(engs[0].token_ids[:B], engs[1].token_ids[:B])
+        for e in engs:
+            e.capture(B)
+        for step in range(3):
+            for e in engs:
+                e.replay(B, 1)
+            torch.cuda.synchronize()
+            assert torch.equal(engs[0].logits[:B], engs[1].logits[:B]) and torch.equal(engs[0].token_ids[:B], engs[1].token_ids[:B]), (B, step)
+        assert all(e.oob_count() == 0 for e in engs)
+
+
 def test_module_graph_matches_engine():
     """The reference-shaped Python module graph (LinearFactory / FMHA impl / RMSNorm modules) and the C++ step
     driver compute the same layer: the driver's small-batch step fuses QKV+RoPE+KV-write and the residual adds into

@@ -7,6 +7,7 @@ usage: fullk64_time.py [--product] [--ms 64,32,17] [--variants "5=2;6=1;6=2;7=1;
 import argparse, os, sys
 ap = argparse.ArgumentParser(); ap.add_argument("--ms", default="64,32,17"); ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--product", action="store_true"); ap.add_argument("--variants", default="")
+ap.add_argument("--resident", action="store_true", help="also time with ONE weight copy (stays in the Infinity Cache / L2): what a perfect weight prefetch would buy")
 a = ap.parse_args()
 if not a.product:
     os.environ["MI355_TUNING_LIB"] = "1"
@@ -55,6 +56,10 @@ for M in [int(m) for m in a.ms.split(",")]:
              timed(lambda i: ops.linear_residual_img(xi, wo[i % len(wo)], res, out=out, tile_sumsq=ssq), len(wo))]
         setv(var, False)
         print(f"M={M:3d} [{var or 'default':8s}]  qkv+rope+kv {t[0]:6.2f}  o+residual {t[1]:6.2f} us (graph replay, launch gaps included)", flush=True)
+        if a.resident and not var:
+            t = [timed(lambda i: ops.qkv_rope_kv_write_img(xi, wq[0], None, cs, pos, bt, kv, sc, nh, nkv, hd, page), 4),
+                 timed(lambda i: ops.linear_residual_img(xi, wo[0], res, out=out, tile_sumsq=ssq), 4)]
+            print(f"M={M:3d} [resident]  qkv+rope+kv {t[0]:6.2f}  o+residual {t[1]:6.2f} us (one weight copy: cache-resident)", flush=True)
     t = [timed(lambda i: ops.qkv_rope_kv_write(x, wq[i % len(wq)], None, cs, pos, bt, kv, sc, nh, nkv, hd, page), len(wq)),
          timed(lambda i: ops.linear_residual(x, wo[i % len(wo)], res, out=out, tile_sumsq=ssq), len(wo))]
     print(f"M={M:3d} [row-major]  qkv+rope+kv {t[0]:6.2f}  o+residual {t[1]:6.2f} us (gemm_fullk.hip, fragments gathered from the row-major tensor)", flush=True)

@@ -4,6 +4,7 @@
 import argparse, ctypes as C, os, sys
 ap = argparse.ArgumentParser(); ap.add_argument("--ms", default="64,48,32,17"); ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--set", default="", help="k=v,... -> mi355_debug_set (tuning build): 7=1 no activation traffic, 7=2 no weight traffic, 7=3 neither")
+ap.add_argument("--resident", action="store_true", help="also ONE weight copy (36 MB: stays in the Infinity Cache): what a perfect weight prefetch would buy")
 a = ap.parse_args()
 if a.set: os.environ["MI355_TUNING_LIB"] = "1"
 import torch
@@ -44,4 +45,7 @@ for M in [int(m) for m in a.ms.split(",")]:
         ns[1] = lib.mi355_linear_partial(x.data_ptr(), M, C.byref(w), slabs.data_ptr(), 16, st())
         if fold: lib.mi355_add_rmsnorm(None, slabs.data_ptr(), ns[1], wd[0].N_pad, None, res.data_ptr(), r2.data_ptr(), gamma.data_ptr(), 1e-6, M, H, y.data_ptr(), st())
     t = [timed(lambda i: new(i, False), 10), timed(lambda i: new(i, True), 10), timed(lambda i: old(i, False), 10), timed(lambda i: old(i, True), 10)]
+    if a.resident:
+        tr = timed(lambda i: new(0, False), 4)
+        print(f"M={M:3d}  down: image K-quarters, ONE weight copy (cache-resident) {tr:6.2f} us", flush=True)
     print(f"M={M:3d}  down: image K-quarters {t[0]:6.2f} ({ns[0]} slabs), + fold {t[1]:6.2f}   |   staged {t[2]:6.2f} ({ns[1]} slabs), + fold {t[3]:6.2f} us (graph replay, gaps included)", flush=True)
