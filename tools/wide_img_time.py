@@ -5,6 +5,7 @@ Qwen2-7B shape, weights rotating through HBM-resident copies, graph replay.  usa
 stream without weight traffic, 3 = without any main-loop traffic."""
 import argparse, os, sys
 ap = argparse.ArgumentParser(); ap.add_argument("--ms", default="64,32"); ap.add_argument("--iters", type=int, default=30); ap.add_argument("--tuning", action="store_true"); ap.add_argument("--dbg", default="")
+ap.add_argument("--resident", action="store_true", help="also ONE weight copy (72 MB: stays in the Infinity Cache) and a HALF-resident mix")
 a = ap.parse_args()
 if a.tuning:
     os.environ["MI355_TUNING_LIB"] = "1"
@@ -41,4 +42,7 @@ for M in [int(m) for m in a.ms.split(",")]:
             tv = timed(lambda i: ops.linear_deferred_norm_img(xi, (ssq, 1e-6, 1), wg[i % 8], None, _C.EPI_SILU_MUL), 8)
             print(f"M={M:3d}  image + deferred norm, switch {v:2d}: {tv:6.2f} us", flush=True)
         lib.mi355_debug_set(0, 0)
+    if a.resident:
+        tr = timed(lambda i: ops.linear_deferred_norm_img(xi, (ssq, 1e-6, 1), wg[0], None, _C.EPI_SILU_MUL), 4)
+        print(f"M={M:3d}  image + deferred norm, ONE weight copy (cache-resident): {tr:6.2f} us", flush=True)
     print(f"M={M:3d}  gate_up + SiLU: row-major {t[0]:6.2f}   image {t[1]:6.2f}   image + deferred norm {t[2]:6.2f} us (graph replay, gaps included)", flush=True)
