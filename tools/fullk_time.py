@@ -7,6 +7,7 @@ import argparse, os, sys
 ap = argparse.ArgumentParser(); ap.add_argument("--ms", default="1,4,8,16"); ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--product", action="store_true"); ap.add_argument("--set", default="", help="k=v,... -> mi355_debug_set (tuning build)")
 ap.add_argument("--sweep", default="", help="k=v1,v2,...: repeat the measurement for every value of debug key k (tuning build)")
+ap.add_argument("--resident", action="store_true", help="also ONE weight copy per linear (cache-resident): what a perfect weight prefetch would buy")
 a = ap.parse_args()
 if not a.product:
     os.environ["MI355_TUNING_LIB"] = "1"
@@ -58,5 +59,11 @@ for M in [int(m) for m in a.ms.split(",")]:
              timed(lambda i: ops.linear_residual(x, wo[i % len(wo)], res, out=out), len(wo)),
              timed(lambda i: ops.norm_linear(res, norm, wg[i % len(wg)], None, _C.EPI_SILU_MUL), len(wg)),
              timed(lambda i: ops.linear_residual(act, wd[i % len(wd)], res, out=out), len(wd))]
+        if a.resident:
+            tr = [timed(lambda i: ops.qkv_rope_kv_write(res, wq[0], None, cs, pos, bt, kv, sc, nh, nkv, hd, page, norm=norm), 4),
+                  timed(lambda i: ops.linear_residual(x, wo[0], res, out=out), 4),
+                  timed(lambda i: ops.norm_linear(res, norm, wg[0], None, _C.EPI_SILU_MUL), 4),
+                  timed(lambda i: ops.linear_residual(act, wd[0], res, out=out), 4)]
+            print(f"M={M:3d} [one weight copy: cache-resident]  qkv {tr[0]:6.2f}  o {tr[1]:6.2f}  gate_up {tr[2]:6.2f}  down {tr[3]:6.2f}  sum {sum(tr):6.2f} us", flush=True)
         tag = "" if sv is None else f" [{sweep_k}={sv}]"
         print(f"M={M:3d}{tag}  qkv {t[0]:6.2f}  o {t[1]:6.2f}  gate_up {t[2]:6.2f}  down {t[3]:6.2f}  sum {sum(t):6.2f} us (graph replay, launch gaps included)", flush=True)
