@@ -19,6 +19,7 @@ this path, each function citing the reference lines it follows.  Pinning status
     have that dtype): PINNED against the same reference implementations executed on bf16 tensors ->
     tests/golden/ref_layers_bf16.npz (RMSNorm bit-equal; RoPE / attention within one bf16 ulp).
   * Scaled RoPE styles (linear / llama3 / yarn): PINNED bit for bit, see rope_inv_freq and oracle/gen_rope_golden.py.
+  * Dynamic-NTK RoPE styles (rope_dynamic_ntk_bases): PARITY UNPINNED -- device code only in the reference, restated from the header.
   * Chain rejection sampling (speculative verify): PINNED against the reference's own known-answer kernel tests
     (bindings/cuda/test/CudaSpeculativeSamplingTest.cc:36-366, transcribed in tests/spec_vectors.py).
   * W4A16 / W8A16 GEMM results and INT8 KV-cache numerics: PARITY UNPINNED — the reference
@@ -98,8 +99,8 @@ def rope_inv_freq(rope_dim: int, theta: float, scaling: Optional[dict] = None) -
       * llama3: wavelength-banded rescale                     Llama3Rope, :418-442
       * yarn: ramp between interpolated and extrapolated      YarnRope, :366-416 (correction range from beta_fast / beta_slow,
         original max positions; cos / sin scaled by mscale = 0.1 ln(factor) + 1, Llama.get_mscale models/llama.py:30-34)
-    scaling: {"type", "factor", ...} with HF's key names.  DynamicNTK styles are not tabulable (base depends on the request
-    length) and are refused."""
+    scaling: {"type", "factor", ...} with HF's key names.  The DynamicNTK styles have no single step per frequency (the base
+    depends on the cached length): see rope_dynamic_ntk_bases."""
     idx = torch.arange(0, rope_dim, 2).float()
     inv = 1.0 / torch.pow(torch.tensor(float(theta)), idx / rope_dim)
     if not scaling:
@@ -131,12 +132,48 @@ def rope_inv_freq(rope_dim: int, theta: float, scaling: Optional[dict] = None) -
         out = (inv / factor) * (1 - mask) + inv * mask
         mscale = float(scaling.get("mscale_override", 0.1 * math.log(factor) + 1.0 if factor > 1 else 1.0))
         return out, mscale
-    raise ValueError(f"rope scaling {kind!r} has no position-indexed table (dynamic NTK depends on the request length)")
+    raise ValueError(f"rope scaling {kind!r}: no single step per frequency (dynamic NTK: rope_dynamic_ntk_bases)")
+
+
+DYNAMIC_NTK_KINDS = ("dynamic", "qwen_dynamic")
+
+
+def rope_dynamic_ntk_bases(rope_dim: int, theta: float, max_pos: int, scaling: dict) -> torch.Tensor:
+    """Base of the rotation per DECODE position under the dynamic-NTK styles, fp32 [max_pos].  The reference's decode writer
+    passes the number of tokens already cached -- the position p of the new token -- as `seq_len`
+    (fused_rope_kvcache_kernel.cu:1341-1392: sequence_length = sequence_lengths[b], tlength = sequence_length), and apply_rope
+    replaces the base once it exceeds the original context (rotary_position_embedding.h:925-951):
+      * "dynamic"      (RopeStyle::DynamicNTK, :889-893): base (scale p / orig - (scale - 1)) ^ (dim / (dim - 2)), scale = factor
+      * "qwen_dynamic" (RopeStyle::QwenDynamicNTK, :895-902): base (max(2 ^ ceil(log2(p / orig) + 1) - 1, 1)) ^ (dim / (dim - 2))
+    so for decode the style IS a function of the position.  (A prompt longer than the original context rotates ALL its tokens with
+    the base of the prompt length, context_rope: not a position-indexed table; the host refuses that case.)
+    UNPINNED: restated from the header's device code, which cannot run here; no golden vectors for these two styles."""
+    kind = scaling.get("rope_type", scaling.get("type"))
+    orig = int(scaling["original_max_position_embeddings"])
+    p = torch.arange(max_pos, dtype=torch.float32)
+    expo = torch.tensor(float(rope_dim) / (rope_dim - 2.0), dtype=torch.float32)
+    base = torch.full((max_pos,), float(theta), dtype=torch.float32)
+    if kind == "dynamic":
+        scale = torch.tensor(float(scaling.get("factor", 1.0)), dtype=torch.float32)
+        grown = base * torch.pow(scale * p / float(orig) - (scale - 1.0), expo)
+    elif kind == "qwen_dynamic":
+        ctx = torch.log(p.clamp(min=1.0) / float(orig)) / math.log(2.0) + 1.0
+        ntk = torch.clamp(torch.pow(torch.tensor(2.0), torch.ceil(ctx)) - 1.0, min=1.0)
+        grown = base * torch.pow(ntk, expo)
+    else:
+        raise ValueError(f"not a dynamic-NTK style: {kind!r}")
+    return torch.where(p > float(orig), grown, base)
 
 
 def rope_cos_sin_scaled(rope_dim: int, theta: float, max_pos: int, scaling: Optional[dict] = None) -> torch.Tensor:
     """{cos, sin} table [max_pos][dim/2][2] of a scaled style: angle = pos * rope_inv_freq, both scaled by mscale
-    (normal_rope + sin_cos_scale(), rotary_position_embedding.h:350-416)."""
+    (normal_rope + sin_cos_scale(), rotary_position_embedding.h:350-416).  Dynamic-NTK styles: row p with the base of position p
+    (rope_dynamic_ntk_bases, DefaultRope: angle = p / base_p ^ (2 i / dim))."""
+    if scaling and scaling.get("rope_type", scaling.get("type")) in DYNAMIC_NTK_KINDS:
+        bases = rope_dynamic_ntk_bases(rope_dim, theta, max_pos, scaling)
+        idx = torch.arange(0, rope_dim, 2).float() / rope_dim
+        freqs = torch.arange(max_pos).float()[:, None] / torch.pow(bases[:, None], idx[None, :])
+        return torch.stack((freqs.cos(), freqs.sin()), dim=-1).contiguous()
     inv, mscale = rope_inv_freq(rope_dim, theta, scaling)
     freqs = torch.outer(torch.arange(max_pos).float(), inv)
     return torch.stack((freqs.cos() * mscale, freqs.sin() * mscale), dim=-1).contiguous()

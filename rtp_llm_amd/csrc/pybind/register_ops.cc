@@ -42,7 +42,7 @@ struct AttentionConfigs {            // rtp_llm/cpp/model_utils/AttentionConfig.
     int64_t head_num = 0, kv_head_num = 0, size_per_head = 0, tokens_per_block = 16, max_seq_len = 8192;
     int64_t rope_dim = 0;
     double  rope_base = 10000.0, softmax_extra_scale = 1.0;
-    // RopeConfig.h:7-40: style (1 Base, 5 Yarn, 6 Llama3; linear = Base with scale), scale = HF factor, factor1 / factor2 =
+    // RopeConfig.h:7-40: style (1 Base, 3 DynamicNTK, 4 QwenDynamicNTK, 5 Yarn, 6 Llama3; linear = Base with scale), scale = HF factor, factor1 / factor2 =
     // beta_slow / beta_fast (yarn) or low_freq_factor / high_freq_factor (llama3), rope_max_pos = original max positions
     int64_t rope_style = 1, rope_max_pos = 0;
     double  rope_scale = 1.0, rope_factor1 = 1.0, rope_factor2 = 1.0, rope_extrapolation_factor = 1.0, rope_mscale = 1.0;
@@ -92,9 +92,28 @@ inline torch::Tensor build_rope_table(const AttentionConfigs& c) {
         auto keep = (1 - torch::clamp((torch::arange(hd / 2).to(torch::kFloat32) - first) / (last - first), 0, 1)) * c.rope_extrapolation_factor;
         step = (step / c.rope_scale) * (1 - keep) + step * keep;
         gain = c.rope_mscale;
+    } else if (c.rope_style == 3 || c.rope_style == 4) {
+        // DynamicNTK (3) / QwenDynamicNTK (4), rotary_position_embedding.h:889-902 + :925-951: past the original context the base grows with
+        // seq_len, and the DECODE writer passes the cached length -- the new token's position -- as seq_len
+        // (fused_rope_kvcache_kernel.cu:1341-1392): one base per table row, angle = p / base_p ^ (2 i / hd) (rope_inv_freq, :324-327)
+        auto pos   = torch::arange(c.max_seq_len).to(torch::kFloat32);
+        auto power = torch::tensor((float)((double)hd / ((double)hd - 2.0)));
+        auto base0 = torch::full({c.max_seq_len}, (float)c.rope_base);
+        const double ctx = (double)c.rope_max_pos;
+        TORCH_CHECK(ctx > 0, "dynamic-NTK rope: rope_config.max_pos (the original context) must be set");
+        torch::Tensor grown;
+        if (c.rope_style == 3) {
+            auto f = torch::tensor((float)c.rope_scale);
+            grown = base0 * torch::pow(f * pos / ctx - (f - 1.0), power);
+        } else {
+            auto octave = torch::ceil(torch::log(torch::clamp_min(pos, 1.0) / ctx) / std::log(2.0) + 1.0);
+            grown = base0 * torch::pow(torch::clamp_min(torch::exp2(octave) - 1.0, 1.0), power);
+        }
+        auto bases = torch::where(pos > ctx, grown, base0);
+        auto angle = pos.unsqueeze(1) / torch::pow(bases.unsqueeze(1), (idx / (double)hd).unsqueeze(0));
+        return torch::stack({angle.cos(), angle.sin()}, -1).contiguous();
     } else {
-        TORCH_CHECK(false, "rope style ", c.rope_style, ": only Base / linear, Yarn (5) and Llama3 (6) fold into the position table; the "
-                    "dynamic-NTK styles depend on the request length");
+        TORCH_CHECK(false, "rope style ", c.rope_style, ": Base / linear (1), DynamicNTK (3), QwenDynamicNTK (4), Yarn (5) and Llama3 (6) are tabulated by position");
     }
     auto freqs = torch::outer(torch::arange(c.max_seq_len).to(torch::kFloat32), step);
     return torch::stack({freqs.cos() * gain, freqs.sin() * gain}, -1).contiguous();

@@ -67,11 +67,15 @@ def config_from_hf(cfg: dict, name: str = "hf-model") -> Tuple[ModelConfig, dict
     rs = cfg.get("rope_scaling") or {}
     kind = rs.get("rope_type", rs.get("type", "default")) if rs else "default"
     if kind not in ("default", None):
-        # linear / llama3 / yarn fold into the position-indexed cos/sin table (model.rope_frequencies); the dynamic-NTK styles
-        # (base as a function of the request length) would decode with wrong rotations and stay refused
-        if kind not in ("linear", "llama3", "yarn"):
-            raise NotImplementedError(f"rope_scaling={rs}: only base / linear / llama3 / yarn RoPE are on this decode path")
+        # linear / llama3 / yarn fold into the position-indexed cos/sin table (model.rope_frequencies); "dynamic" (models/llama.py:95-96,
+        # gpt_neox.py:128-134: RopeStyle::DynamicNTK, scale = factor, original context = max_position_embeddings) gets one base per position
+        if kind not in ("linear", "llama3", "yarn", "dynamic"):
+            raise NotImplementedError(f"rope_scaling={rs}: only base / linear / llama3 / yarn / dynamic RoPE are on this decode path")
         mc.rope_scaling = dict(rs)
+        if kind == "dynamic":
+            mc.rope_scaling.setdefault("original_max_position_embeddings", int(cfg.get("max_position_embeddings", 2048)))
+    if cfg.get("use_dynamic_ntk"):   # Qwen-1 (models/qwen.py:293-295): RopeStyle::QwenDynamicNTK over seq_length
+        mc.rope_scaling = {"rope_type": "qwen_dynamic", "original_max_position_embeddings": int(cfg.get("seq_length", 8192))}
     if cfg.get("use_sliding_window"):
         raise NotImplementedError("sliding-window attention is not on this decode path")
     q = cfg.get("quantization_config") or {}

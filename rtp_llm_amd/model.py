@@ -256,7 +256,8 @@ def rope_frequencies(hd: int, theta: float, scaling: Optional[dict]):
       * llama3: long wavelengths / factor, short ones kept, a linear blend between the two bands      Llama3Rope, :418-442
       * yarn: blend of interpolated (1 / factor) and original steps along a ramp over the channel index, whose ends come from
         beta_fast / beta_slow rotations over the original context; table scaled by 0.1 ln(factor) + 1      YarnRope, :366-416
-    Dynamic-NTK styles (:889-902) change the base with the request length: not a function of the position alone, refused."""
+    Dynamic-NTK styles (:889-902) change the base with the cached length -- for decode that IS the position: rope_table builds their
+    rows one base per position (dynamic_ntk_base); they have no single step per channel and are not served here."""
     step = 1.0 / torch.pow(torch.tensor(float(theta)), torch.arange(0, hd, 2).float() / hd)
     kind = (scaling or {}).get("rope_type", (scaling or {}).get("type"))
     if kind in (None, "default"):
@@ -281,14 +282,41 @@ def rope_frequencies(hd: int, theta: float, scaling: Optional[dict]):
         keep = (1 - torch.clamp((torch.arange(hd // 2).float() - first) / (last - first), 0, 1)) * float(scaling.get("extrapolation_factor", 1.0))
         gain = 0.1 * math.log(factor) + 1.0 if factor > 1 else 1.0
         return (step / factor) * (1 - keep) + step * keep, gain
-    raise NotImplementedError(f"rope_scaling type {kind!r}: dynamic-NTK bases depend on the request length; only base / linear / "
-                              "llama3 / yarn fold into the position-indexed table of this path")
+    raise NotImplementedError(f"rope_scaling type {kind!r}: no single step per channel (base / linear / llama3 / yarn have one; the dynamic-NTK "
+                              "styles go through dynamic_ntk_base)")
+
+
+DYNAMIC_NTK = ("dynamic", "qwen_dynamic")
+
+
+def dynamic_ntk_base(hd: int, theta: float, positions: torch.Tensor, scaling: dict) -> torch.Tensor:
+    """fp32 base of the rotation at each decode position under RopeStyle::DynamicNTK ("dynamic") / QwenDynamicNTK ("qwen_dynamic"),
+    rotary_position_embedding.h:889-902 + :925-951.  The decode writer hands apply_rope the cached length as seq_len
+    (fused_rope_kvcache_kernel.cu:1341-1392), i.e. the new token's position: past the original context the base grows with it."""
+    pos = positions.float()
+    ctx = float(int(scaling["original_max_position_embeddings"]))
+    power = torch.tensor(hd / (hd - 2.0), dtype=torch.float32)
+    theta_t = torch.full_like(pos, float(theta))
+    kind = scaling.get("rope_type", scaling.get("type"))
+    if kind == "dynamic":
+        f = torch.tensor(float(scaling.get("factor", 1.0)), dtype=torch.float32)
+        stretched = theta_t * torch.pow(f * pos / ctx - (f - 1.0), power)
+    else:
+        octave = torch.ceil(torch.log(torch.clamp(pos, min=1.0) / ctx) / math.log(2.0) + 1.0)
+        stretched = theta_t * torch.pow(torch.clamp(torch.exp2(octave) - 1.0, min=1.0), power)
+    return torch.where(pos > ctx, stretched, theta_t)
 
 
 def rope_table(cfg: ModelConfig, device) -> torch.Tensor:
     """fp32 {cos,sin} table [max_pos][hd/2][2] (genBaseCache / genYarnCache, cpp/model_utils/RopeCache.cc:16-81; the styles the
     reference computes in-kernel on ROCm are tabulated the same way: rope_frequencies); built on the host in fp32 so every
     rank holds identical bits."""
+    kind = (cfg.rope_scaling or {}).get("rope_type", (cfg.rope_scaling or {}).get("type"))
+    if kind in DYNAMIC_NTK:   # one base per position (decode: the cached length is the position)
+        pos = torch.arange(cfg.max_pos)
+        chan = torch.arange(0, cfg.hd, 2).float() / cfg.hd
+        angle = pos.float()[:, None] / torch.pow(dynamic_ntk_base(cfg.hd, cfg.rope_theta, pos, cfg.rope_scaling)[:, None], chan[None, :])
+        return torch.stack((angle.cos(), angle.sin()), dim=-1).contiguous().to(device)
     step, gain = rope_frequencies(cfg.hd, cfg.rope_theta, cfg.rope_scaling)
     freqs = torch.outer(torch.arange(cfg.max_pos).float(), step)
     if gain != 1.0:
@@ -520,6 +548,10 @@ class DecoderEngine:
         prompt token (its K/V is in the cache afterwards: decoding continues with the sampled token at position len)."""
         nseq = len(prompts)
         start = [0] * nseq if start is None else list(start)
+        rs = self.cfg.rope_scaling or {}
+        if rs.get("rope_type", rs.get("type")) in DYNAMIC_NTK and any(s + len(p) > int(rs["original_max_position_embeddings"]) for s, p in zip(start, prompts)):
+            # context_rope rotates EVERY token of such a prompt with the base of the prompt length: not the position-indexed table
+            raise NotImplementedError("dynamic-NTK RoPE: a prompt past the original context needs a per-request table; feed it through the decode path")
         bt = torch.as_tensor(block_table, dtype=torch.int32)
         self.check_room([s + len(p) for s, p in zip(start, prompts)], 0, bt, "prefill")
         dev, st = self.device, self._st()

@@ -264,10 +264,28 @@ def test_rope_styles_oracle_pinned_and_product_table(golden_dir=os.path.join(os.
           "rope_scaling": {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 8192}}
     mc, _ = loader.config_from_hf(hf)
     assert mc.rope_scaling["rope_type"] == "llama3"
+    # dynamic-NTK styles (rotary_position_embedding.h:889-902, :925-951): for DECODE the base is a function of the position (the writer
+    # passes the cached length as seq_len) -- one base per table row.  Host table == oracle table bit for bit (two independent
+    # restatements), rows inside the original context carry the unchanged base, the bases match the header's formulas by hand.
+    mc, _ = loader.config_from_hf({**hf, "rope_scaling": {"type": "dynamic", "factor": 2.0}})
+    assert mc.rope_scaling == {"type": "dynamic", "factor": 2.0, "original_max_position_embeddings": 131072}     # gpt_neox.py:128-134
+    mc, _ = loader.config_from_hf({**{k: v for k, v in hf.items() if k != "rope_scaling"}, "use_dynamic_ntk": True, "seq_length": 2048})
+    assert mc.rope_scaling == {"rope_type": "qwen_dynamic", "original_max_position_embeddings": 2048}            # models/qwen.py:293-295
     with pytest.raises(NotImplementedError):
-        loader.config_from_hf({**hf, "rope_scaling": {"type": "dynamic", "factor": 2.0}})
-    with pytest.raises(NotImplementedError):
-        model.rope_table(model.ModelConfig("t", 1, 256, 2, 2, 64, 512, 1024, rope_scaling={"type": "dynamic", "factor": 2.0}), "cpu")
+        loader.config_from_hf({**hf, "rope_scaling": {"type": "longrope", "factor": 2.0}})
+    for rs in ({"rope_type": "dynamic", "factor": 4.0, "original_max_position_embeddings": 64}, {"rope_type": "qwen_dynamic", "original_max_position_embeddings": 64}):
+        cfg = model.ModelConfig("t", 1, 256, 4, 2, 64, 512, 1024, rope_theta=1e4, max_pos=300, rope_scaling=rs)
+        tab = model.rope_table(cfg, "cpu")
+        assert torch.equal(tab, oracle.rope_cos_sin_scaled(64, 1e4, 300, rs))
+        chan = torch.arange(0, 64, 2).float() / 64
+        plain = torch.arange(300).float()[:, None] / torch.pow(torch.tensor(1e4), chan)[None, :]            # rope_inv_freq (:324-327): t / base^(2i/d)
+        assert torch.equal(tab[:65, :, 0], plain[:65].cos()) and float((tab[65:, :, 0] - plain[65:].cos()).abs().max()) > 0.5
+        bases = oracle.rope_dynamic_ntk_bases(64, 1e4, 300, rs)
+        if rs["rope_type"] == "dynamic":
+            assert abs(float(bases[128]) - 1e4 * (4.0 * 128 / 64 - 3.0) ** (64 / 62.0)) < 1e-2 * 1e4 * 1e-3
+        else:   # 128 = 2 x 64: log2 + 1 = 2 -> 2^2 - 1 = 3; 129: ceil(2.01) = 3 -> 7
+            assert abs(float(bases[128]) - 1e4 * 3.0 ** (64 / 62.0)) < 1.0 and abs(float(bases[129]) - 1e4 * 7.0 ** (64 / 62.0)) < 1.0
+        assert float(bases[64]) == 1e4 and float(bases[65]) > 1e4
     # the native shim tabulates the same styles from RopeConfig's field meanings (style 5 / 6, factor1 / factor2, max_pos, mscale)
     from rtp_llm_amd import native_ops
     ops = native_ops.load()
@@ -281,7 +299,13 @@ def test_rope_styles_oracle_pinned_and_product_table(golden_dir=os.path.join(os.
     want = oracle.rope_cos_sin_scaled(128, 5e5, 96, {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
                                                      "original_max_position_embeddings": 8192})
     assert torch.allclose(ops.rope_table(c), want, atol=2e-6, rtol=0)
-    c.rope_style = 3
+    c.rope_base, c.rope_style, c.rope_scale, c.rope_max_pos, c.max_seq_len = 10000.0, 3, 4.0, 32, 96          # DynamicNTK: base(p) past 32 positions
+    want = oracle.rope_cos_sin_scaled(128, 1e4, 96, {"rope_type": "dynamic", "factor": 4.0, "original_max_position_embeddings": 32})
+    assert torch.allclose(ops.rope_table(c), want, atol=2e-6, rtol=0) and float((want[40] - oracle.rope_cos_sin(128, 1e4, 96)[40]).abs().max()) > 0.5
+    c.rope_style = 4                                                                                            # QwenDynamicNTK
+    want = oracle.rope_cos_sin_scaled(128, 1e4, 96, {"rope_type": "qwen_dynamic", "original_max_position_embeddings": 32})
+    assert torch.allclose(ops.rope_table(c), want, atol=2e-6, rtol=0)
+    c.rope_style = 2                                                                                            # Glm2: not on this path
     with pytest.raises(RuntimeError):
         ops.rope_table(c)
 

@@ -658,7 +658,9 @@ def test_engine_large_batch_step_matches_oracle(parity):
 @pytest.mark.parametrize("scaling", [
     {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 16},
     {"type": "yarn", "factor": 4.0, "original_max_position_embeddings": 16, "beta_fast": 32, "beta_slow": 1},
-    {"type": "linear", "factor": 2.0}])
+    {"type": "linear", "factor": 2.0},
+    {"rope_type": "dynamic", "factor": 4.0, "original_max_position_embeddings": 16},      # RopeStyle::DynamicNTK: base(p) past the original context
+    {"rope_type": "qwen_dynamic", "original_max_position_embeddings": 8}])                # RopeStyle::QwenDynamicNTK
 def test_engine_scaled_rope_styles_match_oracle(scaling):
     """RoPE styles beyond Base (rotary_position_embedding.h:904-970: Llama-3.1 `llama3`, yarn, linear): a style only changes
     the position-indexed cos/sin table, so the kernels are the Base ones -- what is checked is that the table the engine
@@ -701,3 +703,16 @@ def test_engine_scaled_rope_styles_match_oracle(scaling):
         t0 = oracle.greedy(a)
     assert diverged
     print(f"scaled RoPE {scaling.get('rope_type', scaling.get('type'))}: max |logit error| {worst:.2e} over {steps} steps")
+    if scaling.get("rope_type") in model.DYNAMIC_NTK:
+        # a prompt past the original context is rotated with the base of ITS length (context_rope): not the position table -- refused, while a
+        # prompt inside the original context is the Base rotation and goes through
+        eng2 = model.DecoderEngine(cfg, model.weights_to(w, DEV), kv_int8=False, page=page, num_blocks=64, max_batch=4, max_seq_len=64, device=DEV)
+        with pytest.raises(NotImplementedError):
+            eng2.prefill([list(range(1, 30))], bt[:1])
+        short = list(range(1, 1 + int(scaling["original_max_position_embeddings"])))
+        lg = eng2.prefill([short], bt[:1])
+        okp = oracle.OracleKV(cfg.num_layers, 1, False)
+        ref = None
+        for pos_, t_ in enumerate(short):
+            _, ref = odec.forward_tokens(torch.tensor([t_], dtype=torch.int32), torch.tensor([pos_], dtype=torch.int32), okp, [0])
+        assert torch.allclose(lg.cpu(), ref, **TOL), float((lg.cpu() - ref).abs().max())

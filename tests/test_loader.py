@@ -87,7 +87,7 @@ def test_bf16_checkpoint_tensors_are_converted(tmp_path):
         assert torch.equal(L0["qkv_bias"], L1["qkv_bias"]) and torch.equal(L0["qkv"].q, L1["qkv"].q)
 
 
-@pytest.mark.parametrize("extra", [{"rope_scaling": {"rope_type": "dynamic", "factor": 8.0}}, {"rope_scaling": {"type": "longrope", "factor": 2.0}},
+@pytest.mark.parametrize("extra", [{"rope_scaling": {"rope_type": "mrope", "factor": 8.0}}, {"rope_scaling": {"type": "longrope", "factor": 2.0}},
                                    {"use_sliding_window": True}])
 def test_unsupported_position_schemes_are_rejected(tmp_path, extra):
     canon = model.synth_model(CFG, "fp16", "cpu", seed=9)
