@@ -41,8 +41,10 @@ struct WideParams {
     unsigned long long* stamps; // DBG & 4: wall_clock64 at start / after prologue / after the main loop / at the end, per wave
 };
 
-// tiles per round of the K-slice merge: all of them where the 8 x T x MB KB fit the LDS (<= 32 rows: one round, one barrier pair), 3 above
-constexpr int wide_merge_tiles(int MB, int T) { return MB <= 2 ? T : 3; }
+// LDS of the K-slice merge, ONE round at every row-block count: up to three row blocks every wave parks all its T x MB accumulator sets
+// (<= 120 KB); at four (160 KB would not fit) a wave keeps the row block whose index is its K slice in registers -- it is the wave that sums
+// that row block -- and parks the other three (120 KB)
+constexpr size_t wide_merge_bytes(int MB, int T) { return (size_t)8 * T * (MB == 4 ? 3 : MB) * 1024; }
 
 // T = tiles per wave; a block owns 2T tiles.  RING = chunks of weights a wave keeps requested ahead of the one it multiplies: 1 at 64 rows
 // (a phase of 20 four-MFMA units outlasts the HBM latency; the registers are the B fragments'), 2 at <= 32 rows, where a phase is
@@ -64,8 +66,9 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
     static_assert(XF <= NU - 8, "fragment writes, the barrier and the fragment reads must fit one phase");
     static_assert(RING == 1 || (RING == 2 && GS > 0), "two chunks ahead: group-wise instances only (per-channel meta lives in slot 0)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TR = wide_merge_tiles(MB, T);          // tiles per round of the K-slice merge
-    constexpr size_t RS_OFF = ((size_t)8 * TR * MB * 1024 > (size_t)2 * 4 * 4 * MB * 1024) ? (size_t)8 * TR * MB * 1024 : (size_t)2 * 4 * 4 * MB * 1024;   // behind the stage / merge regions: 64 floats
+    constexpr bool KEEP = MB == 4 && !(DBG & 8);         // merge: see wide_merge_bytes (DBG & 8, tuning build: the two-round form of rounds 1-4, for A/B)
+    constexpr int  TR = (MB == 4 && !KEEP) ? 3 : T;      // tiles per round
+    constexpr size_t RS_OFF = (wide_merge_bytes(MB, T) > (size_t)2 * 4 * 4 * MB * 1024) ? wide_merge_bytes(MB, T) : (size_t)2 * 4 * 4 * MB * 1024;   // behind the stage / merge regions: 64 floats
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -282,34 +285,68 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
     if constexpr (HAND) asm volatile("s_nop 15" ::: "memory"); // the last MFMAs' results are read by compiler code below
     __syncthreads(); // fragment regions are reused by the merge below
 
-    // ---- merge the four K slices through LDS (TR tiles per round), epilogue
+    // ---- merge the four K slices through LDS (one round), epilogue
     f32x4* red = reinterpret_cast<f32x4*>(smem);
+    // the summed set (tile tb of the block, row block mb): per-channel scale (W8), deferred RMSNorm, epilogue store
+    auto finish = [&](f32x4 v, int tb, int mb) {
+        const int m = mb * 16 + i, n0 = (t0 + tb) * 16 + q * 4;
+        if (WBITS != 16 && !GROUPED) {
 #pragma unroll
-    for (int r0 = 0; r0 < T; r0 += TR) {
-        if (r0) __syncthreads();
-#pragma unroll
-        for (int t = r0; t < r0 + TR && t < T; ++t)
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) red[((wave * TR + (t - r0)) * MB + mb) * 64 + lane] = acc[t][mb];
-        __syncthreads();
-        const int ntr = (T - r0 < TR) ? T - r0 : TR;
-        for (int id = wave; id < 2 * ntr * MB; id += NW) {
-            const int h = id / (ntr * MB), rem = id - h * (ntr * MB), tt = rem / MB, mb = rem - tt * MB;
-            const int tb = h * T + r0 + tt;              // tile inside the block
-            if (tb >= ntiles) continue;
-            f32x4 v = red[(((h * NKS + 0) * TR + tt) * MB + mb) * 64 + lane];
-#pragma unroll
-            for (int s = 1; s < NKS; ++s) v += red[(((h * NKS + s) * TR + tt) * MB + mb) * 64 + lane];
-            const int m = mb * 16 + i, n0 = (t0 + tb) * 16 + q * 4;
-            if (WBITS != 16 && !GROUPED) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint32_t mm = __builtin_amdgcn_raw_buffer_load_b32(rm, (uint32_t)(n0 + r) * 4u, 0, 0);
-                    v[r] *= (float)as_h2(mm)[1];
-                }
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t mm = __builtin_amdgcn_raw_buffer_load_b32(rm, (uint32_t)(n0 + r) * 4u, 0, 0);
+                v[r] *= (float)as_h2(mm)[1];
             }
-            if (wp.ssq && m < p.M) v *= reinterpret_cast<const float*>(smem + RS_OFF)[m];   // deferred RMSNorm of row m (see WideParams)
-            if (m < p.M) gemm_store(p, v, m, n0, blockIdx.y);
+        }
+        if (wp.ssq && m < p.M) v *= reinterpret_cast<const float*>(smem + RS_OFF)[m];   // deferred RMSNorm of row m (see WideParams)
+        if (m < p.M) gemm_store(p, v, m, n0, blockIdx.y);
+    };
+    if constexpr (KEEP) {
+        // wave (th, ks) parks the T x 3 sets of the row blocks != ks and sums row block ks of its half's T tiles: slices in order 0..3 as the
+        // two-round form did (its own slice straight from the registers), so the bits are the same
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                if (mb != ks) red[((size_t)(wave * (T * 3) + t * 3 + (mb < ks ? mb : mb - 1))) * 64 + lane] = acc[t][mb];
+        __syncthreads();
+        auto sum_kept = [&](auto ks_c) {
+            constexpr int KS = decltype(ks_c)::value;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int tb = th * T + t;
+                if (tb >= ntiles) continue;
+                f32x4 v;
+#pragma unroll
+                for (int s = 0; s < NKS; ++s) {
+                    const f32x4 term = (s == KS) ? acc[t][KS] : red[((size_t)((th * NKS + s) * (T * 3) + t * 3 + (KS < s ? KS : KS - 1))) * 64 + lane];
+                    v = (s == 0) ? term : v + term;
+                }
+                finish(v, tb, KS);
+            }
+        };
+        if (ks == 0) sum_kept(std::integral_constant<int, 0>{});
+        else if (ks == 1) sum_kept(std::integral_constant<int, 1>{});
+        else if (ks == 2) sum_kept(std::integral_constant<int, 2>{});
+        else sum_kept(std::integral_constant<int, MB - 1>{});
+    } else {
+#pragma unroll
+        for (int r0 = 0; r0 < T; r0 += TR) {
+            if (r0) __syncthreads();
+#pragma unroll
+            for (int t = r0; t < r0 + TR && t < T; ++t)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) red[((wave * TR + (t - r0)) * MB + mb) * 64 + lane] = acc[t][mb];
+            __syncthreads();
+            const int ntr = (T - r0 < TR) ? T - r0 : TR;
+            for (int id = wave; id < 2 * ntr * MB; id += NW) {
+                const int h = id / (ntr * MB), rem = id - h * (ntr * MB), tt = rem / MB, mb = rem - tt * MB;
+                const int tb = h * T + r0 + tt;          // tile inside the block
+                if (tb >= ntiles) continue;
+                f32x4 v = red[(((h * NKS + 0) * TR + tt) * MB + mb) * 64 + lane];
+#pragma unroll
+                for (int s = 1; s < NKS; ++s) v += red[(((h * NKS + s) * TR + tt) * MB + mb) * 64 + lane];
+                finish(v, tb, mb);
+            }
         }
     }
     if constexpr (DBG & 4) {
@@ -323,7 +360,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
 template <int WBITS, int MB, int GS, int T, int DBG = 0, int RING = 1>
 int launch_wide_t(const WideParams& wp, hipStream_t st) {
     auto k = gemm_wide_kernel<WBITS, MB, GS, T, DBG, RING>;
-    constexpr size_t red_b = (size_t)8 * wide_merge_tiles(MB, T) * MB * 1024, stage_b = (size_t)2 * 4 * 4 * MB * 1024;
+    constexpr size_t red_b = wide_merge_bytes(MB, T), stage_b = (size_t)2 * 4 * 4 * MB * 1024;
     constexpr size_t lds = (red_b > stage_b ? red_b : stage_b) + 256;   // + 1 / rms of the rows (deferred norm)
     if (int e = raise_dynamic_lds((const void*)k, "gemm_wide")) return e;
     hipLaunchKernelGGL(k, dim3(wp.G, wp.g.nsplit), dim3(512), lds, st, wp);
@@ -410,6 +447,7 @@ static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_
     else if (group_size == 32) rc = WIDE_W4_(1);
 #ifdef MI355_TUNING
     else if (mb2 && WIDE_DBG == 16) rc = launch_wide_t<4, 2, 4, T, 0, 1>(wp, st);   // one chunk ahead (the round-2..4 instance)
+    else if (!mb2 && WIDE_DBG == 18) rc = launch_wide_t<4, 4, 4, T, 8>(wp, st);       // K-slice merge in two rounds (rounds 1-4)
     else if (mb2 && WIDE_DBG == 17) rc = launch_wide_t<4, 2, 4, T, 0, 2>(wp, st);   // two row blocks whatever the row count
     else if (mb2 && WIDE_DBG == 2)  rc = launch_wide_t<4, 2, 4, T, 2, 2>(wp, st);   // instruction stream without weight traffic
     else if (mb2 && WIDE_DBG == 3)  rc = launch_wide_t<4, 2, 4, T, 3, 2>(wp, st);   // ... without any main-loop traffic
