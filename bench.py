@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+TRAFFIC_FILE = "r05_traffic.json"   # profiles/: PMC traffic of the engine's linears, tools/engine_traffic.sh
 
 WORKLOADS = {
     # name: (model, weight kind, kv_int8, default batch, default ctx, page)
@@ -297,35 +298,50 @@ def main():
     if args.shard_of > 1:
         out["invalid"] = f"debug run: one rank's shard of tp={args.shard_of}, collectives omitted"
 
-    if rank == 0 and world == 1:
-        # ---- roofline of the dominant kernel (weight-only dequant GEMM): algorithmic bytes / HIP-event time
-        bps = bytes_per_step(cfg, eng, B, ctx, kv_int8)
-        reset()
-        prof = eng.profile(B, 4)
+    def roofline_of(cfg_r, eng_r, reset_r, label, traffic_ok):
+        """`roofline` of the dominant kernel family (the four weight-only dequant GEMMs of a layer) on THIS rank's engine: algorithmic
+        bytes per launch (packed weights + activations in and out; under TP the rank's shard of both) / the mean HIP-event
+        duration of those launches, measured live on the launch stream by mi355_decoder_profile (eager steps).  Under TP every rank of
+        the group must call it together: the eager steps run the in-step all-reduces."""
+        bps_r = bytes_per_step(cfg_r, eng_r, B, ctx, kv_int8)
+        reset_r()
+        prof_r = eng_r.profile(B, 4)
         torch.cuda.synchronize()
-        gq = prof["gemm_quant"]
-        n_launch_step = 4 * cfg.num_layers
-        act_bytes = B * 2 * (cfg.hidden * 2 + cfg.nh * cfg.hd + (cfg.nh + 2 * cfg.nkv) * cfg.hd + 2 * cfg.inter) * cfg.num_layers
-        alg_bytes_launch = (bps["linears"] + act_bytes) / n_launch_step
+        gq = prof_r["gemm_quant"]
+        n_launch_step = 4 * cfg_r.num_layers
+        act_bytes = B * 2 * (cfg_r.hidden * 2 + cfg_r.nh * cfg_r.hd + (cfg_r.nh + 2 * cfg_r.nkv) * cfg_r.hd + 2 * cfg_r.inter) * cfg_r.num_layers
+        alg_bytes_launch = (bps_r["linears"] + act_bytes) / n_launch_step
         avg_ms = gq["ms"] / max(1, gq["launches"])
         ach = alg_bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_src = None, None
-        try:  # HBM read + write bytes per launch of THESE launches (the engine's four linears per layer), from the committed
-            # rocprofv3 --pmc passes over `bench.py --no-graph` (tools/engine_traffic.sh -> profiles/r04_traffic.json); PMC
-            # collection needs its own profiled runs, so it cannot happen inside this timed invocation: the value is static --
-            # and only quoted while the GEMM sources still hash to what was measured (a stale file reports null)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json"))).get(args.workload)
-            if tj and tj.get("batch") == B:
-                if tj.get("gemm_sources_sha") == gemm_sources_sha():
-                    traffic, traffic_src = int(tj["gemm_quant_bytes_per_launch"]), tj.get("source")
-                else:
-                    traffic_src = "stale: profiles/r04_traffic.json was collected for different sources of the GEMM / fold kernels (re-run tools/engine_traffic.sh)"
-        except Exception:  # noqa: BLE001
-            traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "the four quantised linears of a layer: gemm_fullk64_kernel (qkv + RoPE + KV write, o + residual), gemm_wide_kernel (gate_up + SiLU), gemm_splitk64_kernel (down)", "achieved": round(ach, 1),
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                           "bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_ms * 1e3, 3),
-                           "launches_timed": gq["launches"]}
+        if traffic_ok:
+            try:  # HBM read + write bytes per launch of THESE launches (the engine's four linears per layer), from the committed
+                # rocprofv3 --pmc passes over `bench.py --no-graph` (tools/engine_traffic.sh -> profiles/r05_traffic.json); PMC
+                # collection needs its own profiled runs, so it cannot happen inside this timed invocation: the value is static --
+                # and only quoted while the GEMM sources still hash to what was measured (a stale file reports null)
+                tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE))).get(args.workload)
+                if tj and tj.get("batch") == B:
+                    if tj.get("gemm_sources_sha") == gemm_sources_sha():
+                        traffic, traffic_src = int(tj["gemm_quant_bytes_per_launch"]), tj.get("source")
+                    else:
+                        traffic_src = f"stale: profiles/{TRAFFIC_FILE} was collected for different sources of the GEMM / fold kernels (re-run tools/engine_traffic.sh)"
+            except Exception:  # noqa: BLE001
+                traffic = None
+        else:
+            traffic_src = "no PMC pass exists for a TP shard (needs the multi-GPU node): null"
+        rl = {"bound": "hbm", "kernel": "the four quantised linears of a layer (qkv + RoPE + KV write, o + residual, gate_up + SiLU, down): gemm_fullk64_kernel / "
+                                        "gemm_wide_kernel / gemm_splitk64_kernel on the image path, gemm_wq_kernel otherwise", "layout": label,
+              "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+              "bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_ms * 1e3, 3), "launches_timed": gq["launches"]}
+        return rl, bps_r, prof_r
+
+    if rank == 0 and world > 1:   # N > 1: the line carries `roofline` and `cpu_baseline` too (rank 0's replica here; replaced by its TP shard below)
+        out["roofline"], _, _ = roofline_of(cfg, eng, reset, out["config"]["parallelism"], False)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg_full, kind, kv_int8, B, ctx)
+    if rank == 0 and world == 1:
+        # ---- roofline of the dominant kernel (weight-only dequant GEMM): algorithmic bytes / HIP-event time
+        out["roofline"], bps, prof = roofline_of(cfg, eng, reset, "tp1", True)
         total_b = sum(bps.values())
         out["step_roofline"] = {"bytes_per_step": int(total_b), "achieved_GBs": round(total_b / (ms_per_step * 1e-3) / 1e9, 1),
                                 "frac_of_8TBs": round(total_b / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -446,6 +462,12 @@ def main():
             for _ in range(3):
                 torch.cuda.synchronize(); barrier(); t0r = time.perf_counter(); trun(args.steps); torch.cuda.synchronize()
                 t_repeats.append(round(max_over_ranks(time.perf_counter() - t0r) / args.steps * 1e3, 4))
+            # roofline of the headline layout: every rank profiles its shard together (the eager steps run the in-step all-reduces)
+            tp_roof = None
+            try:
+                tp_roof, _, _ = roofline_of(tcfg, teng, treset, f"tp{tpn} (rank 0's shard)", False)
+            except Exception as e:  # noqa: BLE001
+                log(f"[rank {rank}] roofline pass of the TP layout failed ({type(e).__name__}: {e}); the line keeps the replica's")
             st = ar.status() if ar is not None else 0
             if st != 0:
                 raise RuntimeError(f"all-reduce spin timed out (status {st})")
@@ -461,6 +483,9 @@ def main():
                        scaling="strong" if dpn == 1 else "strong within a tp group, weak across the dp groups")
             out["config"].update(parallelism=tp_info["parallelism"], global_batch=B * dpn)
             out["tp_layout"], out["replica_layout"] = tp_info, replica
+            if tp_roof is not None:
+                out["replica_layout"]["roofline"] = out.get("roofline")
+                out["roofline"] = tp_roof
         except Exception as e:  # noqa: BLE001
             out["tp_layout"] = {"error": f"{type(e).__name__}: {e}"}
             out["replica_layout"] = replica
