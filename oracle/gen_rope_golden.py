@@ -9,6 +9,12 @@
             rtp_llm/models/llama.py:108-116); the published formula it implements is transformers' (5.15.0)
             modeling_rope_utils._compute_llama3_parameters, executed here for Llama-3.1's shipped rope_scaling.
 
+  * dynamic NTK ("dynamic"): the reference's own torch form of the style, DeepseekV3DynamicNTKScalingRotaryEmbedding
+            (rtp_llm/models/rotary_embedding/deepseek_rotary_embedding.py:80-113; in-kernel form DynamicNTK,
+            rotary_position_embedding.h:889-893), executed unmodified for a range of lengths past the original context: the
+            inverse frequencies of each length and the table row of its last position.  (QwenDynamicNTK, :895-902, has no torch form
+            in the reference: it stays unpinned.)
+
     python oracle/gen_rope_golden.py
 """
 import importlib.util
@@ -52,6 +58,20 @@ def main():
         assert att == 1.0
         out[tag + "_cfg"] = np.array([hd, theta, rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"], rs["original_max_position_embeddings"]], dtype=np.float64)
         out[tag + "_inv_freq"] = inv.float().numpy()
+    # dynamic NTK: the class rebuilds inv_freq from the length it is asked for (base in double precision, the rest fp32)
+    spec = importlib.util.spec_from_file_location("deepseek_rotary_embedding", os.path.join(REF, "rtp_llm/models/rotary_embedding/deepseek_rotary_embedding.py"))
+    dre = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dre)
+    for tag, (dim, base, factor, orig) in {"dynntk_a": (128, 1000000, 4.0, 32), "dynntk_b": (64, 10000, 2.0, 16)}.items():
+        lens = [orig - 3, orig, orig + 1, orig + 2, orig + 7, 2 * orig, 3 * orig + 5, 8 * orig]
+        inv, cos, sin = [], [], []
+        for S in lens:
+            m = dre.DeepseekV3DynamicNTKScalingRotaryEmbedding(dim, max_position_embeddings=orig, base=base, scaling_factor=factor)
+            m._set_cos_sin_cache(S, "cpu", torch.float32)
+            inv.append(m.inv_freq.numpy().copy()); cos.append(m.cos_cached[S - 1, :dim // 2].numpy().copy()); sin.append(m.sin_cached[S - 1, :dim // 2].numpy().copy())
+        out[tag + "_cfg"] = np.array([dim, base, factor, orig], dtype=np.float64)
+        out[tag + "_lens"] = np.array(lens, dtype=np.int64)
+        out[tag + "_inv_freq"] = np.stack(inv); out[tag + "_cos_last"] = np.stack(cos); out[tag + "_sin_last"] = np.stack(sin)
     np.savez(os.path.join(OUT, "rope_styles.npz"), **out)
     print("wrote", os.path.join(OUT, "rope_styles.npz"), {k: v.shape for k, v in out.items()})
 

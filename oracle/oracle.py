@@ -19,7 +19,11 @@ this path, each function citing the reference lines it follows.  Pinning status
     have that dtype): PINNED against the same reference implementations executed on bf16 tensors ->
     tests/golden/ref_layers_bf16.npz (RMSNorm bit-equal; RoPE / attention within one bf16 ulp).
   * Scaled RoPE styles (linear / llama3 / yarn): PINNED bit for bit, see rope_inv_freq and oracle/gen_rope_golden.py.
-  * Dynamic-NTK RoPE styles (rope_dynamic_ntk_bases): PARITY UNPINNED -- device code only in the reference, restated from the header.
+  * Dynamic-NTK RoPE (rope_dynamic_ntk_bases): "dynamic" PINNED (2e-6 relative: fp32 here and on the device, double in the torch form) against
+    the reference's own torch form of the style, DeepseekV3DynamicNTKScalingRotaryEmbedding (rtp_llm/models/rotary_embedding/
+    deepseek_rotary_embedding.py:80-113 -> tests/golden/rope_styles.npz dynntk_*, tests/test_cpu_host.py); that the DECODE writer passes the
+    cached length as seq_len is read off the device code (fused_rope_kvcache_kernel.cu:1341-1392).  "qwen_dynamic": PARITY UNPINNED --
+    device code only in the reference, restated from the header.
   * Chain rejection sampling (speculative verify): PINNED against the reference's own known-answer kernel tests
     (bindings/cuda/test/CudaSpeculativeSamplingTest.cc:36-366, transcribed in tests/spec_vectors.py).
   * W4A16 / W8A16 GEMM results and INT8 KV-cache numerics: PARITY UNPINNED — the reference
@@ -151,7 +155,9 @@ def rope_dynamic_ntk_bases(rope_dim: int, theta: float, max_pos: int, scaling: d
       * "qwen_dynamic" (RopeStyle::QwenDynamicNTK, :895-902): base (max(2 ^ ceil(log2(p / orig) + 1) - 1, 1)) ^ (dim / (dim - 2))
     so for decode the style IS a function of the position.  (A prompt longer than the original context rotates ALL its tokens with
     the base of the prompt length, context_rope: not a position-indexed table; the host refuses that case.)
-    UNPINNED: restated from the header's device code, which cannot run here; no golden vectors for these two styles."""
+    "dynamic" is pinned by the reference's torch form of the same formula (DeepseekV3DynamicNTKScalingRotaryEmbedding,
+    deepseek_rotary_embedding.py:80-113; golden vectors dynntk_* of tests/golden/rope_styles.npz); "qwen_dynamic" is UNPINNED: restated from
+    the header's device code, which cannot run here."""
     kind = scaling.get("rope_type", scaling.get("type"))
     orig = int(scaling["original_max_position_embeddings"])
     p = torch.arange(max_pos, dtype=torch.float32)

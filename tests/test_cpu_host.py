@@ -286,6 +286,29 @@ def test_rope_styles_oracle_pinned_and_product_table(golden_dir=os.path.join(os.
         else:   # 128 = 2 x 64: log2 + 1 = 2 -> 2^2 - 1 = 3; 129: ceil(2.01) = 3 -> 7
             assert abs(float(bases[128]) - 1e4 * 3.0 ** (64 / 62.0)) < 1.0 and abs(float(bases[129]) - 1e4 * 7.0 ** (64 / 62.0)) < 1.0
         assert float(bases[64]) == 1e4 and float(bases[65]) > 1e4
+    # "dynamic" pinned by the reference's own torch form of the style (DeepseekV3DynamicNTKScalingRotaryEmbedding,
+    # rtp_llm/models/rotary_embedding/deepseek_rotary_embedding.py:80-113, executed by oracle/gen_rope_golden.py): the inverse frequencies
+    # it rebuilds for a length S are those of the oracle's / the product's base at S (the class raises the base in double precision,
+    # the device code and its restatements in fp32: 2e-6 relative), inside the original context the plain base; and the table row the
+    # class holds for its last position S - 1 equals that position rotated with the base of S
+    for tag in ("dynntk_a", "dynntk_b"):
+        dim, base, factor, orig = (float(v) for v in g[tag + "_cfg"])
+        dim, orig = int(dim), int(orig)
+        rs = {"rope_type": "dynamic", "factor": factor, "original_max_position_embeddings": orig}
+        lens = [int(v) for v in g[tag + "_lens"]]
+        bases_o = oracle.rope_dynamic_ntk_bases(dim, base, max(lens) + 1, rs)
+        bases_p = model.dynamic_ntk_base(dim, base, torch.arange(max(lens) + 1), rs)
+        assert torch.equal(bases_o, bases_p)
+        chan = torch.arange(0, dim, 2).float() / dim
+        for i, S in enumerate(lens):
+            inv_ref = torch.from_numpy(g[tag + "_inv_freq"][i])
+            inv = 1.0 / torch.pow(bases_o[S], chan)
+            assert torch.allclose(inv, inv_ref, rtol=2e-6, atol=0), (tag, S, float(((inv - inv_ref) / inv_ref).abs().max()))
+            if S <= orig:
+                assert float(bases_o[S]) == base
+            ang = (S - 1) * inv
+            assert torch.allclose(ang.cos(), torch.from_numpy(g[tag + "_cos_last"][i]), atol=2e-4 * S / orig + 1e-6)
+            assert torch.allclose(ang.sin(), torch.from_numpy(g[tag + "_sin_last"][i]), atol=2e-4 * S / orig + 1e-6)
     # the native shim tabulates the same styles from RopeConfig's field meanings (style 5 / 6, factor1 / factor2, max_pos, mscale)
     from rtp_llm_amd import native_ops
     ops = native_ops.load()
