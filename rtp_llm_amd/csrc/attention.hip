@@ -516,9 +516,9 @@ __global__ __launch_bounds__(64 * NW) void paged_attn_kernel(const AttnParams p)
             if (p.P == 1) {
                 const float inv = l > 0.f ? 1.f / l : 0.f;          // padding row / empty context: zeros, not NaN
                 u32x2 ov;
-                if (BF && p.img_mblk > 0) {   // an image holds fp16 (common.h): the bf16-rounded outputs, converted exactly
-                    ov[0] = act_pack<false>(act_round<true>(acc[0] * inv), act_round<true>(acc[1] * inv));
-                    ov[1] = act_pack<false>(act_round<true>(acc[2] * inv), act_round<true>(acc[3] * inv));
+                if (BF && p.img_mblk > 0) {   // an image holds fp16 (common.h): the bf16-rounded outputs x 2^-8 (img_val)
+                    ov[0] = act_pack<false>(img_val<true>(act_round<true>(acc[0] * inv)), img_val<true>(act_round<true>(acc[1] * inv)));
+                    ov[1] = act_pack<false>(img_val<true>(act_round<true>(acc[2] * inv)), img_val<true>(act_round<true>(acc[3] * inv)));
                 } else {
                     ov[0] = act_pack<BF>(acc[0] * inv, acc[1] * inv); ov[1] = act_pack<BF>(acc[2] * inv, acc[3] * inv);
                 }
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void attn_reduce_kernel(const AttnParams p) {
     const float inv = l > 0.f ? 1.f / l : 0.f;
     uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + out_index(p, row, (gid - row * p.nh) * HD + lane * CPL, HD);
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) dst[c] = (BF && p.img_mblk > 0) ? act_to_bits<false>(act_round<true>(acc[c] * inv)) : act_to_bits<BF>(acc[c] * inv);
+    for (int c = 0; c < CPL; ++c) dst[c] = (BF && p.img_mblk > 0) ? act_to_bits<false>(img_val<true>(act_round<true>(acc[c] * inv))) : act_to_bits<BF>(acc[c] * inv);
 }
 
 #ifdef MI355_TUNING

@@ -204,15 +204,26 @@ __device__ __forceinline__ float rt_round(float v, bool bf) { return bf ? act_ro
 // runs (profiles/r04_fullk64_access_patterns.txt: 19.8 vs 11.2 us for the QKV launch at 64 rows).  The producers (RMSNorm,
 // attention) write this order directly: their 16-byte stores keep their size, only the address changes.
 // An image ALWAYS holds fp16: the GEMMs that read it run fp16 MFMAs on operand-side dequantised weights.  A bf16 step converts
-// on the way in (img_pack8 below) -- exact for every bf16 value inside the fp16 range (|x| < 65504; below 2^-14 it keeps fewer
-// bits, below 2^-24 it is zero: magnitudes that do not matter next to a row's typical element).
+// on the way in (img_pack8 below).  bf16 reaches 3.4e38, fp16 65504 -- and the SiLU * up product of a bf16 checkpoint is where
+// "massive activations" live -- so the image of a BF16 tensor holds fp16(x 2^-8) (kImgBfScale: exact, a power of two), saturated at
+// +-65504, and every GEMM that reads such an image multiplies its fp32 accumulators by 2^8 (kImgBfUnscale; gemm_fullk64 / gemm_wide /
+// gemm_splitk64, exact).  Range: |x| < 1.6e7.  Precision: elements below 2^-6 land in fp16's subnormals and keep an ABSOLUTE
+// spacing of 2^-16 -- finer than bf16's own spacing down to |x| = 2^-8, and below that 2^-17 absolute next to a row's typical
+// element.  (The deferred-norm image gamma 2^-e h' carries its own exponent, e + 8 for bf16: engine.cpp.)  fp16 steps: unscaled.
+constexpr float kImgBfScale = 0.00390625f, kImgBfUnscale = 256.f;
+// the fp16 an image stores for element v (already rounded to the BF-typed tensor it stands for)
+template <bool BF> __device__ __forceinline__ float img_val(float v) {
+    if constexpr (!BF) return v;
+    return __builtin_amdgcn_fmed3f(v * kImgBfScale, -65504.f, 65504.f);
+}
+__device__ __forceinline__ float rt_img_val(float v, bool bf) { return bf ? img_val<true>(v) : v; }
 // Element index of x[row][col]; mblk = row blocks of the image = ceil(M / 16).
 // 8 values of a BF-typed tensor (already rounded to it) -> the 16 bytes an image stores
 template <bool BF> __device__ __forceinline__ u32x4 img_pack8(const float (&o)[8]) {
     if constexpr (!BF) return act_pack8<false>(o);
     float r[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = act_round<true>(o[i]);
+    for (int i = 0; i < 8; ++i) r[i] = img_val<true>(act_round<true>(o[i]));
     return act_pack8<false>(r);
 }
 __host__ __device__ __forceinline__ size_t act_img_index(int row, int col, int mblk) {

@@ -291,7 +291,13 @@ static int add_rmsnorm_launch(const void* x_f16, const float* partials, int32_t 
     const int vpt = cdiv(H / 8, 512);
     mi355_touch_t tc = {};
     int spare = 0;                                   // blocks past the rows: 8 per 8 units (see the kernel), only while the launch stays inside one round of the CUs
-    if (touch && touch->qw && touch->n_units > 0 && touch->hh > 0 && M + cdiv(touch->n_units, 8) * 8 <= 256) { tc = *touch; spare = cdiv(touch->n_units, 8) * 8; if (TUNE(3) > 0) tc.delay = TUNE(3); }
+    static const int n_cus = [] {                    // CUs of the device (MI355X in SPX mode: 256); the touch relies on block b running on XCD b % 8
+        int dev = 0, n = 0;                          // (observed there, speed only): other CU counts / partition modes get no spare blocks
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        (void)hipGetLastError();
+        return n;
+    }();
+    if (touch && touch->qw && touch->n_units > 0 && touch->hh > 0 && n_cus == 256 && M + cdiv(touch->n_units, 8) * 8 <= n_cus) { tc = *touch; spare = cdiv(touch->n_units, 8) * 8; if (TUNE(3) > 0) tc.delay = TUNE(3); }
 #define L_(V, B)                                                                                                        \
     hipLaunchKernelGGL((add_rmsnorm_kernel<V, B>), dim3(M + spare), dim3(512), 0, st, (const f16*)x_f16, partials, nsplit, ld, M, \
                        (const f16*)bias, (const f16*)residual_in, (f16*)residual_out, (const f16*)weight, eps, H, (f16*)y, y_img_mblk, tc)
@@ -335,8 +341,17 @@ __global__ __launch_bounds__(256) void act_image_pack_kernel(const u32x4* __rest
     const int m = idx / nvec, c0 = (idx - m * nvec) * 8;
     const size_t a = ((size_t)m * K + c0) >> 3, b = act_img_index(m, c0, mblk) >> 3;
     float v[8];
-    if (unpack) { act_unpack8<false>(src[b], v); dst[a] = act_pack8<BF>(v); }
-    else        { act_unpack8<BF>(src[a], v);    dst[b] = act_pack8<false>(v); }
+    if (unpack) {
+        act_unpack8<false>(src[b], v);
+        if constexpr (BF) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= kImgBfUnscale;      // the image of a bf16 tensor holds x 2^-8 (common.h)
+        }
+        dst[a] = act_pack8<BF>(v);
+    } else {
+        act_unpack8<BF>(src[a], v);
+        dst[b] = img_pack8<BF>(v);
+    }
 }
 } // namespace
 
@@ -344,8 +359,8 @@ extern "C" size_t mi355_act_image_bytes(int32_t M, int32_t K) {
     return (M <= 0 || K <= 0) ? 0 : (size_t)cdiv(M, 16) * 16 * (size_t)((K + 31) & ~31) * 2;
 }
 
-// direction 0: row-major x [M][K] of act_dtype -> image (fp16: bf16 rows are converted, exactly inside the fp16 range);
-// 1: image -> row-major tensor of act_dtype
+// direction 0: row-major x [M][K] of act_dtype -> image (fp16; the image of a bf16 tensor holds x 2^-8, common.h img_val);
+// 1: image (of a tensor of act_dtype) -> row-major tensor of act_dtype
 extern "C" int mi355_act_image_pack(const void* src, int32_t M, int32_t K, void* dst, int32_t direction, int32_t act_dtype, mi355_stream_t stream) {
     MI355_CHECK_ARG(src && dst && M > 0 && M <= 64 && K > 0 && K % 32 == 0, "act_image_pack: M=%d (1..64) K=%d (%% 32 == 0)", M, K);
     MI355_CHECK_ARG(act_dtype == MI355_ACT_F16 || act_dtype == MI355_ACT_BF16, "act_image_pack: act_dtype=%d", act_dtype);

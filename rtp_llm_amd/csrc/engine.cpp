@@ -269,10 +269,7 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     // the 17-64-row full-K launches: W4 group-wise, K <= 5760 (gemm_fullk64.hip), single rank
     // (either activation dtype: the images are fp16, the epilogues store the step's dtype -- the few-row launches above are fp16 only,
     // mi355_fullk_weight_ok)
-    auto w64ok = [&](const mi355_weight_t* w) {
-        return w->qweight && w->meta && w->wbits == 4 && (w->group_size == 128 || w->group_size == 64 || w->group_size == 32) &&
-               w->K % 128 == 0 && w->K_pad == w->K && w->K_pad / 128 >= 4 && w->K_pad / 128 <= 45 && w->N % 16 == 0;
-    };
+    auto w64ok = [&](const mi355_weight_t* w) { return mi355_fullk64_weight_ok(w) != 0; };   // the launchers' own predicate (gemm.hip)
     d->img_qkv = cfg->kv_dtype == (bf_act ? MI355_KV_BF16 : MI355_KV_FP16) && cfg->rope_dim == cfg->hd && cfg->tp_size == 1;
     d->img_o = cfg->tp_size == 1;
     for (const auto& L : d->layers) { d->img_qkv = d->img_qkv && w64ok(&L.qkv); d->img_o = d->img_o && w64ok(&L.o); }
@@ -285,6 +282,9 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     for (const auto& L : d->layers)
         d->img_down = d->img_down && L.down.K % 128 == 0 && L.down.K_pad == L.down.K &&
                       mi355_gemm_splitk64_plan(64, L.down.N_pad / 16, L.down.K_pad / 128, L.down.wbits, L.down.group_size, kMaxSplits, nullptr) > 0;
+    // bf16: the wide GEMM's image entry only exists with an image OUTPUT (gemm.hip mi355_linear_deferred_norm_img): without the
+    // K-quarter down launch that reads it, gate_up goes back to norm launch + staged kernel instead of failing every step
+    if (bf_act && !d->img_down) d->img_gate_up = false;
     if (d->img_gate_up) {   // exponent of the deferred norm per layer: the largest |weight| of post_norm, read back once
         std::vector<uint16_t> g(cfg->hidden);
         for (const auto& L : d->layers) {

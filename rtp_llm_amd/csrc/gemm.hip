@@ -846,6 +846,10 @@ static bool img_weight_ok(const mi355_weight_t* w) {
            w->K % 128 == 0 && w->K_pad == w->K && w->K_pad / 128 >= 4 && w->N % 16 == 0;
 }
 
+// the predicate of the full-K image launches (gemm_fullk64.hip: <= 15 K-slice waves of <= 3 chunks), shared with decoder_create so
+// that the step driver and the launchers cannot drift apart
+extern "C" int mi355_fullk64_weight_ok(const mi355_weight_t* w) { return img_weight_ok(w) && w->K_pad / 128 <= 45; }
+
 // what block u of gemm_fullk64's QKV launch reads (internal.h: mi355_touch_t), for the spare blocks of the launch in front of it
 extern "C" int mi355_qkv_touch_plan(const mi355_weight_t* wqkv, int32_t hd, void* sink, mi355_touch_t* out) {
     if (!out || !sink || !img_weight_ok(wqkv) || (hd != 64 && hd != 128) || wqkv->N % hd != 0) return MI355_ERR_UNSUPPORTED;

@@ -242,17 +242,17 @@ __device__ __forceinline__ void gemm_store(const GemmParams& p, f32x4 v, int m, 
         for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
     }
     if (p.bf16 && p.y_img && p.mode != MODE_F32) {   // bf16 tensors around an fp16 image (wide kernel's image entry; no bias): the values the
-        if (p.mode == MODE_F16) {                        // bf16 tensor would hold, stored as fp16 (exact inside its range, see common.h)
+        if (p.mode == MODE_F16) {                        // bf16 tensor would hold x 2^-8, stored as fp16 (img_val, common.h)
             f16x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (f16)act_round<true>(v[r]);
+            for (int r = 0; r < 4; ++r) o[r] = (f16)img_val<true>(act_round<true>(v[r]));
             *reinterpret_cast<f16x4*>((f16*)p.y + act_img_index(m, n0, (p.M + 15) >> 4)) = o;
         } else {
             f16x2 o;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const float g = act_round<true>(v[2 * t]), u = act_round<true>(v[2 * t + 1]);
-                o[t] = (f16)act_round<true>((g / (1.f + __expf(-g))) * u);
+                o[t] = (f16)img_val<true>(act_round<true>((g / (1.f + __expf(-g))) * u));   // the SiLU product is where bf16 checkpoints exceed 65504
             }
             *reinterpret_cast<f16x2*>((f16*)p.y + act_img_index(m, n0 >> 1, (p.M + 15) >> 4)) = o;
         }

@@ -205,6 +205,10 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
     if (m >= p.M) continue;
 
     const bool bf = fp.bf16 != 0;                   // dtype of everything 16-bit around the GEMM (the image and the weights' dequant are fp16)
+    if (bf) {                                       // the image of a bf16 tensor holds x 2^-8 (common.h img_val): exact in fp32
+#pragma unroll
+        for (int t = 0; t < TPB; ++t) v[t] *= kImgBfUnscale;
+    }
     if constexpr (EPI == FK_RESID) {
 #pragma unroll
         for (int t = 0; t < TPB; ++t) {

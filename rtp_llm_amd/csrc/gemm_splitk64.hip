@@ -153,6 +153,7 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
         f32x4 v = red[((size_t)e) * 64 + lane];
 #pragma unroll
         for (int w = 1; w < NW; ++w) v += red[((size_t)w * (T * MB) + e) * 64 + lane];
+        if (p.bf16) v *= kImgBfUnscale;                  // the image of a bf16 tensor holds x 2^-8 (common.h img_val)
         if (m < p.M && t0 + t < p.NT)
             st_slab(rs, (uint32_t)((((size_t)by * p.M + m) * p.N_pad + (t0 + t) * 16 + q * 4) * 4), v);
     }

@@ -298,6 +298,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
             }
         }
         if (wp.ssq && m < p.M) v *= reinterpret_cast<const float*>(smem + RS_OFF)[m];   // deferred RMSNorm of row m (see WideParams)
+        else if (p.x_img && p.bf16) v *= kImgBfUnscale;   // a plain image of a bf16 tensor holds x 2^-8 (common.h img_val; the deferred norm's has its own exponent)
         if (m < p.M) gemm_store(p, v, m, n0, blockIdx.y);
     };
     if constexpr (KEEP) {

@@ -91,14 +91,27 @@ class CustomAllReduce:
         keys = [None] * self.world
         dist.all_gather_object(keys, self._device_key(), group=group)
         self.shared_device = len(set(keys)) < len(keys)
+        if self.shared_device and self.rank == 0:
+            import sys
+            print(f"[rtp_llm_amd.distributed] {self.world} ranks on {len(set(keys))} device(s): ranks share a GPU, the all-reduce spin bound is raised to 30 s",
+                  file=sys.stderr, flush=True)
         if self.shared_device if spin_timeout_ms is None else True:
             self.set_spin_timeout_ms(30000 if spin_timeout_ms is None else spin_timeout_ms)
 
     @staticmethod
     def _device_key():
         import socket
-        p = torch.cuda.get_device_properties(torch.cuda.current_device())
-        ident = getattr(p, "uuid", None) or (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", -1), getattr(p, "pci_device_id", -1))
+        import os
+        idx = torch.cuda.current_device()
+        p = torch.cuda.get_device_properties(idx)
+        ident = getattr(p, "uuid", None)
+        if not ident and getattr(p, "pci_bus_id", None) is not None:
+            ident = (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", -1))
+        if not ident:
+            # a torch build that exposes neither a uuid nor a PCI id: the ordinal inside this process's visible set -- never ONE key for
+            # every rank of a host (that would read as "all ranks share a device" and raise the spin bound on a real multi-GPU node)
+            ident = ("ordinal", idx, os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "")),
+                     os.environ.get("ROCR_VISIBLE_DEVICES", ""))
         return (socket.gethostname(), str(ident))
 
     def set_spin_timeout_ms(self, ms: int) -> None:

@@ -184,27 +184,29 @@ def qkv_rope_kv_write(x: torch.Tensor, wqkv: PackedWeight, qkv_bias, cos_sin, po
 # ---- activation images (5-64-row steps): see include/mi355_decode.h, mi355_act_image_*
 class ActImage:
     """The [M][K] activations of a 5-64-row step in the order the full-K launches read them (one dense 1 KB run per MFMA fragment)."""
-    def __init__(self, data: torch.Tensor, M: int, K: int):
-        self.data, self.M, self.K = data, M, K
+    def __init__(self, data: torch.Tensor, M: int, K: int, src: torch.dtype = torch.float16):
+        """src: dtype of the tensor the image stands for.  The data is always fp16; the image of a bf16 tensor holds x 2^-8, saturated
+        (csrc/common.h img_val: bf16 activations may exceed the fp16 range), and the GEMMs reading it scale their accumulators back."""
+        self.data, self.M, self.K, self.src = data, M, K, src
 
-    def unpack(self, dtype: torch.dtype = torch.float16) -> torch.Tensor:
-        """The row-major [M, K] tensor (fp16, or the image's values rounded to bf16)."""
-        out = torch.empty(self.M, self.K, dtype=dtype, device=self.data.device)
+    def unpack(self, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        """The row-major [M, K] tensor in the image's source dtype (or converted to `dtype`)."""
+        out = torch.empty(self.M, self.K, dtype=self.src, device=self.data.device)
         _C.check(_C.lib().mi355_act_image_pack(self.data.data_ptr(), self.M, self.K, out.data_ptr(), 1, _dt(out), _stream()), "act_image_pack")
-        return out
+        return out if dtype is None or dtype == self.src else out.to(dtype)
 
 
-def _new_image(M: int, K: int, dtype, device) -> ActImage:
+def _new_image(M: int, K: int, dtype, device, src: torch.dtype = torch.float16) -> ActImage:
     n = _C.lib().mi355_act_image_bytes(M, K) // 2
-    return ActImage(torch.zeros(n, dtype=dtype, device=device), M, K)
+    return ActImage(torch.zeros(n, dtype=dtype, device=device), M, K, src)
 
 
 def act_image_pack(x: torch.Tensor) -> ActImage:
-    """Row-major [M, K] -> image.  Images hold fp16 (the GEMMs that read them run fp16 MFMAs): bf16 rows are converted, exactly
-    inside the fp16 range."""
+    """Row-major [M, K] -> image.  Images hold fp16 (the GEMMs that read them run fp16 MFMAs): bf16 rows are stored as x 2^-8
+    (ActImage.src)."""
     _chk_act(x, "act_image_pack.x")
     M, K = x.shape
-    img = _new_image(M, K, torch.float16, x.device)
+    img = _new_image(M, K, torch.float16, x.device, x.dtype)
     _C.check(_C.lib().mi355_act_image_pack(x.data_ptr(), M, K, img.data.data_ptr(), 0, _dt(x), _stream()), "act_image_pack")
     return img
 
@@ -213,7 +215,7 @@ def add_rmsnorm_img(x: torch.Tensor, residual: Optional[torch.Tensor], weight: t
     """(y_img, residual_out): add_rmsnorm (rmsnorm when residual is None) with y written as an activation image."""
     _chk_act(x, "add_rmsnorm_img.x"); _chk_act(weight, "add_rmsnorm_img.weight", x)
     M, H = x.shape
-    img = _new_image(M, H, torch.float16, x.device)          # fp16 whatever the dtype of x (a bf16 result is converted on the way in)
+    img = _new_image(M, H, torch.float16, x.device, x.dtype)  # fp16 data whatever the dtype of x (a bf16 result is converted on the way in)
     res_out = torch.empty_like(x) if residual is not None else None
     _C.check(_C.lib().mi355_add_rmsnorm_img(x.data_ptr(), None, 0, 0, _p(bias), _p(residual), _p(res_out), weight.data_ptr(), eps, M, H,
                                             img.data.data_ptr(), _dt(x), _stream()), "add_rmsnorm_img")
@@ -226,7 +228,7 @@ def paged_attention_rows_img(q: torch.Tensor, kv_base, scale_base, block_table: 
     _chk_act(q, "paged_attention_rows_img.q"); _chk(block_table, torch.int32, "block_table"); _chk(positions, torch.int32, "positions")
     T, nh, hd = q.shape
     kv = kv_struct(kv_base, scale_base, page, nkv, hd, q.dtype)
-    img = _new_image(T, nh * hd, torch.float16, q.device)
+    img = _new_image(T, nh * hd, torch.float16, q.device, q.dtype)
     need = _C.lib().mi355_paged_attn_workspace_bytes(T, nh, hd, max_seq_len)
     ws = _workspace(need, q.device)
     _C.check(_C.lib().mi355_paged_attn_rows_img(q.data_ptr(), C.byref(kv), block_table.data_ptr(), block_table.shape[1], positions.data_ptr(),
@@ -304,7 +306,7 @@ def linear_deferred_norm_img(xg: ActImage, dn, w: PackedWeight, bias: Optional[t
         st = _C.DeferredNorm(ssq.data_ptr(), w.K // 16, ssq.shape[1], float(eps), float(2.0 ** e))
     N_out = w.N // 2 if (epilogue & _C.EPI_SILU_MUL) else w.N
     if epilogue & _C.EPI_OUT_IMAGE:          # the output as an activation image (the input of linear_partial_img)
-        yi = _new_image(xg.M, N_out, torch.float16, xg.data.device)
+        yi = _new_image(xg.M, N_out, torch.float16, xg.data.device, act)
         y = yi.data
     else:
         yi = None

@@ -316,7 +316,10 @@ def test_image_path_layer_with_bf16_tensors_vs_oracle(M):
     xn_img, _ = ops.add_rmsnorm_img(h0.to(DEV), None, g_in.to(DEV), eps)
     assert xn_img.data.dtype == torch.float16
     xn_ref = oracle.rmsnorm(h0, g_in, eps)
-    assert torch.equal(xn_img.unpack().cpu(), xn_ref.to(torch.float16))                  # the bf16 result, converted exactly
+    # the bf16 result x 2^-8 as fp16 (csrc/common.h img_val): exact down to |x| = 2^-6, an absolute spacing of 2^-16 below
+    got_xn = xn_img.unpack().cpu()
+    assert got_xn.dtype == BF and torch.allclose(got_xn.float(), xn_ref.float(), atol=2.0 ** -17, rtol=0)
+    assert torch.equal(got_xn[xn_ref.abs() >= 2.0 ** -6], xn_ref[xn_ref.abs() >= 2.0 ** -6])
     max_blocks, nblk = 8, 1024
     c2 = model.ModelConfig("t", 1, H, nh, nkv, hd, 64, 128, max_pos=max_blocks * page)
     cs = oracle.rope_cos_sin(hd, c2.rope_theta, c2.max_pos)
@@ -344,9 +347,51 @@ def test_image_path_layer_with_bf16_tensors_vs_oracle(M):
     assert isinstance(act_img, ops.ActImage)
     act_ref = oracle.silu_mul(oracle.linear(oracle.rmsnorm(h1.cpu(), g_post, eps), Wg, None))
     act = act_img.unpack().cpu()
-    assert torch.equal(act, act.to(BF).to(torch.float16))                                 # bf16-representable values
+    assert act.dtype == BF                                                                # the image stands for a bf16 tensor
     assert torch.allclose(act.float(), act_ref.float(), **TOL), float((act.float() - act_ref.float()).abs().max())
     slabs = ops.linear_partial_img(act_img, wd)
     assert slabs is not None
     down_ref = oracle.linear(act.to(BF), Wd, None)
     assert torch.allclose(slabs.sum(0)[:, :H].cpu(), down_ref.float(), atol=4e-2, rtol=2e-2)
+
+
+def test_bf16_images_carry_activations_beyond_the_fp16_range():
+    """bf16 reaches 3.4e38, an activation image stores fp16: the image of a bf16 tensor holds x 2^-8 (csrc/common.h img_val) and the GEMMs
+    that read it multiply their accumulators by 2^8, so the "massive activations" of bf16 checkpoints -- the SiLU * up product above
+    all -- pass through the image launches: values up to 1.6e7 instead of inf beyond 65504.  Checked on the two places
+    they occur: down_proj reading such an image, and gate_up's SiLU epilogue writing one."""
+    cfg = model.QWEN2_7B
+    H, I, M = cfg.hidden, cfg.inter, 17
+    g = _gen(99)
+    cd = model.synth_linear(I, H, "w4", "cpu", _gen(5), zeros="centered")
+    wd, Wd = cd.pack(dtype=BF).to(DEV), _dense(cd)
+    x = torch.randn(M, I, generator=g)
+    big = torch.rand(M, I, generator=g) < 1e-3                      # a few elements per row far beyond the fp16 range
+    x = torch.where(big, x * 4e5, x).to(BF)
+    assert float(x.float().abs().max()) > 65504 * 4
+    img = ops.act_image_pack(x.to(DEV))
+    assert torch.isfinite(img.data.float()).all()
+    back = img.unpack().cpu()
+    keep = x.abs() >= 2.0 ** -6
+    assert torch.equal(back[keep], x[keep]) and torch.allclose(back.float(), x.float(), atol=2.0 ** -17, rtol=0)
+    slabs = ops.linear_partial_img(img, wd)
+    assert slabs is not None
+    got, ref = slabs.sum(0)[:, :H].cpu(), oracle.linear(x, Wd, None, out_f32=True)
+    assert torch.isfinite(got).all() and torch.allclose(got, ref, atol=2e-3 * float(ref.abs().max()), rtol=1e-2), float((got - ref).abs().max())
+    # gate_up with scales x 700: gate and up are O(300) (xavier weights give O(0.4) on normalised rows), their SiLU product reaches 1e5-1e6
+    cg = model.synth_linear(H, 2 * I, "w4", "cpu", _gen(6), zeros="centered")
+    cg.scales = (cg.scales.float() * 700).half()
+    wg, Wg = cg.pack(gate_up=True, dtype=BF).to(DEV), _dense(cg)
+    co = model.synth_linear(H, H, "w4", "cpu", _gen(7), zeros="centered")
+    wo = co.pack(dtype=BF).to(DEV)
+    h0 = (torch.randn(M, H, generator=g) * 2.0).to(BF)
+    g_post = (1.0 + 0.2 * torch.randn(H, generator=g)).to(BF)
+    attn = (torch.randn(M, H, generator=g) * 0.5).to(BF)
+    h1, xg, ssq, e = ops.linear_residual_prenorm_img(ops.act_image_pack(attn.to(DEV)), wo, h0.to(DEV), g_post.to(DEV))
+    act_img = ops.linear_deferred_norm_img(xg, (ssq, 1e-6, e), wg, None, _C.EPI_SILU_MUL | _C.EPI_OUT_IMAGE, act=BF)
+    act_ref = oracle.silu_mul(oracle.linear(oracle.rmsnorm(h1.cpu(), g_post, 1e-6), Wg, None))
+    assert float(act_ref.float().abs().max()) > 2 * 65504, float(act_ref.float().abs().max())
+    assert torch.isfinite(act_img.data.float()).all()
+    act = act_img.unpack().cpu().float()
+    # the products of two O(300) bf16-rounded factors: relative tolerance of the bf16 steps (3e-2), absolute 1e-3 of the largest element
+    assert torch.allclose(act, act_ref.float(), atol=1e-3 * float(act_ref.float().abs().max()), rtol=3e-2), float((act - act_ref.float()).abs().max())

@@ -198,4 +198,7 @@ def test_full_depth_bf16_b64_vs_oracle(full_model, parity):
     for l in range(cfg.num_layers):
         for b in range(64):
             kvcache.write_tokens(eng.kv[l], None, bt[b], 0, base.K[l][b][:CTX - 1], base.V[l][b][:CTX - 1])
-    _run("bf16-b64", cfg, eng, odec, base.fork(64), bt, 64, 1, parity)
+    # bf16 keeps 8 significant bits: one ulp of a logit of magnitude 2-4 is 0.016, and 28 layers of one-ulp flips between the
+    # kernels' and the oracle's summation orders reach the lm_head -- 2.9e-2 measured (fp16 at the same depth: 3.7e-3), so the step is
+    # held to the 3e-2 of the bf16 tests (tests/test_gpu_bf16.py), greedy ids identical on every row whose top-2 margin exceeds it
+    _run("bf16-b64", cfg, eng, odec, base.fork(64), bt, 64, 1, parity, tol=3e-2)
