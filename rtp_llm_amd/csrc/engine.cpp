@@ -9,7 +9,7 @@
 // and the per-batch-size graph capture of rtp_llm/cpp/cuda_graph/cuda_graph_runner.cc.
 //
 // Launches per layer (tp = 1):
-//   * 5-64 rows, W4 group-wise weights, 16-bit cache (round 4): SIX launches, activations handed over as fragment-ordered images
+//   * 5-64 rows (bf16 and per-channel W8: 1-64), W4 group-wise or W8 per-channel weights, 16-bit cache (rounds 4-5): SIX launches, activations handed over as fragment-ordered images
 //     (common.h act_img_index): QKV + bias + RoPE + KV write (gemm_fullk64.hip) -> paged attention (+ partition reduce) ->
 //     O + residual, leaving gamma 2^-e h' as an image and the sums of squares -> gate_up + SiLU with the RMSNorm finished on its
 //     accumulators (gemm_wide.hip) -> down as 4 K-quarters (gemm_splitk64.hip) -> fold: slabs + residual + RMSNorm -> image;
@@ -274,7 +274,9 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     d->img_o = cfg->tp_size == 1;
     for (const auto& L : d->layers) { d->img_qkv = d->img_qkv && w64ok(&L.qkv); d->img_o = d->img_o && w64ok(&L.o); }
     if (TUNE(5) == 2) d->img_qkv = d->img_o = false;   // tuning build: A/B against the split-K + fold launches
-    if (d->img_qkv && d->img_o) d->fuse_rows = bf_act ? 0 : 4;   // bf16: no few-row full-K launches to cross over to (the staged kernels lose at every height)
+    // bf16 / W8: no few-row full-K launches to cross over to (gemm_fullk.hip takes fp16 steps of W4 / fp16 weights; the staged kernels lose
+    // at every height): the image launches serve 1-64 rows
+    if (d->img_qkv && d->img_o) d->fuse_rows = (bf_act || !(d->fuse_qkv && d->fuse_o && d->fuse_down)) ? 0 : 4;
     if (TUNE(6) > 0) d->fuse_rows = TUNE(6) == 99 ? 0 : TUNE(6);   // tuning build: crossover experiments (tools/batch_sweep.py --tune 6=N)
     d->img_gate_up = d->img_o && cfg->hidden % 64 == 0 && TUNE(5) != 3;
     for (const auto& L : d->layers) d->img_gate_up = d->img_gate_up && mi355_gemm_wide_direct_ok(&L.gate_up);

@@ -842,21 +842,22 @@ extern "C" int mi355_fullk_weight_ok(const mi355_weight_t* w) {
 // the launches on activation images (gemm_fullk64 / gemm_splitk64 / gemm_wide image entries): W4 group-wise weights in the native
 // image; the activation dtype of the surrounding tensors is free (the image itself is fp16, see common.h)
 static bool img_weight_ok(const mi355_weight_t* w) {
-    return w && w->qweight && w->meta && w->wbits == 4 && (w->group_size == 128 || w->group_size == 64 || w->group_size == 32) &&
-           w->K % 128 == 0 && w->K_pad == w->K && w->K_pad / 128 >= 4 && w->N % 16 == 0;
+    const bool fmt = w && w->qweight && w->meta && ((w->wbits == 4 && (w->group_size == 128 || w->group_size == 64 || w->group_size == 32)) ||
+                                                    (w->wbits == 8 && w->group_size == 0));   // round 5: per-channel W8 (load-time INT8 autoquant)
+    return fmt && w->K % 128 == 0 && w->K_pad == w->K && w->K_pad / 128 >= 4 && w->N % 16 == 0;
 }
 
 // the predicate of the full-K image launches (gemm_fullk64.hip: <= 15 K-slice waves of <= 3 chunks), shared with decoder_create so
 // that the step driver and the launchers cannot drift apart
-extern "C" int mi355_fullk64_weight_ok(const mi355_weight_t* w) { return img_weight_ok(w) && w->K_pad / 128 <= 45; }
+extern "C" int mi355_fullk64_weight_ok(const mi355_weight_t* w) { return img_weight_ok(w) && w->K_pad / 128 <= (w->wbits == 8 ? 30 : 45); }
 
 // what block u of gemm_fullk64's QKV launch reads (internal.h: mi355_touch_t), for the spare blocks of the launch in front of it
 extern "C" int mi355_qkv_touch_plan(const mi355_weight_t* wqkv, int32_t hd, void* sink, mi355_touch_t* out) {
     if (!out || !sink || !img_weight_ok(wqkv) || (hd != 64 && hd != 128) || wqkv->N % hd != 0) return MI355_ERR_UNSUPPORTED;
     const int KC = wqkv->K_pad / 128;
     out->qw = wqkv->qweight; out->meta = wqkv->meta;
-    out->run_bytes = (uint32_t)KC * 1024u;                               // W4: 1 KB per (tile, chunk), a tile's chunks back to back
-    out->meta_groups = (uint32_t)(wqkv->K_pad / wqkv->group_size); out->meta_stride = (uint32_t)wqkv->N_pad;
+    out->run_bytes = (uint32_t)KC * 256u * (uint32_t)wqkv->wbits;        // 1 KB (W4) / 2 KB (W8) per (tile, chunk), a tile's chunks back to back
+    out->meta_groups = wqkv->group_size > 0 ? (uint32_t)(wqkv->K_pad / wqkv->group_size) : 1u; out->meta_stride = (uint32_t)wqkv->N_pad;
     out->n_units = wqkv->N / 32; out->hh = hd / 32; out->sink = sink; out->delay = 0;
     return MI355_OK;
 }

@@ -546,6 +546,12 @@ bool fullk_shape_ok(const GemmParams& g, int wbits, int& group_size) {
 
 } // namespace
 
+// the launches on activation images (gemm_fullk64.hip): W4 group-wise or per-channel W8 (group_size 0)
+static bool fullk64_shape_ok(const GemmParams& g, int wbits, int group_size) {
+    const bool fmt = (wbits == 4 && (group_size == 128 || group_size == 64 || group_size == 32)) || (wbits == 8 && group_size == 0);
+    return fmt && g.M >= 1 && g.M <= 64 && g.K % 128 == 0 && g.K == g.KC * 128 && (uint64_t)g.M * g.K * 2 < 0x7FFFFFF0ull && g.KC >= 4;
+}
+
 #ifdef MI355_FULLK_STAMPS
 unsigned long long* g_fullk_stamps = nullptr;   // also read by gemm_fullk64.hip
 extern "C" void mi355_debug_fullk_stamps(void* p) { g_fullk_stamps = (unsigned long long*)p; }
@@ -554,7 +560,7 @@ extern "C" void mi355_debug_fullk_stamps(void* p) { g_fullk_stamps = (unsigned l
 #define FK_SET_STAMPS(fp) do { } while (0)
 #endif
 
-// 1-64 rows, W4 group-wise, K <= 5760, activations as an image (mi355_act_image_*): gemm_fullk64.hip
+// 1-64 rows, W4 group-wise (K <= 5760) or per-channel W8 (group_size 0, K <= 3840), activations as an image (mi355_act_image_*): gemm_fullk64.hip
 extern "C" int mi355_gemm_fullk64(const void* fp, int epi, int group_size, mi355_stream_t stream);
 
 static void set_norm(FullKParams& fp, const mi355_fused_norm_t* n) {
@@ -622,7 +628,7 @@ extern "C" int mi355_gemm_fullk_residual_img(const void* gp, int wbits, int grou
                                              mi355_stream_t stream) {
     FullKParams fp{};
     fp.g = *reinterpret_cast<const GemmParams*>(gp);
-    if (wbits != 4 || !fullk_shape_ok(fp.g, wbits, group_size) || fp.g.N % 4 != 0) return MI355_ERR_UNSUPPORTED;
+    if (!fullk64_shape_ok(fp.g, wbits, group_size) || fp.g.N % 4 != 0) return MI355_ERR_UNSUPPORTED;
     fp.res_in = (const f16*)residual_in; fp.res_out = (f16*)residual_out; fp.ssq_out = ssq_out; fp.ssq_ld = ssq_ld;
     fp.xg_img = (f16*)xg_img; fp.xg_gamma = (const f16*)norm_weight; fp.xg_scale = xg_scale;   // deferred RMSNorm of the produced rows (or null)
     fp.bf16 = fp.g.bf16;                                                                      // dtype of bias / residual / norm weight
@@ -635,7 +641,7 @@ extern "C" int mi355_gemm_fullk_rope_img(const void* gp, int wbits, int group_si
                                          mi355_stream_t stream) {
     FullKParams fp{};
     fp.g = *reinterpret_cast<const GemmParams*>(gp);
-    if (wbits != 4 || !fullk_shape_ok(fp.g, wbits, group_size)) return MI355_ERR_UNSUPPORTED;
+    if (!fullk64_shape_ok(fp.g, wbits, group_size)) return MI355_ERR_UNSUPPORTED;
     // a 16-bit cache of the activation dtype (the epilogue stores the rotated K / V rows as they are; INT8 caches: rope_kv.hip)
     if (kv->kv_dtype != (fp.g.bf16 ? MI355_KV_BF16 : MI355_KV_FP16) || (kv->hd != 64 && kv->hd != 128)) return MI355_ERR_UNSUPPORTED;
     fp.bf16 = fp.g.bf16;

@@ -21,18 +21,23 @@
 //     operands (bias / residual rows, position -> block id -> rotation row) were requested before the main loop.
 // Weight image, dequant (operand side: exact subtract of the biased code, one rounding) and epilogue arithmetic are those of
 // gemm_fullk.hip / rope_kv.hip, so the results are interchangeable with the composed launches.
+// Round 5: per-channel W8 (load-time INT8 autoquant, device_impl.py:183-222) instances -- WB = 8: two wave-loads per (tile, chunk),
+// the operand is the exact integer u - 128 (4 v_perm + 4 v_pk_add per 8 weights, no scale), the column's scale multiplies the
+// summed accumulators in the epilogue (staged in LDS by the helper wave with the other epilogue operands).
 #include "gemm_fullk.h"
 
 namespace {
 
 // LDS behind the slices' partial sums: what the epilogue needs besides the sums, staged by the helper wave
 template <int EPI> struct Stage64 {};
-template <> struct Stage64<FK_RESID> { f16 res[64][32]; f16 bias[32]; f16 gam[32]; };          // residual rows / bias / norm weight of the block's two tiles
-template <> struct Stage64<FK_ROPE>  { float cs[64][32]; int pos[64], blk[64]; f16 bias[32]; }; // rotation row of the block's 16 dims per token, position, block id
+template <> struct Stage64<FK_RESID> { f16 res[64][32]; f16 bias[32]; f16 gam[32]; float wsc[32]; };          // residual rows / bias / norm weight of the block's two tiles (+ W8: the columns' scales)
+template <> struct Stage64<FK_ROPE>  { float cs[64][32]; int pos[64], blk[64]; f16 bias[32]; float wsc[32]; }; // rotation row of the block's 16 dims per token, position, block id
 
-template <int GS, int MB, int EPI, int CPW, int RING>
+template <int WB, int GS, int MB, int EPI, int CPW, int RING>
 __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp) {
     constexpr int TPB = 2;
+    constexpr bool W8 = WB == 8;                     // per-channel INT8 (GS is then a dummy 4)
+    constexpr int LPC = WB / 4;                      // 1 KB wave-loads per (tile, chunk)
     constexpr int NSUB = 4 / GS, SPG = 4 / NSUB;     // GS: 4 -> g128, 2 -> g64, 1 -> g32: (zero, scale) words per chunk and column, k-steps per word
     constexpr int NF = CPW * 4 * MB;                 // activation fragments of a wave: (chunk c, k-step s, row block mb), f = (c * 4 + s) * MB + mb
     constexpr uint32_t FLAGS = 0x00020000u, OOBX = 0x80000000u, OOBS = 0x40000000u;   // out of range (lane / wave offsets)
@@ -71,6 +76,11 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
         // =============================================================== helper wave: no K slice.  It stages the epilogue's operands
         // in LDS while the K waves stream: the chain position -> block id -> rotation row is two dependent round trips, and inside a
         // K wave every one of its waits would also wait for the weights and the ring in flight (vmcnt is in order)
+        if constexpr (W8) {                          // per-channel scales of the block's 32 columns: lane = (tile l / 16, column l % 16)
+            float sc = 0.f;
+            if (lane < 32 && tile[lane >> 4] < p.NT) sc = (float)as_h2(p.meta[tile[lane >> 4] * 16 + (lane & 15)])[1];
+            if (lane < 32) sg.wsc[lane] = sc;
+        }
         if constexpr (EPI == FK_RESID) {
             // rows x 32 columns of the residual stream: lane = (row i * 16 + l / 4, 16-byte part l % 4); parts 0-1 tile 0, 2-3 tile 1
             __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)fp.res_in, 0, (uint32_t)((size_t)p.M * p.N * 2), FLAGS);
@@ -120,10 +130,10 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
 #pragma unroll
     for (int t = 0; t < TPB; ++t) {
         const bool ok = tile[t] < p.NT && !(fp.ilv & 2);
-        const char* wb = (const char*)p.qw + ((size_t)tile[t] * p.KC + c0) * 1024;
-        rw[t] = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, ok ? n_ch * 1024 : 0, FLAGS);
+        const char* wb = (const char*)p.qw + ((size_t)tile[t] * p.KC + c0) * (LPC * 1024);
+        rw[t] = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, ok ? n_ch * LPC * 1024 : 0, FLAGS);
         const char* mb_ = (const char*)p.meta + ((size_t)c0 * NSUB * p.N_pad + tile[t] * 16) * 4;
-        rm[t] = __builtin_amdgcn_make_buffer_rsrc((void*)mb_, 0, ok ? ((n_ch * NSUB - 1) * p.N_pad + 16) * 4 : 0, FLAGS);
+        rm[t] = __builtin_amdgcn_make_buffer_rsrc((void*)mb_, 0, (ok && !W8) ? ((n_ch * NSUB - 1) * p.N_pad + 16) * 4 : 0, FLAGS);
     }
     // activations of the slice: the image's fragments (k-step 4 (c0 + c) + s, row block mb), 1 KB each (common.h act_img_index);
     // fp.ilv: timing experiments of the tuning build (1: no activation traffic, 2: no weight traffic -- same instruction stream)
@@ -132,16 +142,19 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (fp.ilv & 1) ? 0u : (uint32_t)(n_ch * 4 * MBLK * 1024), FLAGS);
 
     // ---- 1. all weights of the slice (HBM, non-temporal: read once by one CU)
-    u32x4    wr[CPW][TPB];
+    u32x4    wr[CPW][TPB][LPC];
     uint32_t mr[CPW][TPB][NSUB];
 #pragma unroll
     for (int c = 0; c < CPW; ++c)
 #pragma unroll
         for (int t = 0; t < TPB; ++t) {
-            wr[c][t] = bload128<2 /*nt*/>(rw[t], lane16, (uint32_t)c * 1024u);
 #pragma unroll
-            for (int gi = 0; gi < NSUB; ++gi)
-                mr[c][t][gi] = __builtin_amdgcn_raw_buffer_load_b32(rm[t], jj4, (uint32_t)(c * NSUB + gi) * (uint32_t)p.N_pad * 4u, 0);
+            for (int lp = 0; lp < LPC; ++lp) wr[c][t][lp] = bload128<2 /*nt*/>(rw[t], lane16, (uint32_t)(c * LPC + lp) * 1024u);
+            if constexpr (!W8) {
+#pragma unroll
+                for (int gi = 0; gi < NSUB; ++gi)
+                    mr[c][t][gi] = __builtin_amdgcn_raw_buffer_load_b32(rm[t], jj4, (uint32_t)(c * NSUB + gi) * (uint32_t)p.N_pad * 4u, 0);
+            }
         }
 
     // ---- 2. activation ring, fully static: slot f % RING holds fragment f
@@ -161,15 +174,21 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
         for (int mb = 0; mb < MB; ++mb) acc[t][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const W4Consts w4c = w4_consts();
     const f16x2 c960 = {(f16)960.f, (f16)960.f};
+    const f16x2 zn8 = {(f16)-1152.f, (f16)-1152.f};  // W8: byte u under the exponent of 1024 (v_perm), minus 1024 + 128: the exact integer q
     f16x8 a[TPB];
     static_for<0, NF>([&](auto f_) {
         constexpr int f = decltype(f_)::value, c = f / (4 * MB), s = (f / MB) % 4, mb = f % MB;
         if constexpr (mb == 0) {                     // A fragments of k-step (c, s): one dequant per tile feeds MB MFMAs
 #pragma unroll
             for (int t = 0; t < TPB; ++t) {
-                const uint32_t m = mr[c][t][s / SPG];
-                const f16x2 zn = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u)), sc = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
-                a[t] = dequant_w4_vc(wr[c][t][s], zn, zn + c960, sc, w4c);
+                if constexpr (W8) {                  // wave-load s / 2 of the chunk holds k-steps 2 (s / 2), + 1: two dwords each
+                    const u32x4 w = wr[c][t][s >> 1];
+                    a[t] = dequant_w8<false>(w[(s & 1) * 2], w[(s & 1) * 2 + 1], zn8, zn8);
+                } else {
+                    const uint32_t m = mr[c][t][s / SPG];
+                    const f16x2 zn = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u)), sc = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
+                    a[t] = dequant_w4_vc(wr[c][t][0][s], zn, zn + c960, sc, w4c);
+                }
             }
         }
         const f16x8 b = __builtin_bit_cast(f16x8, xr[f % RING]);
@@ -205,6 +224,12 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
     if (m >= p.M) continue;
 
     const bool bf = fp.bf16 != 0;                   // dtype of everything 16-bit around the GEMM (the image and the weights' dequant are fp16)
+    if constexpr (W8) {                             // per-channel scale of this lane's four columns
+#pragma unroll
+        for (int t = 0; t < TPB; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[t][r] *= sg.wsc[t * 16 + q * 4 + r];
+    }
     if (bf) {                                       // the image of a bf16 tensor holds x 2^-8 (common.h img_val): exact in fp32
 #pragma unroll
         for (int t = 0; t < TPB; ++t) v[t] *= kImgBfUnscale;
@@ -303,9 +328,9 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
     }   // row blocks of this wave
 }
 
-template <int GS, int MB, int EPI, int CPW, int RING>
+template <int WB, int GS, int MB, int EPI, int CPW, int RING>
 int launch64_t(const FullKParams& fp, int blocks, hipStream_t st) {
-    auto k = gemm_fullk64_kernel<GS, MB, EPI, CPW, RING>;
+    auto k = gemm_fullk64_kernel<WB, GS, MB, EPI, CPW, RING>;
     const int NW = cdiv(fp.g.KC, CPW);
     if (NW > 15) return MI355_ERR_UNSUPPORTED;
     const size_t lds = (size_t)NW * 2 * MB * 1024 + sizeof(Stage64<EPI>);
@@ -318,16 +343,23 @@ int launch64_t(const FullKParams& fp, int blocks, hipStream_t st) {
 }
 
 // slice depth by K: up to 30 chunks (K <= 3840) two chunks per wave, up to 45 (K <= 5760) three; <= 15 K waves + the helper
-template <int GS, int MB, int EPI>
+template <int WB, int GS, int MB, int EPI>
 int launch64_k(const FullKParams& fp, int blocks, hipStream_t st) {
     const int KC = fp.g.KC;
 #ifdef MI355_TUNING
-    if (TUNE(6) == 1 && KC <= 30) return launch64_t<GS, MB, EPI, 2, MB>(fp, blocks, st);         // experiment: one k-step in flight
-    if constexpr (GS == 4) if (TUNE(6) == 2 && KC <= 30) return launch64_t<GS, MB, EPI, 2, 3 * MB>(fp, blocks, st);     // experiment: three k-steps
+    if constexpr (WB == 4) {
+    if (TUNE(6) == 1 && KC <= 30) return launch64_t<4, GS, MB, EPI, 2, MB>(fp, blocks, st);         // experiment: one k-step in flight
+    if constexpr (GS == 4) if (TUNE(6) == 2 && KC <= 30) return launch64_t<4, GS, MB, EPI, 2, 3 * MB>(fp, blocks, st);     // experiment: three k-steps
+    }
 #endif
-    if (KC <= 30) return launch64_t<GS, MB, EPI, 2, 2 * MB>(fp, blocks, st);
-    if (KC <= 45) return launch64_t<GS, MB, EPI, 3, (GS == 1 && MB == 4) ? MB : 2 * MB>(fp, blocks, st);   // g32 at 64 rows: 24 (zero, scale) words per wave, one k-step in flight fits 128 registers
+    if constexpr (WB == 8) {   // 32 bytes of weights per lane and chunk: the 64-row instance keeps one k-step of fragments in flight (128 registers)
+        if (KC <= 30) return launch64_t<8, 4, MB, EPI, 2, MB == 4 ? MB : 2 * MB>(fp, blocks, st);
+        return MI355_ERR_UNSUPPORTED;
+    } else {
+    if (KC <= 30) return launch64_t<4, GS, MB, EPI, 2, 2 * MB>(fp, blocks, st);
+    if (KC <= 45) return launch64_t<4, GS, MB, EPI, 3, (GS == 1 && MB == 4) ? MB : 2 * MB>(fp, blocks, st);   // g32 at 64 rows: 24 (zero, scale) words per wave, one k-step in flight fits 128 registers
     return MI355_ERR_UNSUPPORTED;
+    }
 }
 
 } // namespace
@@ -347,32 +379,36 @@ extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi35
     fp.ilv = TUNE(7); fp.rowsplit = 0;
     const GemmParams& g = fp.g;
     if (g.M < 1 || g.M > 64 || g.KC < 4 || g.KC > 45 || g.K != g.KC * 128) return MI355_ERR_UNSUPPORTED;
-    if (group_size != 128 && group_size != 64 && group_size != 32) return MI355_ERR_UNSUPPORTED;
+    const bool w8 = group_size == 0;                 // per-channel INT8 (the callers pass wbits == 8 as group_size 0)
+    if (!w8 && group_size != 128 && group_size != 64 && group_size != 32) return MI355_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int mblk = (g.M + 15) >> 4;                // an instance per row-block count: the activation loads of a block are per row block
-#define F64_(GS_, EPI_, BLOCKS_)                                                                        \
-    return mblk == 1 ? launch64_k<GS_, 1, EPI_>(fp, BLOCKS_, st) : mblk == 2 ? launch64_k<GS_, 2, EPI_>(fp, BLOCKS_, st) \
-         : mblk == 3 ? launch64_k<GS_, 3, EPI_>(fp, BLOCKS_, st) : launch64_k<GS_, 4, EPI_>(fp, BLOCKS_, st)
+#define F64_(WB_, GS_, EPI_, BLOCKS_)                                                                        \
+    return mblk == 1 ? launch64_k<WB_, GS_, 1, EPI_>(fp, BLOCKS_, st) : mblk == 2 ? launch64_k<WB_, GS_, 2, EPI_>(fp, BLOCKS_, st) \
+         : mblk == 3 ? launch64_k<WB_, GS_, 3, EPI_>(fp, BLOCKS_, st) : launch64_k<WB_, GS_, 4, EPI_>(fp, BLOCKS_, st)
     if (epi == FK_ROPE) {
         if (fp.r.hd != 64 && fp.r.hd != 128) return MI355_ERR_UNSUPPORTED;
         const int blocks = (fp.r.nh + 2 * fp.r.nkv) * (fp.r.hd / 32);
-        if (group_size == 128) { F64_(4, FK_ROPE, blocks); }
-        if (group_size == 64)  { F64_(2, FK_ROPE, blocks); }
-        F64_(1, FK_ROPE, blocks);
+        if (w8) { F64_(8, 4, FK_ROPE, blocks); }
+        if (group_size == 128) { F64_(4, 4, FK_ROPE, blocks); }
+        if (group_size == 64)  { F64_(4, 2, FK_ROPE, blocks); }
+        F64_(4, 1, FK_ROPE, blocks);
     }
     if (epi == FK_RESID) {
         const int blocks = cdiv(g.NT, 2);
         if (g.M > 16 && 2 * blocks <= 256 && !(TUNE(4) == 3)) {       // two blocks per tile pair, half of the row blocks each (see the kernel)
             fp.rowsplit = (blocks % 8 == 0) ? 2 : 1;
-#define F64H_(GS_) return mblk <= 2 ? launch64_k<GS_, 1, FK_RESID>(fp, 2 * blocks, st) : launch64_k<GS_, 2, FK_RESID>(fp, 2 * blocks, st)
-            if (group_size == 128) { F64H_(4); }
-            if (group_size == 64)  { F64H_(2); }
-            F64H_(1);
+#define F64H_(WB_, GS_) return mblk <= 2 ? launch64_k<WB_, GS_, 1, FK_RESID>(fp, 2 * blocks, st) : launch64_k<WB_, GS_, 2, FK_RESID>(fp, 2 * blocks, st)
+            if (w8) { F64H_(8, 4); }
+            if (group_size == 128) { F64H_(4, 4); }
+            if (group_size == 64)  { F64H_(4, 2); }
+            F64H_(4, 1);
 #undef F64H_
         }
-        if (group_size == 128) { F64_(4, FK_RESID, blocks); }
-        if (group_size == 64)  { F64_(2, FK_RESID, blocks); }
-        F64_(1, FK_RESID, blocks);
+        if (w8) { F64_(8, 4, FK_RESID, blocks); }
+        if (group_size == 128) { F64_(4, 4, FK_RESID, blocks); }
+        if (group_size == 64)  { F64_(4, 2, FK_RESID, blocks); }
+        F64_(4, 1, FK_RESID, blocks);
     }
 #undef F64_
     return MI355_ERR_UNSUPPORTED;

@@ -31,10 +31,15 @@ struct SplitK64Params {
     int dbg;          // tuning build, timing only (same instruction stream): 1 no activation traffic, 2 no weight traffic
 };
 
-template <int GS, int MB, int T, int CPW, int RING>
+// WB = 8 (round 5): per-channel INT8 weights -- two wave-loads per (tile, chunk), the operand is the exact integer u - 128 (4 v_perm +
+// 4 v_pk_add per 8 weights: a lighter unit than W4's, left to the compiler's schedule), the column's scale multiplies the summed
+// accumulators before the slab store (every K split is scaled alike, so the fold's sum of slabs is the scaled sum).
+template <int WB, int GS, int MB, int T, int CPW, int RING>
 __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params sp) {
     const GemmParams& p = sp.g;
     constexpr int NW = 8;
+    constexpr bool W8 = WB == 8;
+    constexpr int LPC = WB / 4;
     constexpr int NSUB = 4 / GS, SPG = 4 / NSUB;
     constexpr int NKS = CPW * 4;                         // k-steps of a wave (static schedule; past the slice: zero weights, zero activations)
     constexpr uint32_t FLAGS = 0x00020000u, OOBS = 0x40000000u;
@@ -59,28 +64,36 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const bool ok = t0 + t < p.NT && n_ch > 0 && !(sp.dbg & 2);
-        const char* wb = (const char*)p.qw + ((size_t)(t0 + t) * p.KC + c0) * 1024;
-        rw[t] = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, ok ? n_ch * 1024 : 0, FLAGS);
-        const char* mb_ = (const char*)p.meta + ((size_t)c0 * NSUB * p.N_pad + (t0 + t) * 16) * 4;
-        rm[t] = __builtin_amdgcn_make_buffer_rsrc((void*)mb_, 0, ok ? ((n_ch * NSUB - 1) * p.N_pad + 16) * 4 : 0, FLAGS);
+        const char* wb = (const char*)p.qw + ((size_t)(t0 + t) * p.KC + c0) * (LPC * 1024);
+        rw[t] = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, ok ? n_ch * LPC * 1024 : 0, FLAGS);
+        const char* mb_ = (const char*)p.meta + (W8 ? (size_t)(t0 + t) * 16 * 4 : ((size_t)c0 * NSUB * p.N_pad + (t0 + t) * 16) * 4);
+        rm[t] = __builtin_amdgcn_make_buffer_rsrc((void*)mb_, 0, (t0 + t < p.NT) ? (W8 ? 64 : (ok ? ((n_ch * NSUB - 1) * p.N_pad + 16) * 4 : 0)) : 0, FLAGS);
     }
     const int MBLK = (p.M + 15) >> 4;                    // row blocks of the image (<= MB)
     const char* xb = (const char*)p.x + (size_t)c0 * 4 * MBLK * 1024;
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (sp.dbg & 1) ? 0u : (uint32_t)(n_ch * 4 * MBLK * 1024), FLAGS);
     const uint32_t lane16 = lane * 16u, jj4 = jj * 4u;
 
-    u32x4    wr[2][T];                                   // weight ring: chunk c in slot c & 1
+    u32x4    wr[2][T][LPC];                              // weight ring: chunk c in slot c & 1
     uint32_t mr[2][T][NSUB];
     u32x4    xr[RING][MB];                               // activation ring: k-step ks in slot ks % RING
     auto load_w = [&](int c) {                           // c compile-time at every call site
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            wr[c & 1][t] = bload128<2 /*nt*/>(rw[t], lane16, (uint32_t)c * 1024u);
 #pragma unroll
-            for (int gi = 0; gi < NSUB; ++gi)
-                mr[c & 1][t][gi] = __builtin_amdgcn_raw_buffer_load_b32(rm[t], jj4, (uint32_t)(c * NSUB + gi) * (uint32_t)p.N_pad * 4u, 0);
+            for (int lp = 0; lp < LPC; ++lp) wr[c & 1][t][lp] = bload128<2 /*nt*/>(rw[t], lane16, (uint32_t)(c * LPC + lp) * 1024u);
+            if constexpr (!W8) {
+#pragma unroll
+                for (int gi = 0; gi < NSUB; ++gi)
+                    mr[c & 1][t][gi] = __builtin_amdgcn_raw_buffer_load_b32(rm[t], jj4, (uint32_t)(c * NSUB + gi) * (uint32_t)p.N_pad * 4u, 0);
+            }
         }
     };
+    u32x4 sc4[T];                                        // W8: (zero, scale) words of this lane's four columns per tile, for the slab store
+    if constexpr (W8) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) sc4[t] = bload128<0>(rm[t], (uint32_t)q * 16u);
+    }
     auto load_x = [&](int ks) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
@@ -102,6 +115,7 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
         for (int mb = 0; mb < MB; ++mb) acc[t][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const W4Consts w4c = w4_consts();
     const f16x2 c960 = {(f16)960.f, (f16)960.f};
+    const f16x2 zn8 = {(f16)-1152.f, (f16)-1152.f};     // W8: byte u under the exponent of 1024, minus 1024 + 128
     // (zero, scale) of the group in use PER TILE: consecutive units belong to different tiles (k-step-major order), so a tile's words
     // live in its own registers and are refreshed when its next unit starts a new group
     f16x2 zn[T], znb[T], scl[T];
@@ -111,23 +125,33 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
         scl[t] = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
         znb[t] = zn[t] + c960;
     };
-    meta_of(0, 0, 0);
-    u32x4 aE = __builtin_bit_cast(u32x4, dequant_w4_vc(wr[0][0][0], zn[0], znb[0], scl[0], w4c)), aO = aE;   // operand of even / odd units (fixed register tuples)
+    u32x4 aE, aO;                                        // W4: operand of even / odd units (fixed register tuples)
+    if constexpr (!W8) {
+        meta_of(0, 0, 0);
+        aE = __builtin_bit_cast(u32x4, dequant_w4_vc(wr[0][0][0][0], zn[0], znb[0], scl[0], w4c)); aO = aE;
+    }
 
     // ---- units in k-step-major order: u = (ks * T + t), ks = 4 c + s
     constexpr int NU = NKS * T;
     auto unit = [&](auto uc) {
         constexpr int u = decltype(uc)::value;
         constexpr int ks = u / T, t = u % T, c = ks / 4, s = ks % 4;
+        if constexpr (W8) {
+            const u32x4 w = wr[c & 1][t][s >> 1];        // wave-load s / 2 of the chunk: k-steps 2 (s / 2), + 1, two dwords each
+            const f16x8 a = dequant_w8<false>(w[(s & 1) * 2], w[(s & 1) * 2 + 1], zn8, zn8);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[t][mb] = mfma16x16x32(a, __builtin_bit_cast(f16x8, xr[ks % RING][mb]), acc[t][mb]);
+        } else {
         constexpr int un = u + 1, ksn = un / T, tn = un % T, cn = ksn / 4, sn = ksn % 4;   // the unit whose operand this one prepares
         uint32_t wn = 0;
         if constexpr (un < NU) {
             if constexpr (sn % SPG == 0) meta_of(cn, tn, sn);
-            wn = wr[cn & 1][tn][sn];
+            wn = wr[cn & 1][tn][0][sn];
         }
         wide_unit_w4<MB, u % 2 == 0>(aE, aO, wn, w4c, zn[tn % T], znb[tn % T], scl[tn % T], acc[t][0], acc[t][MB > 1 ? 1 : 0], acc[t][MB > 2 ? 2 : 0],
                                      acc[t][MB > 3 ? 3 : 0], xr[ks % RING][0], xr[ks % RING][MB > 1 ? 1 : 0], xr[ks % RING][MB > 2 ? 2 : 0],
                                      xr[ks % RING][MB > 3 ? 3 : 0]);
+        }
         // re-requests right behind the last reader of their registers: the k-step's fragments after its last tile; the chunk's
         // weights after the unit that prepared the last operand taken from them
         if constexpr (t == T - 1 && ks + RING < NKS) load_x(ks + RING);
@@ -139,7 +163,7 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
     constexpr int NU_HEAD = (CPW - 1) * 4 * T;
     static_for<0, NU_HEAD>(unit);
     if (n_ch == CPW) static_for<NU_HEAD, NU>(unit);
-    asm volatile("s_nop 15" ::: "memory");               // the last MFMAs' results are read by compiler code below
+    if constexpr (!W8) asm volatile("s_nop 15" ::: "memory");   // the last MFMAs' results are read by compiler code below
 
     // ---- the K slices meet in LDS; wave w sums the sets e = w, w + 8, ... (set e = tile e / MB, row block e % MB) and stores them
 #pragma unroll
@@ -153,15 +177,23 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
         f32x4 v = red[((size_t)e) * 64 + lane];
 #pragma unroll
         for (int w = 1; w < NW; ++w) v += red[((size_t)w * (T * MB) + e) * 64 + lane];
+        if constexpr (W8) {
+            static_for<0, T>([&](auto t_) {              // this set's tile: its scales live in registers indexed at compile time
+                if (decltype(t_)::value == t) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= (float)as_h2(sc4[decltype(t_)::value][r])[1];
+                }
+            });
+        }
         if (p.bf16) v *= kImgBfUnscale;                  // the image of a bf16 tensor holds x 2^-8 (common.h img_val)
         if (m < p.M && t0 + t < p.NT)
             st_slab(rs, (uint32_t)((((size_t)by * p.M + m) * p.N_pad + (t0 + t) * 16 + q * 4) * 4), v);
     }
 }
 
-template <int GS, int MB, int T, int CPW, int RING>
+template <int WB, int GS, int MB, int T, int CPW, int RING>
 int launch_splitk64_t(const SplitK64Params& sp, int G, hipStream_t st) {
-    auto k = gemm_splitk64_kernel<GS, MB, T, CPW, RING>;
+    auto k = gemm_splitk64_kernel<WB, GS, MB, T, CPW, RING>;
     const size_t lds = (size_t)8 * T * MB * 1024;
     if (lds > 64 * 1024)
         if (int e = raise_dynamic_lds((const void*)k, "gemm_splitk64")) return e;
@@ -176,7 +208,7 @@ int launch_splitk64_t(const SplitK64Params& sp, int G, hipStream_t st) {
 // Plan: four tiles per block; the fewest K splits that put a block on >= 3/4 of the CUs, each wave <= 5 chunks.
 // Returns the number of slabs, or MI355_ERR_UNSUPPORTED (shape not deep / wide enough: the caller stays on gemm.hip).
 extern "C" int mi355_gemm_splitk64_plan(int M, int NT, int KC, int wbits, int group_size, int max_splits, int* cps_out) {
-    if (M < 1 || M > 64 || wbits != 4 || (group_size != 128 && group_size != 64 && group_size != 32)) return MI355_ERR_UNSUPPORTED;
+    if (M < 1 || M > 64 || !((wbits == 4 && (group_size == 128 || group_size == 64 || group_size == 32)) || (wbits == 8 && group_size == 0))) return MI355_ERR_UNSUPPORTED;
     const int G = (NT + 3) / 4;
     int ns = (192 + G - 1) / G;                          // >= 192 blocks
     if (ns < 2) return MI355_ERR_UNSUPPORTED;            // N alone fills the chip: the wide kernel's shape
@@ -205,9 +237,9 @@ extern "C" int mi355_gemm_splitk64(const void* gp, int wbits, int group_size, in
     hipStream_t st = (hipStream_t)stream;
     const int mblk = (g.M + 15) >> 4;                    // row blocks: an instance per count (1 MFMA per unit at <= 16 rows ... 4 at 49-64)
     int rc;
-#define SK_MB_(GS_, MB_) (cpw <= 3 ? launch_splitk64_t<GS_, MB_, 4, 3, 3>(sp, G, st) : launch_splitk64_t<GS_, MB_, 4, 5, 3>(sp, G, st))
-#define SK_(GS_) rc = mblk == 1 ? SK_MB_(GS_, 1) : mblk == 2 ? SK_MB_(GS_, 2) : mblk == 3 ? SK_MB_(GS_, 3) : SK_MB_(GS_, 4)
-    if (group_size == 128) { SK_(4); } else if (group_size == 64) { SK_(2); } else { SK_(1); }
+#define SK_MB_(WB_, GS_, MB_) (cpw <= 3 ? launch_splitk64_t<WB_, GS_, MB_, 4, 3, 3>(sp, G, st) : launch_splitk64_t<WB_, GS_, MB_, 4, 5, 3>(sp, G, st))
+#define SK_(WB_, GS_) rc = mblk == 1 ? SK_MB_(WB_, GS_, 1) : mblk == 2 ? SK_MB_(WB_, GS_, 2) : mblk == 3 ? SK_MB_(WB_, GS_, 3) : SK_MB_(WB_, GS_, 4)
+    if (wbits == 8) { SK_(8, 4); } else if (group_size == 128) { SK_(4, 4); } else if (group_size == 64) { SK_(4, 2); } else { SK_(4, 1); }
 #undef SK_MB_
 #undef SK_
     return rc == MI355_OK ? ns : rc;

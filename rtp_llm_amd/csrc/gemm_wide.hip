@@ -388,7 +388,8 @@ static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_
                             mi355_stream_t stream);
 // does the direct (one launch, no slabs) form take this linear at 1-64 rows?  N alone has to fill the chip (gate_up)
 extern "C" int mi355_gemm_wide_direct_ok(const mi355_weight_t* w) {
-    if (!w || w->wbits != 4 || (w->group_size != 128 && w->group_size != 64 && w->group_size != 32)) return 0;   // either activation dtype: the image entry (gemm.hip) decides
+    if (!w) return 0;                                // either activation dtype: the image entry (gemm.hip) decides
+    if (!((w->wbits == 4 && (w->group_size == 128 || w->group_size == 64 || w->group_size == 32)) || (w->wbits == 8 && w->group_size == 0))) return 0;
     if (w->K % 128 != 0 || w->K_pad != w->K) return 0;
     const int NT = w->N_pad / 16, TB = 10, CUS = 256;
     int G = (NT + TB - 1) / TB;
@@ -432,7 +433,7 @@ static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_
     wp.g = g; wp.G = G; wp.stamps = WIDE_STAMPS;
     wp.ssq = nullptr; wp.ssq_tiles = wp.ssq_ld = 0; wp.eps = 0.f; wp.unscale = 1.f;
     if (dn) {
-        if (want_partial || (wbits == 8)) return MI355_ERR_UNSUPPORTED;   // the scale is applied at the K-slice merge of the W4 instances
+        if (want_partial) return MI355_ERR_UNSUPPORTED;   // the row factors are applied at the K-slice merge (after the per-channel scale of a W8 instance)
         wp.ssq = dn->tile_sumsq; wp.ssq_tiles = dn->tiles; wp.ssq_ld = dn->ld; wp.eps = dn->eps; wp.unscale = dn->unscale;
     }
     if (g.x_img && want_partial) return MI355_ERR_UNSUPPORTED;

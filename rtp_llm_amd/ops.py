@@ -326,7 +326,7 @@ def linear_partial_img(x: ActImage, w: PackedWeight, max_splits: int = 16):
     if x.K != w.K:
         raise _C.Mi355Error(f"linear_partial_img: image K={x.K} against K={w.K}")
     slabs = torch.empty(max_splits, x.M, w.N_pad, dtype=torch.float32, device=x.data.device)
-    ws_struct = weight_struct(w)
+    ws_struct = weight_struct(w, x.src)          # the image of a bf16 tensor holds x 2^-8: the kernel scales the slabs back
     rc = _C.lib().mi355_linear_partial_img(x.data.data_ptr(), x.M, C.byref(ws_struct), slabs.data_ptr(), max_splits, _stream())
     if rc == ERR_UNSUPPORTED:
         return None

@@ -351,7 +351,7 @@ def test_host_side_plans_of_the_image_launches():
     ok = lib.mi355_gemm_wide_direct_ok
     ok.restype, ok.argtypes = C.c_int, [C.POINTER(_C.Weight)]
     mk = lambda K, N, wbits=4, gs=128: _C.Weight(1 << 20, 1 << 21, wbits, K, N, K, N, gs, _C.ACT_F16)   # pointers are never read here
-    assert ok(C.byref(mk(3584, 37888))) == 1 and ok(C.byref(mk(3584, 4608))) == 0 and ok(C.byref(mk(3584, 37888, 8, 0))) == 0
+    assert ok(C.byref(mk(3584, 37888))) == 1 and ok(C.byref(mk(3584, 4608))) == 0 and ok(C.byref(mk(3584, 37888, 8, 0))) == 1 and ok(C.byref(mk(3584, 37888, 8, 128))) == 0
     from rtp_llm_amd import ops as host_ops
     assert [host_ops.norm_exponent(torch.tensor([v])) for v in (0.5, 1.0, 1.5, 2.0, 3.9, 1e9)] == [0, 0, 1, 1, 2, 14]
 

@@ -24,12 +24,18 @@ def _require_native():
     _C.lib()
 
 
-def _w4(K, N, seed, group_size=128):
-    """(packed weight, dense fp32 reference); group_size 0 = fp16 weights (the draft models of speculative decoding)."""
+W8 = -8   # "group size" of the per-channel INT8 format (load-time autoquant, device_impl.py:183-222) in the parameter lists below
+
+
+def _w4(K, N, seed, group_size=128, gate_up=False):
+    """(packed weight, dense fp32 reference); group_size 0 = fp16 weights (the draft models of speculative decoding), W8 = per-channel INT8."""
     gen = torch.Generator(device=DEV).manual_seed(seed)
     if group_size == 0:
         c_dev = model.synth_linear(K, N, "fp16", DEV, gen)
         return c_dev.pack(), c_dev.w.float().cpu()
+    if group_size == W8:
+        c_dev = model.synth_linear(K, N, "int8", DEV, gen)
+        return c_dev.pack(gate_up=gate_up), oracle.dequant_int8(c_dev.q.cpu(), c_dev.scales.cpu())
     c_dev = model.synth_linear(K, N, "w4", DEV, gen, group_size=group_size, zeros="centered")
     c = model.weights_to({"w": c_dev}, "cpu")["w"]
     return c_dev.pack(), oracle.dequant_groupwise(c.q, c.z_eff, c.scales, c.group_size)
@@ -209,8 +215,9 @@ def test_act_image_layout_and_round_trip(M, K):
     assert torch.equal(img.unpack(), x)
 
 
-@pytest.mark.parametrize("K,N,gs", [(3584, 3584, 128), (512, 272, 128), (1024, 256, 64), (512, 128, 32), (4096, 1024, 128), (5120, 512, 128)],
-                         ids=["o", "ragged-n", "g64", "g32", "k4096-three-chunk-slices", "k5120"])
+@pytest.mark.parametrize("K,N,gs", [(3584, 3584, 128), (512, 272, 128), (1024, 256, 64), (512, 128, 32), (4096, 1024, 128), (5120, 512, 128),
+                                    (3584, 3584, W8), (512, 272, W8), (3840, 512, W8)],
+                         ids=["o", "ragged-n", "g64", "g32", "k4096-three-chunk-slices", "k5120", "w8-o", "w8-ragged-n", "w8-k3840"])
 def test_linear_residual_img_vs_oracle(K, N, gs):
     packed, W = _w4(K, N, K + N, gs)
     x = (torch.randn(64, K, generator=torch.Generator().manual_seed(3)) * 0.5).half()
@@ -226,8 +233,9 @@ def test_linear_residual_img_vs_oracle(K, N, gs):
         err = (out.cpu().float() - ref[:M].float()).abs().max()
         assert torch.allclose(out.cpu().float(), ref[:M].float(), **TOL), f"M={M}: max err {err}"
         assert torch.allclose(ssq[:, : N // 16].sum(1).cpu(), (out.cpu().float() ** 2).sum(1), rtol=1e-5)   # exact partial sums of what was stored
-        comp = ops.linear_residual(xd[:M].contiguous(), packed, rd[:M].contiguous(), bd)            # the row-major launch of the same contract
-        assert torch.allclose(out.float(), comp.float(), **TOL)
+        if gs != W8:
+            comp = ops.linear_residual(xd[:M].contiguous(), packed, rd[:M].contiguous(), bd)        # the row-major launch of the same contract
+            assert torch.allclose(out.float(), comp.float(), **TOL)
     # in place on the residual stream, as the step driver calls it; no bias
     r2 = rd.clone()
     ops.linear_residual_img(ops.act_image_pack(xd), packed, r2, None, out=r2)
@@ -237,16 +245,18 @@ def test_linear_residual_img_vs_oracle(K, N, gs):
 def test_img_launches_refuse_other_shapes():
     gen = torch.Generator(device=DEV).manual_seed(1)
     p = model.synth_linear(512, 256, "w4", DEV, gen).pack()
-    p8 = model.synth_linear(512, 256, "int8", DEV, gen).pack()
+    p16 = model.synth_linear(512, 256, "fp16", DEV, gen).pack()                                                                # 16-bit weights: the composed launches
     r = torch.zeros(32, 256, dtype=torch.float16, device=DEV)
-    assert ops.linear_residual_img(ops.act_image_pack(torch.zeros(32, 512, dtype=torch.float16, device=DEV)), p8, r) is None
+    assert ops.linear_residual_img(ops.act_image_pack(torch.zeros(32, 512, dtype=torch.float16, device=DEV)), p16, r) is None
+    p8 = model.synth_linear(3968, 256, "int8", DEV, gen).pack()                                                                 # W8: 31 chunks, past its two-chunk slices
+    assert ops.linear_residual_img(ops.act_image_pack(torch.zeros(32, 3968, dtype=torch.float16, device=DEV)), p8, r) is None
     pk = model.synth_linear(5888, 256, "w4", DEV, gen).pack()                                                                    # 46 chunks: past the slices
     assert ops.linear_residual_img(ops.act_image_pack(torch.zeros(32, 5888, dtype=torch.float16, device=DEV)), pk, r) is None
 
 
 @pytest.mark.parametrize("nh,nkv,hd,hidden,page,q_len,gs", [(28, 4, 128, 3584, 16, 1, 128), (28, 4, 128, 3584, 16, 4, 128), (4, 2, 64, 512, 8, 1, 128),
-                                                            (8, 1, 128, 1024, 16, 2, 64), (6, 2, 64, 512, 16, 1, 32)],
-                         ids=["qwen2-7b", "qwen2-7b-rows4", "hd64", "mqa-rows2-g64", "hd64-g32"])
+                                                            (8, 1, 128, 1024, 16, 2, 64), (6, 2, 64, 512, 16, 1, 32), (28, 4, 128, 3584, 16, 1, W8), (4, 2, 64, 512, 8, 2, W8)],
+                         ids=["qwen2-7b", "qwen2-7b-rows4", "hd64", "mqa-rows2-g64", "hd64-g32", "qwen2-7b-w8", "hd64-rows2-w8"])
 def test_qkv_rope_kv_write_img_vs_oracle(nh, nkv, hd, hidden, page, q_len, gs):
     N = (nh + 2 * nkv) * hd
     packed, W = _w4(hidden, N, hidden + N, gs)
@@ -388,8 +398,8 @@ def test_deferred_norm_chain_vs_oracle(M, gmax, hscale):
     assert ops.linear_deferred_norm_img(ops.act_image_pack(h), None, wo) is None
 
 
-@pytest.mark.parametrize("K,N,gs", [(18944, 3584, 128), (3584, 8192, 128), (4096, 3584, 64), (4096, 3584, 32), (3712, 8192, 128)],
-                         ids=["7b-down", "70b-tp8-down", "g64", "g32", "72b-tp8-down-29-chunks"])
+@pytest.mark.parametrize("K,N,gs", [(18944, 3584, 128), (3584, 8192, 128), (4096, 3584, 64), (4096, 3584, 32), (3712, 8192, 128), (18944, 3584, W8), (4096, 3584, W8)],
+                         ids=["7b-down", "70b-tp8-down", "g64", "g32", "72b-tp8-down-29-chunks", "w8-7b-down", "w8-k4096"])
 def test_linear_partial_img_vs_oracle(K, N, gs):
     """gemm_splitk64.hip: the slabs of a deep-K linear from an activation image sum to oracle.linear (fp32 accumulation, so the sum
     is compared before any fp16 rounding) and fold into the same residual + RMSNorm as the staged kernel's slabs."""
@@ -414,6 +424,40 @@ def test_linear_partial_img_refuses_shapes_outside_its_plan():
     xw = ops.act_image_pack(torch.zeros(32, 3584, dtype=torch.float16, device=DEV))
     assert ops.linear_partial_img(xw, model.synth_linear(3584, 37888, "w4", DEV, gen).pack(gate_up=True)) is None   # N alone fills the chip
     assert ops.linear_partial_img(xw, model.synth_linear(3584, 3584, "int8", DEV, gen).pack()) is None
+
+
+@pytest.mark.parametrize("M,gmax", [(8, 1.2), (16, 30.0), (33, 1.2), (64, 1.2)])
+def test_w8_layer_on_images_vs_oracle(M, gmax):
+    """Per-channel W8 (configs[1]: load-time INT8 autoquant) on the image launches of round 5: O + residual with the deferred-norm operands
+    (gemm_fullk64 W8) -> gate_up + SiLU with the RMSNorm finished on the accumulators, image out (gemm_wide W8) -> down as K quarters
+    (gemm_splitk64 W8), at the Qwen2-7B widths, against the oracle's rmsnorm / linear / silu_mul on the dequantised weights."""
+    cfg = model.QWEN2_7B
+    H, I = cfg.hidden, cfg.inter
+    wo, Wo = _w4(H, H, 11, W8)
+    wg, Wg = _w4(H, 2 * I, 12, W8, gate_up=True)
+    wd, Wd = _w4(I, H, 13, W8)
+    Wg_cols = Wg                                          # dense reference in canonical [gate | up] column order (the pack interleaves)
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, H, generator=g) * 0.5).half()
+    res = (torch.randn(M, H, generator=g) * 3.0).half()
+    gamma = (1.0 + 0.2 * torch.randn(H, generator=g)).half()
+    gamma[::97] = gmax
+    eps = 1e-6
+    r = ops.linear_residual_prenorm_img(ops.act_image_pack(x.to(DEV)), wo, res.to(DEV), gamma.to(DEV))
+    assert r is not None, "per-channel W8, K = 3584: the image kernel must take it"
+    h, xg, ssq, e = r
+    h_ref = (oracle.linear(x, Wo, None).float() + res.float()).half()
+    assert torch.allclose(h.cpu().float(), h_ref.float(), **TOL), float((h.cpu().float() - h_ref.float()).abs().max())
+    act_img = ops.linear_deferred_norm_img(xg, (ssq, eps, e), wg, None, _C.EPI_SILU_MUL | _C.EPI_OUT_IMAGE)
+    assert isinstance(act_img, ops.ActImage), "per-channel W8 gate_up: the wide GEMM's image entry must take it"
+    act_ref = oracle.silu_mul(oracle.linear(oracle.rmsnorm(h.cpu(), gamma, eps), Wg_cols, None))
+    act = act_img.unpack().cpu()
+    assert torch.allclose(act.float(), act_ref.float(), **TOL), float((act.float() - act_ref.float()).abs().max())
+    slabs = ops.linear_partial_img(act_img, wd)
+    assert slabs is not None and slabs.shape[0] == 4
+    y = slabs.sum(0)[:, :H].cpu()
+    ref = act.float() @ Wd
+    assert torch.allclose(y, ref, atol=1e-2, rtol=1e-2), float((y - ref).abs().max())
 
 
 @pytest.mark.parametrize("M", [5, 17, 40, 64])
