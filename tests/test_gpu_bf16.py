@@ -394,4 +394,8 @@ def test_bf16_images_carry_activations_beyond_the_fp16_range():
     assert torch.isfinite(act_img.data.float()).all()
     act = act_img.unpack().cpu().float()
     # the products of two O(300) bf16-rounded factors: relative tolerance of the bf16 steps (3e-2), absolute 1e-3 of the largest element
-    assert torch.allclose(act, act_ref.float(), atol=1e-3 * float(act_ref.float().abs().max()), rtol=3e-2), float((act - act_ref.float()).abs().max())
+    ref = act_ref.float()
+    excess = (act - ref).abs() - (1e-3 * float(ref.abs().max()) + 3e-2 * ref.abs())
+    i = int(excess.argmax())
+    assert float(excess.max()) <= 0, (f"worst element: got {float(act.reshape(-1)[i])} want {float(ref.reshape(-1)[i])}, max |ref| {float(ref.abs().max())}, "
+                                       f"{int((excess > 0).sum())} of {excess.numel()} outside")
