@@ -464,6 +464,12 @@ int mi355_allreduce_sum_dt(mi355_allreduce_t* ar, const void* x, void* out, int3
 int mi355_allreduce_fused_dt(mi355_allreduce_t* ar, const void* x, const float* partials, int32_t nsplit, int32_t ld,
                              const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
                              int32_t T, int32_t H, void* y, int32_t act_dtype, mi355_stream_t stream);
+/* mi355_allreduce_fused_dt with y written as an activation image (mi355_act_image_*; T <= 64, H % 32 == 0): under tensor parallelism the
+ * all-reduce point behind down_proj (modules/hybrid/dense_mlp.py:104-105) feeds the next layer's QKV launch on images
+ * (mi355_qkv_rope_kv_write_img), as mi355_add_rmsnorm_img does at tp = 1.  Same numbers, other addresses. */
+int mi355_allreduce_fused_img_dt(mi355_allreduce_t* ar, const void* x, const float* partials, int32_t nsplit, int32_t ld,
+                                 const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
+                                 int32_t T, int32_t H, void* y_img, int32_t act_dtype, mi355_stream_t stream);
 
 /* Greedy sampling under a vocab-split lm_head: ids[b] = argmax over ALL ranks' logit slices (this rank holds columns
  * [vocab_offset, vocab_offset + V_local)), lowest global index on ties; identical on every rank.  Exchanges 8 bytes per

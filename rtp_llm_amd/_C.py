@@ -120,6 +120,7 @@ SIGNATURES = {
     "mi355_allreduce_sum": (i32, [vp, vp, vp, i32, i32, vp]),
     "mi355_allreduce_fused": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, vp]),
     "mi355_allreduce_fused_dt": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, i32, vp]),
+    "mi355_allreduce_fused_img_dt": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, i32, vp]),
     "mi355_allreduce_sum_dt": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "mi355_allreduce_argmax": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "mi355_decoder_attach_allreduce": (i32, [vp, vp, i32]),

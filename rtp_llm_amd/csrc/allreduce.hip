@@ -69,6 +69,7 @@ struct FusedParams {
     f16*         res_out;      // residual stream out / plain all-reduce result
     const f16*   weight;       // RMSNorm weight (null: no norm)
     f16*         y;            // normed output
+    int          y_img_mblk;   // > 0: y is an activation image of that many row blocks (common.h act_img_index: the next QKV launch reads it)
     float        eps;
     int          T, H;
     const uint32_t* pf;        // in-launch prefetch (mi355_allreduce_set_prefetch): the waves that only wait at the flag barrier touch
@@ -290,7 +291,8 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
             act_unpack8<BF>(win[t], wv);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = wv[e] * act_round<BF>(v[t][e] * rs);
-            *reinterpret_cast<u32x4*>(p.y + (size_t)row * p.H + vi * 8) = act_pack8<BF>(o);
+            if (p.y_img_mblk > 0) *reinterpret_cast<u32x4*>(p.y + act_img_index(row, vi * 8, p.y_img_mblk)) = img_pack8<BF>(o);   // the same 16 bytes at the image's address (fp16; bf16: x 2^-8)
+            else                  *reinterpret_cast<u32x4*>(p.y + (size_t)row * p.H + vi * 8) = act_pack8<BF>(o);
         }
     }
     __syncthreads();
@@ -555,9 +557,28 @@ extern "C" int mi355_allreduce_fused(mi355_allreduce_t* a, const void* x_f16, co
     return mi355_allreduce_fused_dt(a, x_f16, partials, nsplit, ld, bias, residual_in, residual_out, weight, eps, T, H, y, MI355_ACT_F16, stream);
 }
 
+static int allreduce_fused_launch(mi355_allreduce_t* a, const void* x_f16, const float* partials, int32_t nsplit, int32_t ld,
+                                  const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
+                                  int32_t T, int32_t H, void* y, int y_img_mblk, int32_t act_dtype, mi355_stream_t stream);
+
 extern "C" int mi355_allreduce_fused_dt(mi355_allreduce_t* a, const void* x_f16, const float* partials, int32_t nsplit, int32_t ld,
                                         const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
                                         int32_t T, int32_t H, void* y, int32_t act_dtype, mi355_stream_t stream) {
+    return allreduce_fused_launch(a, x_f16, partials, nsplit, ld, bias, residual_in, residual_out, weight, eps, T, H, y, 0, act_dtype, stream);
+}
+
+// the same with the normed output written as an activation image (mi355_act_image_*, <= 64 rows): what the next layer's QKV launch on
+// images reads under tensor parallelism (the tp = 1 step gets it from mi355_add_rmsnorm_img)
+extern "C" int mi355_allreduce_fused_img_dt(mi355_allreduce_t* a, const void* x_f16, const float* partials, int32_t nsplit, int32_t ld,
+                                            const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
+                                            int32_t T, int32_t H, void* y_img, int32_t act_dtype, mi355_stream_t stream) {
+    MI355_CHECK_ARG(y_img && T <= 64 && H % 32 == 0, "allreduce_fused_img: T=%d (<= 64) H=%d (%% 32 == 0), y_img required", T, H);
+    return allreduce_fused_launch(a, x_f16, partials, nsplit, ld, bias, residual_in, residual_out, weight, eps, T, H, y_img, cdiv(T, 16), act_dtype, stream);
+}
+
+static int allreduce_fused_launch(mi355_allreduce_t* a, const void* x_f16, const float* partials, int32_t nsplit, int32_t ld,
+                                  const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
+                                  int32_t T, int32_t H, void* y, int y_img_mblk, int32_t act_dtype, mi355_stream_t stream) {
     MI355_CHECK_ARG(a && a->ready, "allreduce: context not opened (mi355_allreduce_open)");
     MI355_CHECK_ARG(act_dtype == MI355_ACT_F16 || act_dtype == MI355_ACT_BF16, "allreduce: act_dtype=%d", act_dtype);
     MI355_CHECK_ARG((x_f16 != nullptr) != (partials != nullptr), "allreduce: exactly one of x_f16 / partials");
@@ -570,7 +591,7 @@ extern "C" int mi355_allreduce_fused_dt(mi355_allreduce_t* a, const void* x_f16,
     p.ar = dev_view(a);
     p.x = (const f16*)x_f16; p.partials = partials; p.nsplit = nsplit; p.ld = ld; p.bias = (const f16*)bias;
     p.res_in = (const f16*)residual_in; p.res_out = (f16*)residual_out; p.weight = (const f16*)weight; p.y = (f16*)y;
-    p.eps = eps; p.T = T; p.H = H;
+    p.eps = eps; p.T = T; p.H = H; p.y_img_mblk = y_img_mblk;
     p.pf = (const uint32_t*)a->pf_ptr; p.pf_lines = (uint32_t)(a->pf_bytes >> 7); p.pf_sink = (uint32_t*)a->status + 32;
     a->pf_ptr = nullptr; a->pf_bytes = 0;                    // one launch only
     const int grid = T < kMaxBlocks ? T : kMaxBlocks;

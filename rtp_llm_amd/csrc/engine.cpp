@@ -86,6 +86,11 @@ struct mi355_decoder {
     // 1-64 rows (tp = 1): QKV + bias + RoPE + KV write and O + residual as one full-K launch each (gemm_fullk64.hip), their
     // activations handed over as images by the producing launches (RMSNorm fold, attention): 7 launches per layer instead of 8 + no slabs
     bool   img_qkv, img_o;
+    // tensor parallelism with the in-step all-reduce attached (round 5): the column-parallel QKV shard runs as the same image launch --
+    // the fused all-reduce behind down_proj (and the first norm of the step) write the image it reads; the row-parallel O / down shards
+    // keep their slab launches (their partial sums meet in the all-reduce launch either way)
+    bool   tp_img_qkv;
+    int    tp_fuse_rows;    // up to this many rows the TP step keeps the few-row QKV launch (row-major input)
     // ... and the post-attention RMSNorm deferred into gate_up's accumulators (mi355_deferred_norm_t): the O launch leaves
     // gamma 2^-e h' as an image + the per-tile sums of h'^2, the wide GEMM applies rsqrt(mean h'^2 + eps) 2^e: 6 launches per layer
     bool   img_gate_up;
@@ -273,6 +278,10 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     d->img_qkv = cfg->kv_dtype == (bf_act ? MI355_KV_BF16 : MI355_KV_FP16) && cfg->rope_dim == cfg->hd && cfg->tp_size == 1;
     d->img_o = cfg->tp_size == 1;
     for (const auto& L : d->layers) { d->img_qkv = d->img_qkv && w64ok(&L.qkv); d->img_o = d->img_o && w64ok(&L.o); }
+    d->tp_img_qkv = cfg->tp_size > 1 && cfg->kv_dtype == (bf_act ? MI355_KV_BF16 : MI355_KV_FP16) && cfg->rope_dim == cfg->hd && cfg->hidden % 32 == 0 &&
+                    cfg->max_batch >= 1 && TUNE(5) != 2;
+    for (const auto& L : d->layers) d->tp_img_qkv = d->tp_img_qkv && mi355_fullk64_qkv_ok(&L.qkv, cfg->hd) != 0;
+    d->tp_fuse_rows = (bf_act || !d->fuse_qkv) ? 0 : 4;
     if (TUNE(5) == 2) d->img_qkv = d->img_o = false;   // tuning build: A/B against the split-K + fold launches
     // bf16 / W8: no few-row full-K launches to cross over to (gemm_fullk.hip takes fp16 steps of W4 / fp16 weights; the staged kernels lose
     // at every height): the image launches serve 1-64 rows
@@ -354,7 +363,7 @@ extern "C" int mi355_decoder_begin_rows(mi355_decoder_t* d, int32_t nseq, int32_
         RUN(MI355_KC_OTHER, mi355_embedding(d->bufs.token_ids, B, d->model.embedding, c.hidden, d->model.vocab_full, d->resid, st));
     }
     if (c.tp_size == 1 || d->ar) {
-        if (d->img_qkv && B > d->fuse_rows)
+        if ((d->img_qkv && B > d->fuse_rows) || (d->tp_img_qkv && d->ar && B > d->tp_fuse_rows))
             RUN(MI355_KC_NORM, mi355_add_rmsnorm_img(d->resid, nullptr, 0, 0, nullptr, nullptr, nullptr, d->layers[0].input_norm, c.rms_eps, B,
                                                      c.hidden, d->xn_img, ADT, st));
         else
@@ -520,11 +529,12 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
     }
     int ns = 0;
     mi355_kv_layer_t kv = kv_of(d, l);
-    const bool small = B <= d->fuse_rows;
+    const bool tp_img = d->tp_img_qkv && d->ar && B > d->tp_fuse_rows;   // TP: the QKV shard on the image the all-reduce launch wrote
+    const bool small = tp_img ? false : B <= d->fuse_rows;
     const bool normed = small && d->fuse_norm;            // no norm launches in this step: see fuse_norm
     const int pf = c.tp_size == 1 ? d->pf_mask : 0;       // (tp > 1: the side stream belongs to comm_with_prefetch)
     if (int e = pf_join(d, st)) return e;                  // this layer's QKV weights, requested behind the previous down GEMM
-    const bool mid_qkv = d->img_qkv && B > d->fuse_rows, mid_o = d->img_o && B > d->fuse_rows;   // 1-64 rows: full-K launches on activation images
+    const bool mid_qkv = (d->img_qkv && B > d->fuse_rows) || tp_img, mid_o = d->img_o && B > d->fuse_rows;   // 1-64 rows: full-K launches on activation images
     if (mid_qkv) {
         RUN(MI355_KC_GEMM_QUANT, mi355_qkv_rope_kv_write_img(d->xn_img, B, &L.qkv, L.qkv_bias, d->model.cos_sin, c.rope_dim, c.max_pos,
                                                              d->bufs.positions, d->bufs.block_table, c.max_blocks_per_seq, d->q_len, c.nh,
@@ -645,8 +655,11 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
                                                  c.rms_eps, B, c.hidden, d->xn, ADT, st));
     } else if (d->ar) {
         const mi355_weight_t* next_w = (l + 1 < c.num_layers) ? &d->layers[l + 1].qkv : &d->model.lm_head;
+        const bool next_img = d->tp_img_qkv && B > d->tp_fuse_rows && l + 1 < c.num_layers;   // the next layer's QKV shard reads an image (the final norm feeds lm_head: row-major)
         RUN(MI355_KC_COMM, comm_with_prefetch(d, st, next_w, [&]() {
-            return mi355_allreduce_fused_dt(d->ar, nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
+            return next_img ? mi355_allreduce_fused_img_dt(d->ar, nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
+                                                           c.rms_eps, B, c.hidden, d->xn_img, ADT, st)
+                            : mi355_allreduce_fused_dt(d->ar, nullptr, d->partials, ns, L.down.N_pad, nullptr, d->resid, d->resid, next_norm,
                                          c.rms_eps, B, c.hidden, d->xn, ADT, st); }));
     } else {
         RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(nullptr, d->partials, ns, L.down.N_pad, nullptr, nullptr, d->bufs.ar_buf, nullptr,

@@ -850,6 +850,14 @@ static bool img_weight_ok(const mi355_weight_t* w) {
 // the predicate of the full-K image launches (gemm_fullk64.hip: <= 15 K-slice waves of <= 3 chunks), shared with decoder_create so
 // that the step driver and the launchers cannot drift apart
 extern "C" int mi355_fullk64_weight_ok(const mi355_weight_t* w) { return img_weight_ok(w) && w->K_pad / 128 <= (w->wbits == 8 ? 30 : 45); }
+// ... of the QKV launch with its RoPE epilogue: beyond 45 chunks (hidden 8192) only the g128 instances of <= 2 row blocks per block
+// exist, i.e. the row-split form: the tile pairs have to leave half of the 256 CUs free (a TP shard's do)
+extern "C" int mi355_fullk64_qkv_ok(const mi355_weight_t* w, int32_t hd) {
+    if (!img_weight_ok(w) || (hd != 64 && hd != 128) || w->N % hd != 0) return 0;
+    const int KC = w->K_pad / 128;
+    if (KC <= (w->wbits == 8 ? 30 : 45)) return 1;
+    return w->wbits == 4 && w->group_size == 128 && KC <= 75 && 2 * (w->N / 32) <= 256;
+}
 
 // what block u of gemm_fullk64's QKV launch reads (internal.h: mi355_touch_t), for the spare blocks of the launch in front of it
 extern "C" int mi355_qkv_touch_plan(const mi355_weight_t* wqkv, int32_t hd, void* sink, mi355_touch_t* out) {

@@ -358,6 +358,9 @@ int launch64_k(const FullKParams& fp, int blocks, hipStream_t st) {
     } else {
     if (KC <= 30) return launch64_t<4, GS, MB, EPI, 2, 2 * MB>(fp, blocks, st);
     if (KC <= 45) return launch64_t<4, GS, MB, EPI, 3, (GS == 1 && MB == 4) ? MB : 2 * MB>(fp, blocks, st);   // g32 at 64 rows: 24 (zero, scale) words per wave, one k-step in flight fits 128 registers
+    // K <= 9600 (hidden 8192: the QKV shard of Llama-3-70B / Qwen2-72B under TP 8): five chunks per wave; their 40 weight registers fit
+    // the 128-register budget up to two row blocks per block -- the launcher only comes here with <= 32 rows per block (row split)
+    if constexpr (MB <= 2 && GS == 4) { if (KC <= 75) return launch64_t<4, GS, MB, EPI, 5, 2 * MB>(fp, blocks, st); }
     return MI355_ERR_UNSUPPORTED;
     }
 }
@@ -378,7 +381,7 @@ extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi35
 #endif
     fp.ilv = TUNE(7); fp.rowsplit = 0;
     const GemmParams& g = fp.g;
-    if (g.M < 1 || g.M > 64 || g.KC < 4 || g.KC > 45 || g.K != g.KC * 128) return MI355_ERR_UNSUPPORTED;
+    if (g.M < 1 || g.M > 64 || g.KC < 4 || g.KC > 75 || g.K != g.KC * 128) return MI355_ERR_UNSUPPORTED;
     const bool w8 = group_size == 0;                 // per-channel INT8 (the callers pass wbits == 8 as group_size 0)
     if (!w8 && group_size != 128 && group_size != 64 && group_size != 32) return MI355_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -386,9 +389,19 @@ extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi35
 #define F64_(WB_, GS_, EPI_, BLOCKS_)                                                                        \
     return mblk == 1 ? launch64_k<WB_, GS_, 1, EPI_>(fp, BLOCKS_, st) : mblk == 2 ? launch64_k<WB_, GS_, 2, EPI_>(fp, BLOCKS_, st) \
          : mblk == 3 ? launch64_k<WB_, GS_, 3, EPI_>(fp, BLOCKS_, st) : launch64_k<WB_, GS_, 4, EPI_>(fp, BLOCKS_, st)
+#define F64H_(WB_, GS_, EPI_) return mblk <= 2 ? launch64_k<WB_, GS_, 1, EPI_>(fp, 2 * blocks, st) : launch64_k<WB_, GS_, 2, EPI_>(fp, 2 * blocks, st)
     if (epi == FK_ROPE) {
         if (fp.r.hd != 64 && fp.r.hd != 128) return MI355_ERR_UNSUPPORTED;
         const int blocks = (fp.r.nh + 2 * fp.r.nkv) * (fp.r.hd / 32);
+        // a rank's shard of the QKV columns under tensor parallelism (Qwen2-7B tp2: 72 tile pairs, Llama-3-70B tp8: 40) or a small model
+        // leaves more than half of the CUs without a block: two blocks per pair, half of the row blocks each, as for the O projection
+        if (g.M > 16 && 2 * blocks <= 256 && !(TUNE(4) == 3)) {
+            fp.rowsplit = (blocks % 8 == 0) ? 2 : 1;
+            if (w8) { F64H_(8, 4, FK_ROPE); }
+            if (group_size == 128) { F64H_(4, 4, FK_ROPE); }
+            if (group_size == 64)  { F64H_(4, 2, FK_ROPE); }
+            F64H_(4, 1, FK_ROPE);
+        }
         if (w8) { F64_(8, 4, FK_ROPE, blocks); }
         if (group_size == 128) { F64_(4, 4, FK_ROPE, blocks); }
         if (group_size == 64)  { F64_(4, 2, FK_ROPE, blocks); }
@@ -398,12 +411,10 @@ extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi35
         const int blocks = cdiv(g.NT, 2);
         if (g.M > 16 && 2 * blocks <= 256 && !(TUNE(4) == 3)) {       // two blocks per tile pair, half of the row blocks each (see the kernel)
             fp.rowsplit = (blocks % 8 == 0) ? 2 : 1;
-#define F64H_(WB_, GS_) return mblk <= 2 ? launch64_k<WB_, GS_, 1, FK_RESID>(fp, 2 * blocks, st) : launch64_k<WB_, GS_, 2, FK_RESID>(fp, 2 * blocks, st)
-            if (w8) { F64H_(8, 4); }
-            if (group_size == 128) { F64H_(4, 4); }
-            if (group_size == 64)  { F64H_(4, 2); }
-            F64H_(4, 1);
-#undef F64H_
+            if (w8) { F64H_(8, 4, FK_RESID); }
+            if (group_size == 128) { F64H_(4, 4, FK_RESID); }
+            if (group_size == 64)  { F64H_(4, 2, FK_RESID); }
+            F64H_(4, 1, FK_RESID);
         }
         if (w8) { F64_(8, 4, FK_RESID, blocks); }
         if (group_size == 128) { F64_(4, 4, FK_RESID, blocks); }
@@ -411,5 +422,6 @@ extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi35
         F64_(4, 1, FK_RESID, blocks);
     }
 #undef F64_
+#undef F64H_
     return MI355_ERR_UNSUPPORTED;
 }

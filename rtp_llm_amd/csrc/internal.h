@@ -17,6 +17,7 @@ int mi355_paged_decode_attn_ex(const void* q, const mi355_kv_layer_t* kv, const 
                                size_t workspace_bytes, mi355_stream_t stream);
 int mi355_fullk_weight_ok(const mi355_weight_t* w);
 int mi355_fullk64_weight_ok(const mi355_weight_t* w);     /* gemm.hip: the full-K launches on activation images (gemm_fullk64.hip) take this linear */
+int mi355_fullk64_qkv_ok(const mi355_weight_t* w, int32_t hd);   /* ... as the QKV + RoPE launch (also K up to 9600 when its tile pairs leave half the chip free) */
 int mi355_gemm_wide_direct_ok(const mi355_weight_t* w);   /* gemm_wide.hip: the one-launch form takes this linear (N fills the chip) */
 int mi355_gemm_splitk64_plan(int M, int NT, int KC, int wbits, int group_size, int max_splits, int* cps_out);   /* gemm_splitk64.hip: slabs, or < 0 */
 int mi355_prefetch(const void* ptr, size_t bytes, void* sink, mi355_stream_t stream);

@@ -376,6 +376,16 @@ def test_committed_bench_line_and_traffic_file_follow_the_contract():
     assert tj["gemm_sources_sha_over"] == list(bench.TRAFFIC_KERNEL_SOURCES)
     if tj["gemm_sources_sha"] == bench.gemm_sources_sha():          # else bench.py reports traffic: null ("stale")
         assert rf["traffic"] == int(tj["gemm_quant_bytes_per_launch"]) and rf["traffic"] >= 0.9 * rf["bytes_per_launch"]
+    # N > 1: the line carries `roofline` (the headline TP layout's shard of rank 0) and `cpu_baseline` too -- dry runs of the driver's N = 2 / 8
+    # launch lines with every rank on ONE GPU (timing meaningless, the fields are what is checked)
+    for n in (2, 8):
+        dj = json.loads(open(os.path.join(root, "profiles", f"r05_dryrun_{n}ranks_one_gpu.json")).read().strip().splitlines()[-1])
+        assert dj["n_gpus"] == n and "tp_layout" in dj and "error" not in dj["tp_layout"] and "replica_layout" in dj
+        r2, c2 = dj["roofline"], dj["cpu_baseline"]
+        assert r2["bound"] == "hbm" and r2["layout"].startswith("tp") and abs(r2["frac"] - r2["achieved"] / r2["peak"]) < 1e-3 and r2["traffic"] is None
+        assert abs(r2["achieved"] - r2["bytes_per_launch"] / r2["avg_launch_us"] / 1e3) / r2["achieved"] < 1e-2
+        assert c2["kind"] == "port" and c2["cores"] >= 1 and c2["value"] > 0
+        assert dj["replica_layout"]["roofline"]["layout"].startswith("dp")
     pj = json.load(open(os.path.join(root, "profiles", "r04_parity_greedy_ids.json")))    # tests/conftest.py: the full-width end-to-end record
     assert pj["summary"]["rows"] >= 400 and pj["summary"]["exact"] >= pj["summary"]["safe"]
     assert all(r["max_abs_logit_err"] <= r["tol"] and (r["exact"] == r["rows"] or r["safe"] < r["rows"]) for r in pj["records"])
