@@ -227,8 +227,22 @@ def main():
             "final_norm": (1.0 + 0.1 * torch.randn(cfg.hidden, device=dev, generator=gshared)).half(),
             "lm_head": model.synth_linear(cfg.hidden, cfg.vocab, "fp16", dev, gen),
         }
+        shard_dbg = args.shard_of > 1 and world == 1
         eng = model.DecoderEngine(cfg, weights, kv_int8=kv_int8, page=page, num_blocks=num_blocks, max_batch=B,
-                                  max_seq_len=max_seq_len, device=dev, tp_size=tp, vocab_full=cfg_full.vocab, dtype=dtype)
+                                  max_seq_len=max_seq_len, device=dev, tp_size=args.shard_of if shard_dbg else tp, vocab_full=cfg_full.vocab, dtype=dtype)
+        if shard_dbg:
+            # ONE rank's tensor-parallel step as the TP engine runs it -- per-rank shapes, the fused all-reduce launches in place -- with a
+            # world-1 all-reduce context (the rank "exchanges" with itself: same launches and flag protocol, no xGMI hop, sums of one rank:
+            # numbers meaningless, timing = the rank's kernels)
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                import socket
+                with socket.socket() as so:
+                    so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+                dist.init_process_group(backend="gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+            ar1 = distributed.CustomAllReduce(max_bytes=B * cfg_full.hidden * 2, rank=0, world=1)
+            eng.attach_allreduce(ar1, 0)
+            eng._ar_keep = ar1
         del weights, layers
         torch.cuda.empty_cache()
         fill_kv_random(eng, B, ctx, seed=2 + rank)
@@ -296,7 +310,8 @@ def main():
     if args.debug_set:
         out["invalid"] = f"debug run with --debug-set {args.debug_set} (tuning build of the library)"
     if args.shard_of > 1:
-        out["invalid"] = f"debug run: one rank's shard of tp={args.shard_of}, collectives omitted"
+        out["invalid"] = (f"debug run: ONE rank's step of a tp={args.shard_of} layout on one GPU -- per-rank shapes, the fused all-reduce launches in place "
+                          f"with a world-1 context (no xGMI hop)")
 
     def roofline_of(cfg_r, eng_r, reset_r, label, traffic_ok):
         """`roofline` of the dominant kernel family (the four weight-only dequant GEMMs of a layer) on THIS rank's engine: algorithmic

@@ -347,7 +347,15 @@ def test_host_side_plans_of_the_image_launches():
     assert plan(64, 224, 148, 4, 128, 16, C.byref(cps)) == 4 and cps.value == 37
     assert plan(8, 224, 148, 4, 128, 16, C.byref(cps)) == 4                       # the same plan at every row count
     assert plan(64, 2368, 28, 4, 128, 16, C.byref(cps)) < 0                       # gate_up: N alone fills the chip -> the wide kernel's shape
-    assert plan(64, 224, 148, 8, 0, 16, C.byref(cps)) < 0 and plan(65, 224, 148, 4, 128, 16, C.byref(cps)) < 0   # W8 / > 64 rows: not this kernel
+    assert plan(64, 224, 148, 8, 0, 16, C.byref(cps)) == 4 and cps.value == 37    # per-channel W8 (round 5): the same K quarters
+    assert plan(64, 224, 148, 8, 128, 16, C.byref(cps)) < 0 and plan(65, 224, 148, 4, 128, 16, C.byref(cps)) < 0   # group-wise W8 / > 64 rows: not this kernel
+    qok = lib.mi355_fullk64_qkv_ok
+    qok.restype, qok.argtypes = C.c_int, [C.POINTER(_C.Weight), C.c_int]
+    mkw = lambda K, N, wbits=4, gs=128: _C.Weight(1 << 20, 1 << 21, wbits, K, N, K, N, gs, _C.ACT_F16)
+    # QKV + RoPE as one launch on an image: Qwen2-7B (K 3584, W4 or W8); hidden 8192 (64 chunks) only as a TP shard whose tile pairs leave
+    # half the chip free -- Llama-3-70B tp 8: (8 + 2) heads of 128 = 1280 columns, 40 pairs; the unsplit 10240 columns: no
+    assert qok(C.byref(mkw(3584, 4608)), 128) == 1 and qok(C.byref(mkw(3584, 4608, 8, 0)), 128) == 1
+    assert qok(C.byref(mkw(8192, 1280)), 128) == 1 and qok(C.byref(mkw(8192, 10240)), 128) == 0 and qok(C.byref(mkw(8192, 1280, 8, 0)), 128) == 0
     ok = lib.mi355_gemm_wide_direct_ok
     ok.restype, ok.argtypes = C.c_int, [C.POINTER(_C.Weight)]
     mk = lambda K, N, wbits=4, gs=128: _C.Weight(1 << 20, 1 << 21, wbits, K, N, K, N, gs, _C.ACT_F16)   # pointers are never read here
