@@ -450,6 +450,11 @@ int mi355_allreduce_fused(mi355_allreduce_t* ar, const void* x_f16, const float*
                           const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
                           int32_t T, int32_t H, void* y, mi355_stream_t stream);
 
+/* Hand-over protocol of the context's launches: 0 (default) = the published rows are stored write-through at system scope (sc0 sc1) and
+ * ordered in front of the flags by the wave's own s_waitcnt; 1 = plain stores between system-scope release / acquire fences (an L2
+ * write-back + invalidate per block; rounds 1-4).  Results are identical; also settable with MI355_AR_FULL_FENCES=1 at creation. */
+int mi355_allreduce_set_full_fences(mi355_allreduce_t* ar, int32_t on);
+
 /* In-launch prefetch for the NEXT mi355_allreduce_fused[_dt] launch of this context (cleared by that launch): while a block waits
  * for its peers' flags its other waves touch one dword per 128-byte line of [ptr, ptr + bytes) -- normally the weight shard of the
  * GEMM that consumes the all-reduce -- so the HBM fetch runs under the xGMI exchange without a side stream (the reference's

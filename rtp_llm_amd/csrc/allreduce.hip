@@ -22,6 +22,7 @@
 // Greedy sampling under a vocab-split lm_head uses the same transport for (max logit, global index) pairs instead of
 // gathering the logits (PyWrappedModel.cc:915-936 gathers [B, V/tp] fp32 per rank; only 8 bytes per row are needed when
 // every top_k == 1).
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 #include <new>
@@ -57,6 +58,7 @@ struct ArDev {                             // device-visible part of the context
     uint32_t        data_bytes;            // bytes of one peer buffer (both parities): buffer range of the remote loads
     int             rank, world;
     unsigned long long spin_ticks;         // bound of every wait for a peer, in 100 MHz wall-clock ticks
+    int             full_fences;           // 1: the round-1..4 hand-over (plain stores + system-scope release / acquire fences); 0: see publish16
 };
 
 struct FusedParams {
@@ -87,6 +89,22 @@ __device__ __forceinline__ size_t row_off(const ArDev& ar, int row, int grid, in
 __device__ __forceinline__ u32x4 load_sys(__amdgpu_buffer_rsrc_t r, uint32_t off) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 17 /* sc0 | sc1 */);
 }
+// Publishing store into this rank's registered buffer.  Round 5: system-scope WRITE-THROUGH (sc0 sc1) -- the bytes go to memory, the
+// line is not kept in the XCD's L2 -- so that what orders them in front of the flags is the wave's own `s_waitcnt vmcnt(0)` instead of
+// a system-scope release fence.  That fence is `buffer_wbl2 sc0 sc1`: a write-back of the XCD's WHOLE L2 -- including the split-K
+// slabs the GEMM in front just left there -- per block, and its acquire twin `buffer_inv sc0 sc1` drops every line the next GEMM
+// could still have used; the peers' copies are read with sc0 sc1 loads, which never look at a local line, so nothing needs
+// invalidating.  (LLVM's gfx942 memory model: a system-scope atomic store is `store sc0 sc1`, made visible in program order by
+// `s_waitcnt vmcnt(0)`; MI355X_MICROARCH.md lists {sc0 sc1 stores and loads on both sides} + drained flag as a valid hand-over and
+// prices the fence pair at 3.5 us and more once lines are dirty.)  One rank's step of tp = 2 (bench.py --shard-of 2): see
+// profiles/r05_tp_allreduce_protocol.txt.  mi355_allreduce_set_full_fences(ar, 1) / MI355_AR_FULL_FENCES=1 bring the old form back.
+__device__ __forceinline__ void publish16(const ArDev& ar, __amdgpu_buffer_rsrc_t mine, size_t elem_off, u32x4 v) {
+    if (ar.full_fences) *reinterpret_cast<u32x4*>(ar.my_data + elem_off) = v;
+    else __builtin_amdgcn_raw_buffer_store_b128(v, mine, (uint32_t)(elem_off * 2), 0, 17 /* sc0 | sc1 */);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t my_rsrc(const ArDev& ar) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)ar.my_data, 0, ar.data_bytes, 0x00020000u);
+}
 
 // Raise this block's flag at every peer, then wait for every peer's flag of the same epoch.  Executed by the whole block.
 // slot0: 0 = the call's first barrier, 8 = the second barrier of a two-shot call (its own flag slots, same epoch value).
@@ -104,7 +122,8 @@ __device__ __forceinline__ void pf_fold(const PfRegs& r, uint32_t* sink) {
 }
 __device__ __forceinline__ void peer_barrier(const ArDev& ar, int b, uint32_t epoch, int slot0 = 0, const uint32_t* pf = nullptr,
                                              uint32_t pf_lines = 0, PfRegs* pfv = nullptr) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: this block's published rows first
+    if (ar.full_fences) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: this block's published rows first
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // every wave's write-through stores have reached memory (publish16)
     __syncthreads();
     const int t = threadIdx.x;
     if (pfv) {
@@ -125,7 +144,8 @@ __device__ __forceinline__ void peer_barrier(const ArDev& ar, int b, uint32_t ep
         }
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (ar.full_fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    else asm volatile("" ::: "memory");                    // the peers' rows are read with sc0 sc1 loads (load_sys): no local line to invalidate
 }
 
 // TWO = false: one-shot (every rank reads every peer's copy of every row: (N - 1) T H elements over its links -- cheapest for
@@ -142,6 +162,7 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
     const int nvec = p.H >> 3;
     const uint32_t epoch = ar.epoch[b] + 1;
     const size_t par = (epoch & 1) * ar.parity_elems;
+    const __amdgpu_buffer_rsrc_t mine_rs = my_rsrc(ar);
     // ---- stage 0: local row (split-K reduce + bias), fp16, into the registered buffer
     for (int row = b; row < p.T; row += gridDim.x) {
 #pragma unroll
@@ -183,7 +204,7 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
             } else {
                 o = *reinterpret_cast<const u32x4*>(p.x + (size_t)row * p.H + c0);
             }
-            *reinterpret_cast<u32x4*>(ar.my_data + par + row_off(ar, row, gridDim.x, p.H) + c0) = o;
+            publish16(ar, mine_rs, par + row_off(ar, row, gridDim.x, p.H) + c0, o);
         }
     }
     PfRegs pfv;
@@ -215,7 +236,7 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
                         for (int e = 0; e < 8; ++e) a[e] += h[e];
                     }
                 }
-                *reinterpret_cast<u32x4*>(ar.my_data + par + ar.res_elems + row_off(ar, row, gridDim.x, p.H) + vi * 8) = act_pack8<BF>(a);
+                publish16(ar, mine_rs, par + ar.res_elems + row_off(ar, row, gridDim.x, p.H) + vi * 8, act_pack8<BF>(a));
             }
         }
         peer_barrier(ar, b, epoch, 8);
@@ -318,9 +339,10 @@ __global__ __launch_bounds__(256) void allgather_hidden_kernel(const GatherParam
     const int H = p.n * ar.world, nv = p.n >> 3;
     const uint32_t epoch = ar.epoch[b] + 1;
     const size_t par = (epoch & 1) * ar.parity_elems;
+    const __amdgpu_buffer_rsrc_t mine_rs = my_rsrc(ar);
     for (int row = b; row < p.T; row += gridDim.x)
         for (int vi = tid; vi < nv; vi += 256)
-            *reinterpret_cast<f16x8*>(ar.my_data + par + row_off(ar, row, gridDim.x, H) + vi * 8) = *reinterpret_cast<const f16x8*>(p.x + (size_t)row * p.n + vi * 8);
+            publish16(ar, mine_rs, par + row_off(ar, row, gridDim.x, H) + vi * 8, *reinterpret_cast<const u32x4*>(p.x + (size_t)row * p.n + vi * 8));
     peer_barrier(ar, b, epoch);
 #pragma unroll
     for (int r = 0; r < kMaxWorld; ++r) {
@@ -362,7 +384,8 @@ __global__ __launch_bounds__(64) void allreduce_argmax_kernel(const ArgmaxParams
         }
         if (l == 0) {
             u32x2 rec = {__builtin_bit_cast(uint32_t, bv), (uint32_t)(bi + p.vocab_offset)};
-            *reinterpret_cast<u32x2*>(ar.my_data + par + ar.aux_elems + (size_t)row * 4) = rec;   // 8 bytes per row
+            if (ar.full_fences) *reinterpret_cast<u32x2*>(ar.my_data + par + ar.aux_elems + (size_t)row * 4) = rec;   // 8 bytes per row
+            else __builtin_amdgcn_raw_buffer_store_b64(rec, my_rsrc(ar), (uint32_t)((par + ar.aux_elems + (size_t)row * 4) * 2), 0, 17 /* sc0 | sc1: write-through, see publish16 */);
         }
     }
     peer_barrier(ar, b, epoch);
@@ -405,6 +428,7 @@ struct mi355_allreduce {
     unsigned long long spin_ticks;
     const void* pf_ptr = nullptr;      // mi355_allreduce_set_prefetch: range the next fused launch touches while it waits
     size_t      pf_bytes = 0;
+    int     full_fences = 0;           // mi355_allreduce_set_full_fences
 };
 
 namespace {
@@ -448,7 +472,7 @@ ArDev dev_view(const mi355_allreduce* a) {
     d.res_elems = (region + kAuxBytes) / 2;
     d.slot_elems = a->slot_bytes / 2;
     d.data_bytes = (uint32_t)(2 * (2 * region + kAuxBytes));
-    d.rank = a->rank; d.world = a->world; d.spin_ticks = a->spin_ticks;
+    d.rank = a->rank; d.world = a->world; d.spin_ticks = a->spin_ticks; d.full_fences = a->full_fences;
     return d;
 }
 
@@ -467,6 +491,7 @@ extern "C" mi355_allreduce_t* mi355_allreduce_create(int32_t rank, int32_t world
     mi355_allreduce* a = new (std::nothrow) mi355_allreduce();
     if (!a) return nullptr;
     a->rank = rank; a->world = world; a->ready = false; a->spin_ticks = kSpinTicks;
+    { const char* e = getenv("MI355_AR_FULL_FENCES"); a->full_fences = (e && e[0] == '1') ? 1 : 0; }
     a->max_bytes = (max_bytes + 255) & ~(size_t)255;
     a->slot_bytes = slot_bytes;
     for (int r = 0; r < kMaxWorld; ++r) { a->peer_data[r] = a->peer_flags[r] = nullptr; a->opened[r] = false; }
@@ -526,6 +551,15 @@ extern "C" void mi355_allreduce_destroy(mi355_allreduce_t* a) {
 extern "C" int mi355_allreduce_set_spin_timeout_ms(mi355_allreduce_t* a, int32_t ms) {
     MI355_CHECK_ARG(a && ms >= 1 && ms <= 600000, "allreduce_set_spin_timeout_ms: ms=%d (1..600000)", ms);
     a->spin_ticks = (unsigned long long)ms * 100000ull;
+    return MI355_OK;
+}
+
+// Hand-over protocol of every later launch of this context: 0 (default) = write-through publishing stores + drained flags (publish16),
+// 1 = plain stores between system-scope release / acquire fences (rounds 1-4).  Same results either way; every rank of a group must
+// use the same setting only for timing comparisons -- the two forms interoperate.
+extern "C" int mi355_allreduce_set_full_fences(mi355_allreduce_t* a, int32_t on) {
+    MI355_CHECK_ARG(a, "allreduce_set_full_fences: null context");
+    a->full_fences = on ? 1 : 0;
     return MI355_OK;
 }
 

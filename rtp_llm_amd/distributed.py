@@ -114,6 +114,11 @@ class CustomAllReduce:
                      os.environ.get("ROCR_VISIBLE_DEVICES", ""))
         return (socket.gethostname(), str(ident))
 
+    def set_full_fences(self, on: bool) -> None:
+        """Hand-over protocol of later launches: False (default) = write-through publishing stores + drained flags, True = plain stores
+        between system-scope release / acquire fences (rounds 1-4).  Same results (mi355_allreduce_set_full_fences)."""
+        self._C.check(self.lib.mi355_allreduce_set_full_fences(self.handle, 1 if on else 0), "allreduce_set_full_fences")
+
     def set_spin_timeout_ms(self, ms: int) -> None:
         """Bound of every in-kernel wait for a peer; applies to launches enqueued or captured afterwards."""
         self._C.check(self.lib.mi355_allreduce_set_spin_timeout_ms(self.handle, int(ms)), "allreduce_set_spin_timeout_ms")
