@@ -216,8 +216,8 @@ def test_act_image_layout_and_round_trip(M, K):
 
 
 @pytest.mark.parametrize("K,N,gs", [(3584, 3584, 128), (512, 272, 128), (1024, 256, 64), (512, 128, 32), (4096, 1024, 128), (5120, 512, 128),
-                                    (3584, 3584, W8), (512, 272, W8), (3840, 512, W8)],
-                         ids=["o", "ragged-n", "g64", "g32", "k4096-three-chunk-slices", "k5120", "w8-o", "w8-ragged-n", "w8-k3840"])
+                                    (3584, 3584, W8), (512, 272, W8), (3840, 512, W8), (8192, 512, 128)],
+                         ids=["o", "ragged-n", "g64", "g32", "k4096-three-chunk-slices", "k5120", "w8-o", "w8-ragged-n", "w8-k3840", "k8192-five-chunk-slices-row-split"])
 def test_linear_residual_img_vs_oracle(K, N, gs):
     packed, W = _w4(K, N, K + N, gs)
     x = (torch.randn(64, K, generator=torch.Generator().manual_seed(3)) * 0.5).half()
@@ -250,8 +250,11 @@ def test_img_launches_refuse_other_shapes():
     assert ops.linear_residual_img(ops.act_image_pack(torch.zeros(32, 512, dtype=torch.float16, device=DEV)), p16, r) is None
     p8 = model.synth_linear(3968, 256, "int8", DEV, gen).pack()                                                                 # W8: 31 chunks, past its two-chunk slices
     assert ops.linear_residual_img(ops.act_image_pack(torch.zeros(32, 3968, dtype=torch.float16, device=DEV)), p8, r) is None
-    pk = model.synth_linear(5888, 256, "w4", DEV, gen).pack()                                                                    # 46 chunks: past the slices
-    assert ops.linear_residual_img(ops.act_image_pack(torch.zeros(32, 5888, dtype=torch.float16, device=DEV)), pk, r) is None
+    pk = model.synth_linear(9728, 256, "w4", DEV, gen).pack()                                                                    # 76 chunks: past the five-chunk slices
+    assert ops.linear_residual_img(ops.act_image_pack(torch.zeros(32, 9728, dtype=torch.float16, device=DEV)), pk, r) is None
+    pw = model.synth_linear(5888, 4608, "w4", DEV, gen).pack()                                                                   # 46 chunks x 144 tile pairs: no room for the row split
+    rw = torch.zeros(64, 4608, dtype=torch.float16, device=DEV)                                                                  # that the five-chunk slices need above 32 rows
+    assert ops.linear_residual_img(ops.act_image_pack(torch.zeros(64, 5888, dtype=torch.float16, device=DEV)), pw, rw) is None
 
 
 @pytest.mark.parametrize("nh,nkv,hd,hidden,page,q_len,gs", [(28, 4, 128, 3584, 16, 1, 128), (28, 4, 128, 3584, 16, 4, 128), (4, 2, 64, 512, 8, 1, 128),
