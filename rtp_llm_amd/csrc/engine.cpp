@@ -91,6 +91,9 @@ struct mi355_decoder {
     // keep their slab launches (their partial sums meet in the all-reduce launch either way)
     bool   tp_img_qkv;
     int    tp_fuse_rows;    // up to this many rows the TP step keeps the few-row QKV launch (row-major input)
+    // ... and the row-parallel down_proj shard as K quarters (gemm_splitk64.hip) from the image the gate_up shard's SiLU epilogue writes:
+    // 2-4 slabs into the fused all-reduce launch instead of up to 15
+    bool   tp_img_down;
     // ... and the post-attention RMSNorm deferred into gate_up's accumulators (mi355_deferred_norm_t): the O launch leaves
     // gamma 2^-e h' as an image + the per-tile sums of h'^2, the wide GEMM applies rsqrt(mean h'^2 + eps) 2^e: 6 launches per layer
     bool   img_gate_up;
@@ -282,6 +285,10 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
                     cfg->max_batch >= 1 && TUNE(5) != 2;
     for (const auto& L : d->layers) d->tp_img_qkv = d->tp_img_qkv && mi355_fullk64_qkv_ok(&L.qkv, cfg->hd) != 0;
     d->tp_fuse_rows = (bf_act || !d->fuse_qkv) ? 0 : 4;
+    d->tp_img_down = cfg->tp_size > 1 && cfg->inter % 32 == 0 && TUNE(5) != 4 && TUNE(5) != 2;
+    for (const auto& L : d->layers)
+        d->tp_img_down = d->tp_img_down && L.down.K % 128 == 0 && L.down.K_pad == L.down.K && L.down.K == cfg->inter && L.gate_up.N == 2 * cfg->inter &&
+                         mi355_gemm_splitk64_plan(64, L.down.N_pad / 16, L.down.K_pad / 128, L.down.wbits, L.down.group_size, kMaxSplits, nullptr) > 0;
     if (TUNE(5) == 2) d->img_qkv = d->img_o = false;   // tuning build: A/B against the split-K + fold launches
     // bf16 / W8: no few-row full-K launches to cross over to (gemm_fullk.hip takes fp16 steps of W4 / fp16 weights; the staged kernels lose
     // at every height): the image launches serve 1-64 rows
@@ -623,8 +630,9 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
         const mi355_fused_norm_t fn = {d->ssq, c.hidden / 16, (c.hidden / 16 + 3) & ~3, L.post_norm, c.rms_eps};
         RUN(MI355_KC_GEMM_QUANT, mi355_norm_linear(d->resid, B, &fn, &L.gate_up, nullptr, d->act, MI355_EPI_SILU_MUL, st));
     } else {
-        RUN(MI355_KC_GEMM_QUANT, mi355_linear_direct(d->xn, B, &L.gate_up, nullptr, d->act, MI355_EPI_SILU_MUL, d->partials,
-                                                     d->partials_bytes, st));
+        const bool gi = d->tp_img_down && d->ar && B > d->tp_fuse_rows;   // TP: the SiLU output of the shard as the image the K-quarter down launch reads
+        RUN(MI355_KC_GEMM_QUANT, mi355_linear_direct(d->xn, B, &L.gate_up, nullptr, gi ? d->act_img : d->act, MI355_EPI_SILU_MUL | (gi ? MI355_EPI_OUT_IMAGE : 0),
+                                                     d->partials, d->partials_bytes, st));
     }
     int ns = 0;
     const void* next_norm = (l + 1 < c.num_layers) ? d->layers[l + 1].input_norm : d->model.final_norm;
@@ -636,7 +644,7 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
         if (!normed || last) RUN(MI355_KC_NORM, mi355_rmsnorm_dt(d->resid, next_norm, c.rms_eps, B, c.hidden, d->xn, ADT, st));
         return MI355_OK;
     }
-    if (d->img_o && d->img_gate_up && d->img_down && B > d->fuse_rows)
+    if ((d->img_o && d->img_gate_up && d->img_down && B > d->fuse_rows) || (d->tp_img_down && d->ar && B > d->tp_fuse_rows))
         RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial_img(d->act_img, B, &L.down, d->partials, kMaxSplits, st));
     else
         RUN(MI355_KC_GEMM_QUANT, ns = mi355_linear_partial(d->act, B, &L.down, d->partials, kMaxSplits, st));

@@ -433,8 +433,14 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry_f32, (uint32_t)(((size_t)m * p.ldy + n0) * 4), 0, 16 /*sc1*/);
                 } else if (p.mode == MODE_F16) {
                     u32x2 o;
-                    o[0] = act_pack<BF>(v[0], v[1]); o[1] = act_pack<BF>(v[2], v[3]);
-                    *reinterpret_cast<u32x2*>((f16*)p.y + (size_t)m * p.ldy + n0) = o;
+                    if (p.y_img) {   // activation image (common.h): fp16 of the BF-typed tensor's values (x 2^-8 for bf16)
+                        o[0] = act_pack<false>(img_val<BF>(act_round<BF>(v[0])), img_val<BF>(act_round<BF>(v[1])));
+                        o[1] = act_pack<false>(img_val<BF>(act_round<BF>(v[2])), img_val<BF>(act_round<BF>(v[3])));
+                        *reinterpret_cast<u32x2*>((f16*)p.y + act_img_index(m, n0, (p.M + 15) >> 4)) = o;
+                    } else {
+                        o[0] = act_pack<BF>(v[0], v[1]); o[1] = act_pack<BF>(v[2], v[3]);
+                        *reinterpret_cast<u32x2*>((f16*)p.y + (size_t)m * p.ldy + n0) = o;
+                    }
                 } else { // MODE_SILU: (gate, up) interleaved; round GEMM output to the activation dtype first
                     float sg[2];
 #pragma unroll
@@ -442,7 +448,10 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
                         const float g = act_round<BF>(v[2 * t]), u = act_round<BF>(v[2 * t + 1]);
                         sg[t] = (g / (1.f + __expf(-g))) * u;
                     }
-                    *reinterpret_cast<uint32_t*>((f16*)p.y + (size_t)m * p.ldy + (n0 >> 1)) = act_pack<BF>(sg[0], sg[1]);
+                    if (p.y_img)
+                        *reinterpret_cast<uint32_t*>((f16*)p.y + act_img_index(m, n0 >> 1, (p.M + 15) >> 4)) = act_pack<false>(img_val<BF>(act_round<BF>(sg[0])), img_val<BF>(act_round<BF>(sg[1])));
+                    else
+                        *reinterpret_cast<uint32_t*>((f16*)p.y + (size_t)m * p.ldy + (n0 >> 1)) = act_pack<BF>(sg[0], sg[1]);
                 }
             }
         }
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(64 * NWN * KG) void gemm_wq_kernel(const GemmParams
 template <bool BF>
 __global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* __restrict__ partials, int nsplit,
                                                               int M, int N, int N_pad, const f16* __restrict__ bias,
-                                                              void* y, int ldy, int mode) {
+                                                              void* y, int ldy, int mode, int y_img_mblk) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int n4  = N_pad >> 2;
     if (idx >= M * n4) return;
@@ -482,8 +491,14 @@ __global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* __res
         *reinterpret_cast<f32x4*>((float*)y + (size_t)m * ldy + n0) = v;
     } else if (mode == MODE_F16) {
         u32x2 o;
-        o[0] = act_pack<BF>(v[0], v[1]); o[1] = act_pack<BF>(v[2], v[3]);
-        *reinterpret_cast<u32x2*>((f16*)y + (size_t)m * ldy + n0) = o;
+        if (y_img_mblk > 0) {   // activation image (common.h): fp16, the values of the BF-typed tensor (x 2^-8 for bf16) at the image's addresses
+            o[0] = act_pack<false>(img_val<BF>(act_round<BF>(v[0])), img_val<BF>(act_round<BF>(v[1])));
+            o[1] = act_pack<false>(img_val<BF>(act_round<BF>(v[2])), img_val<BF>(act_round<BF>(v[3])));
+            *reinterpret_cast<u32x2*>((f16*)y + act_img_index(m, n0, y_img_mblk)) = o;
+        } else {
+            o[0] = act_pack<BF>(v[0], v[1]); o[1] = act_pack<BF>(v[2], v[3]);
+            *reinterpret_cast<u32x2*>((f16*)y + (size_t)m * ldy + n0) = o;
+        }
     } else {
         float sg[2];
 #pragma unroll
@@ -491,15 +506,18 @@ __global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* __res
             const float g = act_round<BF>(v[2 * t]), u = act_round<BF>(v[2 * t + 1]);
             sg[t] = (g / (1.f + __expf(-g))) * u;
         }
-        *reinterpret_cast<uint32_t*>((f16*)y + (size_t)m * ldy + (n0 >> 1)) = act_pack<BF>(sg[0], sg[1]);
+        if (y_img_mblk > 0)
+            *reinterpret_cast<uint32_t*>((f16*)y + act_img_index(m, n0 >> 1, y_img_mblk)) = act_pack<false>(img_val<BF>(act_round<BF>(sg[0])), img_val<BF>(act_round<BF>(sg[1])));
+        else
+            *reinterpret_cast<uint32_t*>((f16*)y + (size_t)m * ldy + (n0 >> 1)) = act_pack<BF>(sg[0], sg[1]);
     }
 }
 
 void launch_reduce_epilogue(const float* partials, int nsplit, int M, int N, int N_pad, const f16* bias, void* y, int ldy, int mode, bool bf,
-                            hipStream_t st) {
+                            hipStream_t st, int y_img_mblk = 0) {
     const int total = M * (N_pad / 4);
-    if (bf) hipLaunchKernelGGL(reduce_epilogue_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, st, partials, nsplit, M, N, N_pad, bias, y, ldy, mode);
-    else    hipLaunchKernelGGL(reduce_epilogue_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, st, partials, nsplit, M, N, N_pad, bias, y, ldy, mode);
+    if (bf) hipLaunchKernelGGL(reduce_epilogue_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, st, partials, nsplit, M, N, N_pad, bias, y, ldy, mode, y_img_mblk);
+    else    hipLaunchKernelGGL(reduce_epilogue_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, st, partials, nsplit, M, N, N_pad, bias, y, ldy, mode, y_img_mblk);
 }
 
 // ------------------------------------------------------------------ dispatch
@@ -803,7 +821,14 @@ extern "C" int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_
     p.mode = mode; p.bias = (const f16*)bias; p.y = y;
     p.ldy = (mode == MODE_SILU) ? w->N / 2 : w->N;
     const bool bf = p.bf16;
-    if (!bf && M <= 8 && w->wbits != 16 && (TUNE(4) == 2 || TUNE(7) == 1)) {
+    // MI355_EPI_OUT_IMAGE: the 16-bit output as an activation image (what a launch on images reads next: under TP the SiLU output of the
+    // gate_up shard for down_proj's K-quarter launch) -- the kernels' common store and the slab fold below both know the layout
+    const bool out_img = (epilogue & MI355_EPI_OUT_IMAGE) != 0;
+    if (out_img) {
+        MI355_CHECK_ARG(mode != MODE_F32 && p.ldy % 32 == 0 && !(bf && bias), "linear_direct: an image output is a 16-bit tensor with a multiple of 32 columns (bf16: no bias)");
+        p.y_img = 1;
+    }
+    if (!bf && !out_img && M <= 8 && w->wbits != 16 && (TUNE(4) == 2 || TUNE(7) == 1)) {
         const int rc = mi355_gemm_smallm(&p, w->wbits, w->group_size, 0, 1, stream);
         if (rc >= 0) return MI355_OK;
         if (rc != MI355_ERR_UNSUPPORTED) return rc;
@@ -827,7 +852,7 @@ extern "C" int mi355_linear_direct(const void* x, int32_t M, const mi355_weight_
     p.mode = MODE_PARTIAL; p.partials = (float*)workspace; p.bias = nullptr; p.y = nullptr;
     if (int e = launch_gemm(p, w->wbits, w->group_size, g.cfg, (hipStream_t)stream)) return e;
     launch_reduce_epilogue((const float*)workspace, g.nsplit, M, w->N, w->N_pad, (const f16*)bias, y, (mode == MODE_SILU) ? w->N / 2 : w->N, mode, bf,
-                           (hipStream_t)stream);
+                           (hipStream_t)stream, out_img ? cdiv(M, 16) : 0);
     MI355_CHECK_LAUNCH("reduce_epilogue_kernel");
     return MI355_OK;
 }

@@ -427,6 +427,53 @@ def _worker(rank, world, port, q, mode):
                 tok = nxt
                 eng.token_ids[:B].copy_(tok)
             assert ar.status() == 0 and eng.oob_count() == 0
+        elif mode == "engine7b":
+            # Qwen2-7B's widths (hidden 3584, 28 q / 4 kv heads, FFN 18944) at tp = world, 2 layers, small vocabulary: the TP step of round 5 at
+            # the shapes bench.py times -- QKV shard on the image launch (row split: 72 tile pairs at tp 2), gate_up shard's SiLU output as an
+            # image, down_proj shard as 4 K quarters (gemm_splitk64) into the fused all-reduce, which writes the next QKV image -- captured
+            # per rank, against the unsplit oracle; 24 rows (two row blocks) and 5 rows (one)
+            cfg = model.ModelConfig("qwen2-7b-2l", 2, 3584, 28, 4, 128, 18944, 2048, max_pos=64)
+            w = model.synth_model(cfg, "w4", "cpu", seed=41, zeros="centered")
+            V = cfg.vocab
+            layers = [model.split_layer_tp(L, cfg, world, rank) for L in w["layers"]]
+            head = w["lm_head"].cols(rank * (V // world), (rank + 1) * (V // world))
+            shard = {"layers": layers, "embedding": w["embedding"], "final_norm": w["final_norm"], "lm_head": head}
+            Bmax, page = 24, 16
+            eng = model.DecoderEngine(cfg.per_rank(world), model.weights_to(shard, dev), kv_int8=False, page=page, num_blocks=Bmax * 2,
+                                      max_batch=Bmax, max_seq_len=32, device=dev, tp_size=world, vocab_full=V)
+            eng.attach_allreduce(ar, rank * (V // world))
+            if rank == 0:
+                dense = lambda c: (c.w.float() if c.kind == "fp16" else oracle.dequant_groupwise(c.q, c.z_eff, c.scales, c.group_size))
+                ow = {"embedding": w["embedding"], "final_norm": w["final_norm"], "lm_head": dense(w["lm_head"]),
+                      "layers": [{"input_norm": L["input_norm"], "post_norm": L["post_norm"], "qkv_bias": L["qkv_bias"],
+                                  **{k: dense(L[k]) for k in ("qkv", "o", "gate_up", "down")}} for L in w["layers"]]}
+                odec = oracle.OracleDecoder({**cfg.__dict__}, ow)
+            del w, shard, layers, head
+            bt = torch.arange(Bmax * 2, dtype=torch.int32).reshape(Bmax, 2)
+            for B in (24, 5):
+                okv = oracle.OracleKV(cfg.num_layers, B, False) if rank == 0 else None
+                tok = torch.randint(0, V, (B,), generator=torch.Generator().manual_seed(3 + B), dtype=torch.int32)
+                eng.set_inputs(tok.tolist(), [0] * B, bt[:B])
+                dist.barrier()
+                eng.capture(B)
+                for step in range(3):
+                    pos = torch.full((B,), step, dtype=torch.int32)
+                    eng.replay(B, 1)
+                    torch.cuda.synchronize()
+                    full = torch.cat(_gather_cpu(eng.logits[:B].cpu(), world), dim=1)
+                    mine = eng.token_ids[:B].cpu()
+                    allids = _gather_cpu(mine, world)
+                    assert all(torch.equal(allids[0], o) for o in allids[1:])
+                    assert torch.equal(mine, torch.argmax(full, -1).int())
+                    nxt = torch.zeros(B, dtype=torch.int32)
+                    if rank == 0:
+                        _, ref = odec.forward_tokens(tok, pos, okv, list(range(B)))
+                        assert torch.allclose(full, ref, atol=1e-2, rtol=1e-2), (B, step, float((full - ref).abs().max()))
+                        nxt = oracle.greedy(ref).int()
+                    dist.broadcast(nxt, 0)
+                    tok = nxt
+                    eng.token_ids[:B].copy_(tok)
+            assert ar.status() == 0 and eng.oob_count() == 0
         elif mode == "engine70full":
             # BASELINE configs[3] at its real per-rank shapes: Llama-3-70B widths (hidden 8192, 64 q / 8 kv heads, FFN 28672, the
             # whole 128256-token vocabulary), TP 8, batch 32 at context 2048 -- 2 of the 80 layers, every rank's shard
@@ -512,7 +559,7 @@ def _worker(rank, world, port, q, mode):
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("mode,world", [("kernels", 2), ("engine", 2), ("transport", 2), ("bf16", 2), ("bf16", 4), ("timeout", 2), ("twoshot", 3), ("mixed", 2), ("kernels", 4),
-                                        ("kernels", 8), ("twoshot", 4), ("twoshot", 8), ("engine70", 8), ("engine70full", 8), ("kernels_ff", 2), ("engine_ff", 2), ("twoshot_ff", 3)])
+                                        ("kernels", 8), ("twoshot", 4), ("twoshot", 8), ("engine70", 8), ("engine70full", 8), ("kernels_ff", 2), ("engine_ff", 2), ("twoshot_ff", 3), ("engine7b", 2), ("engine7b", 4)])
 def test_custom_allreduce_processes_on_one_gpu(mode, world):
     assert torch.cuda.is_available()
     port = _free_port()
