@@ -10,7 +10,8 @@ the HIP kernels and the oracle's fp32 matmuls accumulate along the residual stre
   * the first step of each also runs EAGERLY through the segment calls (mi355_decoder_begin / layer_attn / layer_mlp), and the
     residual stream after every half layer is compared with the oracle's: the per-layer max |delta h| shows where a drift starts;
     max |h'| is recorded against the fp16 range the deferred-norm image has (|gamma 2^-e h'| <= |h'|);
-  * one bf16 step at B = 64 (bf16 KV cache).
+  * one bf16 step at B = 64 (bf16 KV cache);
+  * configs[1] at full depth: per-channel W8 (load-time INT8 autoquant), B = 16, two steps on the W8 image launches of round 5.
 
 Reference: Qwen3Model.forward / Qwen3DecoderLayer.forward (rtp_llm/models_py/model_desc/qwen3.py:57-79,124-138), the generate loop of
 standalone/auto_model.py:144-265.  The oracle dequantises ONE layer at a time (932 MB fp32) so the host never holds the 26 GB of a
@@ -56,8 +57,9 @@ class _LazyLayers:
         if l != self.at:
             L = self.layers[l]
             self.cur = None
+            dq = lambda c: oracle.dequant_int8(c.q, c.scales) if c.kind == "int8" else oracle.dequant_groupwise(c.q, c.z_eff, c.scales, c.group_size)
             self.cur = {"input_norm": self.cast(L["input_norm"]), "post_norm": self.cast(L["post_norm"]), "qkv_bias": self.cast(L["qkv_bias"]),
-                        **{k: oracle.dequant_groupwise(L[k].q, L[k].z_eff, L[k].scales, L[k].group_size) for k in ("qkv", "o", "gate_up", "down")}}
+                        **{k: dq(L[k]) for k in ("qkv", "o", "gate_up", "down")}}
             self.at = l
         return self.cur
 
@@ -202,3 +204,23 @@ def test_full_depth_bf16_b64_vs_oracle(full_model, parity):
     # kernels' and the oracle's summation orders reach the lm_head -- 2.9e-2 measured (fp16 at the same depth: 3.7e-3), so the step is
     # held to the 3e-2 of the bf16 tests (tests/test_gpu_bf16.py), greedy ids identical on every row whose top-2 margin exceeds it
     _run("bf16-b64", cfg, eng, odec, base.fork(64), bt, 64, 1, parity, tol=3e-2)
+
+
+def test_full_depth_w8a16_b16_vs_oracle(parity):
+    """BASELINE configs[1] at full depth: Qwen2-7B with load-time INT8 autoquant (per-channel W8, device_impl.py:183-222), 28 layers, B = 16,
+    ctx 1024, fp16 cache -- the W8 instances of the image launches (gemm_fullk64 / gemm_wide / gemm_splitk64) over the whole depth."""
+    cfg = model.ModelConfig("qwen2-7b", 28, 3584, 28, 4, 128, 18944, 152064, max_pos=CTX + 16)
+    w_dev = model.synth_model(cfg, "int8", DEV, seed=29)
+    w = model.weights_to(w_dev, "cpu")
+    B = 16
+    eng, mb = _engine(cfg, w_dev, B, torch.float16)
+    del w_dev
+    odec = oracle.OracleDecoder({**cfg.__dict__}, {"embedding": w["embedding"], "final_norm": w["final_norm"],
+                                                   "lm_head": w["lm_head"].w.float(), "layers": _LazyLayers(w["layers"])})
+    g = torch.Generator().manual_seed(9)
+    bt = torch.randperm(B * mb, generator=g).reshape(B, mb).to(torch.int32)
+    base = _TensorKV.fill(cfg.num_layers, B, CTX + STEPS, CTX - 1, cfg.nkv, cfg.hd, torch.float16, g)
+    for l in range(cfg.num_layers):
+        for b in range(B):
+            kvcache.write_tokens(eng.kv[l], None, bt[b], 0, base.K[l][b][:CTX - 1], base.V[l][b][:CTX - 1])
+    _run("w8a16-b16", cfg, eng, odec, base.fork(B), bt, B, STEPS, parity)
