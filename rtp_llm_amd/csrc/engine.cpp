@@ -284,11 +284,15 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     d->tp_img_qkv = cfg->tp_size > 1 && cfg->kv_dtype == (bf_act ? MI355_KV_BF16 : MI355_KV_FP16) && cfg->rope_dim == cfg->hd && cfg->hidden % 32 == 0 &&
                     cfg->max_batch >= 1 && TUNE(5) != 2;
     for (const auto& L : d->layers) d->tp_img_qkv = d->tp_img_qkv && mi355_fullk64_qkv_ok(&L.qkv, cfg->hd) != 0;
-    d->tp_fuse_rows = (bf_act || !d->fuse_qkv) ? 0 : 4;
     d->tp_img_down = cfg->tp_size > 1 && cfg->inter % 32 == 0 && TUNE(5) != 4 && TUNE(5) != 2;
     for (const auto& L : d->layers)
         d->tp_img_down = d->tp_img_down && L.down.K % 128 == 0 && L.down.K_pad == L.down.K && L.down.K == cfg->inter && L.gate_up.N == 2 * cfg->inter &&
                          mi355_gemm_splitk64_plan(64, L.down.N_pad / 16, L.down.K_pad / 128, L.down.wbits, L.down.group_size, kMaxSplits, nullptr) > 0;
+    // from how many rows the TP step takes the image launches: with the down shard as K quarters they win from ONE row (one rank of tp 2,
+    // b = 1 / 2 / 4: 1.67 / 1.68 / 1.72 ms against 1.75 / 1.77 / 1.82 with the few-row QKV launch + 15 staged slabs; profiles/r05_tp_small_batch_crossover.txt);
+    // without that plan the few-row QKV launch keeps its rows (the tp = 1 crossover)
+    d->tp_fuse_rows = (bf_act || !d->fuse_qkv || d->tp_img_down) ? 0 : 4;
+    if (TUNE(6) > 0) d->tp_fuse_rows = TUNE(6) == 99 ? 0 : TUNE(6);   // tuning build: crossover experiments
     if (TUNE(5) == 2) d->img_qkv = d->img_o = false;   // tuning build: A/B against the split-K + fold launches
     // bf16 / W8: no few-row full-K launches to cross over to (gemm_fullk.hip takes fp16 steps of W4 / fp16 weights; the staged kernels lose
     // at every height): the image launches serve 1-64 rows
