@@ -301,6 +301,13 @@ int mi355_linear_residual_prenorm_img(const void* x_img, int32_t M, const mi355_
  * activation image, with the deferred norm applied to the accumulators (dn may be null: a plain linear on an image) */
 int mi355_linear_deferred_norm_img(const void* xg_img, int32_t M, const mi355_deferred_norm_t* dn, const mi355_weight_t* w,
                                    const void* bias, void* y, int32_t epilogue, mi355_stream_t stream);
+/* y = epilogue(x W + bias) in ONE launch from an activation image for a linear whose N does NOT fill the chip in the wide GEMM's form -- a
+ * column-parallel shard under tensor parallelism (gate_up of Qwen2-7B at tp 2 / 4, of Llama-3-70B at tp 8: DenseMLP.gate_up_proj,
+ * modules/hybrid/dense_mlp.py:95-103, split by ffn_sp_neg1, utils/model_weight.py:265-277): 2-5 tiles per block, all of K inside the block's
+ * 8 K-slice waves, fused SiLU-gate / image output (MI355_EPI_SILU_MUL, MI355_EPI_OUT_IMAGE).  W4 g128, 1 <= M <= 64; MI355_ERR_UNSUPPORTED when
+ * no tile count puts 160-256 blocks on the chip (the caller uses mi355_linear_forward / the wide GEMM). */
+int mi355_linear_direct_img(const void* x_img, int32_t M, const mi355_weight_t* w, const void* bias, void* y, int32_t epilogue,
+                            mi355_stream_t stream);
 /* fp32 split-K slabs [n][M][N_pad] of a deep-K linear (down_proj) from an activation image, for mi355_add_rmsnorm(_img) to fold:
  * returns n (<= max_splits, <= 16), or MI355_ERR_UNSUPPORTED (not W4 group-wise / more than 64 rows / K too short or too deep for
  * 8 K-slice waves of <= 5 chunks per block: the caller uses mi355_linear_partial on the row-major tensor) */

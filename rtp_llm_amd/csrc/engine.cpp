@@ -94,6 +94,9 @@ struct mi355_decoder {
     // ... and the row-parallel down_proj shard as K quarters (gemm_splitk64.hip) from the image the gate_up shard's SiLU epilogue writes:
     // 2-4 slabs into the fused all-reduce launch instead of up to 15
     bool   tp_img_down;
+    // ... and the column-parallel gate_up shard as ONE launch from an image (gemm_splitk64.hip, direct form) instead of the staged split-K kernel + fold:
+    // the fused all-reduce behind the O shard then writes its normed rows as that image (into xg_img: unused under TP otherwise)
+    bool   tp_img_gate;
     // ... and the post-attention RMSNorm deferred into gate_up's accumulators (mi355_deferred_norm_t): the O launch leaves
     // gamma 2^-e h' as an image + the per-tile sums of h'^2, the wide GEMM applies rsqrt(mean h'^2 + eps) 2^e: 6 launches per layer
     bool   img_gate_up;
@@ -288,6 +291,10 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     for (const auto& L : d->layers)
         d->tp_img_down = d->tp_img_down && L.down.K % 128 == 0 && L.down.K_pad == L.down.K && L.down.K == cfg->inter && L.gate_up.N == 2 * cfg->inter &&
                          mi355_gemm_splitk64_plan(64, L.down.N_pad / 16, L.down.K_pad / 128, L.down.wbits, L.down.group_size, kMaxSplits, nullptr) > 0;
+    d->tp_img_gate = d->tp_img_down && cfg->hidden % 32 == 0 && TUNE(5) != 3;
+    for (const auto& L : d->layers)
+        d->tp_img_gate = d->tp_img_gate && L.gate_up.K % 128 == 0 && L.gate_up.K_pad == L.gate_up.K &&
+                         mi355_gemm_splitk64_direct_plan(64, L.gate_up.N_pad / 16, L.gate_up.K_pad / 128, L.gate_up.wbits, L.gate_up.group_size) > 0;
     // from how many rows the TP step takes the image launches: with the down shard as K quarters they win from ONE row (one rank of tp 2,
     // b = 1 / 2 / 4: 1.67 / 1.68 / 1.72 ms against 1.75 / 1.77 / 1.82 with the few-row QKV launch + 15 staged slabs; profiles/r05_tp_small_batch_crossover.txt);
     // without that plan the few-row QKV launch keeps its rows (the tp = 1 crossover)
@@ -602,8 +609,11 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
         RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid, L.post_norm,
                                              c.rms_eps, B, c.hidden, d->xn, ADT, st));
     } else if (d->ar) { // split-K reduce + all-reduce + residual + post-attention norm in one launch
+        const bool gimg = d->tp_img_gate && B > d->tp_fuse_rows;   // the gate_up shard reads an image (one launch, gemm_splitk64 direct form)
         RUN(MI355_KC_COMM, comm_with_prefetch(d, st, &L.gate_up, [&]() {
-            return mi355_allreduce_fused_dt(d->ar, nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid, L.post_norm,
+            return gimg ? mi355_allreduce_fused_img_dt(d->ar, nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid, L.post_norm,
+                                                       c.rms_eps, B, c.hidden, d->xg_img, ADT, st)
+                        : mi355_allreduce_fused_dt(d->ar, nullptr, d->partials, ns, L.o.N_pad, nullptr, d->resid, d->resid, L.post_norm,
                                          c.rms_eps, B, c.hidden, d->xn, ADT, st); }));
     } else { // local split-K reduce -> fp16 tensor for the TP all-reduce
         RUN(MI355_KC_NORM, mi355_add_rmsnorm_dt(nullptr, d->partials, ns, L.o.N_pad, nullptr, nullptr, d->bufs.ar_buf, nullptr,
@@ -635,7 +645,10 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
         RUN(MI355_KC_GEMM_QUANT, mi355_norm_linear(d->resid, B, &fn, &L.gate_up, nullptr, d->act, MI355_EPI_SILU_MUL, st));
     } else {
         const bool gi = d->tp_img_down && d->ar && B > d->tp_fuse_rows;   // TP: the SiLU output of the shard as the image the K-quarter down launch reads
-        RUN(MI355_KC_GEMM_QUANT, mi355_linear_direct(d->xn, B, &L.gate_up, nullptr, gi ? d->act_img : d->act, MI355_EPI_SILU_MUL | (gi ? MI355_EPI_OUT_IMAGE : 0),
+        if (gi && d->tp_img_gate)   // ... and the shard itself as one launch on the image the all-reduce behind the O shard wrote
+            RUN(MI355_KC_GEMM_QUANT, mi355_linear_direct_img(d->xg_img, B, &L.gate_up, nullptr, d->act_img, MI355_EPI_SILU_MUL | MI355_EPI_OUT_IMAGE, st));
+        else
+            RUN(MI355_KC_GEMM_QUANT, mi355_linear_direct(d->xn, B, &L.gate_up, nullptr, gi ? d->act_img : d->act, MI355_EPI_SILU_MUL | (gi ? MI355_EPI_OUT_IMAGE : 0),
                                                      d->partials, d->partials_bytes, st));
     }
     int ns = 0;

@@ -35,6 +35,7 @@ extern "C" int mi355_gemm_fullk_residual_img(const void* gp, int wbits, int grou
                                              float* ssq_out, int ssq_ld, const void* norm_weight, float xg_scale, void* xg_img,
                                              mi355_stream_t stream);
 extern "C" int mi355_gemm_splitk64(const void* gp, int wbits, int group_size, int max_splits, mi355_stream_t stream);
+extern "C" int mi355_gemm_splitk64_direct(const void* gp, int wbits, int group_size, mi355_stream_t stream);
 extern "C" int mi355_gemm_wide_img(const void* gp, int wbits, int group_size, const mi355_deferred_norm_t* dn, mi355_stream_t stream);
 extern "C" int mi355_gemm_fullk_rope_img(const void* gp, int wbits, int group_size, const float* cos_sin, int32_t max_pos,
                                          const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq,
@@ -988,6 +989,25 @@ extern "C" int mi355_linear_deferred_norm_img(const void* xg_img, int32_t M, con
         p.y_img = 1;
     }
     return mi355_gemm_wide_img(&p, w->wbits, w->group_size, dn, stream);
+}
+
+// y = epilogue(x W + bias) in ONE launch from an activation image, for a linear whose N does not fill the chip in the wide GEMM's form: a column-parallel
+// shard under tensor parallelism (gemm_splitk64.hip, direct form).  MI355_ERR_UNSUPPORTED when the shape has no plan (the caller stays on mi355_linear_direct).
+extern "C" int mi355_linear_direct_img(const void* x_img, int32_t M, const mi355_weight_t* w, const void* bias, void* y, int32_t epilogue,
+                                       mi355_stream_t stream) {
+    if (int e = check_weight(w)) return e;
+    MI355_CHECK_ARG(x_img && y && M > 0, "linear_direct_img: bad args (M=%d)", M);
+    if (M < 1 || M > 64 || !img_weight_ok(w)) return MI355_ERR_UNSUPPORTED;
+    if (w->act_dtype == MI355_ACT_BF16 && (!(epilogue & MI355_EPI_OUT_IMAGE) || bias)) return MI355_ERR_UNSUPPORTED;   // as mi355_linear_deferred_norm_img
+    GemmParams p; fill_params(p, x_img, M, w);
+    p.mode = (epilogue & MI355_EPI_OUT_F32) ? MODE_F32 : (epilogue & MI355_EPI_SILU_MUL) ? MODE_SILU : MODE_F16;
+    p.bias = (const f16*)bias; p.y = y; p.ldy = (p.mode == MODE_SILU) ? w->N / 2 : w->N;
+    p.x_img = 1; p.x_bytes = (uint32_t)mi355_act_image_bytes(M, w->K);
+    if (epilogue & MI355_EPI_OUT_IMAGE) {
+        MI355_CHECK_ARG(p.mode != MODE_F32 && p.ldy % 32 == 0, "linear_direct_img: an image output is a 16-bit tensor with a multiple of 32 columns");
+        p.y_img = 1;
+    }
+    return mi355_gemm_splitk64_direct(&p, w->wbits, w->group_size, stream);
 }
 
 // Split-K slabs of a deep-K linear (down_proj) at 1-64 rows from an activation image (gemm_splitk64.hip): returns the number of

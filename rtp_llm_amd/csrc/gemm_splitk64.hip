@@ -31,6 +31,11 @@ struct SplitK64Params {
     int dbg;          // tuning build, timing only (same instruction stream): 1 no activation traffic, 2 no weight traffic
 };
 
+// Direct form (round 5, mi355_gemm_splitk64_direct): ONE K split and T = 2..5 tiles per block with the fused epilogue of the wide GEMM (bias / SiLU-mul,
+// row-major or image output) -- for a column-parallel SHARD under tensor parallelism (gate_up of Qwen2-7B at tp 2: 1184 tiles, Llama-3-70B at tp 8: 448), whose
+// N / tp columns leave the wide GEMM's 10-tiles-per-block form on half the chip (its phase structure needs >= 4 tiles per wave) and went through the staged
+// split-K kernel + a fold launch: 19.0 + 5.3 us for 36 MB at tp 2.  Here every wave loads its own fragments, so few tiles per block cost nothing but the
+// activation loads (T tiles share them).
 // WB = 8 (round 5): per-channel INT8 weights -- two wave-loads per (tile, chunk), the operand is the exact integer u - 128 (4 v_perm +
 // 4 v_pk_add per 8 weights: a lighter unit than W4's, left to the compiler's schedule), the column's scale multiplies the summed
 // accumulators before the slab store (every K split is scaled alike, so the fold's sum of slabs is the scaled sum).
@@ -186,8 +191,10 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
             });
         }
         if (p.bf16) v *= kImgBfUnscale;                  // the image of a bf16 tensor holds x 2^-8 (common.h img_val)
-        if (m < p.M && t0 + t < p.NT)
-            st_slab(rs, (uint32_t)((((size_t)by * p.M + m) * p.N_pad + (t0 + t) * 16 + q * 4) * 4), v);
+        if (m < p.M && t0 + t < p.NT) {
+            if (p.mode == MODE_PARTIAL) st_slab(rs, (uint32_t)((((size_t)by * p.M + m) * p.N_pad + (t0 + t) * 16 + q * 4) * 4), v);
+            else gemm_store(p, v, m, (t0 + t) * 16 + q * 4, 0);   // direct form (one K split): bias / fp16 / SiLU-mul store, row-major or image
+        }
     }
 }
 
@@ -195,6 +202,7 @@ template <int WB, int GS, int MB, int T, int CPW, int RING>
 int launch_splitk64_t(const SplitK64Params& sp, int G, hipStream_t st) {
     auto k = gemm_splitk64_kernel<WB, GS, MB, T, CPW, RING>;
     const size_t lds = (size_t)8 * T * MB * 1024;
+    if (lds > 160 * 1024) return MI355_ERR_UNSUPPORTED;
     if (lds > 64 * 1024)
         if (int e = raise_dynamic_lds((const void*)k, "gemm_splitk64")) return e;
     if (sp.xmap > 0) hipLaunchKernelGGL(k, dim3(G * sp.g.nsplit), dim3(512), lds, st, sp);
@@ -219,6 +227,42 @@ extern "C" int mi355_gemm_splitk64_plan(int M, int NT, int KC, int wbits, int gr
     if ((cps + 7) / 8 > 5 || cps < 8 || G * ns > 512) return MI355_ERR_UNSUPPORTED;   // every wave >= 1 chunk, <= 5
     if (cps_out) *cps_out = cps;
     return ns;
+}
+
+// Direct form: tiles per block T in 5..2 such that the blocks fill 5/8 .. all of the 256 CUs in ONE round, every wave <= 5 chunks (T >= 3) or <= 8 (T = 2).
+// Returns T, or MI355_ERR_UNSUPPORTED (W4 g128, 1-64 rows only).
+extern "C" int mi355_gemm_splitk64_direct_plan(int M, int NT, int KC, int wbits, int group_size) {
+    if (M < 1 || M > 64 || wbits != 4 || group_size != 128 || KC < 8) return MI355_ERR_UNSUPPORTED;
+    const int cpw = (KC + 7) / 8;
+    for (int T = 5; T >= 2; --T) {
+        const int G = (NT + T - 1) / T;
+        if (G >= 160 && G <= 256 && cpw <= (T == 2 ? 8 : 5)) return T;
+    }
+    return MI355_ERR_UNSUPPORTED;
+}
+
+// gp: GemmParams with x = activation image, mode / y / bias / ldy / y_img of a direct linear (not MODE_PARTIAL)
+extern "C" int mi355_gemm_splitk64_direct(const void* gp, int wbits, int group_size, mi355_stream_t stream) {
+    SplitK64Params sp;
+    sp.g = *reinterpret_cast<const GemmParams*>(gp);
+    sp.dbg = 0; sp.xmap = 0;
+    GemmParams& g = sp.g;
+    if (g.K != g.KC * 128 || g.mode == MODE_PARTIAL || !g.y) return MI355_ERR_UNSUPPORTED;
+    const int T = mi355_gemm_splitk64_direct_plan(g.M, g.NT, g.KC, wbits, group_size);
+    if (T < 0) return T;
+    g.nsplit = 1; g.cps = g.KC;
+    const int G = (g.NT + T - 1) / T, cpw = (g.KC + 7) / 8;
+    hipStream_t st = (hipStream_t)stream;
+    const int mblk = (g.M + 15) >> 4;
+    // activation ring: 3 k-steps, 2 where T x MB accumulators + a two-chunk weight ring of T tiles leave no room for the third
+#define SKD_T_(T_, CPW_, RING_) (mblk == 1 ? launch_splitk64_t<4, 4, 1, T_, CPW_, RING_>(sp, G, st) : mblk == 2 ? launch_splitk64_t<4, 4, 2, T_, CPW_, RING_>(sp, G, st) \
+                                 : mblk == 3 ? launch_splitk64_t<4, 4, 3, T_, CPW_, RING_>(sp, G, st) : launch_splitk64_t<4, 4, 4, T_, CPW_, RING_>(sp, G, st))
+    // CPW = the chunks of the longest slice exactly (waves one chunk short skip the last chunk's units; a larger CPW would run them on zeros)
+    if (T == 5) return cpw <= 4 ? SKD_T_(5, 4, 2) : SKD_T_(5, 5, 2);
+    if (T == 4) return cpw <= 3 ? SKD_T_(4, 3, 3) : cpw == 4 ? SKD_T_(4, 4, 3) : SKD_T_(4, 5, 3);
+    if (T == 3) return cpw <= 4 ? SKD_T_(3, 4, 3) : SKD_T_(3, 5, 3);
+    return cpw <= 5 ? SKD_T_(2, 5, 3) : SKD_T_(2, 8, 2);   // eight-chunk slices: two k-steps of activations in flight (three spill at four row blocks)
+#undef SKD_T_
 }
 
 // gp: GemmParams with x = activation image, partials = slabs; returns the number of slabs written.

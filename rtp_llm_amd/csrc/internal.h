@@ -20,6 +20,7 @@ int mi355_fullk64_weight_ok(const mi355_weight_t* w);     /* gemm.hip: the full-
 int mi355_fullk64_qkv_ok(const mi355_weight_t* w, int32_t hd);   /* ... as the QKV + RoPE launch (also K up to 9600 when its tile pairs leave half the chip free) */
 int mi355_gemm_wide_direct_ok(const mi355_weight_t* w);   /* gemm_wide.hip: the one-launch form takes this linear (N fills the chip) */
 int mi355_gemm_splitk64_plan(int M, int NT, int KC, int wbits, int group_size, int max_splits, int* cps_out);   /* gemm_splitk64.hip: slabs, or < 0 */
+int mi355_gemm_splitk64_direct_plan(int M, int NT, int KC, int wbits, int group_size);   /* gemm_splitk64.hip, direct form: tiles per block, or < 0 */
 int mi355_prefetch(const void* ptr, size_t bytes, void* sink, mi355_stream_t stream);
 /* Touch plan: the blocks a latency-bound launch has to spare (the slab fold in front of a QKV launch: 64 blocks on 256 CUs) read one dword per
  * 128-byte line of the weights the NEXT launch streams, so that its first requests are served by the Infinity Cache (or the XCD's L2)

@@ -320,6 +320,27 @@ def linear_deferred_norm_img(xg: ActImage, dn, w: PackedWeight, bias: Optional[t
     return yi if yi is not None else y
 
 
+def linear_direct_img(x: ActImage, w: PackedWeight, bias: Optional[torch.Tensor] = None, epilogue: int = _C.EPI_NONE):
+    """epilogue(x @ W + bias) in one launch from an image for a narrow N (a column-parallel TP shard; gemm_splitk64.hip, direct form); None when no plan exists.
+    The tensors around the GEMM have the image's source dtype."""
+    _chk(x.data, torch.float16, "linear_direct_img.x")
+    if x.K != w.K:
+        raise _C.Mi355Error(f"linear_direct_img: image K={x.K} against K={w.K}")
+    N_out = w.N // 2 if (epilogue & _C.EPI_SILU_MUL) else w.N
+    if epilogue & _C.EPI_OUT_IMAGE:
+        yi = _new_image(x.M, N_out, torch.float16, x.data.device, x.src)
+        y = yi.data
+    else:
+        yi = None
+        y = torch.empty(x.M, N_out, dtype=torch.float32 if (epilogue & _C.EPI_OUT_F32) else x.src, device=x.data.device)
+    ws_struct = weight_struct(w, x.src)
+    rc = _C.lib().mi355_linear_direct_img(x.data.data_ptr(), x.M, C.byref(ws_struct), _p(bias), y.data_ptr(), epilogue, _stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    _C.check(rc, "linear_direct_img")
+    return yi if yi is not None else y
+
+
 def linear_partial_img(x: ActImage, w: PackedWeight, max_splits: int = 16):
     """fp32 split-K slabs [n, M, N_pad] of a deep-K linear from an activation image (gemm_splitk64.hip); None when not taken."""
     _chk(x.data, torch.float16, "linear_partial_img.x")
