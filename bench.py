@@ -157,10 +157,11 @@ def main():
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--debug-set", default="", help="debug only: 'idx=val,...' forwarded to mi355_debug_set (kernel A/B switches)")
+    ap.add_argument("--attn-ps", type=int, default=0, help="debug only (tuning build): tokens per attention partition instead of the planner's choice")
     ap.add_argument("--prefetch", type=int, default=None, help="weight-prefetch mask (mi355_decoder_set_weight_prefetch); default: the engine's")
     args = ap.parse_args()
 
-    if args.debug_set:   # kernel A/B switches exist only in the tuning build (python -m rtp_llm_amd.build --tuning)
+    if args.debug_set or args.attn_ps:   # kernel A/B switches exist only in the tuning build (python -m rtp_llm_amd.build --tuning)
         os.environ["MI355_TUNING_LIB"] = "1"
     from rtp_llm_amd import _C, distributed, model
 
@@ -176,6 +177,9 @@ def main():
     _C.lib()  # fail loudly when the HIP extension is missing
     for kv in filter(None, args.debug_set.split(",")):
         _C.lib().mi355_debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
+    if args.attn_ps:
+        _C.lib().mi355_debug_set_attn.argtypes = [C.c_int]
+        _C.lib().mi355_debug_set_attn(args.attn_ps)
 
     mname, kind, kv_int8, dB, dctx, page = WORKLOADS[args.workload]
     page = args.page or page
@@ -307,8 +311,8 @@ def main():
     }
     if args.layers:
         out["invalid"] = f"debug run with --layers {args.layers}"
-    if args.debug_set:
-        out["invalid"] = f"debug run with --debug-set {args.debug_set} (tuning build of the library)"
+    if args.debug_set or args.attn_ps:
+        out["invalid"] = f"debug run with --debug-set {args.debug_set} --attn-ps {args.attn_ps} (tuning build of the library)"
     if args.shard_of > 1:
         out["invalid"] = (f"debug run: ONE rank's step of a tp={args.shard_of} layout on one GPU -- per-rank shapes, the fused all-reduce launches in place "
                           f"with a world-1 context (no xGMI hop)")
