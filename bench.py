@@ -474,6 +474,31 @@ def main():
             if captured:
                 teng.capture(B)
             trun = (lambda n: teng.replay(B, n)) if captured else (lambda n: [teng.step(B) for _ in range(n)])
+
+            def ranks_agree():
+                """Every rank of a TP group must hold the SAME bits in the final normed hidden state (rank-order fp32 sums in both all-reduce
+                points of every layer): the only check of the cross-device hand-over that exists -- development had one GPU.  A rank that
+                read a stale peer row diverges here."""
+                treset(); trun(2); torch.cuda.synchronize()
+                bits = teng.hidden[:B].contiguous().view(torch.int16).to(torch.int64).cpu()
+                t = torch.stack([bits.sum(), (bits * bits).sum(), (bits * torch.arange(1, bits.numel() + 1).view_as(bits) % 1000003).sum()])
+                outs = [torch.zeros_like(t) for _ in range(tpn)]
+                dist.all_gather(outs, t, group=grp)
+                return all(torch.equal(outs[0], o) for o in outs)
+
+            protocol = "rccl" if ar is None else ("write-through publishing stores + drained flags (round 5)" if ar.hand_over == "write-through" else
+                                                  "plain stores + system-scope release / acquire fences (the context's known-answer check chose it)")
+            agree = ranks_agree()
+            if not agree and ar is not None and ar.hand_over == "write-through":
+                # the hand-over without system-scope fences has never run across two devices: if the ranks disagree, take the fenced form
+                # of rounds 1-4 (csrc/allreduce.hip, mi355_allreduce_set_full_fences), capture again and check again
+                log(f"[rank {rank}] TP ranks disagree with the write-through hand-over: switching to system-scope release / acquire fences")
+                ar.set_full_fences(True)
+                if captured:
+                    teng.attach_allreduce(ar, (rank % tpn) * tcfg.vocab)   # drops the captured graphs
+                    treset(); teng.capture(B)
+                protocol = "plain stores + system-scope release / acquire fences (fallback: the write-through hand-over left the ranks in disagreement)"
+                agree = ranks_agree()
             t_el, t_p50 = timed(trun, treset)
             # the same three extra blocks of K steps as for the replica layout, so that `ms_per_step_repeats` of the line belongs to the
             # layout `value` / `ms_per_step` are quoted on (max over ranks: a TP step ends when its slowest rank does)
@@ -492,7 +517,7 @@ def main():
                 raise RuntimeError(f"all-reduce spin timed out (status {st})")
             tp_info = {"parallelism": f"tp{tpn}" + (f" x dp{dpn}" if dpn > 1 else ""), "global_batch": B * dpn,
                        "tokens_per_s": round(B * dpn * args.steps / t_el, 1), "ms_per_step": round(t_el / args.steps * 1e3, 4),
-                       "p50_ms": round(t_p50, 4), "graph": captured,
+                       "p50_ms": round(t_p50, 4), "graph": captured, "ranks_bit_identical": bool(agree), "hand_over": protocol,
                        "collectives": ("hand-written one-shot peer-read all-reduce over IPC/xGMI, fused with split-K reduce + residual + "
                                        "RMSNorm (2 per layer) + cross-rank greedy argmax; no RCCL on the data path") if ar is not None else
                                       ("RCCL fallback (IPC peer mapping unavailable): ncclAllReduce on the local split-K fold (2 per layer) + "

@@ -58,11 +58,17 @@ def tp_rank() -> int:
 _custom_ar = None
 
 
+def _C_err(msg):
+    from . import _C
+    return _C.Mi355Error(msg)
+
+
 class CustomAllReduce:
     """Host side of csrc/allreduce.hip (the role of TrtllmArFusionHandle + its Python wrapper, base/rocm/trt_allreduce.py:
     51-230): create the context, exchange the IPC handle blobs through the (CPU-capable) process group, open the peers."""
 
-    def __init__(self, max_bytes: int, group=None, rank: Optional[int] = None, world: Optional[int] = None, spin_timeout_ms: Optional[int] = None):
+    def __init__(self, max_bytes: int, group=None, rank: Optional[int] = None, world: Optional[int] = None, spin_timeout_ms: Optional[int] = None,
+                 verify: bool = True):
         import ctypes as C
         from . import _C
         self._C, self.lib = _C, _C.lib()
@@ -97,6 +103,47 @@ class CustomAllReduce:
                   file=sys.stderr, flush=True)
         if self.shared_device if spin_timeout_ms is None else True:
             self.set_spin_timeout_ms(30000 if spin_timeout_ms is None else spin_timeout_ms)
+        self._group = group
+        self.hand_over = "full-fences" if os.environ.get("MI355_AR_FULL_FENCES") == "1" else "write-through"
+        if verify and self.world > 1:
+            self._verify_hand_over()
+
+    def _known_answer_round(self, rounds: int = 6) -> bool:
+        """A few all-reduces of rank-specific integer patterns (every partial sum exact in fp32 and fp16) on both buffer parities: True when
+        this rank obtained the expected sums bit for bit every time."""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        H = 1024
+        T = max(1, min(64, self.max_bytes // (H * 2)))
+        idx = torch.arange(T * H, dtype=torch.int64).reshape(T, H)
+        ok = True
+        for it in range(rounds):
+            pats = [((idx * (r + 3) + it * 7 + r) % 61 - 30).to(torch.float16) for r in range(self.world)]    # |value| <= 30: sums of 8 ranks exact
+            want = sum(p.float() for p in pats).to(torch.float16)
+            got = self.all_reduce(pats[self.rank].to(dev).clone())
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(got.cpu(), want)
+        return ok and self.status() == 0
+
+    def _verify_hand_over(self) -> None:
+        """The write-through hand-over (no system-scope fences, csrc/allreduce.hip publish16) was developed with several processes on ONE GPU;
+        the first thing a context does on a node is a known-answer check on every rank.  If any rank sees a wrong sum the whole group takes
+        the fenced form of rounds 1-4 and checks again; if that fails too the constructor raises on every rank together."""
+        import sys
+        for attempt in ("write-through", "full-fences"):
+            if attempt == "full-fences":
+                self.set_full_fences(True)
+                self.hand_over = "full-fences"
+            elif self.hand_over != "write-through":
+                continue
+            oks = [None] * self.world
+            dist.all_gather_object(oks, bool(self._known_answer_round()), group=self._group)
+            if all(oks):
+                return
+            if self.rank == 0:
+                print(f"[rtp_llm_amd.distributed] all-reduce known-answer check failed with the {attempt} hand-over on ranks "
+                      f"{[r for r, o in enumerate(oks) if not o]}", file=sys.stderr, flush=True)
+        self.close()
+        raise _C_err("CustomAllReduce: the all-reduce known-answer check fails with both hand-over forms")
 
     @staticmethod
     def _device_key():
