@@ -672,7 +672,8 @@ int launch_attn(const void* q, const mi355_kv_layer_t* kv, const int32_t* block_
     dim3 grid(p.P, kv->nkv, B * p.ntile);
 #define L_(HD_, I8_, NT_, NW_, NG_) hipLaunchKernelGGL((paged_attn_kernel<HD_, I8_, NT_, NW_, NG_>), grid, dim3(64 * NW_), 0, st, p)
 #ifdef MI355_TUNING
-#define L2_(HD_, I8_) do { if (NT == 1) { if (TUNE(6) == 3) L_(HD_, I8_, 1, 4, 3); else if (TUNE(6) == 4) L_(HD_, I8_, 1, 4, 4); else if (TUNE(6) == 2) L_(HD_, I8_, 1, 4, 2); else L_(HD_, I8_, 1, 4, (I8_ ? 4 : 2)); } else L_(HD_, I8_, 2, 4, 2); } while (0)
+#define L2_(HD_, I8_) do { if (NT == 1) { if (TUNE(6) == 3) L_(HD_, I8_, 1, 4, 3); else if (TUNE(6) == 4) L_(HD_, I8_, 1, 4, 4); else if (TUNE(6) == 2) L_(HD_, I8_, 1, 4, 2); \
+                                            else if (TUNE(6) == 8) L_(HD_, I8_, 1, 8, 2); else if (TUNE(6) == 9) L_(HD_, I8_, 1, 8, 3); else L_(HD_, I8_, 1, 4, (I8_ ? 4 : 2)); } else L_(HD_, I8_, 2, 4, 2); } while (0)
 #else
 // INT8 groups are 8 KB: four of them in flight per wave (the bytes two fp16 groups hold); measured b = 64, ctx 4096: 77.2 -> 66.7 us
 // (NG = 3: 72.7), ctx 1024 unchanged; fp16 loses with more than two (28.4 -> 30.6 us at ctx 1024)
