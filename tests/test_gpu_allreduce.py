@@ -473,6 +473,19 @@ def _worker(rank, world, port, q, mode):
                     dist.broadcast(nxt, 0)
                     tok = nxt
                     eng.token_ids[:B].copy_(tok)
+            # a target-verify step under TP (configs[4]'s shape of work: q_len rows per sequence, causal inside the paged attention) on the same image
+            # launches: 4 sequences x 5 rows at positions 3..7 behind the three tokens the 5-row run above cached (okv still holds them on rank 0)
+            nseq, q_len = 4, 5
+            toks = torch.randint(0, V, (nseq * q_len,), generator=torch.Generator().manual_seed(77), dtype=torch.int32)
+            pos = (3 + torch.arange(q_len, dtype=torch.int32)).repeat(nseq)
+            eng.set_inputs(toks.tolist(), pos.tolist(), bt[:nseq])
+            dist.barrier()
+            eng.forward(nseq * q_len, q_len)
+            torch.cuda.synchronize()
+            full = torch.cat(_gather_cpu(eng.logits[:nseq * q_len].cpu(), world), dim=1)
+            if rank == 0:
+                _, ref = odec.forward_tokens(toks, pos, okv, [b for b in range(nseq) for _ in range(q_len)])
+                assert torch.allclose(full, ref, atol=1e-2, rtol=1e-2), ("verify rows", float((full - ref).abs().max()))
             assert ar.status() == 0 and eng.oob_count() == 0
         elif mode == "engine70full":
             # BASELINE configs[3] at its real per-rank shapes: Llama-3-70B widths (hidden 8192, 64 q / 8 kv heads, FFN 28672, the
