@@ -105,7 +105,7 @@ enum {
     MI355_EPI_NONE     = 0,
     MI355_EPI_SILU_MUL = 1, /* columns are interleaved (gate,up) pairs; y is [M, N/2] */
     MI355_EPI_OUT_F32  = 2, /* y is fp32 [M, N] (lm_head logits) */
-    MI355_EPI_OUT_IMAGE = 4, /* mi355_linear_deferred_norm_img only: the 16-bit y is written as an activation image (mi355_act_image_*) */
+    MI355_EPI_OUT_IMAGE = 4, /* mi355_linear_deferred_norm_img / mi355_linear_direct_img: the 16-bit y is written as an activation image (mi355_act_image_*) */
     /* kernel-family hints (per call, for A/B tests; results stay within the same tolerance): */
     MI355_HINT_STAGED        = 0x100, /* 16 < M <= 64: take the LDS-staged kernel instead of the register-resident one */
     MI355_HINT_NO_PERSISTENT = 0x200  /* M <= 8: skip the persistent x-resident kernel */
@@ -263,7 +263,9 @@ int mi355_qkv_rope_kv_write(const void* x, int32_t M, const mi355_weight_t* wqkv
  * block are never read back as results.  Producers: mi355_add_rmsnorm_img (y), mi355_paged_attn_rows_img (out), or
  * mi355_act_image_pack from a row-major tensor (direction 1: back).  Consumers: mi355_qkv_rope_kv_write_img,
  * mi355_linear_residual_img: same arguments and results as the entry points without the suffix (no fused norm: the producer
- * normed), W4 group-wise weights, 1 <= M <= 64 (two- / four-row-block instances; the step driver takes them from 5 rows), K <= 5760, else MI355_ERR_UNSUPPORTED.
+ * normed), W4 group-wise weights (K <= 5760; up to 9600 where the launch splits its rows over two blocks per tile pair: a TP shard) or per-channel W8
+ * (load-time INT8 autoquant, device_impl.py:183-222; K <= 3840), 1 <= M <= 64 (an instance per row-block count; the step driver takes them from 5 rows,
+ * from 1 for bf16 / W8 / under tensor parallelism), else MI355_ERR_UNSUPPORTED.
  * Reference boundary these keep: modules/hybrid/causal_attention.py:75-93 (qkv_proj -> rope / kv write -> attention -> o_proj),
  * model_desc/qwen3.py:57-79 (norm -> attention -> residual add).
  */
@@ -281,7 +283,10 @@ typedef struct {
 } mi355_deferred_norm_t;
 size_t mi355_act_image_bytes(int32_t M, int32_t K);
 /* direction 0: row-major [M][K] tensor of act_dtype -> image; 1: image -> row-major tensor of act_dtype.  An image always holds fp16
- * (the GEMMs that read it run fp16 MFMAs): bf16 rows are converted, exactly inside the fp16 range. */
+ * (the GEMMs that read it run fp16 MFMAs).  The image of a BF16 tensor holds fp16(x * 2^-8), saturated at +-65504: bf16 activations up to
+ * 1.6e7 (the SiLU * up product of a bf16 checkpoint) pass through, every consumer launch scales its fp32 accumulators by 2^8 (it knows the
+ * dtype from mi355_weight_t.act_dtype); exact for |x| >= 2^-6, an absolute spacing of 2^-16 below.  So an image is only meaningful together
+ * with the dtype of the tensor it stands for. */
 int mi355_act_image_pack(const void* src, int32_t M, int32_t K, void* dst, int32_t direction, int32_t act_dtype, mi355_stream_t stream);
 int mi355_add_rmsnorm_img(const void* x, const float* partials, int32_t nsplit, int32_t ld, const void* bias,
                           const void* residual_in, void* residual_out, const void* weight, float eps, int32_t M, int32_t H,
