@@ -547,6 +547,33 @@ def _worker(rank, world, port, q, mode):
                 tok = nxt
                 eng.token_ids[:B].copy_(tok)
             assert ar.status() == 0 and eng.oob_count() == 0
+        elif mode == "stress":
+            # the write-through hand-over (no system-scope fences) under UNEVEN load, every word checked: 600 all-reduces of alternating geometry with integer
+            # patterns (every partial sum exact), one rank delayed at random, and a 256 MB copy running on a second stream of every rank so that the
+            # CUs' memory queues, the L2s and the fabric are busy while rows are published and pulled
+            noise_src = torch.empty(64 << 20, dtype=torch.float32, device=dev).normal_()
+            noise_dst = torch.empty_like(noise_src)
+            side = torch.cuda.Stream()
+            shapes = [(64, 3584), (cap(100), 1024), (5, 8192), (32, 3584), (1, 896)]
+            gs = torch.Generator().manual_seed(1234)          # the same on every rank: who sleeps when
+            bad = 0
+            for it in range(600):
+                T, H = shapes[it % len(shapes)]
+                idx = torch.arange(T * H, dtype=torch.int64).reshape(T, H)
+                pats = [((idx * (r + 3) + it * 11 + r) % 61 - 30).to(torch.float16) for r in range(world)]
+                want = sum(p.float() for p in pats).to(torch.float16)
+                if it % 3 == 0:
+                    with torch.cuda.stream(side):
+                        noise_dst.copy_(noise_src, non_blocking=True)
+                if int(torch.randint(0, world, (1,), generator=gs)) == rank and it % 7 == 0:
+                    torch.cuda._sleep(int(2e6))               # this rank arrives ~1 ms late
+                got = ar.all_reduce(pats[rank].to(dev).clone())
+                if it % 50 == 49 or it < 5:
+                    torch.cuda.synchronize()
+                bad += int(not torch.equal(got.cpu(), want))
+            torch.cuda.synchronize()
+            assert bad == 0, f"{bad} of 600 all-reduces differ from the exact sums"
+            assert ar.status() == 0 and ar.hand_over == "write-through"
         elif mode == "timeout":
             x = torch.ones(4, 3584, dtype=torch.float16, device=dev)
             ar.all_reduce(x.clone()); torch.cuda.synchronize(); dist.barrier()
@@ -572,7 +599,7 @@ def _worker(rank, world, port, q, mode):
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("mode,world", [("kernels", 2), ("engine", 2), ("transport", 2), ("bf16", 2), ("bf16", 4), ("timeout", 2), ("twoshot", 3), ("mixed", 2), ("kernels", 4),
-                                        ("kernels", 8), ("twoshot", 4), ("twoshot", 8), ("engine70", 8), ("engine70full", 8), ("kernels_ff", 2), ("engine_ff", 2), ("twoshot_ff", 3), ("engine7b", 2), ("engine7b", 4)])
+                                        ("kernels", 8), ("twoshot", 4), ("twoshot", 8), ("engine70", 8), ("engine70full", 8), ("kernels_ff", 2), ("engine_ff", 2), ("twoshot_ff", 3), ("engine7b", 2), ("engine7b", 4), ("stress", 2), ("stress", 4), ("stress", 8)])
 def test_custom_allreduce_processes_on_one_gpu(mode, world):
     assert torch.cuda.is_available()
     port = _free_port()
