@@ -486,19 +486,21 @@ def main():
                 dist.all_gather(outs, t, group=grp)
                 return all(torch.equal(outs[0], o) for o in outs)
 
-            protocol = "rccl" if ar is None else ("write-through publishing stores + drained flags (round 5)" if ar.hand_over == "write-through" else
-                                                  "plain stores + system-scope release / acquire fences (the context's known-answer check chose it)")
+            HAND_OVER = {"ll": "data-tagged granules (<= 64-row calls) + write-through publishing stores and flags (round 5)",
+                         "write-through": "write-through publishing stores + drained flags, no granules",
+                         "full-fences": "plain stores + system-scope release / acquire fences (rounds 1-4)"}
             agree = ranks_agree()
-            if not agree and ar is not None and ar.hand_over == "write-through":
-                # the hand-over without system-scope fences has never run across two devices: if the ranks disagree, take the fenced form
-                # of rounds 1-4 (csrc/allreduce.hip, mi355_allreduce_set_full_fences), capture again and check again
-                log(f"[rank {rank}] TP ranks disagree with the write-through hand-over: switching to system-scope release / acquire fences")
-                ar.set_full_fences(True)
+            while not agree and ar is not None and ar.hand_over != "full-fences":
+                # the fence-free hand-overs have never run across two devices: if the ranks disagree, step down one form (csrc/allreduce.hip,
+                # mi355_allreduce_set_protocol), capture again and check again
+                nxt = ar.PROTOCOLS[ar.PROTOCOLS.index(ar.hand_over) + 1]
+                log(f"[rank {rank}] TP ranks disagree with the {ar.hand_over} hand-over: switching to {nxt}")
+                ar.set_protocol(nxt)
                 if captured:
                     teng.attach_allreduce(ar, (rank % tpn) * tcfg.vocab)   # drops the captured graphs
                     treset(); teng.capture(B)
-                protocol = "plain stores + system-scope release / acquire fences (fallback: the write-through hand-over left the ranks in disagreement)"
                 agree = ranks_agree()
+            protocol = "rccl" if ar is None else HAND_OVER[ar.hand_over]
             t_el, t_p50 = timed(trun, treset)
             # the same three extra blocks of K steps as for the replica layout, so that `ms_per_step_repeats` of the line belongs to the
             # layout `value` / `ms_per_step` are quoted on (max over ranks: a TP step ends when its slowest rank does)

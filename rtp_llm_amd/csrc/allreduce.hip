@@ -59,6 +59,7 @@ struct ArDev {                             // device-visible part of the context
     int             rank, world;
     unsigned long long spin_ticks;         // bound of every wait for a peer, in 100 MHz wall-clock ticks
     int             full_fences;           // 1: the round-1..4 hand-over (plain stores + system-scope release / acquire fences); 0: see publish16
+    size_t          ll_elems;              // element offset of the granule region inside a parity (kMaxBlocks slots of 2 x slot_elems): see the LL form below
 };
 
 struct FusedParams {
@@ -154,15 +155,25 @@ __device__ __forceinline__ void peer_barrier(const ArDev& ar, int b, uint32_t ep
 // its result region, and after a second flag barrier every rank fetches each row ONCE from its owner: 2 (N - 1) / N T H
 // elements per rank instead of (N - 1) T H (trtllm_allreduce_fusion.cu:606-692 is the reference's two-shot form).
 // BF: the tensors (x, bias, residual, weight, y and the exchanged copies) are bf16; the sums stay fp32 in rank order
-template <int VPT, bool TWO, bool BF = false>
+// LL = the low-latency form for the <= 64 rows of a decode step (one row per block): the published data carries its own flag.  Every 4 bytes of payload
+// travel in a naturally aligned 8-byte GRANULE {payload, epoch} written by ONE write-through store (two granules per 16-byte store: a store may only ever
+// tear between granules); a peer polls the granules themselves -- system-scope loads -- until every tag equals the call's epoch.  No flag table, no block
+// barrier between publishing and pulling, the rank's own rows stay in registers: one fabric round trip per all-reduce instead of flag hop + data round trip
+// (NCCL's LL protocol; MI355X_MICROARCH.md "handoff-1to1": data-tagged granules 0.8-1.0 us against 1.7-1.9 x that with a separate flag).  The granule region
+// is double-buffered by the epoch's parity like the tensor region, tags are monotonic epochs (the buffer starts zeroed, epochs at 1), so a stale granule can
+// never pass for a fresh one; the reuse argument of the tensor region holds unchanged (a rank can only publish call e + 2 after pulling every peer's call
+// e + 1, which a peer publishes after it finished pulling call e).
+template <int VPT, bool TWO, bool BF = false, bool LL = false>
 __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams p) {
     constexpr int NTH = 512;
+    static_assert(!(LL && TWO), "the granule form is one-shot");
     const ArDev& ar = p.ar;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nvec = p.H >> 3;
     const uint32_t epoch = ar.epoch[b] + 1;
     const size_t par = (epoch & 1) * ar.parity_elems;
     const __amdgpu_buffer_rsrc_t mine_rs = my_rsrc(ar);
+    u32x4 own[VPT];                                    // LL: this rank's row (one row per block), kept for the rank-order sum
     // ---- stage 0: local row (split-K reduce + bias), fp16, into the registered buffer
     for (int row = b; row < p.T; row += gridDim.x) {
 #pragma unroll
@@ -204,11 +215,23 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
             } else {
                 o = *reinterpret_cast<const u32x4*>(p.x + (size_t)row * p.H + c0);
             }
-            publish16(ar, mine_rs, par + row_off(ar, row, gridDim.x, p.H) + c0, o);
+            if constexpr (LL) {
+                own[t] = o;
+                const uint32_t goff = (uint32_t)((par + ar.ll_elems + (size_t)(row % gridDim.x) * 2 * ar.slot_elems + (size_t)(row / gridDim.x) * 2 * p.H + 2 * c0) * 2);
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){o[0], epoch, o[1], epoch}, mine_rs, goff, 0, 17 /* sc0 | sc1 */);
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){o[2], epoch, o[3], epoch}, mine_rs, goff + 16u, 0, 17);
+            } else {
+                publish16(ar, mine_rs, par + row_off(ar, row, gridDim.x, p.H) + c0, o);
+            }
         }
     }
     PfRegs pfv;
-    peer_barrier(ar, b, epoch, 0, p.pf, p.pf_lines, &pfv);
+    if constexpr (LL) {
+#pragma unroll
+        for (int i = 0; i < kPfIters; ++i) pfv.v[i] = 0u;
+    } else {
+        peer_barrier(ar, b, epoch, 0, p.pf, p.pf_lines, &pfv);
+    }
     // ---- stage 1: rank-ordered fp32 sum of the N copies, residual add, RMSNorm
     __amdgpu_buffer_rsrc_t rp[kMaxWorld];
 #pragma unroll
@@ -259,6 +282,26 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
 #pragma unroll
                 for (int r = 0; r < kMaxWorld; ++r)
                     if (r == owner) in[0] = load_sys(rp[r], roff);
+            } else if constexpr (LL) {
+                const uint32_t goff = (uint32_t)((par + ar.ll_elems + (size_t)(row % gridDim.x) * 2 * ar.slot_elems + (size_t)(row / gridDim.x) * 2 * p.H + 2 * c0) * 2);
+                u32x4 ga[kMaxWorld], gb[kMaxWorld];
+#pragma unroll
+                for (int r = 0; r < kMaxWorld; ++r)
+                    if (r < ar.world && r != ar.rank) { ga[r] = load_sys(rp[r], goff); gb[r] = load_sys(rp[r], goff + 16u); }   // all peers in flight together
+                const unsigned long long t0 = wall_clock64();
+#pragma unroll
+                for (int r = 0; r < kMaxWorld; ++r) {
+                    if (r < ar.world && r != ar.rank) {
+                        while (ga[r][1] != epoch || ga[r][3] != epoch || gb[r][1] != epoch || gb[r][3] != epoch) {   // granules not there yet: ask again
+                            if (wall_clock64() - t0 > ar.spin_ticks) { atomicExch(ar.status, 1 + r); break; }
+                            __builtin_amdgcn_s_sleep(1);
+                            ga[r] = load_sys(rp[r], goff); gb[r] = load_sys(rp[r], goff + 16u);
+                        }
+                        in[r] = (u32x4){ga[r][0], ga[r][2], gb[r][0], gb[r][2]};
+                    } else if (r == ar.rank) {
+                        in[r] = own[t];
+                    }
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < kMaxWorld; ++r)
@@ -429,6 +472,7 @@ struct mi355_allreduce {
     const void* pf_ptr = nullptr;      // mi355_allreduce_set_prefetch: range the next fused launch touches while it waits
     size_t      pf_bytes = 0;
     int     full_fences = 0;           // mi355_allreduce_set_full_fences
+    int     ll = 1;                    // mi355_allreduce_set_protocol: the granule (LL) form for <= 64-row fused / sum calls
 };
 
 namespace {
@@ -467,11 +511,12 @@ ArDev dev_view(const mi355_allreduce* a) {
     }
     d.epoch = a->epoch; d.status = a->status;
     const size_t region = (size_t)kMaxBlocks * a->slot_bytes;
-    d.parity_elems = (2 * region + kAuxBytes) / 2;
+    d.parity_elems = (4 * region + kAuxBytes) / 2;          // per parity: tensor slots | records | two-shot result slots | granule slots (2 x)
     d.aux_elems = region / 2;
     d.res_elems = (region + kAuxBytes) / 2;
+    d.ll_elems = (2 * region + kAuxBytes) / 2;
     d.slot_elems = a->slot_bytes / 2;
-    d.data_bytes = (uint32_t)(2 * (2 * region + kAuxBytes));
+    d.data_bytes = (uint32_t)(2 * (4 * region + kAuxBytes));
     d.rank = a->rank; d.world = a->world; d.spin_ticks = a->spin_ticks; d.full_fences = a->full_fences;
     return d;
 }
@@ -484,7 +529,7 @@ extern "C" mi355_allreduce_t* mi355_allreduce_create(int32_t rank, int32_t world
     // slot: the block's share of the largest message (rows of a block sit back to back) + one row of the widest tensor (8192 fp16)
     const size_t slot_bytes = ((max_bytes + kMaxBlocks - 1) / kMaxBlocks + 16384 + 255) & ~(size_t)255;
     if (rank < 0 || world < 1 || world > kMaxWorld || rank >= world || !handle_out || max_bytes == 0 ||
-        2 * (2 * (size_t)kMaxBlocks * slot_bytes + kAuxBytes) >= 0xFFFFFF00ull) {
+        2 * (4 * (size_t)kMaxBlocks * slot_bytes + kAuxBytes) >= 0xFFFFFF00ull) {
         mi355_set_error("allreduce_create: rank=%d world=%d (1..%d) max_bytes=%zu", rank, world, kMaxWorld, max_bytes);
         return nullptr;
     }
@@ -492,12 +537,13 @@ extern "C" mi355_allreduce_t* mi355_allreduce_create(int32_t rank, int32_t world
     if (!a) return nullptr;
     a->rank = rank; a->world = world; a->ready = false; a->spin_ticks = kSpinTicks;
     { const char* e = getenv("MI355_AR_FULL_FENCES"); a->full_fences = (e && e[0] == '1') ? 1 : 0; }
+    { const char* e = getenv("MI355_AR_NO_LL"); a->ll = (a->full_fences || (e && e[0] == '1')) ? 0 : 1; }
     a->max_bytes = (max_bytes + 255) & ~(size_t)255;
     a->slot_bytes = slot_bytes;
     for (int r = 0; r < kMaxWorld; ++r) { a->peer_data[r] = a->peer_flags[r] = nullptr; a->opened[r] = false; }
     HandleBlob hb;
     memset(&hb, 0, sizeof(hb));
-    a->data  = alloc_shared(2 * (2 * (size_t)kMaxBlocks * slot_bytes + kAuxBytes), &hb.data);   // per parity: tensor slots | records | two-shot result slots
+    a->data  = alloc_shared(2 * (4 * (size_t)kMaxBlocks * slot_bytes + kAuxBytes), &hb.data);   // per parity: tensor slots | records | two-shot result slots | granule slots (2 x)
     a->flags = alloc_shared((size_t)kMaxBlocks * kFlagRow * 4, &hb.flags);
     a->epoch = nullptr; a->status = nullptr;
     if (!a->data || !a->flags || hipMalloc((void**)&a->epoch, kMaxBlocks * 4 + 256) != hipSuccess ||
@@ -560,6 +606,15 @@ extern "C" int mi355_allreduce_set_spin_timeout_ms(mi355_allreduce_t* a, int32_t
 extern "C" int mi355_allreduce_set_full_fences(mi355_allreduce_t* a, int32_t on) {
     MI355_CHECK_ARG(a, "allreduce_set_full_fences: null context");
     a->full_fences = on ? 1 : 0;
+    if (on) a->ll = 0;
+    return MI355_OK;
+}
+
+// 0: data-tagged granules (LL) for the <= 64-row one-shot calls + write-through publishing stores for the rest (default); 1: write-through publishing
+// stores + flags everywhere; 2: plain stores between system-scope release / acquire fences (rounds 1-4).  Same results.
+extern "C" int mi355_allreduce_set_protocol(mi355_allreduce_t* a, int32_t mode) {
+    MI355_CHECK_ARG(a && mode >= 0 && mode <= 2, "allreduce_set_protocol: mode=%d (0..2)", mode);
+    a->ll = mode == 0; a->full_fences = mode == 2;
     return MI355_OK;
 }
 
@@ -632,6 +687,14 @@ static int allreduce_fused_launch(mi355_allreduce_t* a, const void* x_f16, const
     MI355_CHECK_ARG((size_t)cdiv(T, grid) * H * 2 <= a->slot_bytes, "allreduce: %d rows of %d per block exceed the %zu-byte slot", cdiv(T, grid), H, a->slot_bytes);
     hipStream_t st = (hipStream_t)stream;
     const bool two = T > kOneShotRows && a->world > 2;   // (N - 1) vs 2 (N - 1) / N reads per element: equal at N = 2
+    if (a->ll && !a->full_fences && T <= kOneShotRows && !p.pf) {   // one row per block, granules (the in-launch prefetch rides on the flag barrier: not here)
+#define LL_(V, B) hipLaunchKernelGGL((allreduce_fused_kernel<V, false, B, true>), dim3(grid), dim3(512), 0, st, p)
+        if (act_dtype == MI355_ACT_BF16) { if (H / 8 <= 512) LL_(1, true); else LL_(2, true); }
+        else                             { if (H / 8 <= 512) LL_(1, false); else LL_(2, false); }
+#undef LL_
+        MI355_CHECK_LAUNCH("allreduce_fused_kernel (LL)");
+        return MI355_OK;
+    }
 #define L_(V, W, B) hipLaunchKernelGGL((allreduce_fused_kernel<V, W, B>), dim3(grid), dim3(512), 0, st, p)
     if (act_dtype == MI355_ACT_BF16) {
         if (H / 8 <= 512) { if (two) L_(1, true, true); else L_(1, false, true); }

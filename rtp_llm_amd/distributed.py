@@ -104,7 +104,8 @@ class CustomAllReduce:
         if self.shared_device if spin_timeout_ms is None else True:
             self.set_spin_timeout_ms(30000 if spin_timeout_ms is None else spin_timeout_ms)
         self._group = group
-        self.hand_over = "full-fences" if os.environ.get("MI355_AR_FULL_FENCES") == "1" else "write-through"
+        self.hand_over = ("full-fences" if os.environ.get("MI355_AR_FULL_FENCES") == "1" else
+                          "write-through" if os.environ.get("MI355_AR_NO_LL") == "1" else "ll")
         if verify and self.world > 1:
             self._verify_hand_over()
 
@@ -124,17 +125,23 @@ class CustomAllReduce:
             ok = ok and torch.equal(got.cpu(), want)
         return ok and self.status() == 0
 
+    PROTOCOLS = ("ll", "write-through", "full-fences")     # mi355_allreduce_set_protocol modes 0 / 1 / 2
+
+    def set_protocol(self, name: str) -> None:
+        """"ll": data-tagged granules for the <= 64-row calls + write-through stores and flags for the rest (default); "write-through": stores + flags
+        everywhere; "full-fences": plain stores between system-scope release / acquire fences (rounds 1-4).  Same results."""
+        self._C.check(self.lib.mi355_allreduce_set_protocol(self.handle, self.PROTOCOLS.index(name)), "allreduce_set_protocol")
+        self.hand_over = name
+
     def _verify_hand_over(self) -> None:
-        """The write-through hand-over (no system-scope fences, csrc/allreduce.hip publish16) was developed with several processes on ONE GPU;
-        the first thing a context does on a node is a known-answer check on every rank.  If any rank sees a wrong sum the whole group takes
-        the fenced form of rounds 1-4 and checks again; if that fails too the constructor raises on every rank together."""
+        """The fence-free hand-overs (granules; write-through stores + flags: csrc/allreduce.hip) were developed with several processes on ONE GPU;
+        the first thing a context does on a node is a known-answer check on every rank.  If any rank sees a wrong sum the whole group steps down
+        one form (ll -> write-through -> full-fences) and checks again; if the fenced form of rounds 1-4 fails too the constructor raises on
+        every rank together."""
         import sys
-        for attempt in ("write-through", "full-fences"):
-            if attempt == "full-fences":
-                self.set_full_fences(True)
-                self.hand_over = "full-fences"
-            elif self.hand_over != "write-through":
-                continue
+        for attempt in self.PROTOCOLS[self.PROTOCOLS.index(self.hand_over):]:
+            if attempt != self.hand_over:
+                self.set_protocol(attempt)
             oks = [None] * self.world
             dist.all_gather_object(oks, bool(self._known_answer_round()), group=self._group)
             if all(oks):
@@ -143,28 +150,13 @@ class CustomAllReduce:
                 print(f"[rtp_llm_amd.distributed] all-reduce known-answer check failed with the {attempt} hand-over on ranks "
                       f"{[r for r, o in enumerate(oks) if not o]}", file=sys.stderr, flush=True)
         self.close()
-        raise _C_err("CustomAllReduce: the all-reduce known-answer check fails with both hand-over forms")
-
-    @staticmethod
-    def _device_key():
-        import socket
-        import os
-        idx = torch.cuda.current_device()
-        p = torch.cuda.get_device_properties(idx)
-        ident = getattr(p, "uuid", None)
-        if not ident and getattr(p, "pci_bus_id", None) is not None:
-            ident = (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", -1))
-        if not ident:
-            # a torch build that exposes neither a uuid nor a PCI id: the ordinal inside this process's visible set -- never ONE key for
-            # every rank of a host (that would read as "all ranks share a device" and raise the spin bound on a real multi-GPU node)
-            ident = ("ordinal", idx, os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "")),
-                     os.environ.get("ROCR_VISIBLE_DEVICES", ""))
-        return (socket.gethostname(), str(ident))
+        raise _C_err("CustomAllReduce: the all-reduce known-answer check fails with every hand-over form")
 
     def set_full_fences(self, on: bool) -> None:
         """Hand-over protocol of later launches: False (default) = write-through publishing stores + drained flags, True = plain stores
         between system-scope release / acquire fences (rounds 1-4).  Same results (mi355_allreduce_set_full_fences)."""
         self._C.check(self.lib.mi355_allreduce_set_full_fences(self.handle, 1 if on else 0), "allreduce_set_full_fences")
+        self.hand_over = "full-fences" if on else "write-through"
 
     def set_spin_timeout_ms(self, ms: int) -> None:
         """Bound of every in-kernel wait for a peer; applies to launches enqueued or captured afterwards."""
