@@ -152,6 +152,22 @@ class CustomAllReduce:
         self.close()
         raise _C_err("CustomAllReduce: the all-reduce known-answer check fails with every hand-over form")
 
+    @staticmethod
+    def _device_key():
+        import socket
+        import os
+        idx = torch.cuda.current_device()
+        p = torch.cuda.get_device_properties(idx)
+        ident = getattr(p, "uuid", None)
+        if not ident and getattr(p, "pci_bus_id", None) is not None:
+            ident = (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", -1))
+        if not ident:
+            # a torch build that exposes neither a uuid nor a PCI id: the ordinal inside this process's visible set -- never ONE key for
+            # every rank of a host (that would read as "all ranks share a device" and raise the spin bound on a real multi-GPU node)
+            ident = ("ordinal", idx, os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "")),
+                     os.environ.get("ROCR_VISIBLE_DEVICES", ""))
+        return (socket.gethostname(), str(ident))
+
     def set_full_fences(self, on: bool) -> None:
         """Hand-over protocol of later launches: False (default) = write-through publishing stores + drained flags, True = plain stores
         between system-scope release / acquire fences (rounds 1-4).  Same results (mi355_allreduce_set_full_fences)."""
