@@ -486,8 +486,8 @@ def main():
                 dist.all_gather(outs, t, group=grp)
                 return all(torch.equal(outs[0], o) for o in outs)
 
-            HAND_OVER = {"ll": "data-tagged granules (<= 64-row calls) + write-through publishing stores and flags (round 5)",
-                         "write-through": "write-through publishing stores + drained flags, no granules",
+            HAND_OVER = {"ll": "data-tagged granules (<= 64-row calls) + write-through publishing stores and flags (opt-in: MI355_AR_LL=1)",
+                         "write-through": "write-through publishing stores + drained flags (round 5)",
                          "full-fences": "plain stores + system-scope release / acquire fences (rounds 1-4)"}
             agree = ranks_agree()
             while not agree and ar is not None and ar.hand_over != "full-fences":

@@ -466,12 +466,14 @@ int mi355_allreduce_fused(mi355_allreduce_t* ar, const void* x_f16, const float*
  * ordered in front of the flags by the wave's own s_waitcnt; 1 = plain stores between system-scope release / acquire fences (an L2
  * write-back + invalidate per block; rounds 1-4).  Results are identical; also settable with MI355_AR_FULL_FENCES=1 at creation. */
 int mi355_allreduce_set_full_fences(mi355_allreduce_t* ar, int32_t on);
-/* The hand-over as one setting.  0 (default): the <= 64-row one-shot calls of a decode step publish DATA-TAGGED GRANULES -- every 4 payload bytes in an
- * aligned 8-byte {payload, epoch} written by one write-through store; a peer polls the granules themselves: no flag table, no block barrier, one fabric
- * round trip per all-reduce (NCCL's LL protocol) -- and everything else uses write-through publishing stores + flags; 1: write-through stores + flags
- * everywhere; 2: plain stores between system-scope release / acquire fences (rounds 1-4).  Results are bit-identical in all three; MI355_AR_NO_LL=1 /
- * MI355_AR_FULL_FENCES=1 select 1 / 2 at creation. */
+/* The hand-over as one setting.  1 (default): write-through publishing stores + flags; 0 (opt-in, also MI355_AR_LL=1 at creation): the <= 64-row one-shot
+ * calls of a decode step publish DATA-TAGGED GRANULES -- every 4 payload bytes in an aligned 8-byte {payload, epoch} written by one write-through store; a
+ * peer polls the granules themselves: no flag table, no block barrier, one fabric round trip per all-reduce (NCCL's LL protocol) -- everything else as 1;
+ * 2: plain stores between system-scope release / acquire fences (rounds 1-4).  Results are bit-identical in all three.  The granule form is validated with
+ * 2 and 4 processes on one GPU and is left off by default: what it saves is an xGMI hop no development box had. */
 int mi355_allreduce_set_protocol(mi355_allreduce_t* ar, int32_t mode);
+/* a spin that timed out leaves mi355_allreduce_status != 0 for good; clear it once the host has dealt with the cause */
+int mi355_allreduce_clear_status(mi355_allreduce_t* ar, mi355_stream_t stream);
 
 /* In-launch prefetch for the NEXT mi355_allreduce_fused[_dt] launch of this context (cleared by that launch): while a block waits
  * for its peers' flags its other waves touch one dword per 128-byte line of [ptr, ptr + bytes) -- normally the weight shard of the

@@ -120,6 +120,7 @@ SIGNATURES = {
     "mi355_allreduce_set_spin_timeout_ms": (i32, [vp, i32]),
     "mi355_allreduce_set_full_fences": (i32, [vp, i32]),
     "mi355_allreduce_set_protocol": (i32, [vp, i32]),
+    "mi355_allreduce_clear_status": (i32, [vp, vp]),
     "mi355_allreduce_sum": (i32, [vp, vp, vp, i32, i32, vp]),
     "mi355_allreduce_fused": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, vp]),
     "mi355_allreduce_fused_dt": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, i32, vp]),

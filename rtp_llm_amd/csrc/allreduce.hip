@@ -472,7 +472,7 @@ struct mi355_allreduce {
     const void* pf_ptr = nullptr;      // mi355_allreduce_set_prefetch: range the next fused launch touches while it waits
     size_t      pf_bytes = 0;
     int     full_fences = 0;           // mi355_allreduce_set_full_fences
-    int     ll = 1;                    // mi355_allreduce_set_protocol: the granule (LL) form for <= 64-row fused / sum calls
+    int     ll = 0;                    // mi355_allreduce_set_protocol(0) / MI355_AR_LL=1: the granule (LL) form for <= 64-row fused / sum calls (opt-in)
 };
 
 namespace {
@@ -537,7 +537,7 @@ extern "C" mi355_allreduce_t* mi355_allreduce_create(int32_t rank, int32_t world
     if (!a) return nullptr;
     a->rank = rank; a->world = world; a->ready = false; a->spin_ticks = kSpinTicks;
     { const char* e = getenv("MI355_AR_FULL_FENCES"); a->full_fences = (e && e[0] == '1') ? 1 : 0; }
-    { const char* e = getenv("MI355_AR_NO_LL"); a->ll = (a->full_fences || (e && e[0] == '1')) ? 0 : 1; }
+    { const char* e = getenv("MI355_AR_LL"); a->ll = (!a->full_fences && e && e[0] == '1') ? 1 : 0; }
     a->max_bytes = (max_bytes + 255) & ~(size_t)255;
     a->slot_bytes = slot_bytes;
     for (int r = 0; r < kMaxWorld; ++r) { a->peer_data[r] = a->peer_flags[r] = nullptr; a->opened[r] = false; }
@@ -610,8 +610,10 @@ extern "C" int mi355_allreduce_set_full_fences(mi355_allreduce_t* a, int32_t on)
     return MI355_OK;
 }
 
-// 0: data-tagged granules (LL) for the <= 64-row one-shot calls + write-through publishing stores for the rest (default); 1: write-through publishing
-// stores + flags everywhere; 2: plain stores between system-scope release / acquire fences (rounds 1-4).  Same results.
+// 1 (default): write-through publishing stores + flags everywhere; 0: data-tagged granules (LL) for the <= 64-row one-shot calls + write-through stores for
+// the rest -- OPT-IN: on one GPU it saves ~1 % of a rank's step (profiles/r05_tp_allreduce_granules.txt; the hop it removes is an xGMI hop), passes the
+// two- and four-process checks, and times out with EIGHT processes time-slicing one GPU (every thread of every block polls: the single-GPU setup cannot say
+// whether a real node likes it); 2: plain stores between system-scope release / acquire fences (rounds 1-4).  Same results in all three.
 extern "C" int mi355_allreduce_set_protocol(mi355_allreduce_t* a, int32_t mode) {
     MI355_CHECK_ARG(a && mode >= 0 && mode <= 2, "allreduce_set_protocol: mode=%d (0..2)", mode);
     a->ll = mode == 0; a->full_fences = mode == 2;
@@ -627,6 +629,16 @@ extern "C" int mi355_allreduce_set_prefetch(mi355_allreduce_t* a, const void* pt
     MI355_CHECK_ARG(a && ((uintptr_t)ptr & 3) == 0, "allreduce_set_prefetch: null context or unaligned pointer");
     a->pf_ptr = bytes ? ptr : nullptr;
     a->pf_bytes = ptr ? (bytes < ((size_t)1 << 38) ? bytes : ((size_t)1 << 38)) : 0;
+    return MI355_OK;
+}
+
+// Clear the status word (a bounded spin that timed out leaves it set for good: the host decides when a context is usable again)
+extern "C" int mi355_allreduce_clear_status(mi355_allreduce_t* a, mi355_stream_t stream) {
+    MI355_CHECK_ARG(a, "allreduce_clear_status: null");
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemset(a->status, 0, 4) != hipSuccess) {
+        mi355_set_error("allreduce_clear_status: %s", hipGetErrorString(hipGetLastError()));
+        return MI355_ERR_HIP;
+    }
     return MI355_OK;
 }
 

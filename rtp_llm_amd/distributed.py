@@ -105,7 +105,7 @@ class CustomAllReduce:
             self.set_spin_timeout_ms(30000 if spin_timeout_ms is None else spin_timeout_ms)
         self._group = group
         self.hand_over = ("full-fences" if os.environ.get("MI355_AR_FULL_FENCES") == "1" else
-                          "write-through" if os.environ.get("MI355_AR_NO_LL") == "1" else "ll")
+                          "ll" if os.environ.get("MI355_AR_LL") == "1" else "write-through")
         if verify and self.world > 1:
             self._verify_hand_over()
 
@@ -128,8 +128,8 @@ class CustomAllReduce:
     PROTOCOLS = ("ll", "write-through", "full-fences")     # mi355_allreduce_set_protocol modes 0 / 1 / 2
 
     def set_protocol(self, name: str) -> None:
-        """"ll": data-tagged granules for the <= 64-row calls + write-through stores and flags for the rest (default); "write-through": stores + flags
-        everywhere; "full-fences": plain stores between system-scope release / acquire fences (rounds 1-4).  Same results."""
+        """"write-through" (default): write-through publishing stores + flags; "ll" (opt-in): data-tagged granules for the <= 64-row calls, the rest as
+        write-through; "full-fences": plain stores between system-scope release / acquire fences (rounds 1-4).  Same results."""
         self._C.check(self.lib.mi355_allreduce_set_protocol(self.handle, self.PROTOCOLS.index(name)), "allreduce_set_protocol")
         self.hand_over = name
 
@@ -142,6 +142,7 @@ class CustomAllReduce:
         for attempt in self.PROTOCOLS[self.PROTOCOLS.index(self.hand_over):]:
             if attempt != self.hand_over:
                 self.set_protocol(attempt)
+                self._C.check(self.lib.mi355_allreduce_clear_status(self.handle, self._st()), "allreduce_clear_status")   # a timed-out spin of the form before
             oks = [None] * self.world
             dist.all_gather_object(oks, bool(self._known_answer_round()), group=self._group)
             if all(oks):

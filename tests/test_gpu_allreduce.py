@@ -35,8 +35,8 @@ def _worker(rank, world, port, q, mode):
     if mode.endswith("_ff"):      # the hand-over of rounds 1-4 (plain stores between system-scope release / acquire fences) instead of the
         os.environ["MI355_AR_FULL_FENCES"] = "1"   # fence-free forms of round 5: every form passes the same checks
         mode = mode[:-3]
-    elif mode.endswith("_wt"):    # write-through publishing stores + flags everywhere (no data-tagged granules for the <= 64-row calls)
-        os.environ["MI355_AR_NO_LL"] = "1"
+    elif mode.endswith("_ll"):    # data-tagged granules (LL) for the <= 64-row calls instead of publishing stores + flags: opt-in form
+        os.environ["MI355_AR_LL"] = "1"
         mode = mode[:-3]
     try:
         import torch.distributed as dist
@@ -576,7 +576,7 @@ def _worker(rank, world, port, q, mode):
                 bad += int(not torch.equal(got.cpu(), want))
             torch.cuda.synchronize()
             assert bad == 0, f"{bad} of 300 all-reduces differ from the exact sums"
-            assert ar.status() == 0 and ar.hand_over == "ll"
+            assert ar.status() == 0 and ar.hand_over == ("ll" if os.environ.get("MI355_AR_LL") == "1" else "write-through")
         elif mode == "timeout":
             x = torch.ones(4, 3584, dtype=torch.float16, device=dev)
             ar.all_reduce(x.clone()); torch.cuda.synchronize(); dist.barrier()
@@ -602,7 +602,7 @@ def _worker(rank, world, port, q, mode):
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("mode,world", [("kernels", 2), ("engine", 2), ("transport", 2), ("bf16", 2), ("bf16", 4), ("timeout", 2), ("twoshot", 3), ("mixed", 2), ("kernels", 4),
-                                        ("kernels", 8), ("twoshot", 4), ("twoshot", 8), ("engine70", 8), ("engine70full", 8), ("kernels_ff", 2), ("engine_ff", 2), ("twoshot_ff", 3), ("kernels_wt", 2), ("kernels_wt", 4), ("engine_wt", 2), ("mixed_wt", 2), ("engine7b", 2), ("engine7b", 4), ("stress", 2), ("stress", 4)])   # (8 ranks time-slicing ONE GPU under this load run into the spin bound: a property of the single-GPU setup)
+                                        ("kernels", 8), ("twoshot", 4), ("twoshot", 8), ("engine70", 8), ("engine70full", 8), ("kernels_ff", 2), ("engine_ff", 2), ("twoshot_ff", 3), ("kernels_ll", 2), ("kernels_ll", 4), ("engine_ll", 2), ("mixed_ll", 2), ("stress_ll", 2), ("stress_ll", 4), ("engine7b_ll", 2), ("engine7b", 2), ("engine7b", 4), ("stress", 2), ("stress", 4)])   # (8 ranks time-slicing ONE GPU under this load run into the spin bound: a property of the single-GPU setup)
 def test_custom_allreduce_processes_on_one_gpu(mode, world):
     assert torch.cuda.is_available()
     port = _free_port()
