@@ -140,6 +140,58 @@ def cpu_baseline(cfg, kind, kv_int8, B, ctx, budget_s=25.0):
             "ms_per_step": round(step * 1e3, 1)}
 
 
+def spawn_plan(n, argv, port, one_gpu=False):
+    """The N child processes `python bench.py --gpus N ...` starts when it is NOT already one rank of a launcher (no WORLD_SIZE in the
+    environment): one process per GPU with the torchrun environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT),
+    the same command line.  The reference starts one process per rank the same way (rtp_llm/start_server.py:597-720; test idiom
+    modules/base/rocm/test/trt_allreduce_test.py:381-470)."""
+    plan = []
+    for r in range(n):
+        env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+               "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0", "MI355_BENCH_SELF_SPAWNED": "1"}
+        if one_gpu:
+            env["MI355_BENCH_ONE_GPU"] = "1"
+        plan.append({"cmd": [sys.executable, os.path.abspath(__file__)] + list(argv), "env": env})
+    return plan
+
+
+def spawn_ranks(n, argv, child_cmd=None, grace_s=90.0):
+    """Start the ranks of spawn_plan, wait for all of them.  Rank 0 inherits stdout (it prints the one JSON line); the other ranks' stdout
+    goes to stderr.  A rank that exits non-zero makes the whole run non-zero: its peers get `grace_s` to finish (the bench has its own
+    fallbacks and watchdogs), then the ones THIS process started are terminated."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    plan = spawn_plan(n, argv, port, one_gpu=os.environ.get("MI355_BENCH_ONE_GPU") == "1")
+    procs = []
+    for r, p in enumerate(plan):
+        cmd = child_cmd if child_cmd is not None else p["cmd"]
+        procs.append(subprocess.Popen(cmd, env={**os.environ, **p["env"]}, stdout=None if r == 0 else sys.stderr))
+    rc, failed_at = 0, None
+    while any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0) and rc == 0:
+                rc, failed_at = p.returncode, time.time()
+                log(f"[bench] rank {r} exited with {p.returncode}")
+        if failed_at is not None and time.time() - failed_at > grace_s:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    for r, p in enumerate(procs):
+        try:
+            p.wait(timeout=10)
+        except Exception:  # noqa: BLE001
+            p.kill()
+        if p.returncode != 0 and rc == 0:
+            rc = p.returncode or 1
+            log(f"[bench] rank {r} exited with {p.returncode}")
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,6 +213,10 @@ def main():
     ap.add_argument("--prefetch", type=int, default=None, help="weight-prefetch mask (mi355_decoder_set_weight_prefetch); default: the engine's")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (no launcher): this process becomes the launcher of N ranks
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     if args.debug_set or args.attn_ps:   # kernel A/B switches exist only in the tuning build (python -m rtp_llm_amd.build --tuning)
         os.environ["MI355_TUNING_LIB"] = "1"
     from rtp_llm_amd import _C, distributed, model
@@ -168,7 +224,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    if world != args.gpus:   # under a launcher the launcher's world is the truth (torchrun --nproc-per-node); without one, --gpus N > 1 spawned the ranks above
         log(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
     if os.environ.get("MI355_BENCH_ONE_GPU") == "1":   # debug: several ranks on device 0 (control-plane check on a 1-GPU box)
         local_rank = 0

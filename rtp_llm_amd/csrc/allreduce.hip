@@ -502,6 +502,13 @@ void* alloc_shared(size_t bytes, hipIpcMemHandle_t* handle) {
     return nullptr;
 }
 
+// Bytes of one parity of the registered buffer: tensor slots (kMaxBlocks) | records | two-shot result slots (kMaxBlocks) | granule slots.  The granule
+// (LL) form runs one row per block on <= kOneShotRows blocks and a granule doubles its payload: kOneShotRows slots of 2 x slot_bytes (the
+// round-5 layout reserved kMaxBlocks of them for an opt-in form and halved the largest message a context accepts).
+static inline size_t parity_bytes(size_t slot_bytes) {
+    return 2 * (size_t)kMaxBlocks * slot_bytes + kAuxBytes + 2 * (size_t)kOneShotRows * slot_bytes;
+}
+
 ArDev dev_view(const mi355_allreduce* a) {
     ArDev d;
     d.my_data = (f16*)a->data;
@@ -511,12 +518,12 @@ ArDev dev_view(const mi355_allreduce* a) {
     }
     d.epoch = a->epoch; d.status = a->status;
     const size_t region = (size_t)kMaxBlocks * a->slot_bytes;
-    d.parity_elems = (4 * region + kAuxBytes) / 2;          // per parity: tensor slots | records | two-shot result slots | granule slots (2 x)
+    d.parity_elems = parity_bytes(a->slot_bytes) / 2;       // per parity: tensor slots | records | two-shot result slots | granule slots (kOneShotRows x 2 slots)
     d.aux_elems = region / 2;
     d.res_elems = (region + kAuxBytes) / 2;
     d.ll_elems = (2 * region + kAuxBytes) / 2;
     d.slot_elems = a->slot_bytes / 2;
-    d.data_bytes = (uint32_t)(2 * (4 * region + kAuxBytes));
+    d.data_bytes = (uint32_t)(2 * parity_bytes(a->slot_bytes));
     d.rank = a->rank; d.world = a->world; d.spin_ticks = a->spin_ticks; d.full_fences = a->full_fences;
     return d;
 }
@@ -529,7 +536,7 @@ extern "C" mi355_allreduce_t* mi355_allreduce_create(int32_t rank, int32_t world
     // slot: the block's share of the largest message (rows of a block sit back to back) + one row of the widest tensor (8192 fp16)
     const size_t slot_bytes = ((max_bytes + kMaxBlocks - 1) / kMaxBlocks + 16384 + 255) & ~(size_t)255;
     if (rank < 0 || world < 1 || world > kMaxWorld || rank >= world || !handle_out || max_bytes == 0 ||
-        2 * (4 * (size_t)kMaxBlocks * slot_bytes + kAuxBytes) >= 0xFFFFFF00ull) {
+        2 * parity_bytes(slot_bytes) >= 0xFFFFFF00ull) {
         mi355_set_error("allreduce_create: rank=%d world=%d (1..%d) max_bytes=%zu", rank, world, kMaxWorld, max_bytes);
         return nullptr;
     }
@@ -543,7 +550,7 @@ extern "C" mi355_allreduce_t* mi355_allreduce_create(int32_t rank, int32_t world
     for (int r = 0; r < kMaxWorld; ++r) { a->peer_data[r] = a->peer_flags[r] = nullptr; a->opened[r] = false; }
     HandleBlob hb;
     memset(&hb, 0, sizeof(hb));
-    a->data  = alloc_shared(2 * (4 * (size_t)kMaxBlocks * slot_bytes + kAuxBytes), &hb.data);   // per parity: tensor slots | records | two-shot result slots | granule slots (2 x)
+    a->data  = alloc_shared(2 * parity_bytes(slot_bytes), &hb.data);   // per parity: tensor slots | records | two-shot result slots | granule slots
     a->flags = alloc_shared((size_t)kMaxBlocks * kFlagRow * 4, &hb.flags);
     a->epoch = nullptr; a->status = nullptr;
     if (!a->data || !a->flags || hipMalloc((void**)&a->epoch, kMaxBlocks * 4 + 256) != hipSuccess ||
@@ -606,7 +613,7 @@ extern "C" int mi355_allreduce_set_spin_timeout_ms(mi355_allreduce_t* a, int32_t
 extern "C" int mi355_allreduce_set_full_fences(mi355_allreduce_t* a, int32_t on) {
     MI355_CHECK_ARG(a, "allreduce_set_full_fences: null context");
     a->full_fences = on ? 1 : 0;
-    if (on) a->ll = 0;
+    a->ll = 0;                                   // either value names a flag form: the granule form is only reachable through mi355_allreduce_set_protocol(a, 0)
     return MI355_OK;
 }
 
@@ -699,7 +706,8 @@ static int allreduce_fused_launch(mi355_allreduce_t* a, const void* x_f16, const
     MI355_CHECK_ARG((size_t)cdiv(T, grid) * H * 2 <= a->slot_bytes, "allreduce: %d rows of %d per block exceed the %zu-byte slot", cdiv(T, grid), H, a->slot_bytes);
     hipStream_t st = (hipStream_t)stream;
     const bool two = T > kOneShotRows && a->world > 2;   // (N - 1) vs 2 (N - 1) / N reads per element: equal at N = 2
-    if (a->ll && !a->full_fences && T <= kOneShotRows && !p.pf) {   // one row per block, granules (the in-launch prefetch rides on the flag barrier: not here)
+    if (a->ll && !a->full_fences && T <= kOneShotRows) {   // one row per block, granules.  The choice depends on context state only (every rank of a group holds the
+        // same: distributed.CustomAllReduce agrees on it at creation) -- never on the prefetch pointer, which rides on the flag barrier and is simply unused here
 #define LL_(V, B) hipLaunchKernelGGL((allreduce_fused_kernel<V, false, B, true>), dim3(grid), dim3(512), 0, st, p)
         if (act_dtype == MI355_ACT_BF16) { if (H / 8 <= 512) LL_(1, true); else LL_(2, true); }
         else                             { if (H / 8 <= 512) LL_(1, false); else LL_(2, false); }

@@ -214,7 +214,8 @@ constexpr float kImgBfScale = 0.00390625f, kImgBfUnscale = 256.f;
 // the fp16 an image stores for element v (already rounded to the BF-typed tensor it stands for)
 template <bool BF> __device__ __forceinline__ float img_val(float v) {
     if constexpr (!BF) return v;
-    return __builtin_amdgcn_fmed3f(v * kImgBfScale, -65504.f, 65504.f);
+    const float s = v * kImgBfScale;
+    return s != s ? s : __builtin_amdgcn_fmed3f(s, -65504.f, 65504.f);   // saturate, but a NaN stays a NaN (v_med3 would return a bound: ADVICE r05)
 }
 __device__ __forceinline__ float rt_img_val(float v, bool bf) { return bf ? img_val<true>(v) : v; }
 // Element index of x[row][col]; mblk = row blocks of the image = ceil(M / 16).

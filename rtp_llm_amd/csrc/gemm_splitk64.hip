@@ -39,7 +39,9 @@ struct SplitK64Params {
 // WB = 8 (round 5): per-channel INT8 weights -- two wave-loads per (tile, chunk), the operand is the exact integer u - 128 (4 v_perm +
 // 4 v_pk_add per 8 weights: a lighter unit than W4's, left to the compiler's schedule), the column's scale multiplies the summed
 // accumulators before the slab store (every K split is scaled alike, so the fold's sum of slabs is the scaled sum).
-template <int WB, int GS, int MB, int T, int CPW, int RING>
+// DIRECT (round 6): the fused-epilogue store is an instance of its own -- with both stores behind a run-time `mode` the slab instances of the headline's
+// down_proj carried gemm_store's code and registers and measured 17.2 -> 17.6 us (profiles/r06_r04_vs_r05_same_box.txt).
+template <int WB, int GS, int MB, int T, int CPW, int RING, bool DIRECT = false>
 __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params sp) {
     const GemmParams& p = sp.g;
     constexpr int NW = 8;
@@ -192,15 +194,15 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
         }
         if (p.bf16) v *= kImgBfUnscale;                  // the image of a bf16 tensor holds x 2^-8 (common.h img_val)
         if (m < p.M && t0 + t < p.NT) {
-            if (p.mode == MODE_PARTIAL) st_slab(rs, (uint32_t)((((size_t)by * p.M + m) * p.N_pad + (t0 + t) * 16 + q * 4) * 4), v);
+            if constexpr (!DIRECT) st_slab(rs, (uint32_t)((((size_t)by * p.M + m) * p.N_pad + (t0 + t) * 16 + q * 4) * 4), v);
             else gemm_store(p, v, m, (t0 + t) * 16 + q * 4, 0);   // direct form (one K split): bias / fp16 / SiLU-mul store, row-major or image
         }
     }
 }
 
-template <int WB, int GS, int MB, int T, int CPW, int RING>
+template <int WB, int GS, int MB, int T, int CPW, int RING, bool DIRECT = false>
 int launch_splitk64_t(const SplitK64Params& sp, int G, hipStream_t st) {
-    auto k = gemm_splitk64_kernel<WB, GS, MB, T, CPW, RING>;
+    auto k = gemm_splitk64_kernel<WB, GS, MB, T, CPW, RING, DIRECT>;
     const size_t lds = (size_t)8 * T * MB * 1024;
     if (lds > 160 * 1024) return MI355_ERR_UNSUPPORTED;
     if (lds > 64 * 1024)
@@ -255,8 +257,8 @@ extern "C" int mi355_gemm_splitk64_direct(const void* gp, int wbits, int group_s
     hipStream_t st = (hipStream_t)stream;
     const int mblk = (g.M + 15) >> 4;
     // activation ring: 3 k-steps, 2 where T x MB accumulators + a two-chunk weight ring of T tiles leave no room for the third
-#define SKD_T_(T_, CPW_, RING_) (mblk == 1 ? launch_splitk64_t<4, 4, 1, T_, CPW_, RING_>(sp, G, st) : mblk == 2 ? launch_splitk64_t<4, 4, 2, T_, CPW_, RING_>(sp, G, st) \
-                                 : mblk == 3 ? launch_splitk64_t<4, 4, 3, T_, CPW_, RING_>(sp, G, st) : launch_splitk64_t<4, 4, 4, T_, CPW_, RING_>(sp, G, st))
+#define SKD_T_(T_, CPW_, RING_) (mblk == 1 ? launch_splitk64_t<4, 4, 1, T_, CPW_, RING_, true>(sp, G, st) : mblk == 2 ? launch_splitk64_t<4, 4, 2, T_, CPW_, RING_, true>(sp, G, st) \
+                                 : mblk == 3 ? launch_splitk64_t<4, 4, 3, T_, CPW_, RING_, true>(sp, G, st) : launch_splitk64_t<4, 4, 4, T_, CPW_, RING_, true>(sp, G, st))
     // CPW = the chunks of the longest slice exactly (waves one chunk short skip the last chunk's units; a larger CPW would run them on zeros)
     if (T == 5) return cpw <= 4 ? SKD_T_(5, 4, 2) : SKD_T_(5, 5, 2);
     if (T == 4) return cpw <= 3 ? SKD_T_(4, 3, 3) : cpw == 4 ? SKD_T_(4, 4, 3) : SKD_T_(4, 5, 3);

@@ -104,25 +104,66 @@ class CustomAllReduce:
         if self.shared_device if spin_timeout_ms is None else True:
             self.set_spin_timeout_ms(30000 if spin_timeout_ms is None else spin_timeout_ms)
         self._group = group
-        self.hand_over = ("full-fences" if os.environ.get("MI355_AR_FULL_FENCES") == "1" else
-                          "ll" if os.environ.get("MI355_AR_LL") == "1" else "write-through")
+        # The hand-over form must be ONE for the whole group: the flag forms interoperate with each other but not with the granule form, and an
+        # environment variable set on a subset of the ranks would leave them spinning on each other.  Every rank proposes what its
+        # environment asks for; the group takes the most conservative proposal and every context is set to it explicitly.
+        want = ("full-fences" if os.environ.get("MI355_AR_FULL_FENCES") == "1" else
+                "ll" if os.environ.get("MI355_AR_LL") == "1" else "write-through")
+        wants = [None] * self.world
+        dist.all_gather_object(wants, want, group=group)
+        agreed = self.PROTOCOLS[max(self.PROTOCOLS.index(w) for w in wants)]
+        if len(set(wants)) > 1 and self.rank == 0:
+            import sys
+            print(f"[rtp_llm_amd.distributed] ranks asked for different all-reduce hand-overs {wants}: the group uses {agreed}", file=sys.stderr, flush=True)
+        self.set_protocol(agreed)
         if verify and self.world > 1:
             self._verify_hand_over()
 
-    def _known_answer_round(self, rounds: int = 6) -> bool:
-        """A few all-reduces of rank-specific integer patterns (every partial sum exact in fp32 and fp16) on both buffer parities: True when
-        this rank obtained the expected sums bit for bit every time."""
+    def _known_answer_round(self, rounds: int = 24) -> bool:
+        """Known-answer collectives on every path that publishes through the hand-over under test -- the one-shot sum (<= 64 rows), the two-shot
+        sum (> 64 rows on > 2 ranks: second barrier + result region), the fused residual + RMSNorm form, the all-gather of the hidden dimension and
+        the cross-rank arg-max -- `rounds` times, so both buffer parities are used many times, with one rank (rotating) held back by a matmul in
+        front of its call so that its peers really wait on its flags.  Integer patterns: every partial sum is exact in fp32 and fp16, so the
+        expected bits do not depend on anything but the protocol.  True when this rank saw the expected bits every time."""
         dev = torch.device("cuda", torch.cuda.current_device())
         H = 1024
-        T = max(1, min(64, self.max_bytes // (H * 2)))
-        idx = torch.arange(T * H, dtype=torch.int64).reshape(T, H)
+        rows_max = max(1, self.max_bytes // (H * 2))
+        T1 = min(64, rows_max)
+        T2 = min(160, rows_max) if self.world > 2 else 0          # two-shot geometry (one-shot again if the registered buffer is too small for > 64 rows)
+        ng = 64                                                     # all-gather slice width
+        Tg = max(1, min(16, self.max_bytes // (ng * self.world * 2)))
         ok = True
+        slow = torch.randn(1024, 1024, device=dev)
         for it in range(rounds):
-            pats = [((idx * (r + 3) + it * 7 + r) % 61 - 30).to(torch.float16) for r in range(self.world)]    # |value| <= 30: sums of 8 ranks exact
-            want = sum(p.float() for p in pats).to(torch.float16)
-            got = self.all_reduce(pats[self.rank].to(dev).clone())
-            torch.cuda.synchronize()
-            ok = ok and torch.equal(got.cpu(), want)
+            if it % self.world == self.rank:                        # this rank arrives late this round
+                for _ in range(4):
+                    slow = (slow @ slow).clamp_(-1, 1)
+            for T in filter(None, (T1, T2 if it % 3 == 0 else 0)):
+                idx = torch.arange(T * H, dtype=torch.int64).reshape(T, H)
+                pats = [((idx * (r + 3) + it * 7 + r) % 61 - 30).to(torch.float16) for r in range(self.world)]    # |value| <= 30: sums of 8 ranks exact
+                want = sum(p.float() for p in pats).to(torch.float16)
+                got = self.all_reduce(pats[self.rank].to(dev).clone())
+                ok = ok and torch.equal(got.cpu(), want)
+            if it % 4 == 1:      # fused form: residual add + RMSNorm of the sum (weight 1): the residual out must be sum + residual, bit for bit
+                idx = torch.arange(T1 * H, dtype=torch.int64).reshape(T1, H)
+                pats = [((idx * (r + 5) + it * 3 + r) % 31 - 15).to(torch.float16) for r in range(self.world)]
+                res = ((idx * 11 + it) % 17 - 8).to(torch.float16)
+                _, res_out = self.all_reduce_add_rmsnorm(pats[self.rank].to(dev), res.to(dev), torch.ones(H, dtype=torch.float16, device=dev), 1e-6)
+                ok = ok and torch.equal(res_out.cpu(), (sum(p.float() for p in pats) + res.float()).to(torch.float16))
+            if it % 4 == 2:      # all-gather of the hidden dimension
+                slices = [((torch.arange(Tg * ng, dtype=torch.int64).reshape(Tg, ng) * (r + 2) + it) % 97 - 48).to(torch.float16) for r in range(self.world)]
+                got = self.all_gather_hidden(slices[self.rank].to(dev))
+                ok = ok and torch.equal(got.cpu(), torch.cat(slices, dim=1))
+            if it % 4 == 3:      # cross-rank arg-max: the winner sits in a rank that rotates with the round
+                Bq, Vl = 8, 512
+                base = ((torch.arange(Bq * Vl, dtype=torch.int64).reshape(Bq, Vl) * 7 + it) % 101).float()
+                win_rank, win_col = (it // 4) % self.world, (it * 37) % Vl
+                mine = base.clone()
+                if win_rank == self.rank:
+                    mine[:, win_col] = 1000.0 + it
+                ids = self.argmax(mine.to(dev), self.rank * Vl)
+                ok = ok and bool((ids.cpu() == win_rank * Vl + win_col).all())
+        torch.cuda.synchronize()
         return ok and self.status() == 0
 
     PROTOCOLS = ("ll", "write-through", "full-fences")     # mi355_allreduce_set_protocol modes 0 / 1 / 2

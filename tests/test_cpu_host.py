@@ -398,3 +398,32 @@ def test_committed_bench_line_and_traffic_file_follow_the_contract():
     pj = json.load(open(os.path.join(root, "profiles", "r05_parity_greedy_ids.json")))    # tests/conftest.py: the full-width end-to-end record
     assert pj["summary"]["rows"] >= 400 and pj["summary"]["exact"] >= pj["summary"]["safe"]
     assert all(r["max_abs_logit_err"] <= r["tol"] and (r["exact"] == r["rows"] or r["safe"] < r["rows"]) for r in pj["records"])
+
+
+def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (the shape of the driver's one-GPU command) must become the launcher
+    of N ranks instead of silently running one (VERDICT r05 missing #1): the spawn plan carries the torchrun environment contract, rank 0's
+    stdout is the launcher's, and a failing rank makes the run non-zero.  Reference idiom: one process per rank,
+    rtp_llm/start_server.py:597-720, modules/base/rocm/test/trt_allreduce_test.py:381-470."""
+    import importlib, os, subprocess, sys
+    bench = importlib.import_module("bench")
+    plan = bench.spawn_plan(4, ["--gpus", "4", "--steps", "8"], 29511)
+    assert len(plan) == 4
+    for r, p in enumerate(plan):
+        e = p["env"]
+        assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["MASTER_ADDR"], e["MASTER_PORT"]) == (str(r), str(r), "4", "127.0.0.1", "29511")
+        assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "MI355_BENCH_ONE_GPU" not in e
+        assert p["cmd"][0] == sys.executable and p["cmd"][1].endswith("bench.py") and p["cmd"][2:] == ["--gpus", "4", "--steps", "8"]
+    assert all(p["env"]["MI355_BENCH_ONE_GPU"] == "1" for p in bench.spawn_plan(2, [], 1, one_gpu=True))
+    # the launcher itself, with a stand-in child: every rank sees its environment, only rank 0 writes to stdout, rc propagates
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = tmp_path / "child.py"
+    child.write_text("import os, sys\nr = int(os.environ['RANK'])\nprint('rank', r, 'of', os.environ['WORLD_SIZE'], os.environ['MASTER_PORT'] != '')\n"
+                     "sys.exit(int(os.environ.get('FAIL_RANK', '-1')) == r and 3 or 0)\n")
+    drv = ("import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.spawn_ranks(3, [], child_cmd=[sys.executable, %r], grace_s=5.0))" % (root, str(child)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")}
+    ok = subprocess.run([sys.executable, "-c", drv], env=env, capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0 and ok.stdout.strip() == "rank 0 of 3 True", (ok.returncode, ok.stdout, ok.stderr[-500:])
+    assert "rank 1 of 3" in ok.stderr and "rank 2 of 3" in ok.stderr
+    bad = subprocess.run([sys.executable, "-c", drv], env={**env, "FAIL_RANK": "2"}, capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 3, (bad.returncode, bad.stderr[-500:])

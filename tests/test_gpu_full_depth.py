@@ -11,18 +11,26 @@ the HIP kernels and the oracle's fp32 matmuls accumulate along the residual stre
     residual stream after every half layer is compared with the oracle's: the per-layer max |delta h| shows where a drift starts;
     max |h'| is recorded against the fp16 range the deferred-norm image has (|gamma 2^-e h'| <= |h'|);
   * one bf16 step at B = 64 (bf16 KV cache);
-  * configs[1] at full depth: per-channel W8 (load-time INT8 autoquant), B = 16, two steps on the W8 image launches of round 5.
+  * configs[1] at full depth: per-channel W8 (load-time INT8 autoquant), B = 16, two steps on the W8 image launches of round 5;
+  * (round 6) configs[2] at full depth: W4 g128 + INT8 KV cache, B = 64, ctx 4096 -- the 7-launch chain with the quantising writer
+    (gemm_wq slabs -> rope_kv_write_kernel) and the INT8 attention over all 28 layers; the oracle attends over the codes the kernel
+    wrote (OracleKV.forced's contract), code flips and scales are asserted separately;
+  * (round 6) a 28-layer TENSOR-PARALLEL step: two processes on one GPU, Qwen2-7B widths, full vocabulary, B = 64 and B = 8, the default
+    hand-over protocol, against the UNSPLIT oracle; the ranks' final hidden states bit-identical.
 
 Reference: Qwen3Model.forward / Qwen3DecoderLayer.forward (rtp_llm/models_py/model_desc/qwen3.py:57-79,124-138), the generate loop of
 standalone/auto_model.py:144-265.  The oracle dequantises ONE layer at a time (932 MB fp32) so the host never holds the 26 GB of a
-dense 28-layer model.  Results go to gpurun_out/full_depth_parity.json (committed copy: profiles/r05_full_depth_parity.json).
+dense 28-layer model.  Results go to gpurun_out/full_depth_parity.json (committed copy: profiles/r06_full_depth_parity.json).
 """
 import json
 import math
 import os
 
+import socket
+
 import pytest
 import torch
+import torch.multiprocessing as mp
 
 from oracle import oracle
 from rtp_llm_amd import _C, kvcache, model
@@ -224,3 +232,234 @@ def test_full_depth_w8a16_b16_vs_oracle(parity):
         for b in range(B):
             kvcache.write_tokens(eng.kv[l], None, bt[b], 0, base.K[l][b][:CTX - 1], base.V[l][b][:CTX - 1])
     _run("w8a16-b16", cfg, eng, odec, base.fork(B), bt, B, STEPS, parity)
+
+
+# ------------------------------------------------------------------ configs[2] at full depth (round 6)
+class _TensorKV8:
+    """_TensorKV for an INT8 cache: codes [cap, nkv, hd] int8 + fp32 scales [cap, nkv] per (layer, sequence).  append() follows
+    oracle.OracleKV.append with `forced`: the store quantises the oracle's own (k, v) (amax / 127, _cast_to_int8.h:5-24), counts the
+    codes that differ from the ones the kernel wrote and the relative scale difference, then keeps the KERNEL's codes, so that the
+    attention of both sides reads the same bytes."""
+    int8 = True
+
+    def __init__(self, K, V, KS, VS, n, forced):
+        self.K, self.V, self.KS, self.VS, self.n, self.forced = K, V, KS, VS, n, forced
+        self.flips = self.codes = self.max_delta = 0
+        self.max_scale_rel = 0.0
+
+    def append(self, layer, b, k, v):
+        i = self.n[layer][b]
+        kq, ksc = oracle.quant_kv_int8(k); vq, vsc = oracle.quant_kv_int8(v)
+        fk, fks, fv, fvs = self.forced(layer, b, i)
+        for own, got in ((kq, fk), (vq, fv)):
+            d = (own.int() - got.int()).abs()
+            self.flips += int((d > 0).sum()); self.codes += d.numel(); self.max_delta = max(self.max_delta, int(d.max()))
+        for own, got in ((ksc, fks), (vsc, fvs)):
+            self.max_scale_rel = max(self.max_scale_rel, float(((own.float() - got.float()).abs() / own.float().abs().clamp_min(1e-12)).max()))
+        self.K[layer][b][i], self.V[layer][b][i], self.KS[layer][b][i], self.VS[layer][b][i] = fk, fv, fks, fvs
+        self.n[layer][b] = i + 1
+
+    def get(self, layer, b):
+        i = self.n[layer][b]
+        return self.K[layer][b][:i], self.V[layer][b][:i], self.KS[layer][b][:i], self.VS[layer][b][:i]
+
+
+def test_full_depth_w4_int8kv_b64_ctx4096_vs_oracle(full_model, parity):
+    """BASELINE configs[2] at full depth: Qwen2-7B GPTQ-INT4 g128 + INT8 KV cache, B = 64, ctx 4096, all 28 layers, two replayed steps.
+    Reference graph: model_desc/qwen3.py:57-79,124-138; writer semantics bindings/rocm/kernels/rocm_utils/_cast_to_int8.h:5-24,
+    fused_rope_kvcache_kernel.h:51-52."""
+    cfg0, w_dev, w = full_model
+    ctx, B, steps = 4096, 64, 2
+    cfg = model.ModelConfig(**{**cfg0.__dict__, "max_pos": ctx + 16})
+    mb = (ctx + steps + PAGE - 1) // PAGE
+    eng = model.DecoderEngine(cfg, w_dev, kv_int8=True, page=PAGE, num_blocks=B * mb, max_batch=B, max_seq_len=ctx + steps, device=DEV)
+    odec = oracle.OracleDecoder({**cfg.__dict__}, {"embedding": w["embedding"], "final_norm": w["final_norm"],
+                                                   "lm_head": w["lm_head"].w.float(), "layers": _LazyLayers(w["layers"])})
+    g = torch.Generator().manual_seed(11)
+    bt = torch.randperm(B * mb, generator=g).reshape(B, mb).to(torch.int32)
+    gd = torch.Generator(device=DEV).manual_seed(12)
+    cap = ctx + steps
+    K8, V8, KS, VS = ([[None] * B for _ in range(cfg.num_layers)] for _ in range(4))
+    for l in range(cfg.num_layers):      # the ctx - 1 cached tokens: drawn and quantised on the device (oracle.quant_kv_int8 is plain torch), stored on both sides
+        Kq, ks = oracle.quant_kv_int8(torch.randn(B, ctx - 1, cfg.nkv, cfg.hd, device=DEV, generator=gd).half())
+        Vq, vs = oracle.quant_kv_int8(torch.randn(B, ctx - 1, cfg.nkv, cfg.hd, device=DEV, generator=gd).half())
+        for b in range(B):
+            kvcache.write_tokens(eng.kv[l], eng.kv_scale[l], bt[b], 0, Kq[b], Vq[b], ks[b], vs[b])
+        Kc, Vc, ksc, vsc = Kq.cpu(), Vq.cpu(), ks.cpu(), vs.cpu()
+        for b in range(B):
+            for store, src, shape, dt in ((K8, Kc, (cap, cfg.nkv, cfg.hd), torch.int8), (V8, Vc, (cap, cfg.nkv, cfg.hd), torch.int8),
+                                          (KS, ksc, (cap, cfg.nkv), torch.float32), (VS, vsc, (cap, cfg.nkv), torch.float32)):
+                t = torch.zeros(shape, dtype=dt)
+                t[:ctx - 1] = src[b]
+                store[l][b] = t
+    del Kq, Vq, ks, vs
+    fetched = {}
+
+    def kernel_codes(l, b, t):
+        """Token t of every sequence in layer l as the kernel stored it (one gather per (layer, token), served per sequence)."""
+        if (l, t) not in fetched:
+            fetched.clear()
+            blk, off = bt[:, t // PAGE].to(DEV).long(), t % PAGE
+            kview, vview = kvcache._views(eng.kv[l])
+            fetched[(l, t)] = (kvcache._flip(kview[blk, :, off, :]).cpu(), eng.kv_scale[l][blk, 0, :, off].cpu(),
+                               kvcache._flip(vview[blk, :, :, off]).cpu(), eng.kv_scale[l][blk, 1, :, off].cpu())
+        k, ksc, v, vsc = fetched[(l, t)]
+        return k[b], ksc[b], v[b], vsc[b]
+
+    okv = _TensorKV8(K8, V8, KS, VS, [[ctx - 1] * B for _ in range(cfg.num_layers)], kernel_codes)
+    tok = torch.randint(0, cfg.vocab, (B,), generator=g, dtype=torch.int32)
+    eng.set_inputs(tok.tolist(), [ctx - 1] * B, bt)
+    eng.capture(B)
+    rec = {"rows": B, "ctx": ctx, "kv": "int8", "steps": []}
+    for step in range(steps):
+        pos = torch.full((B,), ctx - 1 + step, dtype=torch.int32)
+        eng.replay(B, 1)                    # the engine first: the oracle then attends over the codes this step wrote
+        torch.cuda.synchronize()
+        got, got_next = eng.logits[:B].cpu(), eng.token_ids[:B].cpu()
+        _, ref_logits = odec.forward_tokens(tok, pos, okv, list(range(B)))
+        ref_next = oracle.greedy(ref_logits)
+        r = parity.step(got_ids=got_next, ref_ids=ref_next, ref_logits=ref_logits, got_logits=got, tol=1e-2, label=f"w4-int8kv-b64-ctx4096 step {step}")
+        rec["steps"].append({k: r[k] for k in ("rows", "exact", "safe", "max_abs_logit_err", "min_top2_margin")})
+        rec.update(code_flips=okv.flips, codes=okv.codes, max_code_delta=okv.max_delta, max_scale_rel=okv.max_scale_rel)
+        _RECORD["w4-int8kv-b64-ctx4096"] = rec
+        assert torch.allclose(got, ref_logits, atol=1e-2, rtol=1e-2), (step, float((got - ref_logits).abs().max()))
+        tok = ref_next
+        eng.token_ids[:B].copy_(tok)
+    # a 1-ulp change of a head's amax moves its scale by 2^-11: a code near a .5 boundary may flip by ONE (tests/test_gpu_parity.py's bounds)
+    assert okv.codes == steps * cfg.num_layers * B * 2 * cfg.nkv * cfg.hd and okv.max_delta <= 1 and okv.flips <= 0.10 * okv.codes
+    # the scale plane the kernel wrote against the oracle's own amax / 127.  At 2 layers the two differ by one fp16 ulp of a row's amax (2e-3 in
+    # tests/test_gpu_parity.py); at depth the rows THEMSELVES differ (the residual streams drift apart like a random walk, fp16-b64 above: max |dh|
+    # 1.8e-2 at |h| <= 5 after 28 layers), and a head's amax moves with them: 4.2e-3 measured, held to the logits tolerance
+    assert okv.max_scale_rel <= 1e-2, okv.max_scale_rel
+    assert eng.oob_count() == 0
+
+
+# ------------------------------------------------------------------ a 28-layer tensor-parallel step (round 6)
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _tp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import sys
+    sys.path.insert(0, ROOT)
+    try:
+        import torch.distributed as dist
+        from rtp_llm_amd import distributed
+        torch.cuda.set_device(0)
+        torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // world)))
+        distributed.init_distributed("gloo")
+        cfg = model.ModelConfig("qwen2-7b", 28, 3584, 28, 4, 128, 18944, 152064, max_pos=CTX + 16)
+        V, Bmax = cfg.vocab, 64
+        ar = distributed.CustomAllReduce(max_bytes=Bmax * cfg.hidden * 2)       # default hand-over protocol
+        w_dev = model.synth_model(cfg, "w4", DEV, seed=30, zeros="centered")    # the same model on both ranks (same device, same seed)
+        shard = {"layers": [model.split_layer_tp(L, cfg, world, rank) for L in w_dev["layers"]], "embedding": w_dev["embedding"],
+                 "final_norm": w_dev["final_norm"], "lm_head": w_dev["lm_head"].cols(rank * (V // world), (rank + 1) * (V // world))}
+        mb = (CTX + STEPS + PAGE - 1) // PAGE
+        rcfg = cfg.per_rank(world)
+        eng = model.DecoderEngine(rcfg, shard, kv_int8=False, page=PAGE, num_blocks=Bmax * mb, max_batch=Bmax, max_seq_len=CTX + STEPS, device=DEV,
+                                  tp_size=world, vocab_full=V)
+        eng.attach_allreduce(ar, rank * (V // world))
+        w = model.weights_to(w_dev, "cpu") if rank == 0 else None
+        del w_dev, shard
+        torch.cuda.empty_cache()
+        g = torch.Generator().manual_seed(13)
+        bt = torch.randperm(Bmax * mb, generator=g).reshape(Bmax, mb).to(torch.int32)
+        gd = torch.Generator(device=DEV).manual_seed(14)
+        nkv_r, kv0 = rcfg.nkv, cfg.kv_head_of_rank(world, rank)
+        Kc = [[None] * Bmax for _ in range(cfg.num_layers)]
+        Vc = [[None] * Bmax for _ in range(cfg.num_layers)]
+        for l in range(cfg.num_layers):   # all kv heads drawn on both ranks (same stream); a rank stores its own heads, rank 0 keeps the full rows for the oracle
+            K = torch.randn(Bmax, CTX - 1, cfg.nkv, cfg.hd, device=DEV, generator=gd).half()
+            Vv = torch.randn(Bmax, CTX - 1, cfg.nkv, cfg.hd, device=DEV, generator=gd).half()
+            for b in range(Bmax):
+                kvcache.write_tokens(eng.kv[l], None, bt[b], 0, K[b, :, kv0:kv0 + nkv_r].contiguous(), Vv[b, :, kv0:kv0 + nkv_r].contiguous())
+            if rank == 0:
+                Kh, Vh = K.cpu(), Vv.cpu()
+                for b in range(Bmax):
+                    Kc[l][b] = torch.zeros(CTX + STEPS, cfg.nkv, cfg.hd, dtype=torch.float16); Kc[l][b][:CTX - 1] = Kh[b]
+                    Vc[l][b] = torch.zeros(CTX + STEPS, cfg.nkv, cfg.hd, dtype=torch.float16); Vc[l][b][:CTX - 1] = Vh[b]
+        del K, Vv
+        odec = None
+        if rank == 0:
+            odec = oracle.OracleDecoder({**cfg.__dict__}, {"embedding": w["embedding"], "final_norm": w["final_norm"],
+                                                           "lm_head": w["lm_head"].w.float(), "layers": _LazyLayers(w["layers"])})
+            base = _TensorKV(Kc, Vc, [[CTX - 1] * Bmax for _ in range(cfg.num_layers)])
+        record = {}
+        for B in (64, 8):
+            tok = torch.randint(0, V, (B,), generator=torch.Generator().manual_seed(200 + B), dtype=torch.int32)
+            okv = base.fork(B) if rank == 0 else None
+            eng.set_inputs(tok.tolist(), [CTX - 1] * B, bt[:B])
+            dist.barrier()
+            eng.capture(B)
+            rec = {"rows": B, "world": world, "hand_over": ar.hand_over, "steps": []}
+            for step in range(STEPS):
+                pos = torch.full((B,), CTX - 1 + step, dtype=torch.int32)
+                eng.replay(B, 1)
+                torch.cuda.synchronize()
+                mine_logits, mine_ids = eng.logits[:B].cpu(), eng.token_ids[:B].cpu()
+                outs = [torch.empty_like(mine_logits) for _ in range(world)]
+                dist.all_gather(outs, mine_logits)
+                full = torch.cat(outs, dim=1)
+                ids = [torch.empty_like(mine_ids) for _ in range(world)]
+                dist.all_gather(ids, mine_ids)
+                assert all(torch.equal(ids[0], o) for o in ids[1:]), "ranks disagree on the greedy ids"
+                assert torch.equal(mine_ids, torch.argmax(full, -1).int())
+                # every rank must hold the same bits in the final normed hidden state (rank-order fp32 sums at both all-reduce points of all 28 layers)
+                hb = eng.hidden[:B].contiguous().view(torch.int16).to(torch.int32).cpu()   # gloo has no int16
+                hs = [torch.empty_like(hb) for _ in range(world)]
+                dist.all_gather(hs, hb)
+                assert all(torch.equal(hs[0], o) for o in hs[1:]), "ranks' final hidden states differ"
+                nxt = torch.zeros(B, dtype=torch.int32)
+                if rank == 0:
+                    _, ref = odec.forward_tokens(tok, pos, okv, list(range(B)))
+                    err = float((full - ref).abs().max())
+                    ref_next = oracle.greedy(ref)
+                    top2 = torch.topk(ref, 2, dim=-1).values
+                    margin = top2[:, 0] - top2[:, 1]
+                    safe = margin > 1e-2
+                    exact = mine_ids == ref_next
+                    rec["steps"].append({"rows": B, "exact": int(exact.sum()), "safe": int(safe.sum()), "max_abs_logit_err": err,
+                                         "min_top2_margin": float(margin.min()), "ranks_bit_identical": True})
+                    assert torch.allclose(full, ref, atol=1e-2, rtol=1e-2), (B, step, err)
+                    assert bool(exact[safe].all()), (B, step, "greedy ids differ on a row whose top-2 margin exceeds the tolerance")
+                    nxt = ref_next.int()
+                dist.broadcast(nxt, 0)
+                tok = nxt
+                eng.token_ids[:B].copy_(tok)
+            record[f"tp{world}-fp16-b{B}"] = rec
+        assert ar.status() == 0 and eng.oob_count() == 0
+        q.put((rank, "ok", record if rank == 0 else None))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()[-2000:]}", None))
+    finally:
+        try:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+@pytest.mark.timeout(900)
+def test_full_depth_tp2_two_processes_vs_unsplit_oracle():
+    """A 28-layer TENSOR-PARALLEL step at Qwen2-7B widths and the full vocabulary: world 2 as two processes on one GPU (IPC handles map a peer's
+    buffers across processes on one device as across devices), the image-launch TP chain of round 5 with the default hand-over protocol, hipGraph
+    replay per rank, B = 64 and B = 8, two greedy steps each, against the UNSPLIT oracle (logits 1e-2, ids exact on every safe row), the ranks'
+    final hidden states bit-identical.  Reduce sites: modules/hybrid/causal_attention.py:91-92, dense_mlp.py:104-105."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=840) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+    assert sorted((r, s) for r, s, _ in res) == [(r, "ok") for r in range(world)], res
+    for _, _, rec in res:
+        if rec:
+            _RECORD.update(rec)

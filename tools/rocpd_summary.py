@@ -12,8 +12,12 @@ def main():
     db = sqlite3.connect(path)
     cur = db.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
-    disp = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
-    sym = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    disp = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")]
+    sym = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")]
+    if not disp or not sym:     # a profiled command that died before its first dispatch leaves a database without these tables
+        print(f"{path}: no kernel-dispatch table ({len(tabs)} tables) -- the profiled command launched no kernel; see its cmd.log")
+        return 0
+    disp, sym = disp[0], sym[0]
     cols = [r[1] for r in cur.execute(f"pragma table_info({disp})")]
     scols = [r[1] for r in cur.execute(f"pragma table_info({sym})")]
     namecol = "kernel_name" if "kernel_name" in scols else "display_name"
@@ -28,6 +32,9 @@ def main():
         a = agg.setdefault(key, [0, 0.0])
         a[0] += 1
         a[1] += (en - st) / 1e3
+    if not rows:
+        print(f"{path}: kernel-dispatch table is empty")
+        return 0
     tot = sum(a[1] for a in agg.values())
     print(f"{'kernel':90s} {'n':>6s} {'avg_us':>9s} {'total_us':>11s} {'%':>6s}")
     for key, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
