@@ -496,6 +496,20 @@ int mi355_allreduce_fused_img_dt(mi355_allreduce_t* ar, const void* x, const flo
                                  const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
                                  int32_t T, int32_t H, void* y_img, int32_t act_dtype, mi355_stream_t stream);
 
+/* Round 6 -- a row-parallel shard without split-K slabs or a publishing stage.  The reference's all-reduce reads its input in place when it already lies
+ * in a registered range (trtllm_allreduce_fusion.cu, TrtllmArFusionHandle: "inputs are first staged into a registered workspace unless already in a
+ * captured/registered range"); here the producing GEMM writes there directly:
+ *   mi355_linear_publish_img            y = 16-bit(xW + bias) of a 1-64-row step (x an activation image, W4 g128 / per-channel W8, K <= 5760, or <= 9600 when
+ *                                       N / 32 <= 128) as ONE full-K launch whose epilogue stores the rows into this rank's registered buffer, in the slot and
+ *                                       parity the NEXT fused all-reduce call of `ar` reads (bias: pass it on rank 0 only);
+ *   mi355_allreduce_fused_published_dt  that call: flag exchange, rank-order fp32 sum of the N ranks' rows, residual add, RMSNorm (y row-major, or an
+ *                                       activation image when y_is_image) -- mi355_allreduce_fused[_img]_dt without its fold + publish stage.
+ * Both on one stream, no other call on `ar` in between.  Reduce sites: modules/hybrid/causal_attention.py:91-92 (O), dense_mlp.py:104-105 (down).
+ * MI355_ERR_UNSUPPORTED (shape / format / a context on the granule protocol): stay on mi355_linear_partial* + mi355_allreduce_fused*. */
+int mi355_linear_publish_img(const void* x_img, int32_t M, const mi355_weight_t* w, const void* bias, mi355_allreduce_t* ar, mi355_stream_t stream);
+int mi355_allreduce_fused_published_dt(mi355_allreduce_t* ar, const void* residual_in, void* residual_out, const void* weight, float eps,
+                                       int32_t T, int32_t H, void* y, int32_t y_is_image, int32_t act_dtype, mi355_stream_t stream);
+
 /* Greedy sampling under a vocab-split lm_head: ids[b] = argmax over ALL ranks' logit slices (this rank holds columns
  * [vocab_offset, vocab_offset + V_local)), lowest global index on ties; identical on every rank.  Exchanges 8 bytes per
  * row instead of gathering the logits (PyWrappedModel.cc:915-936).  positions (may be NULL) += 1.

@@ -96,6 +96,7 @@ SIGNATURES = {
     "mi355_add_rmsnorm_img": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, i32, vp]),
     "mi355_paged_attn_rows_img": (i32, [vp, C.POINTER(KVLayer), vp, i32, vp, i32, i32, i32, f32, i32, vp, vp, sz, vp]),
     "mi355_linear_residual_img": (i32, [vp, i32, C.POINTER(Weight), vp, vp, vp, vp, i32, vp]),
+    "mi355_linear_publish_img": (i32, [vp, i32, C.POINTER(Weight), vp, vp, vp]),
     "mi355_linear_residual_prenorm_img": (i32, [vp, i32, C.POINTER(Weight), vp, vp, vp, vp, i32, vp, vp, i32, vp]),
     "mi355_linear_deferred_norm_img": (i32, [vp, i32, C.POINTER(DeferredNorm), C.POINTER(Weight), vp, vp, i32, vp]),
     "mi355_linear_direct_img": (i32, [vp, i32, C.POINTER(Weight), vp, vp, i32, vp]),
@@ -125,6 +126,7 @@ SIGNATURES = {
     "mi355_allreduce_fused": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, vp]),
     "mi355_allreduce_fused_dt": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, i32, vp]),
     "mi355_allreduce_fused_img_dt": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, i32, vp]),
+    "mi355_allreduce_fused_published_dt": (i32, [vp, vp, vp, vp, f32, i32, i32, vp, i32, i32, vp]),
     "mi355_allreduce_sum_dt": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "mi355_allreduce_argmax": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "mi355_decoder_attach_allreduce": (i32, [vp, vp, i32]),

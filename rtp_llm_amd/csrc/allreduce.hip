@@ -65,7 +65,8 @@ struct ArDev {                             // device-visible part of the context
 struct FusedParams {
     ArDev        ar;
     const f16*   x;            // fp16 [T][H] local tensor, or
-    const float* partials;     // split-K slabs [nsplit][T][ld]
+    const float* partials;     // split-K slabs [nsplit][T][ld], or
+    int          prepub;       // neither: the producing GEMM already wrote this rank's rows into the registered buffer (mi355_linear_publish_img): no stage 0
     int          nsplit, ld;
     const f16*   bias;         // added by rank 0 only (a row-parallel linear has one bias for the sum); may be null
     const f16*   res_in;       // residual stream in (may be null: plain all-reduce)
@@ -174,8 +175,8 @@ __global__ __launch_bounds__(512) void allreduce_fused_kernel(const FusedParams 
     const size_t par = (epoch & 1) * ar.parity_elems;
     const __amdgpu_buffer_rsrc_t mine_rs = my_rsrc(ar);
     u32x4 own[VPT];                                    // LL: this rank's row (one row per block), kept for the rank-order sum
-    // ---- stage 0: local row (split-K reduce + bias), fp16, into the registered buffer
-    for (int row = b; row < p.T; row += gridDim.x) {
+    // ---- stage 0: local row (split-K reduce + bias), fp16, into the registered buffer (prepub: the GEMM in front of this launch did that)
+    for (int row = p.prepub ? p.T : b; row < p.T; row += gridDim.x) {
 #pragma unroll
         for (int t = 0; t < VPT; ++t) {
             const int vi = tid + t * NTH;
@@ -667,7 +668,7 @@ extern "C" int mi355_allreduce_fused(mi355_allreduce_t* a, const void* x_f16, co
 
 static int allreduce_fused_launch(mi355_allreduce_t* a, const void* x_f16, const float* partials, int32_t nsplit, int32_t ld,
                                   const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
-                                  int32_t T, int32_t H, void* y, int y_img_mblk, int32_t act_dtype, mi355_stream_t stream);
+                                  int32_t T, int32_t H, void* y, int y_img_mblk, int32_t act_dtype, mi355_stream_t stream, bool prepub = false);
 
 extern "C" int mi355_allreduce_fused_dt(mi355_allreduce_t* a, const void* x_f16, const float* partials, int32_t nsplit, int32_t ld,
                                         const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
@@ -684,12 +685,35 @@ extern "C" int mi355_allreduce_fused_img_dt(mi355_allreduce_t* a, const void* x_
     return allreduce_fused_launch(a, x_f16, partials, nsplit, ld, bias, residual_in, residual_out, weight, eps, T, H, y_img, cdiv(T, 16), act_dtype, stream);
 }
 
+// Where a producing GEMM writes this rank's [T][H] rows so that the NEXT fused all-reduce launch of the context finds them published
+// (gemm_fullk64.hip FK_PUB via mi355_linear_publish_img; consumer mi355_allreduce_fused_published_dt).  T <= 64: one row per block, row m in slot m of
+// the parity (epoch[m] + 1) & 1, which the GEMM reads off the device-resident counters -- inside a captured graph too.  Not with the granule form
+// (its rows travel as {payload, epoch} pairs written by the all-reduce launch itself).  MI355_ERR_UNSUPPORTED: the caller keeps the slab path.
+extern "C" int mi355_allreduce_publish_target(mi355_allreduce_t* a, int32_t T, int32_t H, mi355_publish_target_t* out) {
+    MI355_CHECK_ARG(a && out, "allreduce_publish_target: null argument");
+    if (!a->ready || a->ll || T < 1 || T > kOneShotRows || H < 8 || H % 8 != 0 || H > 8192 || (size_t)H * 2 > a->slot_bytes || (size_t)T * H * 2 > a->max_bytes)
+        return MI355_ERR_UNSUPPORTED;
+    const ArDev d = dev_view(a);
+    out->epoch = a->epoch; out->data = a->data; out->bytes = d.data_bytes;
+    out->parity_elems = (uint32_t)d.parity_elems; out->slot_elems = (uint32_t)d.slot_elems; out->plain_stores = a->full_fences;
+    return MI355_OK;
+}
+
+// mi355_allreduce_fused[_img]_dt for rows the GEMM in front of it already published (mi355_linear_publish_img on the same stream, no other call of this
+// context in between): flag exchange, rank-order fp32 sum of the N copies, residual add, RMSNorm -- no slab fold, no publishing stage.
+extern "C" int mi355_allreduce_fused_published_dt(mi355_allreduce_t* a, const void* residual_in, void* residual_out, const void* weight, float eps,
+                                                  int32_t T, int32_t H, void* y, int32_t y_is_image, int32_t act_dtype, mi355_stream_t stream) {
+    MI355_CHECK_ARG(!y_is_image || (y && T <= 64 && H % 32 == 0), "allreduce_fused_published: image output needs y, T <= 64, H %% 32 == 0 (T=%d H=%d)", T, H);
+    return allreduce_fused_launch(a, nullptr, nullptr, 0, 0, nullptr, residual_in, residual_out, weight, eps, T, H, y, y_is_image ? cdiv(T, 16) : 0, act_dtype, stream, true);
+}
+
 static int allreduce_fused_launch(mi355_allreduce_t* a, const void* x_f16, const float* partials, int32_t nsplit, int32_t ld,
                                   const void* bias, const void* residual_in, void* residual_out, const void* weight, float eps,
-                                  int32_t T, int32_t H, void* y, int y_img_mblk, int32_t act_dtype, mi355_stream_t stream) {
+                                  int32_t T, int32_t H, void* y, int y_img_mblk, int32_t act_dtype, mi355_stream_t stream, bool prepub) {
     MI355_CHECK_ARG(a && a->ready, "allreduce: context not opened (mi355_allreduce_open)");
     MI355_CHECK_ARG(act_dtype == MI355_ACT_F16 || act_dtype == MI355_ACT_BF16, "allreduce: act_dtype=%d", act_dtype);
-    MI355_CHECK_ARG((x_f16 != nullptr) != (partials != nullptr), "allreduce: exactly one of x_f16 / partials");
+    MI355_CHECK_ARG(prepub ? (!x_f16 && !partials && T <= kOneShotRows && !a->ll) : ((x_f16 != nullptr) != (partials != nullptr)),
+                    "allreduce: exactly one of x_f16 / partials (published rows: neither, T <= %d, not the granule form)", kOneShotRows);
     MI355_CHECK_ARG(T > 0 && H > 0 && H % 8 == 0 && H <= 8192, "allreduce: T=%d H=%d (H %% 8 == 0, H <= 8192)", T, H);
     MI355_CHECK_ARG((size_t)T * H * 2 <= a->max_bytes, "allreduce: message %zu bytes > registered %zu", (size_t)T * H * 2, a->max_bytes);
     MI355_CHECK_ARG(!partials || (nsplit >= 1 && ld >= H && ld % 4 == 0), "allreduce: nsplit=%d ld=%d", nsplit, ld);
@@ -699,7 +723,7 @@ static int allreduce_fused_launch(mi355_allreduce_t* a, const void* x_f16, const
     p.ar = dev_view(a);
     p.x = (const f16*)x_f16; p.partials = partials; p.nsplit = nsplit; p.ld = ld; p.bias = (const f16*)bias;
     p.res_in = (const f16*)residual_in; p.res_out = (f16*)residual_out; p.weight = (const f16*)weight; p.y = (f16*)y;
-    p.eps = eps; p.T = T; p.H = H; p.y_img_mblk = y_img_mblk;
+    p.eps = eps; p.T = T; p.H = H; p.y_img_mblk = y_img_mblk; p.prepub = prepub ? 1 : 0;
     p.pf = (const uint32_t*)a->pf_ptr; p.pf_lines = (uint32_t)(a->pf_bytes >> 7); p.pf_sink = (uint32_t*)a->status + 32;
     a->pf_ptr = nullptr; a->pf_bytes = 0;                    // one launch only
     const int grid = T < kMaxBlocks ? T : kMaxBlocks;

@@ -22,7 +22,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // experiment switches exist only in the tuning build (see gemm.hip); TUNE(i) folds to 0 in the product library
 #ifdef MI355_TUNING
-extern int g_tune[8];
+extern int g_tune[16];
 #define TUNE(i) g_tune[i]
 #else
 #define TUNE(i) 0

@@ -28,7 +28,7 @@
 #include <vector>
 #include "internal.h"
 #ifdef MI355_TUNING
-extern int g_tune[8];   // gemm.hip: experiment switches of the tuning build
+extern int g_tune[16];   // gemm.hip: experiment switches of the tuning build
 #define TUNE(i) g_tune[i]
 #else
 #define TUNE(i) 0
@@ -97,6 +97,9 @@ struct mi355_decoder {
     // ... and the column-parallel gate_up shard as ONE launch from an image (gemm_splitk64.hip, direct form) instead of the staged split-K kernel + fold:
     // the fused all-reduce behind the O shard then writes its normed rows as that image (into xg_img: unused under TP otherwise)
     bool   tp_img_gate;
+    // round 6: the row-parallel O / down shards as ONE full-K launch each whose epilogue writes the rank's rows straight into the registered all-reduce
+    // buffer (mi355_linear_publish_img), consumed by mi355_allreduce_fused_published_dt: no slabs, no fold + publish stage in front of the flag exchange
+    bool   tp_pub_o, tp_pub_down;
     // ... and the post-attention RMSNorm deferred into gate_up's accumulators (mi355_deferred_norm_t): the O launch leaves
     // gamma 2^-e h' as an image + the per-tile sums of h'^2, the wide GEMM applies rsqrt(mean h'^2 + eps) 2^e: 6 launches per layer
     bool   img_gate_up;
@@ -295,6 +298,13 @@ extern "C" mi355_decoder_t* mi355_decoder_create(const mi355_model_config_t* cfg
     for (const auto& L : d->layers)
         d->tp_img_gate = d->tp_img_gate && L.gate_up.K % 128 == 0 && L.gate_up.K_pad == L.gate_up.K &&
                          mi355_gemm_splitk64_direct_plan(64, L.gate_up.N_pad / 16, L.gate_up.K_pad / 128, L.gate_up.wbits, L.gate_up.group_size) > 0;
+    d->tp_pub_o = d->tp_img_qkv && !(TUNE(8) & 1);
+    d->tp_pub_down = d->tp_img_down && !(TUNE(8) & 2);
+    for (const auto& L : d->layers) {
+        d->tp_pub_o = d->tp_pub_o && mi355_fullk64_publish_ok(&L.o) != 0;
+        // down: where K stays inside two or three chunks per wave (K <= 5760: tp 4 of Qwen2-7B, tp 8 of the 70B models); deeper shards keep the K quarters
+        d->tp_pub_down = d->tp_pub_down && mi355_fullk64_publish_ok(&L.down) != 0 && (L.down.K_pad / 128 <= 45 || (TUNE(8) & 4));
+    }
     // from how many rows the TP step takes the image launches: with the down shard as K quarters they win from ONE row (one rank of tp 2,
     // b = 1 / 2 / 4: 1.67 / 1.68 / 1.72 ms against 1.75 / 1.77 / 1.82 with the few-row QKV launch + 15 staged slabs; profiles/r05_tp_small_batch_crossover.txt);
     // without that plan the few-row QKV launch keeps its rows (the tp = 1 crossover)
@@ -536,6 +546,12 @@ extern "C" int mi355_decoder_set_weight_prefetch(mi355_decoder_t* d, int32_t mas
     return MI355_OK;
 }
 
+// does the attached context take published rows for a B-row call right now?  (host-side: not while it is on the granule protocol)
+static bool pub_ready(const mi355_decoder_t* d, int B) {
+    mi355_publish_target_t t;
+    return d->ar && mi355_allreduce_publish_target(d->ar, B, d->cfg.hidden, &t) == MI355_OK;
+}
+
 extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_stream_t stream) {
     if (!d || l < 0 || l >= d->cfg.num_layers || d->B <= 0) { mi355_set_error("decoder_layer_attn: layer=%d", l); return MI355_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
@@ -576,6 +592,17 @@ extern "C" int mi355_decoder_layer_attn(mi355_decoder_t* d, int32_t l, mi355_str
         if (pf & MI355_PF_O_LATE) if (int e = pf_issue(d, st, &L.o, kPfCap)) return e;     // under attention only
     }
     // q_len > 1: rows of one sequence share a pass over its KV, causal mask inside the page walk (is_target_verify)
+    if (tp_img && d->tp_pub_o && B <= 64 && pub_ready(d, B)) {   // TP: attention image -> O shard published in the all-reduce buffer -> exchange + residual + norm
+        RUN(MI355_KC_ATTN, mi355_paged_attn_rows_img(d->q_buf, &kv, d->bufs.block_table, c.max_blocks_per_seq, d->bufs.positions,
+                                                     B / d->q_len, d->q_len, c.nh, 1.0f / sqrtf((float)c.hd), c.max_seq_len, d->attn_img,
+                                                     d->attn_ws, d->attn_ws_bytes, st));
+        if (int e = pf_join(d, st)) return e;
+        RUN(MI355_KC_GEMM_QUANT, mi355_linear_publish_img(d->attn_img, B, &L.o, nullptr, d->ar, st));
+        const bool gimg = d->tp_img_gate;                   // (B > tp_fuse_rows holds: tp_img)
+        RUN(MI355_KC_COMM, comm_with_prefetch(d, st, &L.gate_up, [&]() {
+            return mi355_allreduce_fused_published_dt(d->ar, d->resid, d->resid, L.post_norm, c.rms_eps, B, c.hidden, gimg ? d->xg_img : d->xn, gimg ? 1 : 0, ADT, st); }));
+        return MI355_OK;
+    }
     if (mid_o) {   // the attention output as an image: what the O projection's full-K launch reads
         RUN(MI355_KC_ATTN, mi355_paged_attn_rows_img(d->q_buf, &kv, d->bufs.block_table, c.max_blocks_per_seq, d->bufs.positions,
                                                      B / d->q_len, d->q_len, c.nh, 1.0f / sqrtf((float)c.hd), c.max_seq_len, d->attn_img,
@@ -659,6 +686,14 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
         const bool last = l + 1 == c.num_layers;          // the final norm feeds lm_head: that one stays a launch
         RUN(MI355_KC_GEMM_QUANT, mi355_linear_residual(d->act, B, &L.down, nullptr, d->resid, d->resid, (normed && !last) ? d->ssq : nullptr, (c.hidden / 16 + 3) & ~3, st));
         if (!normed || last) RUN(MI355_KC_NORM, mi355_rmsnorm_dt(d->resid, next_norm, c.rms_eps, B, c.hidden, d->xn, ADT, st));
+        return MI355_OK;
+    }
+    if (d->tp_pub_down && d->ar && B > d->tp_fuse_rows && B <= 64 && pub_ready(d, B)) {   // TP: the down shard published in the all-reduce buffer (act_img: written above, gi)
+        RUN(MI355_KC_GEMM_QUANT, mi355_linear_publish_img(d->act_img, B, &L.down, nullptr, d->ar, st));
+        const mi355_weight_t* next_w = (l + 1 < c.num_layers) ? &d->layers[l + 1].qkv : &d->model.lm_head;
+        const bool next_img = d->tp_img_qkv && l + 1 < c.num_layers;
+        RUN(MI355_KC_COMM, comm_with_prefetch(d, st, next_w, [&]() {
+            return mi355_allreduce_fused_published_dt(d->ar, d->resid, d->resid, next_norm, c.rms_eps, B, c.hidden, next_img ? d->xn_img : d->xn, next_img ? 1 : 0, ADT, st); }));
         return MI355_OK;
     }
     if ((d->img_o && d->img_gate_up && d->img_down && B > d->fuse_rows) || (d->tp_img_down && d->ar && B > d->tp_fuse_rows))

@@ -47,7 +47,7 @@ extern "C" int mi355_gemm_fullk_rope(const void* gp, int wbits, int group_size, 
                                      mi355_stream_t stream);
 
 #ifdef MI355_TUNING
-int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+int g_tune[16] = {0};
 extern unsigned long long* g_wide_stamps;   // gemm_wide.hip: device buffer set by mi355_debug_ptr
 #endif
 
@@ -704,7 +704,7 @@ extern "C" int mi355_gemm_plan(int M, const mi355_weight_t* w, int max_splits, i
 extern int g_wide_dbg;
 extern "C" void mi355_debug_set(int key, int value) {
     if (key == 0) g_wide_dbg = value;
-    if (key >= 0 && key < 8) g_tune[key] = value;
+    if (key >= 0 && key < 16) g_tune[key] = value;
 }
 #endif
 
@@ -955,6 +955,30 @@ extern "C" int mi355_linear_residual_img(const void* x_img, int32_t M, const mi3
     GemmParams p; fill_params(p, x_img, M, w);
     p.mode = MODE_F16; p.bias = (const f16*)bias; p.ldy = w->N;
     return mi355_gemm_fullk_residual_img(&p, w->wbits, w->group_size, residual_in, residual_out, tile_sumsq_out, tile_sumsq_ld, nullptr, 0.f, nullptr, stream);
+}
+
+// Tensor parallelism (round 6): the row-parallel shard of a 1-64-row step -- O behind the attention image, down behind the SiLU image -- as ONE full-K
+// launch whose epilogue writes y = 16-bit(xW + bias) into this rank's REGISTERED all-reduce buffer, where the next mi355_allreduce_fused_published_dt of
+// the context pulls it from: no split-K slabs, no fold + publish stage in front of the flag exchange.  bias: pass it on rank 0 only (one bias for the sum).
+// MI355_ERR_UNSUPPORTED (shape, format, or a context on the granule protocol): the caller stays on mi355_linear_partial* + mi355_allreduce_fused*.
+// Reference slots: the row-parallel linears + all_reduce of modules/hybrid/causal_attention.py:91-92 and dense_mlp.py:104-105.
+extern "C" int mi355_fullk64_publish_ok(const mi355_weight_t* w) {
+    if (!img_weight_ok(w) || w->N % 32 != 0) return 0;
+    if (!((w->wbits == 4 && w->group_size == 128) || (w->wbits == 8 && w->group_size == 0))) return 0;
+    const int KC = w->K_pad / 128;
+    if (KC <= (w->wbits == 8 ? 30 : 45)) return 1;
+    return w->wbits == 4 && KC <= 75 && 2 * (w->N / 32) <= 256;   // five-chunk slices: <= 32 rows per block, i.e. the row-split form (gemm_fullk64.hip)
+}
+extern "C" int mi355_gemm_fullk_publish_img(const void* gp, int wbits, int group_size, const void* tgt, mi355_stream_t stream);
+extern "C" int mi355_linear_publish_img(const void* x_img, int32_t M, const mi355_weight_t* w, const void* bias, mi355_allreduce_t* ar, mi355_stream_t stream) {
+    if (int e = check_weight(w)) return e;
+    MI355_CHECK_ARG(x_img && ar && M > 0, "linear_publish_img: bad args (M=%d)", M);
+    if (M > 64 || !mi355_fullk64_publish_ok(w)) return MI355_ERR_UNSUPPORTED;
+    mi355_publish_target_t tgt;
+    if (int e = mi355_allreduce_publish_target(ar, M, w->N, &tgt)) return e;
+    GemmParams p; fill_params(p, x_img, M, w);
+    p.mode = MODE_F16; p.bias = (const f16*)bias; p.ldy = w->N;
+    return mi355_gemm_fullk_publish_img(&p, w->wbits, w->group_size, &tgt, stream);
 }
 
 extern "C" int mi355_linear_residual_prenorm_img(const void* x_img, int32_t M, const mi355_weight_t* w, const void* bias, const void* residual_in,

@@ -34,6 +34,14 @@ struct FullKParams {
     float        xg_scale;   // 2^-e with e >= log2(max |gamma|): |g| <= |h'|, no overflow whatever the residual stream holds
     int          rowsplit;   // gemm_fullk64.hip: two blocks per tile pair, 32 rows each (block b: pair b / 2, row blocks 2 (b & 1) .. + 1)
     int          bf16;       // gemm_fullk64.hip: bias / residual / norm weight / q / KV cache are bf16 (the activation image and the MFMAs stay fp16)
+    // FK_PUB (gemm_fullk64.hip, tensor parallelism; round 6): y = 16-bit(xW + bias) goes straight into THIS RANK'S REGISTERED ALL-REDUCE BUFFER
+    // (csrc/allreduce.hip), in the slot and parity the next fused all-reduce launch of that context reads -- a row-parallel shard (O / down) then needs
+    // neither split-K slabs nor the fold + publish stage in front of the flag exchange (mi355_allreduce_fused_published_dt).  Row m of a <= 64-row
+    // call lives in slot m (one row per block), parity (epoch[m] + 1) & 1 of the context's device-resident call counters.
+    const uint32_t* pub_epoch;
+    void*           pub_data;
+    uint32_t        pub_bytes, pub_parity_elems, pub_slot_elems;
+    int             pub_plain;  // 1: plain stores (full-fence hand-over: the all-reduce launch's system-scope release fence publishes them); 0: write-through (sc0 sc1)
 #ifdef MI355_FULLK_STAMPS   // tuning build with MI355_EXTRA_CFLAGS=-DMI355_FULLK_STAMPS only: the stamp stores change the schedule
     unsigned long long* stamps;   // tools/fullk_stamps.py: wall_clock64 per wave at entry / requests out (+ 1 / rms there) / first chunk done / loop done / slices met / exit
 #endif
@@ -43,6 +51,6 @@ struct FullKParams {
 #else
 #define FK_STAMP(i) do { } while (0)
 #endif
-enum { FK_PLAIN = 0, FK_RESID = 1, FK_ROPE = 2 };
+enum { FK_PLAIN = 0, FK_RESID = 1, FK_ROPE = 2, FK_PUB = 3 };
 
 } // namespace

@@ -635,6 +635,18 @@ extern "C" int mi355_gemm_fullk_residual_img(const void* gp, int wbits, int grou
     return mi355_gemm_fullk64(&fp, FK_RESID, group_size, stream);
 }
 
+// a row-parallel TP shard (O / down) straight into the rank's registered all-reduce buffer (FK_PUB): tgt = mi355_publish_target_t of internal.h
+extern "C" int mi355_gemm_fullk_publish_img(const void* gp, int wbits, int group_size, const void* tgt_, mi355_stream_t stream) {
+    const mi355_publish_target_t& tgt = *reinterpret_cast<const mi355_publish_target_t*>(tgt_);
+    FullKParams fp{};
+    fp.g = *reinterpret_cast<const GemmParams*>(gp);
+    if (!fullk64_shape_ok(fp.g, wbits, group_size) || fp.g.N % 4 != 0) return MI355_ERR_UNSUPPORTED;
+    fp.bf16 = fp.g.bf16;
+    fp.pub_epoch = tgt.epoch; fp.pub_data = tgt.data; fp.pub_bytes = tgt.bytes; fp.pub_parity_elems = tgt.parity_elems; fp.pub_slot_elems = tgt.slot_elems;
+    fp.pub_plain = tgt.plain_stores;
+    return mi355_gemm_fullk64(&fp, FK_PUB, group_size, stream);
+}
+
 extern "C" int mi355_gemm_fullk_rope_img(const void* gp, int wbits, int group_size, const float* cos_sin, int32_t max_pos,
                                          const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq,
                                          int32_t q_len, int32_t nh, const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count,

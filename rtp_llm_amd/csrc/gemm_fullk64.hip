@@ -31,6 +31,7 @@ namespace {
 // LDS behind the slices' partial sums: what the epilogue needs besides the sums, staged by the helper wave
 template <int EPI> struct Stage64 {};
 template <> struct Stage64<FK_RESID> { f16 res[64][32]; f16 bias[32]; f16 gam[32]; float wsc[32]; };          // residual rows / bias / norm weight of the block's two tiles (+ W8: the columns' scales)
+template <> struct Stage64<FK_PUB>   { f16 bias[32]; float wsc[32]; uint32_t par[64]; };                          // bias of the block's two tiles, parity of every row's slot in the registered all-reduce buffer
 template <> struct Stage64<FK_ROPE>  { float cs[64][32]; int pos[64], blk[64]; f16 bias[32]; float wsc[32]; }; // rotation row of the block's 16 dims per token, position, block id
 
 template <int WB, int GS, int MB, int EPI, int CPW, int RING>
@@ -81,7 +82,14 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
             if (lane < 32 && tile[lane >> 4] < p.NT) sc = (float)as_h2(p.meta[tile[lane >> 4] * 16 + (lane & 15)])[1];
             if (lane < 32) sg.wsc[lane] = sc;
         }
-        if constexpr (EPI == FK_RESID) {
+        if constexpr (EPI == FK_PUB) {
+            // lane = row: the parity of its slot in the NEXT all-reduce call of the context (its blocks add 1 to epoch[row] when they finish)
+            sg.par[lane] = (fp.pub_epoch[lane < p.M ? lane : 0] + 1u) & 1u;
+            const int part = lane & 3, n = tile[part >> 1] * 16 + (part & 1) * 8;
+            u32x4 bv = {0u, 0u, 0u, 0u};
+            if (p.bias && lane < 4 && n < p.N) bv = *reinterpret_cast<const u32x4*>(p.bias + n);
+            if (lane < 4) *reinterpret_cast<u32x4*>(&sg.bias[part * 8]) = bv;
+        } else if constexpr (EPI == FK_RESID) {
             // rows x 32 columns of the residual stream: lane = (row i * 16 + l / 4, 16-byte part l % 4); parts 0-1 tile 0, 2-3 tile 1
             __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)fp.res_in, 0, (uint32_t)((size_t)p.M * p.N * 2), FLAGS);
             const int part = lane & 3, n = tile[part >> 1] * 16 + (part & 1) * 8;
@@ -234,7 +242,23 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
 #pragma unroll
         for (int t = 0; t < TPB; ++t) v[t] *= kImgBfUnscale;
     }
-    if constexpr (EPI == FK_RESID) {
+    if constexpr (EPI == FK_PUB) {
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(fp.pub_data, 0, fp.pub_bytes, FLAGS);
+        const size_t rowbase = (size_t)sg.par[m] * fp.pub_parity_elems + (size_t)m * fp.pub_slot_elems;
+#pragma unroll
+        for (int t = 0; t < TPB; ++t) {
+            const int n0 = tile[t] * 16 + q * 4;
+            if (n0 >= p.N) continue;
+            const uint16_t* bv = reinterpret_cast<const uint16_t*>(&sg.bias[t * 16 + q * 4]);
+            uint16_t ob[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[r] = rt_to_bits(rt_round(v[t][r] + rt_from_bits(bv[r], bf), bf), bf);   // the linear's output is a 16-bit tensor
+            const u32x2 o = {(uint32_t)ob[0] | ((uint32_t)ob[1] << 16), (uint32_t)ob[2] | ((uint32_t)ob[3] << 16)};
+            if (fp.pub_plain) *reinterpret_cast<u32x2*>((f16*)fp.pub_data + rowbase + n0) = o;
+            else __builtin_amdgcn_raw_buffer_store_b64(o, rp, (uint32_t)((rowbase + n0) * 2), 0, 17 /* sc0 | sc1: write-through, see allreduce.hip publish16 */);
+        }
+        FK_STAMP(5);
+    } else if constexpr (EPI == FK_RESID) {
 #pragma unroll
         for (int t = 0; t < TPB; ++t) {
             const int n0 = tile[t] * 16 + q * 4;
@@ -326,6 +350,7 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
         }
     }
     }   // row blocks of this wave
+    if constexpr (EPI == FK_PUB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's published bytes have reached memory before it ends (the kernel boundary then orders them in front of the all-reduce launch's flags)
 }
 
 template <int WB, int GS, int MB, int EPI, int CPW, int RING>
@@ -356,6 +381,15 @@ int launch64_k(const FullKParams& fp, int blocks, hipStream_t st) {
         if (KC <= 30) return launch64_t<8, 4, MB, EPI, 2, MB == 4 ? MB : 2 * MB>(fp, blocks, st);
         return MI355_ERR_UNSUPPORTED;
     } else {
+#ifdef MI355_TUNING
+    // experiment (round 6): deeper activation rings at <= 32 rows per block -- RING = 2 MB keeps ONE fragment in flight per wave at one row block
+    if constexpr (GS == 4 && MB <= 2) {
+        if (TUNE(9) == 1) { if (KC <= 30) return launch64_t<4, GS, MB, EPI, 2, 4 * MB>(fp, blocks, st); if (KC <= 45) return launch64_t<4, GS, MB, EPI, 3, 4 * MB>(fp, blocks, st);
+                            if (KC <= 75) return launch64_t<4, GS, MB, EPI, 5, 4 * MB>(fp, blocks, st); }
+        if (TUNE(9) == 2) { if (KC <= 30) return launch64_t<4, GS, MB, EPI, 2, 8>(fp, blocks, st); if (KC <= 45) return launch64_t<4, GS, MB, EPI, 3, 8 * MB>(fp, blocks, st);
+                            if (KC <= 75) return launch64_t<4, GS, MB, EPI, 5, 8 * MB>(fp, blocks, st); }
+    }
+#endif
     if (KC <= 30) return launch64_t<4, GS, MB, EPI, 2, 2 * MB>(fp, blocks, st);
     if (KC <= 45) return launch64_t<4, GS, MB, EPI, 3, (GS == 1 && MB == 4) ? MB : 2 * MB>(fp, blocks, st);   // g32 at 64 rows: 24 (zero, scale) words per wave, one k-step in flight fits 128 registers
     // K <= 9600 (hidden 8192: the QKV shard of Llama-3-70B / Qwen2-72B under TP 8): five chunks per wave; their 40 weight registers fit
@@ -420,6 +454,17 @@ extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi35
         if (group_size == 128) { F64_(4, 4, FK_RESID, blocks); }
         if (group_size == 64)  { F64_(4, 2, FK_RESID, blocks); }
         F64_(4, 1, FK_RESID, blocks);
+    }
+    if (epi == FK_PUB) {                             // a row-parallel TP shard straight into the registered all-reduce buffer: W4 g128 / per-channel W8
+        if (!w8 && group_size != 128) return MI355_ERR_UNSUPPORTED;
+        const int blocks = cdiv(g.NT, 2);
+        if (g.M > 16 && 2 * blocks <= 256) {
+            fp.rowsplit = (blocks % 8 == 0) ? 2 : 1;
+            if (w8) { F64H_(8, 4, FK_PUB); }
+            F64H_(4, 4, FK_PUB);
+        }
+        if (w8) { F64_(8, 4, FK_PUB, blocks); }
+        F64_(4, 4, FK_PUB, blocks);
     }
 #undef F64_
 #undef F64H_

@@ -39,6 +39,16 @@ int mi355_qkv_touch_plan(const mi355_weight_t* wqkv, int32_t hd, void* sink, mi3
 int mi355_add_rmsnorm_img_touch(const void* x_f16, const float* partials, int32_t nsplit, int32_t ld, const void* bias, const void* residual_in,
                                 void* residual_out, const void* weight, float eps, int32_t M, int32_t H, void* y_img, int32_t act_dtype,
                                 const mi355_touch_t* touch, mi355_stream_t stream);
+/* Round 6, tensor parallelism: a row-parallel shard (O / down) written by its full-K GEMM straight into the rank's registered all-reduce buffer.
+ * allreduce.hip fills the target (slot layout of the NEXT <= 64-row call of the context), gemm.hip's mi355_linear_publish_img passes it to gemm_fullk64.hip. */
+typedef struct {
+    const uint32_t* epoch;                /* device: per-block call counters of the context */
+    void*    data;                        /* this rank's registered buffer */
+    uint32_t bytes, parity_elems, slot_elems;
+    int32_t  plain_stores;                /* full-fence hand-over: plain stores (the all-reduce launch's release fence publishes them) */
+} mi355_publish_target_t;
+int mi355_allreduce_publish_target(mi355_allreduce_t* ar, int32_t T, int32_t H, mi355_publish_target_t* out);
+int mi355_fullk64_publish_ok(const mi355_weight_t* w);    /* gemm.hip: mi355_linear_publish_img takes this linear (W4 g128 / per-channel W8, K <= 5760; up to 9600 when its tile pairs leave half the chip free) */
 int mi355_argmax_candidates(const float* logits, int32_t B, int32_t V, int32_t ld, void* workspace, size_t workspace_bytes,
                             mi355_stream_t stream);
 int mi355_argmax_pairs(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t vocab_offset, void* pairs_out,

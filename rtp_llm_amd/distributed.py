@@ -119,7 +119,7 @@ class CustomAllReduce:
         if verify and self.world > 1:
             self._verify_hand_over()
 
-    def _known_answer_round(self, rounds: int = 24) -> bool:
+    def _known_answer_round(self, rounds: Optional[int] = None) -> bool:
         """Known-answer collectives on every path that publishes through the hand-over under test -- the one-shot sum (<= 64 rows), the two-shot
         sum (> 64 rows on > 2 ranks: second barrier + result region), the fused residual + RMSNorm form, the all-gather of the hidden dimension and
         the cross-rank arg-max -- `rounds` times, so both buffer parities are used many times, with one rank (rotating) held back by a matmul in
@@ -128,6 +128,10 @@ class CustomAllReduce:
         dev = torch.device("cuda", torch.cuda.current_device())
         H = 1024
         rows_max = max(1, self.max_bytes // (H * 2))
+        if rounds is None:
+            rounds = 6 if self.shared_device else 24               # ranks time-slicing ONE device (tests): every call is a chain of process switches
+        if self.shared_device:
+            rows_max = min(rows_max, 768 // self.world)            # ... and every block of every rank has to be resident at once
         T1 = min(64, rows_max)
         T2 = min(160, rows_max) if self.world > 2 else 0          # two-shot geometry (one-shot again if the registered buffer is too small for > 64 rows)
         ng = 64                                                     # all-gather slice width
@@ -242,6 +246,17 @@ class CustomAllReduce:
                                                         weight.data_ptr(), float(eps), t.numel() // H, H, y.data_ptr(),
                                                         self._C.ACT_BF16 if t.dtype == torch.bfloat16 else self._C.ACT_F16, self._st()),
                       "allreduce_fused")
+        return y, res
+
+    def all_reduce_published_add_rmsnorm(self, residual, weight, eps):
+        """all_reduce_add_rmsnorm for rows the GEMM in front of it published in the registered buffer (ops.linear_publish_img on the same stream, no other call
+        of this context in between): (normed, residual_out) (mi355_allreduce_fused_published_dt)."""
+        H = residual.shape[-1]
+        y, res = torch.empty_like(residual), torch.empty_like(residual)
+        self._C.check(self.lib.mi355_allreduce_fused_published_dt(self.handle, residual.data_ptr(), res.data_ptr(), weight.data_ptr(), float(eps),
+                                                                  residual.numel() // H, H, y.data_ptr(), 0,
+                                                                  self._C.ACT_BF16 if residual.dtype == torch.bfloat16 else self._C.ACT_F16, self._st()),
+                      "allreduce_fused_published")
         return y, res
 
     def set_prefetch(self, t: torch.Tensor = None):

@@ -259,6 +259,21 @@ def linear_residual_img(x: ActImage, w: PackedWeight, residual: torch.Tensor, bi
     return out
 
 
+def linear_publish_img(x: ActImage, w: PackedWeight, ar, bias: Optional[torch.Tensor] = None, dtype: torch.dtype = torch.float16) -> bool:
+    """Row-parallel TP shard of a 1-64-row step: y = 16-bit(xW + bias) written by the full-K launch straight into the registered buffer of the all-reduce
+    context `ar` (distributed.CustomAllReduce), for its next all_reduce_published_add_rmsnorm call.  False when the shape / format / protocol is not taken
+    (mi355_linear_publish_img, include/mi355_decode.h)."""
+    _chk(x.data, torch.float16, "linear_publish_img.x")
+    if x.K != w.K:
+        raise _C.Mi355Error(f"linear_publish_img: image {x.M} x {x.K} against K={w.K}")
+    ws_struct = weight_struct(w, dtype)
+    rc = _C.lib().mi355_linear_publish_img(x.data.data_ptr(), x.M, C.byref(ws_struct), _p(bias), ar.handle, _stream())
+    if rc == ERR_UNSUPPORTED:
+        return False
+    _C.check(rc, "linear_publish_img")
+    return True
+
+
 def norm_exponent(weight: torch.Tensor) -> int:
     """e >= log2(max |weight|), e >= 0: the deferred RMSNorm stores weight * 2^-e * h, so that |stored| <= |h|."""
     mx = float(weight.float().abs().max())

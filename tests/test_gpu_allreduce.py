@@ -147,6 +147,67 @@ def _worker(rank, world, port, q, mode):
             full = torch.cat(_gather_cpu(lg, world), dim=1)
             assert torch.equal(ids.cpu(), torch.argmax(full, -1).int()), (ids.cpu(), torch.argmax(full, -1))
             assert ar.status() == 0
+        elif mode == "publish":
+            # round 6: a row-parallel shard written by its full-K GEMM straight into the registered buffer (ops.linear_publish_img, gemm_fullk64 FK_PUB) +
+            # the fused all-reduce that pulls it (mi355_allreduce_fused_published_dt): against the oracle's linear per rank, summed in fp32 in rank order,
+            # residual add and RMSNorm; O / down shapes of Qwen2-7B at tp = world and Llama-3-70B's at tp 8 widths, 1-64 rows; eager, interleaved with
+            # other calls of the context (parities advance), and replayed from a graph (the GEMM reads the parity off the device-resident counters)
+            from rtp_llm_amd import quant
+            shapes = [(3584 // world if world <= 4 else 512, 3584), (1024, 8192), (4736 if world == 4 else 3584, 3584)]
+            for si, (K, N) in enumerate(shapes):
+                gw = torch.Generator().manual_seed(500 + 10 * si + rank)
+                lin = model.synth_linear(K, N, "w4", "cpu", gw, zeros="centered")
+                packed = lin.pack()
+                W = oracle.dequant_groupwise(lin.q, lin.z_eff, lin.scales, lin.group_size)
+                wd = packed.to(dev) if hasattr(packed, "to") else packed
+                gamma = (1 + 0.1 * torch.randn(N, generator=torch.Generator().manual_seed(9))).half()
+                for T in (64, 33, 16, 5, 1):
+                    x = (torch.randn(T, K, generator=gw) * 0.5).half()
+                    res = torch.randn(T, N, generator=torch.Generator().manual_seed(70 + T)).half()
+                    ok = ops.linear_publish_img(ops.act_image_pack(x.to(dev)), wd, ar)
+                    assert ok, (K, N, T)
+                    y, r_out = ar.all_reduce_published_add_rmsnorm(res.to(dev), gamma.to(dev), 1e-6)
+                    torch.cuda.synchronize()
+                    mine = oracle.linear(x, W)                                     # fp16 [T, N]: this rank's shard of the sum
+                    parts = _gather_cpu(mine, world)
+                    acc = torch.zeros(T, N)
+                    for p_ in parts:
+                        acc = acc + p_.float()
+                    ref_res = (acc.half().float() + res.float()).half()
+                    ref_y = oracle.rmsnorm(ref_res, gamma, 1e-6)
+                    # the GEMM's fp32 sums differ from the oracle's in order: 1e-2 like every linear; the ranks must agree bit for bit
+                    assert torch.allclose(r_out.cpu().float(), ref_res.float(), atol=1e-2 * world, rtol=1e-2), (K, N, T, float((r_out.cpu().float() - ref_res.float()).abs().max()))
+                    assert torch.allclose(y.cpu().float(), ref_y.float(), atol=5e-2, rtol=5e-2), (K, N, T)
+                    both = _gather_cpu(r_out.cpu(), world)
+                    assert all(torch.equal(both[0], o) for o in both[1:])
+                    if T % 2:                                                       # an unrelated call in between: the counters of its blocks advance
+                        ar.all_reduce(torch.ones(3, 3584, dtype=torch.float16, device=dev))
+                # published == slab path bit for bit?  Not required (different summation order inside the GEMM); what is required: same as the x_f16 form
+                # fed with the GEMM's own rows.  Check through a graph: 6 replays of (publish GEMM -> published all-reduce), outputs constant
+                T = 24
+                x = (torch.randn(T, K, generator=gw) * 0.5).half().to(dev)
+                img = ops.act_image_pack(x)
+                res = torch.randn(T, N, generator=torch.Generator().manual_seed(71)).half().to(dev)
+                gam = gamma.to(dev)
+                y0, r0 = torch.empty_like(res), torch.empty_like(res)
+                torch.cuda.synchronize(); dist.barrier()
+                stp = torch.cuda.Stream()
+                with torch.cuda.stream(stp):
+                    def run_once():
+                        assert ops.linear_publish_img(img, wd, ar)
+                        _C.check(ar.lib.mi355_allreduce_fused_published_dt(ar.handle, res.data_ptr(), r0.data_ptr(), gam.data_ptr(), 1e-6, T, N, y0.data_ptr(), 0,
+                                                                           _C.ACT_F16, stp.cuda_stream), "published")
+                    run_once(); torch.cuda.synchronize()
+                    want_r, want_y = r0.clone(), y0.clone()
+                    grp = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(grp, stream=stp):
+                        run_once()
+                    for rep in range(7):                                            # odd count: both parities, and the counters end where an eager call expects them
+                        r0.zero_(); y0.zero_()
+                        grp.replay()
+                        torch.cuda.synchronize()
+                        assert torch.equal(r0, want_r) and torch.equal(y0, want_y), (K, N, rep)
+            assert ar.status() == 0
         elif mode == "engine":
             cfg = model.ModelConfig("tiny-tp", 2, 512, 8, 2, 64, 768, 1024, max_pos=256)
             w = model.synth_model(cfg, "w4", "cpu", seed=21, zeros="centered")
@@ -601,7 +662,7 @@ def _worker(rank, world, port, q, mode):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mode,world", [("kernels", 2), ("engine", 2), ("transport", 2), ("bf16", 2), ("bf16", 4), ("timeout", 2), ("twoshot", 3), ("mixed", 2), ("kernels", 4),
+@pytest.mark.parametrize("mode,world", [("kernels", 2), ("publish", 2), ("publish", 4), ("publish_ff", 2), ("engine", 2), ("transport", 2), ("bf16", 2), ("bf16", 4), ("timeout", 2), ("twoshot", 3), ("mixed", 2), ("kernels", 4),
                                         ("kernels", 8), ("twoshot", 4), ("twoshot", 8), ("engine70", 8), ("engine70full", 8), ("kernels_ff", 2), ("engine_ff", 2), ("twoshot_ff", 3), ("kernels_ll", 2), ("kernels_ll", 4), ("engine_ll", 2), ("mixed_ll", 2), ("stress_ll", 2), ("stress_ll", 4), ("engine7b_ll", 2), ("engine7b", 2), ("engine7b", 4), ("stress", 2), ("stress", 4)])   # (8 ranks time-slicing ONE GPU under this load run into the spin bound: a property of the single-GPU setup)
 def test_custom_allreduce_processes_on_one_gpu(mode, world):
     assert torch.cuda.is_available()
