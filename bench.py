@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-TRAFFIC_FILE = "r05_traffic.json"   # profiles/: PMC traffic of the engine's linears, tools/engine_traffic.sh
+TRAFFIC_FILE = "r06_traffic.json"   # profiles/: PMC traffic of the engine's linears, tools/engine_traffic.sh
 
 WORKLOADS = {
     # name: (model, weight kind, kv_int8, default batch, default ctx, page)
@@ -388,7 +388,7 @@ def main():
         alg_bytes_launch = (bps_r["linears"] + act_bytes) / n_launch_step
         avg_ms = gq["ms"] / max(1, gq["launches"])
         ach = alg_bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic, traffic_src = None, None
+        traffic, traffic_src, kernel_us = None, None, None
         if traffic_ok:
             try:  # HBM read + write bytes per launch of THESE launches (the engine's four linears per layer), from the committed
                 # rocprofv3 --pmc passes over `bench.py --no-graph` (tools/engine_traffic.sh -> profiles/r05_traffic.json); PMC
@@ -398,6 +398,7 @@ def main():
                 if tj and tj.get("batch") == B:
                     if tj.get("gemm_sources_sha") == gemm_sources_sha():
                         traffic, traffic_src = int(tj["gemm_quant_bytes_per_launch"]), tj.get("source")
+                        kernel_us = tj.get("gemm_quant_kernel_us_per_launch")
                     else:
                         traffic_src = f"stale: profiles/{TRAFFIC_FILE} was collected for different sources of the GEMM / fold kernels (re-run tools/engine_traffic.sh)"
             except Exception:  # noqa: BLE001
@@ -408,6 +409,13 @@ def main():
                                         "gemm_wide_kernel / gemm_splitk64_kernel on the image path, gemm_wq_kernel otherwise", "layout": label,
               "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
               "bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_ms * 1e3, 3), "launches_timed": gq["launches"]}
+        # `achieved` / `frac` divide by the HIP-event time of EAGER launches, which includes the gap to the next launch (~13 % at b = 64); the same
+        # bytes over the kernels' own begin -> end durations (rocprofv3 --kernel-trace of the same eager launches, committed with the traffic file and
+        # quoted only while the GEMM sources still hash to what was profiled) are what the per-kernel tables of DESIGN.md use
+        if kernel_us:
+            rl["avg_kernel_us"] = round(float(kernel_us), 3)
+            rl["achieved_kernel_time"] = round(alg_bytes_launch / (float(kernel_us) * 1e-6) / 1e9, 1)
+            rl["frac_kernel_time"] = round(rl["achieved_kernel_time"] / HBM_PEAK_GBS, 4)
         return rl, bps_r, prof_r
 
     if rank == 0 and world > 1:   # N > 1: the line carries `roofline` and `cpu_baseline` too (rank 0's replica here; replaced by its TP shard below)

@@ -9,7 +9,11 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   ( cd $R && timeout 240 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_engine_$ctr -o run -- \
       python bench.py --no-graph --steps 3 --warmup 1 --no-cpu-baseline --no-sweep > $O/pmc_engine_$ctr.log 2>&1 )
 done
-python $R/tools/engine_traffic.py $O/pmc_engine_FETCH_SIZE $O/pmc_engine_WRITE_SIZE > $O/pmc_engine_traffic.txt
+# third pass, no counters: kernel durations of the same eager launches (rocprof begin -> end per dispatch, no launch gaps) for the roofline's
+# kernel-time fraction (bench.py roofline.frac_kernel_time; VERDICT r05: the HIP-event time of eager launches includes the gaps)
+( cd $R && timeout 240 rocprofv3 --kernel-trace --output-format csv -d $O/pmc_engine_TIME -o run -- \
+    python bench.py --no-graph --steps 3 --warmup 1 --no-cpu-baseline --no-sweep > $O/pmc_engine_TIME.log 2>&1 )
+python $R/tools/engine_traffic.py $O/pmc_engine_FETCH_SIZE $O/pmc_engine_WRITE_SIZE $O/pmc_engine_TIME > $O/pmc_engine_traffic.txt
 cp $O/traffic.json $O/traffic.json.bak 2>/dev/null
-rm -rf $O/pmc_engine_FETCH_SIZE $O/pmc_engine_WRITE_SIZE
+rm -rf $O/pmc_engine_FETCH_SIZE $O/pmc_engine_WRITE_SIZE $O/pmc_engine_TIME
 cat $O/pmc_engine_traffic.txt

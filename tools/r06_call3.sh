@@ -14,5 +14,15 @@ bash tools/trace_bench.sh llama70b_tp8_shard_b32 --workload llama3-70b-awq --sha
 head -14 $O/kernel_stats_llama70b_tp8_shard_b32.txt
 bash tools/trace_bench.sh tp2_shard_b64 --shard-of 2 --steps 8 --warmup 2 --no-cpu-baseline --no-sweep
 head -14 $O/kernel_stats_tp2_shard_b64.txt
+# 2b. partitions merged inside the attention launch (--debug-set 10=1: the reduce launch of rounds 1-5)
+R2=$O/attn_merge_in_launch.txt; : > $R2
+for v in 1 0; do
+  for b in 1 4 8 16 32; do python bench.py --batch $b --no-cpu-baseline --no-sweep --steps 20 --debug-set 10=$v 2>/dev/null | tail -1 | line "[10=$v] qwen2-7b tp1 b=$b" >> $R2; done
+  python bench.py --workload qwen2-7b-w4a16-kv8 --batch 16 --no-cpu-baseline --no-sweep --steps 20 --debug-set 10=$v 2>/dev/null | tail -1 | line "[10=$v] qwen2-7b kv8 ctx4096 b=16" >> $R2
+  python bench.py --shard-of 2 --no-cpu-baseline --no-sweep --steps 20 --debug-set 10=$v 2>/dev/null | tail -1 | line "[10=$v] qwen2-7b one rank of tp2 b=64" >> $R2
+  python bench.py --workload llama3-70b-awq --shard-of 8 --no-cpu-baseline --no-sweep --steps 10 --debug-set 10=$v 2>/dev/null | tail -1 | line "[10=$v] llama3-70b one rank of tp8 b=32" >> $R2
+done
+cat $R2
+( time python -m pytest tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -8 ) 2>&1 | grep -v "^\[W\|amdgpu.ids" | tail -12
 # 3. the multi-process tests again (startup check bounded on a shared device)
 ( time python -m pytest tests/test_gpu_allreduce.py tests/test_gpu_tp_engine.py -m gpu -q 2>&1 | tail -8 ) > $O/tp_tests.txt 2>&1; grep -v "^\[W\|amdgpu.ids\|Gloo" $O/tp_tests.txt | tail -12
