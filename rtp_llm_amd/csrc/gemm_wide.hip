@@ -224,6 +224,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
         }
     }
     f16x8 a_cur = dq(Slot0{}, 0, 0);
+    if constexpr (DBG & 64) { if (th == 1) __builtin_amdgcn_s_setprio(2); }   // experiment: ONE wave of every SIMD pair runs at a higher priority for the whole loop (asymmetric arbitration)
     if constexpr (DBG & 4) st1 = wall_clock64();
     u32x4 aE = __builtin_bit_cast(u32x4, a_cur), aO = aE;   // HAND: operand of even / odd units (fixed register tuples)
 
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
             if constexpr (HAND) {
                 if constexpr (sn % SPG == 0) meta_of(SlotU{}, tn, sn);
                 const uint32_t wn = wr[SlotU::value][tn][0][sn];
-                wide_unit_w4<MB, u % 2 == 0>(aE, aO, wn, w4c, zn, znb, scl, acc[t][0], acc[t][MB > 1 ? 1 : 0], acc[t][MB > 2 ? 2 : 0],
+                wide_unit_w4<MB, u % 2 == 0, f16x8, (DBG & 32) != 0>(aE, aO, wn, w4c, zn, znb, scl, acc[t][0], acc[t][MB > 1 ? 1 : 0], acc[t][MB > 2 ? 2 : 0],
                                              acc[t][MB > 3 ? 3 : 0], bq[0][s], bq[MB > 1 ? 1 : 0][s], bq[MB > 2 ? 2 : 0][s], bq[MB > 3 ? 3 : 0][s]);
             } else {
                 const f16x8 a_next = dq(SlotU{}, tn, sn);
@@ -450,6 +451,8 @@ static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_
 #ifdef MI355_TUNING
     else if (mb2 && WIDE_DBG == 16) rc = launch_wide_t<4, 2, 4, T, 0, 1>(wp, st);   // one chunk ahead (the round-2..4 instance)
     else if (!mb2 && WIDE_DBG == 18) rc = launch_wide_t<4, 4, 4, T, 8>(wp, st);       // K-slice merge in two rounds (rounds 1-4)
+    else if (mblk == 4 && WIDE_DBG == 32) rc = launch_wide_t<4, 4, 4, T, 32>(wp, st);   // round 6: s_setprio 2 over the unit's MFMA group
+    else if (mblk == 4 && WIDE_DBG == 64) rc = launch_wide_t<4, 4, 4, T, 64>(wp, st);   // round 6: the second wave of every SIMD at priority 2 for the whole loop
     else if (mb2 && WIDE_DBG == 17) rc = launch_wide_t<4, 2, 4, T, 0, 2>(wp, st);   // two row blocks whatever the row count
     else if (mb2 && WIDE_DBG == 2)  rc = launch_wide_t<4, 2, 4, T, 2, 2>(wp, st);   // instruction stream without weight traffic
     else if (mb2 && WIDE_DBG == 3)  rc = launch_wide_t<4, 2, 4, T, 3, 2>(wp, st);   // ... without any main-loop traffic
