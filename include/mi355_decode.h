@@ -608,6 +608,10 @@ size_t mi355_decoder_prefill_workspace_bytes(mi355_decoder_t* d, int32_t max_tok
 int    mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_ids, const int32_t* positions, const int32_t* block_table,
                              int32_t nseq, int32_t q_len, const int32_t* logit_rows, float* logits_out, void* workspace,
                              size_t workspace_bytes, mi355_stream_t stream);
+/* Dynamic-NTK RoPE styles only: {cos, sin} rows [max_pos][rope_dim / 2][2] (fp32, device) the prefill chunks that follow rotate with, or NULL for the model's
+ * table.  The reference's context_rope (bindings/common/kernels/rotary_position_embedding.h:1000-1025) gives every token of a prefill batch the base of the
+ * batch's longest prompt (fused_rope_kvcache_kernel.cu:219-260), while decode uses the base of each position (the model's table). */
+int    mi355_decoder_set_prefill_rope_table(mi355_decoder_t* d, const float* cos_sin);
 
 /* hipGraph: capture one full step for batch B on an internal stream, then replay
  * `nsteps` times back-to-back on `stream` (greedy feedback stays on device). */

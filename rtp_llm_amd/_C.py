@@ -151,6 +151,7 @@ SIGNATURES = {
     "mi355_decoder_step": (i32, [vp, i32, vp]),
     "mi355_decoder_prefill_workspace_bytes": (sz, [vp, i32, i32]),
     "mi355_decoder_prefill": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]),
+    "mi355_decoder_set_prefill_rope_table": (i32, [vp, vp]),
     "mi355_decoder_capture": (i32, [vp, i32]),
     "mi355_decoder_replay": (i32, [vp, i32, i32, vp]),
     "mi355_decoder_profile": (i32, [vp, i32, i32, C.POINTER(f32), C.POINTER(i32), vp]),

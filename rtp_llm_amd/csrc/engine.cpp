@@ -51,6 +51,7 @@ struct mi355_decoder {
     void *resid, *xn, *q_buf, *attn_out, *act, *attn_ws, *argmax_ws;
     void *xn_img, *attn_img;   // activation images (mi355_act_image_*) of the normed hidden rows / the attention output, 5-64-row steps
     int32_t* oob_count; // tokens refused by the KV writer (stale position / block id)
+    const float* prefill_cos_sin = nullptr;   // mi355_decoder_set_prefill_rope_table: {cos, sin} rows of the NEXT prefill chunks (dynamic-NTK prompts past the original context), or null
     mi355_allreduce_t* ar; // attached all-reduce context (tp_size > 1): the TP step runs entirely from C++
     int    vocab_offset;
     // external transport (RCCL) for the same points when the peer mapping is not available: local fold -> fp16 ar_buf ->
@@ -729,6 +730,16 @@ extern "C" int mi355_decoder_layer_mlp(mi355_decoder_t* d, int32_t l, mi355_stre
     return MI355_OK;
 }
 
+// Dynamic-NTK RoPE (rotary_position_embedding.h:889-951) in PREFILL: context_rope (:1000-1025) rotates every token of the batch with ONE base, that of
+// `seq_len` = the longest prompt of the batch (fused_rope_kvcache_kernel.cu:219-260 passes the kernel's padded sequence length), whereas the decode writer
+// uses the base of each position -- which is what the model's table holds.  The host builds the {cos, sin} rows [max_pos][rope_dim / 2][2] for the batch's
+// base and hands them over for the prefill chunks that follow; NULL returns to the model's table.  No effect on decode steps.
+extern "C" int mi355_decoder_set_prefill_rope_table(mi355_decoder_t* d, const float* cos_sin) {
+    if (!d) { mi355_set_error("decoder_set_prefill_rope_table: null decoder"); return MI355_ERR_ARG; }
+    d->prefill_cos_sin = cos_sin;
+    return MI355_OK;
+}
+
 // ------------------------------------------------------------------ prefill
 // One chunk of nseq x q_len prompt tokens through the same weights: large-M GEMMs (gemm_prefill.hip above 128 rows), the
 // rows-mode KV writer, causal multi-row attention over the paged cache (earlier chunks of the same prompt are already
@@ -803,7 +814,7 @@ extern "C" int mi355_decoder_prefill(mi355_decoder_t* d, const int32_t* token_id
         const auto& L = d->layers[l];
         mi355_kv_layer_t kv = kv_of(d, l);
         RUN(MI355_KC_GEMM_QUANT, mi355_linear_forward(b.xn, T, &L.qkv, L.qkv_bias, b.qkv, MI355_EPI_NONE, b.gemm_ws, b.gemm_ws_bytes, st));
-        RUN(MI355_KC_ROPE_KV, mi355_rope_kv_write_rows(b.qkv, nullptr, 0, L.qkv.N, nullptr, d->model.cos_sin, c.rope_dim, c.max_pos, positions,
+        RUN(MI355_KC_ROPE_KV, mi355_rope_kv_write_rows(b.qkv, nullptr, 0, L.qkv.N, nullptr, d->prefill_cos_sin ? d->prefill_cos_sin : d->model.cos_sin, c.rope_dim, c.max_pos, positions,
                                                        block_table, c.max_blocks_per_seq, T, q_len, c.nh, &kv, b.q, d->oob_count, st));
         RUN(MI355_KC_ATTN, mi355_paged_attn_rows(b.q, &kv, block_table, c.max_blocks_per_seq, positions, nseq, q_len, c.nh, scale,
                                                  c.max_seq_len, b.attn, b.attn_ws, b.attn_ws_bytes, st));

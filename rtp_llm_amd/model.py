@@ -307,6 +307,16 @@ def dynamic_ntk_base(hd: int, theta: float, positions: torch.Tensor, scaling: di
     return torch.where(pos > ctx, stretched, theta_t)
 
 
+def prefill_rope_table_dynamic_ntk(cfg: ModelConfig, seq_len: int, device) -> torch.Tensor:
+    """{cos, sin} rows [max_pos][hd / 2][2] of a PREFILL batch under a dynamic-NTK style: one base for every position, that of `seq_len` = the longest
+    prompt of the batch (context_rope -> apply_rope(..., seq_len), rotary_position_embedding.h:925-951,1000-1025)."""
+    pos = torch.arange(cfg.max_pos)
+    base = dynamic_ntk_base(cfg.hd, cfg.rope_theta, torch.tensor([seq_len]), cfg.rope_scaling)[0]
+    chan = torch.arange(0, cfg.hd, 2).float() / cfg.hd
+    angle = pos.float()[:, None] / torch.pow(base, chan[None, :])
+    return torch.stack((angle.cos(), angle.sin()), dim=-1).contiguous().to(device)
+
+
 def rope_table(cfg: ModelConfig, device) -> torch.Tensor:
     """fp32 {cos,sin} table [max_pos][hd/2][2] (genBaseCache / genYarnCache, cpp/model_utils/RopeCache.cc:16-81; the styles the
     reference computes in-kernel on ROCm are tabulated the same way: rope_frequencies); built on the host in fp32 so every
@@ -549,9 +559,23 @@ class DecoderEngine:
         nseq = len(prompts)
         start = [0] * nseq if start is None else list(start)
         rs = self.cfg.rope_scaling or {}
-        if rs.get("rope_type", rs.get("type")) in DYNAMIC_NTK and any(s + len(p) > int(rs["original_max_position_embeddings"]) for s, p in zip(start, prompts)):
-            # context_rope rotates EVERY token of such a prompt with the base of the prompt length: not the position-indexed table
-            raise NotImplementedError("dynamic-NTK RoPE: a prompt past the original context needs a per-request table; feed it through the decode path")
+        ntk_table = None
+        if rs.get("rope_type", rs.get("type")) in DYNAMIC_NTK and max(len(p) for p in prompts) > int(rs["original_max_position_embeddings"]):
+            # context_rope rotates EVERY token of the prefill batch with ONE base, that of the batch's longest prompt (rotary_position_embedding.h:1000-1025,
+            # fused_rope_kvcache_kernel.cu:219-260): a table of its own for these chunks (round 6; the decode steps that follow use the position-indexed one)
+            if any(start):
+                raise NotImplementedError("dynamic-NTK RoPE: a prompt past the original context on top of cached tokens (prefix reuse) is not served")
+            ntk_table = prefill_rope_table_dynamic_ntk(self.cfg, max(len(p) for p in prompts), self.device)
+            _C.check(self.lib.mi355_decoder_set_prefill_rope_table(self.handle, ntk_table.data_ptr()), "decoder_set_prefill_rope_table")
+        try:
+            return self._prefill_chunks(prompts, block_table, chunk, start)
+        finally:
+            if ntk_table is not None:
+                torch.cuda.synchronize()      # the chunks read the table: it may only go once they are done
+                _C.check(self.lib.mi355_decoder_set_prefill_rope_table(self.handle, None), "decoder_set_prefill_rope_table")
+
+    def _prefill_chunks(self, prompts, block_table, chunk, start):
+        nseq = len(prompts)
         bt = torch.as_tensor(block_table, dtype=torch.int32)
         self.check_room([s + len(p) for s, p in zip(start, prompts)], 0, bt, "prefill")
         dev, st = self.device, self._st()

@@ -704,11 +704,38 @@ def test_engine_scaled_rope_styles_match_oracle(scaling):
     assert diverged
     print(f"scaled RoPE {scaling.get('rope_type', scaling.get('type'))}: max |logit error| {worst:.2e} over {steps} steps")
     if scaling.get("rope_type") in model.DYNAMIC_NTK:
-        # a prompt past the original context is rotated with the base of ITS length (context_rope): not the position table -- refused, while a
-        # prompt inside the original context is the Base rotation and goes through
+        # round 6: a PROMPT past the original context is rotated with ONE base, that of the prefill batch's longest prompt (context_rope,
+        # rotary_position_embedding.h:1000-1025; fused_rope_kvcache_kernel.cu:219-260): the prefill chunks take a table of their own
+        # (mi355_decoder_set_prefill_rope_table), the decode steps behind them the position-indexed one.  Oracle: the same tokens fed one by one
+        # through a decoder whose table holds that base at every position, then the usual decoder for the generated tokens (KV carried over).
         eng2 = model.DecoderEngine(cfg, model.weights_to(w, DEV), kv_int8=False, page=page, num_blocks=64, max_batch=4, max_seq_len=64, device=DEV)
-        with pytest.raises(NotImplementedError):
-            eng2.prefill([list(range(1, 30))], bt[:1])
+        longp, shortp = [int(t) for t in torch.randint(1, cfg.vocab, (29,), generator=_gen(9))], [int(t) for t in torch.randint(1, cfg.vocab, (11,), generator=_gen(10))]
+        lgp = eng2.prefill([longp, shortp], bt[:2], chunk=16)            # two chunks; the short prompt is rotated with the LONG prompt's base too
+        opre = oracle.OracleDecoder({**cfg.__dict__}, _oracle_weights(w))
+        opre.cos_sin = model.prefill_rope_table_dynamic_ntk(cfg, len(longp), "cpu")
+        assert float((opre.cos_sin[10] - odec.cos_sin[10]).abs().max()) > 1e-3      # not the decode table's row (position 10 sits below the long prompt's base under both styles)
+        okl = oracle.OracleKV(cfg.num_layers, 2, False)
+        refs = []
+        for b_, pr in enumerate((longp, shortp)):
+            r_ = None
+            for pos_, t_ in enumerate(pr):
+                _, r_ = opre.forward_tokens(torch.tensor([t_], dtype=torch.int32), torch.tensor([pos_], dtype=torch.int32), okl, [b_])
+            refs.append(r_[0])
+        refp = torch.stack(refs)
+        assert torch.allclose(lgp.cpu(), refp, **TOL), float((lgp.cpu() - refp).abs().max())
+        # three decode steps behind the prompts: new tokens at the base of their own position, attending keys rotated at prefill
+        tk = oracle.greedy(refp)
+        eng2.set_inputs(tk.tolist(), [len(longp), len(shortp)], bt[:2])
+        for st_ in range(3):
+            eng2.step(2)
+            torch.cuda.synchronize()
+            posd = torch.tensor([len(longp) + st_, len(shortp) + st_], dtype=torch.int32)
+            _, refd = odec.forward_tokens(tk, posd, okl, [0, 1])
+            assert torch.allclose(eng2.logits[:2].cpu(), refd, **TOL), (st_, float((eng2.logits[:2].cpu() - refd).abs().max()))
+            tk = oracle.greedy(refd)
+            eng2.token_ids[:2].copy_(tk)
+        with pytest.raises(NotImplementedError):                          # on top of cached tokens (prefix reuse): not served
+            eng2.prefill([list(range(1, 30))], bt[2:3], start=[4])
         short = list(range(1, 1 + int(scaling["original_max_position_embeddings"])))
         lg = eng2.prefill([short], bt[:1])
         okp = oracle.OracleKV(cfg.num_layers, 1, False)
