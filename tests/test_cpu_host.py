@@ -365,11 +365,11 @@ def test_host_side_plans_of_the_image_launches():
 
 
 def test_committed_bench_line_and_traffic_file_follow_the_contract():
-    """profiles/r05_bench_default.json is the line `python bench.py` printed on an MI355X: the fields the driver and the judge read are
+    """profiles/r06_bench_default.json is the line `python bench.py` printed on an MI355X: the fields the driver and the judge read are
     there, and the static PMC traffic figure is only quoted for the kernel sources it was measured on (bench.gemm_sources_sha)."""
     import json, os, importlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    line = json.load(open(os.path.join(root, "profiles", "r05_bench_default.json")))
+    line = json.load(open(os.path.join(root, "profiles", "r06_bench_default.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):
         assert k in line, k
@@ -380,14 +380,17 @@ def test_committed_bench_line_and_traffic_file_follow_the_contract():
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert abs(line["value"] - line["config"]["batch"] / line["ms_per_step"] * 1e3) / line["value"] < 1e-3
     bench = importlib.import_module("bench")
-    tj = json.load(open(os.path.join(root, "profiles", "r05_traffic.json")))["qwen2-7b-w4a16"]
+    tj = json.load(open(os.path.join(root, "profiles", "r06_traffic.json")))["qwen2-7b-w4a16"]
     assert tj["gemm_sources_sha_over"] == list(bench.TRAFFIC_KERNEL_SOURCES)
     if tj["gemm_sources_sha"] == bench.gemm_sources_sha():          # else bench.py reports traffic: null ("stale")
         assert rf["traffic"] == int(tj["gemm_quant_bytes_per_launch"]) and rf["traffic"] >= 0.9 * rf["bytes_per_launch"]
-    # N > 1: the line carries `roofline` (the headline TP layout's shard of rank 0) and `cpu_baseline` too -- dry runs of the driver's N = 2 / 8
-    # launch lines with every rank on ONE GPU (timing meaningless, the fields are what is checked)
+    # round 6: the same bytes over the kernels' own durations (rocprofv3 --kernel-trace pass of tools/engine_traffic.sh), beside the eager-event fraction
+    assert abs(rf["avg_kernel_us"] - tj["gemm_quant_kernel_us_per_launch"]) < 1e-2 and rf["avg_kernel_us"] < rf["avg_launch_us"]
+    assert abs(rf["frac_kernel_time"] - rf["bytes_per_launch"] / rf["avg_kernel_us"] / 1e3 / rf["peak"]) < 1e-3 and rf["frac_kernel_time"] > rf["frac"]
+    # N > 1: the line carries `roofline` (the headline TP layout's shard of rank 0) and `cpu_baseline` too -- dry runs of `python bench.py --gpus N` (no
+    # launcher: bench.py starts its own ranks, round 6) with every rank on ONE GPU (timing meaningless, the fields are what is checked)
     for n in (2, 8):
-        dj = json.loads(open(os.path.join(root, "profiles", f"r05_dryrun_{n}ranks_one_gpu.json")).read().strip().splitlines()[-1])
+        dj = json.loads(open(os.path.join(root, "profiles", f"r06_dryrun_selfspawn_{n}ranks_one_gpu.json")).read().strip().splitlines()[-1])
         assert dj["n_gpus"] == n and "tp_layout" in dj and "error" not in dj["tp_layout"] and "replica_layout" in dj
         assert dj["tp_layout"]["ranks_bit_identical"] is True and dj["tp_layout"]["hand_over"].startswith("write-through")
         r2, c2 = dj["roofline"], dj["cpu_baseline"]
@@ -395,7 +398,7 @@ def test_committed_bench_line_and_traffic_file_follow_the_contract():
         assert abs(r2["achieved"] - r2["bytes_per_launch"] / r2["avg_launch_us"] / 1e3) / r2["achieved"] < 1e-2
         assert c2["kind"] == "port" and c2["cores"] >= 1 and c2["value"] > 0
         assert dj["replica_layout"]["roofline"]["layout"].startswith("dp")
-    pj = json.load(open(os.path.join(root, "profiles", "r05_parity_greedy_ids.json")))    # tests/conftest.py: the full-width end-to-end record
+    pj = json.load(open(os.path.join(root, "profiles", "r06_parity_greedy_ids.json")))    # tests/conftest.py: the full-width end-to-end record
     assert pj["summary"]["rows"] >= 400 and pj["summary"]["exact"] >= pj["summary"]["safe"]
     assert all(r["max_abs_logit_err"] <= r["tol"] and (r["exact"] == r["rows"] or r["safe"] < r["rows"]) for r in pj["records"])
 
