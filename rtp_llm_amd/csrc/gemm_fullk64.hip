@@ -29,14 +29,18 @@
 namespace {
 
 // LDS behind the slices' partial sums: what the epilogue needs besides the sums, staged by the helper wave
-template <int EPI> struct Stage64 {};
-template <> struct Stage64<FK_RESID> { f16 res[64][32]; f16 bias[32]; f16 gam[32]; float wsc[32]; };          // residual rows / bias / norm weight of the block's two tiles (+ W8: the columns' scales)
-template <> struct Stage64<FK_PUB>   { f16 bias[32]; float wsc[32]; uint32_t par[64]; };                          // bias of the block's two tiles, parity of every row's slot in the registered all-reduce buffer
-template <> struct Stage64<FK_ROPE>  { float cs[64][32]; int pos[64], blk[64]; f16 bias[32]; float wsc[32]; }; // rotation row of the block's 16 dims per token, position, block id
+template <int EPI, int TPB> struct Stage64 {};
+template <int TPB> struct Stage64<FK_RESID, TPB> { f16 res[64][16 * TPB]; f16 bias[16 * TPB]; f16 gam[16 * TPB]; float wsc[16 * TPB]; };   // residual rows / bias / norm weight of the block's tiles (+ W8: the columns' scales)
+template <int TPB> struct Stage64<FK_PUB, TPB>   { f16 bias[16 * TPB]; float wsc[16 * TPB]; uint32_t par[64]; };                        // bias of the block's tiles, parity of every row's slot in the registered all-reduce buffer
+template <int TPB> struct Stage64<FK_ROPE, TPB>  { float cs[64][16 * TPB]; int pos[64], blk[64]; f16 bias[16 * TPB]; float wsc[16 * TPB]; }; // rotation row of the block's 8 TPB dims per token, position, block id
 
-template <int WB, int GS, int MB, int EPI, int CPW, int RING>
+// TPB (round 6): tiles per block.  2: one (d, d + hd/2) pair of a head / two adjacent tiles (rounds 4-5).  4: two pairs / four tiles with the rows split over MORE blocks
+// -- what bounds these launches is the number of 1 KB wave-loads a block pushes through its CU's vector-memory path (tools/fullk64_stamps.py: the K waves' requests are out
+// between 0.5 and 7 us of a 10.5 us launch), and per 8 MFMAs a (4 tiles x 2 row blocks) block loads 2 fragments + 1 weight KB where a (2 x 4) block loads 4 + 0.5:
+// QKV at 64 rows 504 -> 336 wave-loads per CU on the same 144 blocks, O (4 tiles x 1 row block, 224 blocks) 280 -> 224.
+template <int WB, int GS, int MB, int EPI, int CPW, int RING, int TPB = 2>
 __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp) {
-    constexpr int TPB = 2;
+    static_assert(TPB == 2 || TPB == 4, "tiles per block");
     constexpr bool W8 = WB == 8;                     // per-channel INT8 (GS is then a dummy 4)
     constexpr int LPC = WB / 4;                      // 1 KB wave-loads per (tile, chunk)
     constexpr int NSUB = 4 / GS, SPG = 4 / NSUB;     // GS: 4 -> g128, 2 -> g64, 1 -> g32: (zero, scale) words per chunk and column, k-steps per word
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NW   = (int)(blockDim.x >> 6) - 1;     // K-slice waves; wave NW is the helper
     const int jj = lane & 15, q = lane >> 4;
-    Stage64<EPI>& sg = *reinterpret_cast<Stage64<EPI>*>(smem + (size_t)NW * TPB * MB * 1024);
+    Stage64<EPI, TPB>& sg = *reinterpret_cast<Stage64<EPI, TPB>*>(smem + (size_t)NW * TPB * MB * 1024);
     FK_STAMP(0);
 
     // rowsplit (O projection above 16 rows): the block's activation loads are what bounds the launch, and they are per ROW -- two
@@ -59,74 +63,91 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
     // of a pair are then read twice, 56 KB more per CU pair).  Not for QKV: 144 pairs x 2 = 288 blocks, and the CUs with two of them would set the time.
     // The two blocks of a pair read the same weights: placed on the SAME XCD (block b runs on XCD b % 8 -- observed, used for speed
     // only) the second read comes out of that XCD's L2 instead of crossing the fabric again (rowsplit = 2: pairs a multiple of 8).
-    int pair = (int)blockIdx.x, half = 0;
-    if (fp.rowsplit == 2) { const int slot = (int)blockIdx.x >> 3; pair = (slot >> 1) * 8 + ((int)blockIdx.x & 7); half = slot & 1; }
-    else if (fp.rowsplit) { pair = (int)blockIdx.x >> 1; half = (int)blockIdx.x & 1; }
-    const int rb0 = half * MB;                       // first row block of this block (0 without a row split)
+    // fp.rowsplit: 0 none | 1 two blocks per unit (b / 2, b % 2) | 2 the same with the two blocks of a unit on ONE XCD | 3 four blocks per unit | 4 four, on one XCD
+    int unit = (int)blockIdx.x, part = 0;
+    if (fp.rowsplit == 2)      { const int slot = (int)blockIdx.x >> 3; unit = (slot >> 1) * 8 + ((int)blockIdx.x & 7); part = slot & 1; }
+    else if (fp.rowsplit == 1) { unit = (int)blockIdx.x >> 1; part = (int)blockIdx.x & 1; }
+    else if (fp.rowsplit == 4) { const int slot = (int)blockIdx.x >> 3; unit = (slot >> 2) * 8 + ((int)blockIdx.x & 7); part = slot & 3; }
+    else if (fp.rowsplit == 3) { unit = (int)blockIdx.x >> 2; part = (int)blockIdx.x & 3; }
+    const int rb0 = part * MB;                       // first row block of this block (0 without a row split)
     int tile[TPB];
     if constexpr (EPI == FK_ROPE) {
-        const int hh = fp.r.hd >> 5;                 // tiles per half head
-        const int h = pair / hh, j = pair % hh;
-        tile[0] = h * 2 * hh + j;
-        tile[1] = tile[0] + hh;
+        const int hh = fp.r.hd >> 5;                 // tiles per half head (even: the TPB / 2 pairs of a block belong to one head)
+#pragma unroll
+        for (int pp = 0; pp < TPB / 2; ++pp) {
+            const int pair = unit * (TPB / 2) + pp, h = pair / hh, j = pair % hh;
+            tile[2 * pp] = h * 2 * hh + j;
+            tile[2 * pp + 1] = tile[2 * pp] + hh;
+        }
     } else {
-        tile[0] = pair * 2; tile[1] = tile[0] + 1;
+#pragma unroll
+        for (int t = 0; t < TPB; ++t) tile[t] = unit * TPB + t;
     }
 
     if (wave == NW) {
         // =============================================================== helper wave: no K slice.  It stages the epilogue's operands
         // in LDS while the K waves stream: the chain position -> block id -> rotation row is two dependent round trips, and inside a
         // K wave every one of its waits would also wait for the weights and the ring in flight (vmcnt is in order)
-        if constexpr (W8) {                          // per-channel scales of the block's 32 columns: lane = (tile l / 16, column l % 16)
+        if constexpr (W8) {                          // per-channel scales of the block's 16 TPB columns: lane = (tile l / 16, column l % 16)
             float sc = 0.f;
-            if (lane < 32 && tile[lane >> 4] < p.NT) sc = (float)as_h2(p.meta[tile[lane >> 4] * 16 + (lane & 15)])[1];
-            if (lane < 32) sg.wsc[lane] = sc;
+            if (lane < 16 * TPB && tile[(lane >> 4) % TPB] < p.NT) sc = (float)as_h2(p.meta[tile[(lane >> 4) % TPB] * 16 + (lane & 15)])[1];
+            if (lane < 16 * TPB) sg.wsc[lane] = sc;
         }
+        constexpr int NPART = 2 * TPB;               // 16-byte parts of the block's 16 TPB columns
         if constexpr (EPI == FK_PUB) {
             // lane = row: the parity of its slot in the NEXT all-reduce call of the context (its blocks add 1 to epoch[row] when they finish)
             sg.par[lane] = (fp.pub_epoch[lane < p.M ? lane : 0] + 1u) & 1u;
-            const int part = lane & 3, n = tile[part >> 1] * 16 + (part & 1) * 8;
+            const int part_c = lane % NPART, n = tile[part_c >> 1] * 16 + (part_c & 1) * 8;
             u32x4 bv = {0u, 0u, 0u, 0u};
-            if (p.bias && lane < 4 && n < p.N) bv = *reinterpret_cast<const u32x4*>(p.bias + n);
-            if (lane < 4) *reinterpret_cast<u32x4*>(&sg.bias[part * 8]) = bv;
+            if (p.bias && lane < NPART && n < p.N) bv = *reinterpret_cast<const u32x4*>(p.bias + n);
+            if (lane < NPART) *reinterpret_cast<u32x4*>(&sg.bias[part_c * 8]) = bv;
         } else if constexpr (EPI == FK_RESID) {
-            // rows x 32 columns of the residual stream: lane = (row i * 16 + l / 4, 16-byte part l % 4); parts 0-1 tile 0, 2-3 tile 1
+            // this block's rows x 16 TPB columns of the residual stream: lane = (row l / NPART of the load, 16-byte part l % NPART); parts 2 t, 2 t + 1 = tile t
             __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)fp.res_in, 0, (uint32_t)((size_t)p.M * p.N * 2), FLAGS);
-            const int part = lane & 3, n = tile[part >> 1] * 16 + (part & 1) * 8;
-            u32x4 rv[4];
+            constexpr int RPL = 64 / NPART, NL = MB * 16 / RPL;   // rows per load, loads for the block's MB row blocks
+            const int part_c = lane % NPART, n = tile[part_c >> 1] * 16 + (part_c & 1) * 8;
+            u32x4 rv[NL];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = i * 16 + (lane >> 2);
+            for (int i = 0; i < NL; ++i) {
+                const int row = rb0 * 16 + i * RPL + lane / NPART;
                 rv[i] = bload128<0>(rr, (row < p.M && n < p.N) ? (uint32_t)(((size_t)row * p.N + n) * 2) : OOBX);
             }
             u32x4 bv = {0u, 0u, 0u, 0u}, gv = bv;
-            if (p.bias && lane < 4 && n < p.N) bv = *reinterpret_cast<const u32x4*>(p.bias + n);
-            if (fp.xg_img && lane < 4 && n < p.N) gv = *reinterpret_cast<const u32x4*>(fp.xg_gamma + n);
+            if (p.bias && lane < NPART && n < p.N) bv = *reinterpret_cast<const u32x4*>(p.bias + n);
+            if (fp.xg_img && lane < NPART && n < p.N) gv = *reinterpret_cast<const u32x4*>(fp.xg_gamma + n);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&sg.res[i * 16 + (lane >> 2)][part * 8]) = rv[i];
-            if (lane < 4) { *reinterpret_cast<u32x4*>(&sg.bias[part * 8]) = bv; *reinterpret_cast<u32x4*>(&sg.gam[part * 8]) = gv; }
+            for (int i = 0; i < NL; ++i) {
+                const int row = rb0 * 16 + i * RPL + lane / NPART;
+                if (row < 64) *reinterpret_cast<u32x4*>(&sg.res[row][part_c * 8]) = rv[i];
+            }
+            if (lane < NPART) { *reinterpret_cast<u32x4*>(&sg.bias[part_c * 8]) = bv; *reinterpret_cast<u32x4*>(&sg.gam[part_c * 8]) = gv; }
         } else {
             const RopeEpi& R = fp.r;
             const int half = R.hd >> 1, hh = R.hd >> 5;
-            const int h = tile[0] / (2 * hh), dj = (tile[0] % (2 * hh)) * 16;      // head, first of the block's 16 dims of the lower half
+            const int dj = (tile[0] % (2 * hh)) * 16;                                // first of the block's 8 TPB dims of the lower half (its pairs are adjacent: one run)
             const int row = lane < p.M ? lane : p.M - 1;                             // lane = token
             const int pos_in = R.positions[row];
-            u32x4 bv = {0u, 0u, 0u, 0u};                                             // bias: lanes 0-1 dims dj..dj+15, lanes 2-3 the same of the upper half
-            if (p.bias && lane < 4) bv = *reinterpret_cast<const u32x4*>(p.bias + h * R.hd + (lane >> 1) * half + dj + (lane & 1) * 8);
+            u32x4 bv = {0u, 0u, 0u, 0u};                                             // bias of the block's columns: lane = (tile l / 2, 16-byte part l % 2)
+            if (p.bias && lane < NPART) bv = *reinterpret_cast<const u32x4*>(p.bias + tile[(lane >> 1) % TPB] * 16 + (lane & 1) * 8);
             const int pos = min(max(pos_in, 0), min(R.max_pos, R.max_blocks * R.page) - 1);
             const int blk = R.block_table[(size_t)(row / R.q_len) * R.max_blocks + pos / R.page];
             sg.pos[lane] = pos_in;
-            if (lane < 4) *reinterpret_cast<u32x4*>(&sg.bias[lane * 8]) = bv;
-            // rotation rows: load i covers tokens 8 i + l / 8, 16-byte part l % 8 of the 128-byte run {cos, sin} x 16 dims
-            f32x4 cv[8];
+            if (lane < NPART) *reinterpret_cast<u32x4*>(&sg.bias[lane * 8]) = bv;
+            // rotation rows of THIS block's tokens: a token's run is {cos, sin} x 8 TPB dims = 4 TPB 16-byte parts; load i covers tokens rb0 16 + i TPL + l / CPT, part l % CPT
+            constexpr int CPT = 4 * TPB, TPL = 64 / CPT, NL = MB * 16 / TPL;
+            f32x4 cv[NL];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int pr = __shfl(pos, i * 8 + (lane >> 3));
-                cv[i] = *reinterpret_cast<const f32x4*>(R.cos_sin + ((size_t)pr * half + dj) * 2 + (lane & 7) * 4);
+            for (int i = 0; i < NL; ++i) {
+                const int tok = min(rb0 * 16 + i * TPL + lane / CPT, 63);
+                const int pr = __shfl(pos, tok);
+                cv[i] = *reinterpret_cast<const f32x4*>(R.cos_sin + ((size_t)pr * half + dj) * 2 + (lane % CPT) * 4);
             }
             sg.blk[lane] = blk;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&sg.cs[i * 8 + (lane >> 3)][(lane & 7) * 4]) = cv[i];
+            for (int i = 0; i < NL; ++i) {
+                const int tok = rb0 * 16 + i * TPL + lane / CPT;
+                if (tok < 64) *reinterpret_cast<f32x4*>(&sg.cs[tok][(lane % CPT) * 4]) = cv[i];
+            }
         }
         FK_STAMP(1);
     } else {
@@ -220,13 +241,17 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
     }   // K-slice waves
     __syncthreads();
     FK_STAMP(4);
-    // wave mb sums row block mb of both tiles, in slice order, and finishes it (short K: fewer waves than row blocks, they take turns)
-    for (int mb = wave; mb < MB; mb += NW + 1) {
-    f32x4 v[TPB];
+    // Epilogue jobs: (tile, row block) for the plain epilogues, (tile pair of a head, row block) for RoPE; job j goes to wave j, j + NW + 1, ...: every job sums its
+    // sets in slice order (the bits do not depend on which wave does it) and finishes them.  (Rounds 4-5 gave wave mb ALL tiles of row block mb: MB busy waves.)
+    constexpr int TJ = (EPI == FK_ROPE) ? 2 : 1;    // tiles of a job
+    constexpr int NJ = (TPB / TJ) * MB;
+    for (int job = wave; job < NJ; job += NW + 1) {
+    const int tg = job / MB, mb = job - tg * MB;     // tile group of the block, row block
+    f32x4 v[TJ];
 #pragma unroll
-    for (int t = 0; t < TPB; ++t) {
-        v[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int w = 0; w < NW; ++w) v[t] += red[((size_t)w * (TPB * MB) + t * MB + mb) * 64 + lane];
+    for (int u = 0; u < TJ; ++u) {
+        v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < NW; ++w) v[u] += red[((size_t)w * (TPB * MB) + (tg * TJ + u) * MB + mb) * 64 + lane];
     }
     const int m = (rb0 + mb) * 16 + jj;
     if (m >= p.M) continue;
@@ -234,48 +259,44 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
     const bool bf = fp.bf16 != 0;                   // dtype of everything 16-bit around the GEMM (the image and the weights' dequant are fp16)
     if constexpr (W8) {                             // per-channel scale of this lane's four columns
 #pragma unroll
-        for (int t = 0; t < TPB; ++t)
+        for (int u = 0; u < TJ; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[t][r] *= sg.wsc[t * 16 + q * 4 + r];
+            for (int r = 0; r < 4; ++r) v[u][r] *= sg.wsc[(tg * TJ + u) * 16 + q * 4 + r];
     }
     if (bf) {                                       // the image of a bf16 tensor holds x 2^-8 (common.h img_val): exact in fp32
 #pragma unroll
-        for (int t = 0; t < TPB; ++t) v[t] *= kImgBfUnscale;
+        for (int u = 0; u < TJ; ++u) v[u] *= kImgBfUnscale;
     }
     if constexpr (EPI == FK_PUB) {
         const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(fp.pub_data, 0, fp.pub_bytes, FLAGS);
         const size_t rowbase = (size_t)sg.par[m] * fp.pub_parity_elems + (size_t)m * fp.pub_slot_elems;
-#pragma unroll
-        for (int t = 0; t < TPB; ++t) {
-            const int n0 = tile[t] * 16 + q * 4;
-            if (n0 >= p.N) continue;
-            const uint16_t* bv = reinterpret_cast<const uint16_t*>(&sg.bias[t * 16 + q * 4]);
+        const int n0 = (unit * TPB + tg) * 16 + q * 4;
+        if (n0 < p.N) {
+            const uint16_t* bv = reinterpret_cast<const uint16_t*>(&sg.bias[tg * 16 + q * 4]);
             uint16_t ob[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ob[r] = rt_to_bits(rt_round(v[t][r] + rt_from_bits(bv[r], bf), bf), bf);   // the linear's output is a 16-bit tensor
+            for (int r = 0; r < 4; ++r) ob[r] = rt_to_bits(rt_round(v[0][r] + rt_from_bits(bv[r], bf), bf), bf);   // the linear's output is a 16-bit tensor
             const u32x2 o = {(uint32_t)ob[0] | ((uint32_t)ob[1] << 16), (uint32_t)ob[2] | ((uint32_t)ob[3] << 16)};
             if (fp.pub_plain) *reinterpret_cast<u32x2*>((f16*)fp.pub_data + rowbase + n0) = o;
             else __builtin_amdgcn_raw_buffer_store_b64(o, rp, (uint32_t)((rowbase + n0) * 2), 0, 17 /* sc0 | sc1: write-through, see allreduce.hip publish16 */);
         }
         FK_STAMP(5);
     } else if constexpr (EPI == FK_RESID) {
-#pragma unroll
-        for (int t = 0; t < TPB; ++t) {
-            const int n0 = tile[t] * 16 + q * 4;
-            if (n0 >= p.N) continue;
-            const uint16_t* bv = reinterpret_cast<const uint16_t*>(&sg.bias[t * 16 + q * 4]);
-            const uint16_t* rin = reinterpret_cast<const uint16_t*>(&sg.res[m][t * 16 + q * 4]);
+        const int tl = unit * TPB + tg, n0 = tl * 16 + q * 4;
+        if (n0 < p.N) {
+            const uint16_t* bv = reinterpret_cast<const uint16_t*>(&sg.bias[tg * 16 + q * 4]);
+            const uint16_t* rin = reinterpret_cast<const uint16_t*>(&sg.res[m][tg * 16 + q * 4]);
             float of[4];
             uint16_t ob[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float y = rt_round(v[t][r] + rt_from_bits(bv[r], bf), bf);    // the linear's output is a 16-bit tensor in the reference
+                const float y = rt_round(v[0][r] + rt_from_bits(bv[r], bf), bf);    // the linear's output is a 16-bit tensor in the reference
                 of[r] = rt_round(y + rt_from_bits(rin[r], bf), bf);
                 ob[r] = rt_to_bits(of[r], bf);
             }
             *reinterpret_cast<u32x2*>(fp.res_out + (size_t)m * p.N + n0) = (u32x2){(uint32_t)ob[0] | ((uint32_t)ob[1] << 16), (uint32_t)ob[2] | ((uint32_t)ob[3] << 16)};
             if (fp.xg_img) {                          // deferred RMSNorm: gamma 2^-e h' for the next GEMM (one rounding, from fp32; fp16 image)
-                const uint16_t* gm = reinterpret_cast<const uint16_t*>(&sg.gam[t * 16 + q * 4]);
+                const uint16_t* gm = reinterpret_cast<const uint16_t*>(&sg.gam[tg * 16 + q * 4]);
                 f16x4 g;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g[r] = (f16)(rt_from_bits(gm[r], bf) * fp.xg_scale * of[r]);
@@ -286,19 +307,20 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s2 += of[r] * of[r];
                 s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-                if (q == 0) fp.ssq_out[(size_t)m * fp.ssq_ld + tile[t]] = s2;
+                if (q == 0) fp.ssq_out[(size_t)m * fp.ssq_ld + tl] = s2;
             }
         }
         FK_STAMP(5);
     } else if constexpr (EPI == FK_ROPE) {
-        // tile pair of one head: this lane holds dims d0..d0+3 (v[0]) and d0+half..+3 (v[1]) of row m = token m
+        // tile pair tg of the block: this lane holds dims d0..d0+3 (v[0]) and d0+half..+3 (v[1]) of row m = token m
         const RopeEpi& R = fp.r;
         const int half = R.hd >> 1, hh = R.hd >> 5;
-        const int h  = tile[0] / (2 * hh);
-        const int d0 = (tile[0] % (2 * hh)) * 16 + q * 4;
+        const int pair = unit * (TPB / 2) + tg, tlo = (pair / hh) * 2 * hh + pair % hh;   // the pair's lower tile
+        const int h  = tlo / (2 * hh);
+        const int d0 = (tlo % (2 * hh)) * 16 + q * 4;
         float x0[4], x1[4];
-        const uint16_t* b0 = reinterpret_cast<const uint16_t*>(&sg.bias[q * 4]);
-        const uint16_t* b1 = reinterpret_cast<const uint16_t*>(&sg.bias[16 + q * 4]);
+        const uint16_t* b0 = reinterpret_cast<const uint16_t*>(&sg.bias[(2 * tg) * 16 + q * 4]);
+        const uint16_t* b1 = reinterpret_cast<const uint16_t*>(&sg.bias[(2 * tg + 1) * 16 + q * 4]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             x0[r] = rt_round(v[0][r] + rt_from_bits(b0[r], bf), bf);
@@ -309,7 +331,7 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
         const int pos = min(max(pos_in, 0), pos_lim - 1);
         const bool is_v = h >= R.nh + R.nkv;
         if (!is_v) {
-            const f32x4 cs01 = *reinterpret_cast<const f32x4*>(&sg.cs[m][q * 8]), cs23 = *reinterpret_cast<const f32x4*>(&sg.cs[m][q * 8 + 4]);
+            const f32x4 cs01 = *reinterpret_cast<const f32x4*>(&sg.cs[m][tg * 32 + q * 8]), cs23 = *reinterpret_cast<const f32x4*>(&sg.cs[m][tg * 32 + q * 8 + 4]);
             const float cc[4] = {cs01[0], cs01[2], cs23[0], cs23[2]}, ss[4] = {cs01[1], cs01[3], cs23[1], cs23[3]};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -349,16 +371,16 @@ __global__ __launch_bounds__(1024) void gemm_fullk64_kernel(const FullKParams fp
             for (int r = 0; r < 4; ++r) { dst[(d0 + r) * R.page + tok] = o0[r]; dst[(d0 + r + half) * R.page + tok] = o1[r]; }
         }
     }
-    }   // row blocks of this wave
+    }   // epilogue jobs of this wave
     if constexpr (EPI == FK_PUB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's published bytes have reached memory before it ends (the kernel boundary then orders them in front of the all-reduce launch's flags)
 }
 
-template <int WB, int GS, int MB, int EPI, int CPW, int RING>
+template <int WB, int GS, int MB, int EPI, int CPW, int RING, int TPB = 2>
 int launch64_t(const FullKParams& fp, int blocks, hipStream_t st) {
-    auto k = gemm_fullk64_kernel<WB, GS, MB, EPI, CPW, RING>;
+    auto k = gemm_fullk64_kernel<WB, GS, MB, EPI, CPW, RING, TPB>;
     const int NW = cdiv(fp.g.KC, CPW);
     if (NW > 15) return MI355_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)NW * 2 * MB * 1024 + sizeof(Stage64<EPI>);
+    const size_t lds = (size_t)NW * TPB * MB * 1024 + sizeof(Stage64<EPI, TPB>);
     if (lds > 160 * 1024) return MI355_ERR_UNSUPPORTED;
     if (lds > 64 * 1024)
         if (int e = raise_dynamic_lds((const void*)k, "gemm_fullk64")) return e;
@@ -381,15 +403,6 @@ int launch64_k(const FullKParams& fp, int blocks, hipStream_t st) {
         if (KC <= 30) return launch64_t<8, 4, MB, EPI, 2, MB == 4 ? MB : 2 * MB>(fp, blocks, st);
         return MI355_ERR_UNSUPPORTED;
     } else {
-#ifdef MI355_TUNING
-    // experiment (round 6): deeper activation rings at <= 32 rows per block -- RING = 2 MB keeps ONE fragment in flight per wave at one row block
-    if constexpr (GS == 4 && MB <= 2) {
-        if (TUNE(9) == 1) { if (KC <= 30) return launch64_t<4, GS, MB, EPI, 2, 4 * MB>(fp, blocks, st); if (KC <= 45) return launch64_t<4, GS, MB, EPI, 3, 4 * MB>(fp, blocks, st);
-                            if (KC <= 75) return launch64_t<4, GS, MB, EPI, 5, 4 * MB>(fp, blocks, st); }
-        if (TUNE(9) == 2) { if (KC <= 30) return launch64_t<4, GS, MB, EPI, 2, 8>(fp, blocks, st); if (KC <= 45) return launch64_t<4, GS, MB, EPI, 3, 8 * MB>(fp, blocks, st);
-                            if (KC <= 75) return launch64_t<4, GS, MB, EPI, 5, 8 * MB>(fp, blocks, st); }
-    }
-#endif
     if (KC <= 30) return launch64_t<4, GS, MB, EPI, 2, 2 * MB>(fp, blocks, st);
     if (KC <= 45) return launch64_t<4, GS, MB, EPI, 3, (GS == 1 && MB == 4) ? MB : 2 * MB>(fp, blocks, st);   // g32 at 64 rows: 24 (zero, scale) words per wave, one k-step in flight fits 128 registers
     // K <= 9600 (hidden 8192: the QKV shard of Llama-3-70B / Qwen2-72B under TP 8): five chunks per wave; their 40 weight registers fit
@@ -424,9 +437,21 @@ extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi35
     return mblk == 1 ? launch64_k<WB_, GS_, 1, EPI_>(fp, BLOCKS_, st) : mblk == 2 ? launch64_k<WB_, GS_, 2, EPI_>(fp, BLOCKS_, st) \
          : mblk == 3 ? launch64_k<WB_, GS_, 3, EPI_>(fp, BLOCKS_, st) : launch64_k<WB_, GS_, 4, EPI_>(fp, BLOCKS_, st)
 #define F64H_(WB_, GS_, EPI_) return mblk <= 2 ? launch64_k<WB_, GS_, 1, EPI_>(fp, 2 * blocks, st) : launch64_k<WB_, GS_, 2, EPI_>(fp, 2 * blocks, st)
+#ifdef MI355_TUNING
+    // round-6 experiment, tuning build only (switch 12 = 1): four tiles per block with the rows over more blocks (see the kernel): W4 g128, K <= 3840.  Measured SLOWER than
+    // the pairs at 64 rows (QKV 11.5 vs 11.0 us, O 8.7 vs 8.0, profiles/r06_fullk64_quad_tiles_ab.txt): fewer wave-loads per CU do not shorten these launches.
+    const bool quad_ok = !w8 && group_size == 128 && g.KC <= 30 && TUNE(12) == 1;
+#endif
     if (epi == FK_ROPE) {
         if (fp.r.hd != 64 && fp.r.hd != 128) return MI355_ERR_UNSUPPORTED;
         const int blocks = (fp.r.nh + 2 * fp.r.nkv) * (fp.r.hd / 32);
+#ifdef MI355_TUNING
+        // 33-64 rows where two blocks per PAIR would not fit one round of the 256 CUs (Qwen2-7B: 144 pairs): two pairs of a head per block, two blocks of 32 rows per unit
+        if (quad_ok && g.M > 32 && 2 * blocks > 256 && blocks % 2 == 0 && blocks <= 256) {
+            fp.rowsplit = ((blocks / 2) % 8 == 0) ? 2 : 1;
+            return launch64_t<4, 4, 2, FK_ROPE, 2, 4, 4>(fp, blocks, st);       // (blocks / 2 units) x 2 row halves
+        }
+#endif
         // a rank's shard of the QKV columns under tensor parallelism (Qwen2-7B tp2: 72 tile pairs, Llama-3-70B tp8: 40) or a small model
         // leaves more than half of the CUs without a block: two blocks per pair, half of the row blocks each, as for the O projection
         if (g.M > 16 && 2 * blocks <= 256 && !(TUNE(4) == 3)) {
@@ -443,6 +468,13 @@ extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi35
     }
     if (epi == FK_RESID) {
         const int blocks = cdiv(g.NT, 2);
+#ifdef MI355_TUNING
+        // 49-64 rows: four tiles x ONE row block per block, four blocks per unit (Qwen2-7B O: 56 units -> 224 blocks, as the two-way split of pairs)
+        if (quad_ok && g.M > 48 && g.NT % 4 == 0 && g.NT <= 256) {
+            fp.rowsplit = ((g.NT / 4) % 8 == 0) ? 4 : 3;
+            return launch64_t<4, 4, 1, FK_RESID, 2, 2, 4>(fp, g.NT, st);
+        }
+#endif
         if (g.M > 16 && 2 * blocks <= 256 && !(TUNE(4) == 3)) {       // two blocks per tile pair, half of the row blocks each (see the kernel)
             fp.rowsplit = (blocks % 8 == 0) ? 2 : 1;
             if (w8) { F64H_(8, 4, FK_RESID); }
@@ -458,6 +490,12 @@ extern "C" int mi355_gemm_fullk64(const void* fp_, int epi, int group_size, mi35
     if (epi == FK_PUB) {                             // a row-parallel TP shard straight into the registered all-reduce buffer: W4 g128 / per-channel W8
         if (!w8 && group_size != 128) return MI355_ERR_UNSUPPORTED;
         const int blocks = cdiv(g.NT, 2);
+#ifdef MI355_TUNING
+        if (quad_ok && g.M > 48 && g.NT % 4 == 0 && g.NT <= 256) {
+            fp.rowsplit = ((g.NT / 4) % 8 == 0) ? 4 : 3;
+            return launch64_t<4, 4, 1, FK_PUB, 2, 2, 4>(fp, g.NT, st);
+        }
+#endif
         if (g.M > 16 && 2 * blocks <= 256) {
             fp.rowsplit = (blocks % 8 == 0) ? 2 : 1;
             if (w8) { F64H_(8, 4, FK_PUB); }
