@@ -224,6 +224,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
         }
     }
     f16x8 a_cur = dq(Slot0{}, 0, 0);
+    // experiments (VERDICT r05 item 6 i): the second wave of every SIMD (th = 1: waves w and w + 4 share a SIMD) enters the loop HALF a unit (~44 cycles: 128) or a
+    // whole unit (~90 cycles: 256, the control) behind its partner, so that one dequantises while the other's MFMAs run
+    if constexpr (DBG & 128) { if (th == 1) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 11" ::: "memory"); }
+    if constexpr (DBG & 256) { if (th == 1) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 9" ::: "memory"); }
     if constexpr (DBG & 64) { if (th == 1) __builtin_amdgcn_s_setprio(2); }   // experiment: ONE wave of every SIMD pair runs at a higher priority for the whole loop (asymmetric arbitration)
     if constexpr (DBG & 4) st1 = wall_clock64();
     u32x4 aE = __builtin_bit_cast(u32x4, a_cur), aO = aE;   // HAND: operand of even / odd units (fixed register tuples)
@@ -452,6 +456,8 @@ static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_
     else if (mb2 && WIDE_DBG == 16) rc = launch_wide_t<4, 2, 4, T, 0, 1>(wp, st);   // one chunk ahead (the round-2..4 instance)
     else if (!mb2 && WIDE_DBG == 18) rc = launch_wide_t<4, 4, 4, T, 8>(wp, st);       // K-slice merge in two rounds (rounds 1-4)
     else if (mblk == 4 && WIDE_DBG == 32) rc = launch_wide_t<4, 4, 4, T, 32>(wp, st);   // round 6: s_setprio 2 over the unit's MFMA group
+    else if (mblk == 4 && WIDE_DBG == 128) rc = launch_wide_t<4, 4, 4, T, 128>(wp, st);  // round 6: the second wave of every SIMD half a unit behind its partner
+    else if (mblk == 4 && WIDE_DBG == 256) rc = launch_wide_t<4, 4, 4, T, 256>(wp, st);  // ... a whole unit behind (control)
     else if (mblk == 4 && WIDE_DBG == 64) rc = launch_wide_t<4, 4, 4, T, 64>(wp, st);   // round 6: the second wave of every SIMD at priority 2 for the whole loop
     else if (mb2 && WIDE_DBG == 17) rc = launch_wide_t<4, 2, 4, T, 0, 2>(wp, st);   // two row blocks whatever the row count
     else if (mb2 && WIDE_DBG == 2)  rc = launch_wide_t<4, 2, 4, T, 2, 2>(wp, st);   // instruction stream without weight traffic
