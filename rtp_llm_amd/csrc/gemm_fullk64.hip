@@ -403,6 +403,9 @@ int launch64_k(const FullKParams& fp, int blocks, hipStream_t st) {
         if (KC <= 30) return launch64_t<8, 4, MB, EPI, 2, MB == 4 ? MB : 2 * MB>(fp, blocks, st);
         return MI355_ERR_UNSUPPORTED;
     } else {
+    // very short K (the O shard of a TP 8 rank: K = 1024, or TP 4 of Qwen2-7B: 896): one chunk per wave -- 7-8 K waves instead of 4, half the dependent fragment steps per wave.
+    // Llama-3-70B tp 8 one rank's step 5.50 -> 5.47 ms; 14 chunks (Qwen2-7B tp 2: K = 1792) measured the same either way and keep two (profiles/r06_fullk64_short_k_one_chunk.txt)
+    if (KC <= 8 && TUNE(14) != 1) return launch64_t<4, GS, MB, EPI, 1, 2 * MB>(fp, blocks, st);
     if (KC <= 30) return launch64_t<4, GS, MB, EPI, 2, 2 * MB>(fp, blocks, st);
     if (KC <= 45) return launch64_t<4, GS, MB, EPI, 3, (GS == 1 && MB == 4) ? MB : 2 * MB>(fp, blocks, st);   // g32 at 64 rows: 24 (zero, scale) words per wave, one k-step in flight fits 128 registers
     // K <= 9600 (hidden 8192: the QKV shard of Llama-3-70B / Qwen2-72B under TP 8): five chunks per wave; their 40 weight registers fit
