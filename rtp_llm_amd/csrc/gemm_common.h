@@ -53,6 +53,24 @@
     "v_pk_mul_f16 " N2 ", " N2 ", %[sc]\n\t"                                \
     "v_pk_mul_f16 " N3 ", " N3 ", %[sc]"
 
+// TIMING ONLY (round 6, tuning build): the unit the route "zero point out of the operand" would run -- 4 v_and_or + shift + 4 v_pk_fma_f16 (1024 + u, s, -1024 s)
+// = 9 VALU for the 4 MFMAs.  The operands here are s (u - z) with the zero point applied through the fma's addend (zn / znb times nothing exact): the RESULTS ARE WRONG, the
+// instruction stream is what is measured.
+#define WIDE_UNIT_W4_FMA9(AIN, N0, N1, N2, N3)                              \
+    "v_lshrrev_b32 %[t], 8, %[w]\n\t"                                       \
+    "v_and_or_b32 " N0 ", %[w], %[m0], %[e0]\n\t"                           \
+    "v_mfma_f32_16x16x32_f16 %[c0], " AIN ", %[b0], %[c0]\n\t"              \
+    "v_and_or_b32 " N1 ", %[w], %[m1], %[e1]\n\t"                           \
+    "v_and_or_b32 " N2 ", %[t], %[m0], %[e0]\n\t"                           \
+    "v_mfma_f32_16x16x32_f16 %[c1], " AIN ", %[b1], %[c1]\n\t"              \
+    "v_and_or_b32 " N3 ", %[t], %[m1], %[e1]\n\t"                           \
+    "v_pk_fma_f16 " N0 ", " N0 ", %[sc], %[zn]\n\t"                         \
+    "v_mfma_f32_16x16x32_f16 %[c2], " AIN ", %[b2], %[c2]\n\t"              \
+    "v_pk_fma_f16 " N1 ", " N1 ", %[sc], %[znb]\n\t"                        \
+    "v_pk_fma_f16 " N2 ", " N2 ", %[sc], %[zn]\n\t"                         \
+    "v_mfma_f32_16x16x32_f16 %[c3], " AIN ", %[b3], %[c3]\n\t"              \
+    "v_pk_fma_f16 " N3 ", " N3 ", %[sc], %[znb]"
+
 // Same for 32 rows (2 MFMAs per unit): VALU-issue bound, the MFMAs sit where >= 5 independent VALU follow.
 #define WIDE_UNIT_W4_MB2(AIN, N0, N1, N2, N3)                               \
     "v_lshrrev_b32 %[t], 8, %[w]\n\t"                                       \
@@ -155,7 +173,7 @@ __device__ __forceinline__ W4Consts w4_consts() {
 // One hand-ordered (tile, k-step) unit for MB row blocks (WIDE_UNIT_W4*): the operand of THIS unit sits in the fixed tuple of its
 // parity (even units v[100:103] = aE, odd ones v[104:107] = aO) and the dword `wn` is dequantised into the other tuple for the next
 // unit.  c0..c3 / b0..b3: accumulators (AGPRs) and B fragments of the unit's row blocks; those >= MB are not touched.
-template <int MB, bool EVEN, class BT, bool PRIO = false>
+template <int MB, bool EVEN, class BT, int PRIO = 0>   // PRIO: 0 the product stream, 1 s_setprio experiment, 2 the 9-VALU timing-only stream
 __device__ __forceinline__ void wide_unit_w4(u32x4& aE, u32x4& aO, uint32_t wn, const W4Consts& k, f16x2 zn, f16x2 znb, f16x2 sc,
                                              f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3, const BT& b0, const BT& b1, const BT& b2, const BT& b3) {
     uint32_t tmp;
@@ -166,7 +184,10 @@ __device__ __forceinline__ void wide_unit_w4(u32x4& aE, u32x4& aO, uint32_t wn, 
 #define WU_ACC2_ [c0] "+a"(c0), [c1] "+a"(c1)
 #define WU_ACC3_ [c0] "+a"(c0), [c1] "+a"(c1), [c2] "+a"(c2)
 #define WU_ACC4_ [c0] "+a"(c0), [c1] "+a"(c1), [c2] "+a"(c2), [c3] "+a"(c3)
-    if constexpr (MB == 4 && PRIO) {
+    if constexpr (MB == 4 && PRIO == 2) {
+        if constexpr (EVEN) WU_EVEN_(WIDE_UNIT_W4_FMA9, WU_ACC4_, [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3));
+        else                WU_ODD_(WIDE_UNIT_W4_FMA9, WU_ACC4_, [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3));
+    } else if constexpr (MB == 4 && PRIO == 1) {
         if constexpr (EVEN) WU_EVEN_(WIDE_UNIT_W4_PRIO, WU_ACC4_, [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3));
         else                WU_ODD_(WIDE_UNIT_W4_PRIO, WU_ACC4_, [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3));
     } else if constexpr (MB == 4) {

@@ -41,7 +41,7 @@ struct SplitK64Params {
 // accumulators before the slab store (every K split is scaled alike, so the fold's sum of slabs is the scaled sum).
 // DIRECT (round 6): the fused-epilogue store is an instance of its own -- with both stores behind a run-time `mode` the slab instances of the headline's
 // down_proj carried gemm_store's code and registers and measured 17.2 -> 17.6 us (profiles/r06_r04_vs_r05_same_box.txt).
-template <int WB, int GS, int MB, int T, int CPW, int RING, bool DIRECT = false>
+template <int WB, int GS, int MB, int T, int CPW, int RING, bool DIRECT = false, int UV = 0>   // UV: unit variant (2: the timing-only 9-VALU stream, tuning build)
 __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params sp) {
     const GemmParams& p = sp.g;
     constexpr int NW = 8;
@@ -131,6 +131,10 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
         zn[t]  = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u));
         scl[t] = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
         znb[t] = zn[t] + c960;
+        if constexpr (UV == 2) {                         // timing-only 9-VALU unit: the addends of its fma, -1024 s and -64 s (operand = s u: tame values, wrong results)
+            const f16x2 km = {(f16)-1024.f, (f16)-1024.f}, kb = {(f16)-64.f, (f16)-64.f};
+            zn[t] = scl[t] * km; znb[t] = scl[t] * kb;
+        }
     };
     u32x4 aE, aO;                                        // W4: operand of even / odd units (fixed register tuples)
     if constexpr (!W8) {
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
             if constexpr (sn % SPG == 0) meta_of(cn, tn, sn);
             wn = wr[cn & 1][tn][0][sn];
         }
-        wide_unit_w4<MB, u % 2 == 0>(aE, aO, wn, w4c, zn[tn % T], znb[tn % T], scl[tn % T], acc[t][0], acc[t][MB > 1 ? 1 : 0], acc[t][MB > 2 ? 2 : 0],
+        wide_unit_w4<MB, u % 2 == 0, u32x4, UV>(aE, aO, wn, w4c, zn[tn % T], znb[tn % T], scl[tn % T], acc[t][0], acc[t][MB > 1 ? 1 : 0], acc[t][MB > 2 ? 2 : 0],
                                      acc[t][MB > 3 ? 3 : 0], xr[ks % RING][0], xr[ks % RING][MB > 1 ? 1 : 0], xr[ks % RING][MB > 2 ? 2 : 0],
                                      xr[ks % RING][MB > 3 ? 3 : 0]);
         }
@@ -200,9 +204,9 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
     }
 }
 
-template <int WB, int GS, int MB, int T, int CPW, int RING, bool DIRECT = false>
+template <int WB, int GS, int MB, int T, int CPW, int RING, bool DIRECT = false, int UV = 0>
 int launch_splitk64_t(const SplitK64Params& sp, int G, hipStream_t st) {
-    auto k = gemm_splitk64_kernel<WB, GS, MB, T, CPW, RING, DIRECT>;
+    auto k = gemm_splitk64_kernel<WB, GS, MB, T, CPW, RING, DIRECT, UV>;
     const size_t lds = (size_t)8 * T * MB * 1024;
     if (lds > 160 * 1024) return MI355_ERR_UNSUPPORTED;
     if (lds > 64 * 1024)
@@ -285,6 +289,12 @@ extern "C" int mi355_gemm_splitk64(const void* gp, int wbits, int group_size, in
     int rc;
 #define SK_MB_(WB_, GS_, MB_) (cpw <= 3 ? launch_splitk64_t<WB_, GS_, MB_, 4, 3, 3>(sp, G, st) : launch_splitk64_t<WB_, GS_, MB_, 4, 5, 3>(sp, G, st))
 #define SK_(WB_, GS_) rc = mblk == 1 ? SK_MB_(WB_, GS_, 1) : mblk == 2 ? SK_MB_(WB_, GS_, 2) : mblk == 3 ? SK_MB_(WB_, GS_, 3) : SK_MB_(WB_, GS_, 4)
+#ifdef MI355_TUNING
+    if (wbits == 4 && group_size == 128 && mblk == 4 && cpw > 3 && sp.dbg == 9) {   // round 6, TIMING ONLY (results wrong): the 9-VALU unit of DESIGN 9 J (--debug-set 7=9)
+        rc = launch_splitk64_t<4, 4, 4, 4, 5, 3, false, 2>(sp, G, st);
+        return rc == MI355_OK ? ns : rc;
+    }
+#endif
     if (wbits == 8) { SK_(8, 4); } else if (group_size == 128) { SK_(4, 4); } else if (group_size == 64) { SK_(4, 2); } else { SK_(4, 1); }
 #undef SK_MB_
 #undef SK_

@@ -147,6 +147,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
         zn  = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u));
         scl = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
         if (WBITS == 4) znb = zn + c960;
+        if constexpr ((DBG & 512) != 0) {               // timing-only 9-VALU unit: the addends of its fma, -1024 s and -64 s (operand = s u: tame values, wrong results)
+            const f16x2 km = {(f16)-1024.f, (f16)-1024.f}, kb = {(f16)-64.f, (f16)-64.f};
+            zn = scl * km; znb = scl * kb;
+        }
     };
     auto dq = [&](auto slot_c, int t, int s) -> f16x8 {
         constexpr int SL = decltype(slot_c)::value;
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
             if constexpr (HAND) {
                 if constexpr (sn % SPG == 0) meta_of(SlotU{}, tn, sn);
                 const uint32_t wn = wr[SlotU::value][tn][0][sn];
-                wide_unit_w4<MB, u % 2 == 0, f16x8, (DBG & 32) != 0>(aE, aO, wn, w4c, zn, znb, scl, acc[t][0], acc[t][MB > 1 ? 1 : 0], acc[t][MB > 2 ? 2 : 0],
+                wide_unit_w4<MB, u % 2 == 0, f16x8, (DBG & 32) ? 1 : (DBG & 512) ? 2 : 0>(aE, aO, wn, w4c, zn, znb, scl, acc[t][0], acc[t][MB > 1 ? 1 : 0], acc[t][MB > 2 ? 2 : 0],
                                              acc[t][MB > 3 ? 3 : 0], bq[0][s], bq[MB > 1 ? 1 : 0][s], bq[MB > 2 ? 2 : 0][s], bq[MB > 3 ? 3 : 0][s]);
             } else {
                 const f16x8 a_next = dq(SlotU{}, tn, sn);
@@ -456,6 +460,7 @@ static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_
     else if (mb2 && WIDE_DBG == 16) rc = launch_wide_t<4, 2, 4, T, 0, 1>(wp, st);   // one chunk ahead (the round-2..4 instance)
     else if (!mb2 && WIDE_DBG == 18) rc = launch_wide_t<4, 4, 4, T, 8>(wp, st);       // K-slice merge in two rounds (rounds 1-4)
     else if (mblk == 4 && WIDE_DBG == 32) rc = launch_wide_t<4, 4, 4, T, 32>(wp, st);   // round 6: s_setprio 2 over the unit's MFMA group
+    else if (mblk == 4 && WIDE_DBG == 512) rc = launch_wide_t<4, 4, 4, T, 512>(wp, st);  // round 6, TIMING ONLY (results wrong): the 9-VALU unit of DESIGN 9 J
     else if (mblk == 4 && WIDE_DBG == 128) rc = launch_wide_t<4, 4, 4, T, 128>(wp, st);  // round 6: the second wave of every SIMD half a unit behind its partner
     else if (mblk == 4 && WIDE_DBG == 256) rc = launch_wide_t<4, 4, 4, T, 256>(wp, st);  // ... a whole unit behind (control)
     else if (mblk == 4 && WIDE_DBG == 64) rc = launch_wide_t<4, 4, 4, T, 64>(wp, st);   // round 6: the second wave of every SIMD at priority 2 for the whole loop
