@@ -318,18 +318,6 @@ int mi355_linear_direct_img(const void* x_img, int32_t M, const mi355_weight_t* 
  * 8 K-slice waves of <= 5 chunks per block: the caller uses mi355_linear_partial on the row-major tensor) */
 int mi355_linear_partial_img(const void* x_img, int32_t M, const mi355_weight_t* w, float* partials, int32_t max_splits,
                              mi355_stream_t stream);
-/* Round 6, the zero point OUT of the W4 operand for the deep-K linear at 49-64 rows (DenseMLP.down_proj, modules/hybrid/dense_mlp.py:104-105; the dequantisation it must
- * reproduce: W = scale (q - zero), rtp_llm/device/device_impl.py:242-300): W = s q - s z, so x W = x (s q) - sum_g (s z)[g] X[g] with X[g] the sum of the
- * activations of group g.  The K-quarter blocks multiply by the exact operand s q (one rounding, 9 instead of 13 VALU per 8 weights) and extra blocks on the CUs they
- * leave idle write the zero term as one more fp32 slab.
- * mi355_linear_deferred_norm_img_xs: mi355_linear_deferred_norm_img (SiLU-gate, image output, fp16) that also leaves tile_rowsum_out[tile * 64 + row] (fp32 sum of the
- *   8 stored outputs of W's 16-column tile `tile` in `row`; [N / 16][64] floats).
- * mi355_linear_partial_img_zs: zero_plane = - s z split hi / lo in MFMA-fragment order (rtp_llm_amd/quant.py make_zero_plane; [N_pad / 16][3 ceil(K / 4096)][64][8] fp16),
- *   tile_rowsum as left by the producer of x_img ([K / 8][64]); returns the slab count incl. the zero-term slab, or MI355_ERR_UNSUPPORTED (use mi355_linear_partial_img). */
-int mi355_linear_deferred_norm_img_xs(const void* xg_img, int32_t M, const mi355_deferred_norm_t* dn, const mi355_weight_t* w,
-                                      const void* bias, void* y_img, float* tile_rowsum_out, mi355_stream_t stream);
-int mi355_linear_partial_img_zs(const void* x_img, int32_t M, const mi355_weight_t* w, const void* zero_plane, const float* tile_rowsum,
-                                float* partials, int32_t max_splits, mi355_stream_t stream);
 int mi355_qkv_rope_kv_write_img(const void* x_img, int32_t M, const mi355_weight_t* wqkv, const void* qkv_bias,
                                 const float* cos_sin, int32_t rope_dim, int32_t max_pos, const int32_t* positions,
                                 const int32_t* block_table, int32_t max_blocks_per_seq, int32_t q_len, int32_t nh,

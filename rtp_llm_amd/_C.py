@@ -101,8 +101,6 @@ SIGNATURES = {
     "mi355_linear_deferred_norm_img": (i32, [vp, i32, C.POINTER(DeferredNorm), C.POINTER(Weight), vp, vp, i32, vp]),
     "mi355_linear_direct_img": (i32, [vp, i32, C.POINTER(Weight), vp, vp, i32, vp]),
     "mi355_linear_partial_img": (i32, [vp, i32, C.POINTER(Weight), vp, i32, vp]),
-    "mi355_linear_deferred_norm_img_xs": (i32, [vp, i32, C.POINTER(DeferredNorm), C.POINTER(Weight), vp, vp, vp, vp]),
-    "mi355_linear_partial_img_zs": (i32, [vp, i32, C.POINTER(Weight), vp, vp, vp, i32, vp]),
     "mi355_qkv_rope_kv_write_img": (i32, [vp, i32, C.POINTER(Weight), vp, vp, i32, i32, vp, vp, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
     "mi355_qkv_rope_kv_write": (i32, [vp, i32, C.POINTER(Weight), vp, C.POINTER(FusedNorm), vp, i32, i32, vp, vp, i32, i32, i32, C.POINTER(KVLayer), vp, vp, vp]),
     "mi355_paged_attn_workspace_bytes": (sz, [i32, i32, i32, i32]),

@@ -37,8 +37,6 @@ extern "C" int mi355_gemm_fullk_residual_img(const void* gp, int wbits, int grou
 extern "C" int mi355_gemm_splitk64(const void* gp, int wbits, int group_size, int max_splits, mi355_stream_t stream);
 extern "C" int mi355_gemm_splitk64_direct(const void* gp, int wbits, int group_size, mi355_stream_t stream);
 extern "C" int mi355_gemm_wide_img(const void* gp, int wbits, int group_size, const mi355_deferred_norm_t* dn, mi355_stream_t stream);
-extern "C" int mi355_gemm_wide_img_xs(const void* gp, int wbits, int group_size, const mi355_deferred_norm_t* dn, float* xs_out, mi355_stream_t stream);
-extern "C" int mi355_gemm_splitk64_zs(const void* gp, int wbits, int group_size, int max_splits, const void* zplane, const float* xs, mi355_stream_t stream);
 extern "C" int mi355_gemm_fullk_rope_img(const void* gp, int wbits, int group_size, const float* cos_sin, int32_t max_pos,
                                          const int32_t* positions, const int32_t* block_table, int32_t max_blocks_per_seq,
                                          int32_t q_len, int32_t nh, const mi355_kv_layer_t* kv, void* q_out, int32_t* oob_count,
@@ -1017,21 +1015,6 @@ extern "C" int mi355_linear_deferred_norm_img(const void* xg_img, int32_t M, con
     return mi355_gemm_wide_img(&p, w->wbits, w->group_size, dn, stream);
 }
 
-// mi355_linear_deferred_norm_img with MI355_EPI_SILU_MUL | MI355_EPI_OUT_IMAGE that also leaves tile_rowsum_out[tile * 64 + row] = the fp32 sum of the 8 stored fp16
-// outputs of (16-column tile of W, row): what mi355_linear_partial_img_zs rebuilds the per-group activation sums of the NEXT linear from.  fp16, W4 group-wise, no bf16.
-extern "C" int mi355_linear_deferred_norm_img_xs(const void* xg_img, int32_t M, const mi355_deferred_norm_t* dn, const mi355_weight_t* w,
-                                                 const void* bias, void* y_img, float* tile_rowsum_out, mi355_stream_t stream) {
-    if (int e = check_weight(w)) return e;
-    MI355_CHECK_ARG(xg_img && y_img && tile_rowsum_out && M > 0, "linear_deferred_norm_img_xs: bad args (M=%d)", M);
-    MI355_CHECK_ARG(!dn || (dn->tile_sumsq && dn->tiles == w->K / 16 && dn->tiles <= 512 && dn->tiles % 4 == 0 && dn->ld >= dn->tiles && dn->ld % 4 == 0 && dn->eps > 0.f && dn->unscale > 0.f),
-                    "linear_deferred_norm_img_xs: needs tile_sumsq [M][ld >= K/16 = %d, multiple of 4], eps and unscale", w->K / 16);
-    if (M < 1 || M > 64 || !img_weight_ok(w) || w->act_dtype != MI355_ACT_F16 || w->wbits != 4 || (w->N / 2) % 32 != 0) return MI355_ERR_UNSUPPORTED;
-    GemmParams p; fill_params(p, xg_img, M, w);
-    p.mode = MODE_SILU; p.bias = (const f16*)bias; p.y = y_img; p.ldy = w->N / 2; p.y_img = 1;
-    p.x_img = 1; p.x_bytes = (uint32_t)mi355_act_image_bytes(M, w->K);
-    return mi355_gemm_wide_img_xs(&p, w->wbits, w->group_size, dn, tile_rowsum_out, stream);
-}
-
 // y = epilogue(x W + bias) in ONE launch from an activation image, for a linear whose N does not fill the chip in the wide GEMM's form: a column-parallel
 // shard under tensor parallelism (gemm_splitk64.hip, direct form).  MI355_ERR_UNSUPPORTED when the shape has no plan (the caller stays on mi355_linear_direct).
 extern "C" int mi355_linear_direct_img(const void* x_img, int32_t M, const mi355_weight_t* w, const void* bias, void* y, int32_t epilogue,
@@ -1061,19 +1044,6 @@ extern "C" int mi355_linear_partial_img(const void* x_img, int32_t M, const mi35
     GemmParams p; fill_params(p, x_img, M, w);
     p.x_img = 1; p.x_bytes = (uint32_t)mi355_act_image_bytes(M, w->K); p.partials = partials;
     return mi355_gemm_splitk64(&p, w->wbits, w->group_size, max_splits > 16 ? 16 : max_splits, stream);
-}
-
-// mi355_linear_partial_img with the zero point OUT of the MFMA operand (gemm_splitk64.hip, ZS): 49-64 rows, W4 g128, fp16.  zero_plane = quant.make_zero_plane(w)
-// (- scale x zero split hi / lo, MFMA-fragment order); tile_rowsum = what mi355_linear_deferred_norm_img_xs left for x_img ([K / 8][64] fp32).  Returns the number of
-// slabs (the last one is the zero term), or MI355_ERR_UNSUPPORTED (the caller uses mi355_linear_partial_img).
-extern "C" int mi355_linear_partial_img_zs(const void* x_img, int32_t M, const mi355_weight_t* w, const void* zero_plane, const float* tile_rowsum,
-                                           float* partials, int32_t max_splits, mi355_stream_t stream) {
-    if (int e = check_weight(w)) return e;
-    MI355_CHECK_ARG(x_img && partials && zero_plane && tile_rowsum && M > 0 && max_splits >= 2, "linear_partial_img_zs: bad args (M=%d)", M);
-    if (M < 1 || M > 64 || !img_weight_ok(w) || w->act_dtype != MI355_ACT_F16) return MI355_ERR_UNSUPPORTED;
-    GemmParams p; fill_params(p, x_img, M, w);
-    p.x_img = 1; p.x_bytes = (uint32_t)mi355_act_image_bytes(M, w->K); p.partials = partials;
-    return mi355_gemm_splitk64_zs(&p, w->wbits, w->group_size, max_splits > 16 ? 16 : max_splits, zero_plane, tile_rowsum, stream);
 }
 
 extern "C" int mi355_qkv_rope_kv_write_img(const void* x_img, int32_t M, const mi355_weight_t* wqkv, const void* qkv_bias,

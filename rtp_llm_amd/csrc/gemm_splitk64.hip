@@ -29,14 +29,6 @@ struct SplitK64Params {
     GemmParams g;     // x: activation image; partials: slabs [nsplit][M][N_pad]; cps: chunks per block
     int xmap;         // > 0: 1-D grid, XCDs per K split (see the kernel)
     int dbg;          // tuning build, timing only (same instruction stream): 1 no activation traffic, 2 no weight traffic
-    // ZS (round 6, UV == 2): the zero point leaves the operand.  W = s (u - z) = s u - s z: the K-quarter blocks multiply with the operand s u
-    // (v_pk_fma_f16(1024 + u, s, -1024 s): exact, one rounding, 9 VALU per 8 weights instead of 13) and `nzb` EXTRA blocks -- on the CUs the 224 K-quarter blocks leave
-    // idle -- compute the zero term  - sum_g (s z)[n][g] X[g][m]  as one more slab: X[g][m] = the sum of the activations of group g of row m (rebuilt from the producer's
-    // per-tile row sums xs[tile * 64 + m], 16 tiles of 8 outputs per group), `zplane` = - s z split hi / lo as MFMA A fragments [tile][3 gpad / 32 k-steps][64 lanes][8],
-    // k' = part * gpad + g with the parts (hi . X hi), (hi . X lo), (lo . X hi): exact to 2^-22 (quant.make_zero_plane).  Null zplane: the plain form.
-    const void*  zplane;
-    const float* xs;
-    int nmain, nzb, gpad;   // K-quarter blocks (grid.x beyond them: the zero-term blocks), groups padded to a multiple of 32
 };
 
 // Direct form (round 5, mi355_gemm_splitk64_direct): ONE K split and T = 2..5 tiles per block with the fused epilogue of the wide GEMM (bias / SiLU-mul,
@@ -64,55 +56,6 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int jj = lane & 15, q = lane >> 4;
-    if constexpr (UV == 2) {
-        if ((int)blockIdx.x >= sp.nmain) {
-            // =========================================================== zero-term block (ZS, see SplitK64Params): no K quarter
-            const int zb = (int)blockIdx.x - sp.nmain, GP = sp.gpad, NKZ = 3 * GP / 32, MBLK = (p.M + 15) >> 4;
-            u32x4* bsh = reinterpret_cast<u32x4*>(smem);                 // B fragments of the zero term: [NKZ][4 row blocks][64 lanes] x 16 bytes
-            for (int idx = (int)threadIdx.x; idx < NKZ * 4 * 64; idx += 512) bsh[idx] = (u32x4){0u, 0u, 0u, 0u};
-            __syncthreads();
-            // X[g][m]: wave per group, lane = row; the 16 tile sums of a group in tile order (deterministic), then hi / lo
-            f16* bh = reinterpret_cast<f16*>(smem);
-            for (int g = wave; g < p.KC; g += NW) {
-                const float* src = sp.xs + (size_t)g * 16 * 64 + lane;
-                float v[16];
-#pragma unroll
-                for (int t = 0; t < 16; ++t) v[t] = lane < p.M ? src[t * 64] : 0.f;
-                float x = 0.f;
-#pragma unroll
-                for (int t = 0; t < 16; ++t) x += v[t];
-                const f16 h = (f16)x, l = (f16)(x - (float)h);
-#pragma unroll
-                for (int pp = 0; pp < 3; ++pp) {
-                    const int kp = pp * GP + g, j = kp >> 5, qq = (kp & 31) >> 3, e = kp & 7;
-                    bh[(size_t)(((j * 4 + (lane >> 4)) * 64 + qq * 16 + (lane & 15)) * 8) + e] = (pp == 1) ? l : h;
-                }
-            }
-            __syncthreads();
-            const int tpb = (p.NT + sp.nzb - 1) / sp.nzb;                // tiles of this block, one per wave and round
-            __amdgpu_buffer_rsrc_t rsz = slab_rsrc(p, p.nsplit + 1);
-            for (int tt = wave; tt < tpb; tt += NW) {
-                const int tile = zb * tpb + tt;
-                if (tile >= p.NT) break;
-                const u32x4* zp = reinterpret_cast<const u32x4*>(sp.zplane) + (size_t)tile * NKZ * 64 + lane;
-                f32x4 az[4];
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb) az[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                for (int j = 0; j < NKZ; ++j) {
-                    const f16x8 a = __builtin_bit_cast(f16x8, zp[(size_t)j * 64]);
-#pragma unroll
-                    for (int rb = 0; rb < 4; ++rb)
-                        if (rb < MBLK) az[rb] = mfma16x16x32(a, __builtin_bit_cast(f16x8, bsh[(j * 4 + rb) * 64 + lane]), az[rb]);
-                }
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
-                    const int m = rb * 16 + jj;
-                    if (rb < MBLK && m < p.M) st_slab(rsz, (uint32_t)((((size_t)p.nsplit * p.M + m) * p.N_pad + tile * 16 + q * 4) * 4), az[rb]);
-                }
-            }
-            return;
-        }
-    }
     // block -> (column group, K split).  Every block of a K split reads the same slice of the activation image: with the splits laid
     // out over the XCDs (block b runs on XCD b % 8 -- observed, used for speed only; sp.xmap = XCDs per split) an XCD's L2 fetches one
     // slice instead of the whole image (Qwen2-7B down at 64 rows: 4.8 MB instead of 19 MB crossing the fabric per launch)
@@ -188,7 +131,7 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
         zn[t]  = as_h2(__builtin_amdgcn_perm(m, m, 0x05040504u));
         scl[t] = as_h2(__builtin_amdgcn_perm(m, m, 0x07060706u));
         znb[t] = zn[t] + c960;
-        if constexpr (UV == 2) {                         // ZS: the addends of the 9-VALU unit's fma, -1024 s and -64 s: operand = s u exactly (one rounding); the zero term is the extra blocks' slab
+        if constexpr (UV == 2) {                         // timing-only 9-VALU unit: the addends of its fma, -1024 s and -64 s (operand = s u: tame values, wrong results)
             const f16x2 km = {(f16)-1024.f, (f16)-1024.f}, kb = {(f16)-64.f, (f16)-64.f};
             zn[t] = scl[t] * km; znb[t] = scl[t] * kb;
         }
@@ -196,17 +139,7 @@ __global__ __launch_bounds__(512) void gemm_splitk64_kernel(const SplitK64Params
     u32x4 aE, aO;                                        // W4: operand of even / odd units (fixed register tuples)
     if constexpr (!W8) {
         meta_of(0, 0, 0);
-        if constexpr (UV == 2) {   // ZS: the first operand by the same arithmetic as the unit's stream, fma(1024 + u, s, -1024 s) = s u (meta_of left the addends in zn / znb)
-            const uint32_t w0 = wr[0][0][0][0], w8 = w0 >> 8;
-            u32x4 r;
-            r[0] = __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(as_h2(and_or(w0, w4c.m0, w4c.e0)), scl[0], zn[0]));
-            r[1] = __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(as_h2(and_or(w0, w4c.m1, w4c.e1)), scl[0], znb[0]));
-            r[2] = __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(as_h2(and_or(w8, w4c.m0, w4c.e0)), scl[0], zn[0]));
-            r[3] = __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(as_h2(and_or(w8, w4c.m1, w4c.e1)), scl[0], znb[0]));
-            aE = r; aO = aE;
-        } else {
         aE = __builtin_bit_cast(u32x4, dequant_w4_vc(wr[0][0][0][0], zn[0], znb[0], scl[0], w4c)); aO = aE;
-        }
     }
 
     // ---- units in k-step-major order: u = (ks * T + t), ks = 4 c + s
@@ -278,7 +211,7 @@ int launch_splitk64_t(const SplitK64Params& sp, int G, hipStream_t st) {
     if (lds > 160 * 1024) return MI355_ERR_UNSUPPORTED;
     if (lds > 64 * 1024)
         if (int e = raise_dynamic_lds((const void*)k, "gemm_splitk64")) return e;
-    if (sp.xmap > 0) hipLaunchKernelGGL(k, dim3(G * sp.g.nsplit + (UV == 2 ? sp.nzb : 0)), dim3(512), lds, st, sp);
+    if (sp.xmap > 0) hipLaunchKernelGGL(k, dim3(G * sp.g.nsplit), dim3(512), lds, st, sp);
     else             hipLaunchKernelGGL(k, dim3(G, sp.g.nsplit), dim3(512), lds, st, sp);
     MI355_CHECK_LAUNCH("gemm_splitk64_kernel");
     return MI355_OK;
@@ -318,7 +251,7 @@ extern "C" int mi355_gemm_splitk64_direct_plan(int M, int NT, int KC, int wbits,
 extern "C" int mi355_gemm_splitk64_direct(const void* gp, int wbits, int group_size, mi355_stream_t stream) {
     SplitK64Params sp;
     sp.g = *reinterpret_cast<const GemmParams*>(gp);
-    sp.dbg = 0; sp.xmap = 0; sp.zplane = nullptr; sp.xs = nullptr; sp.nmain = 1 << 30; sp.nzb = 0; sp.gpad = 0;
+    sp.dbg = 0; sp.xmap = 0;
     GemmParams& g = sp.g;
     if (g.K != g.KC * 128 || g.mode == MODE_PARTIAL || !g.y) return MI355_ERR_UNSUPPORTED;
     const int T = mi355_gemm_splitk64_direct_plan(g.M, g.NT, g.KC, wbits, group_size);
@@ -342,7 +275,7 @@ extern "C" int mi355_gemm_splitk64_direct(const void* gp, int wbits, int group_s
 extern "C" int mi355_gemm_splitk64(const void* gp, int wbits, int group_size, int max_splits, mi355_stream_t stream) {
     SplitK64Params sp;
     sp.g = *reinterpret_cast<const GemmParams*>(gp);
-    sp.dbg = TUNE(7); sp.zplane = nullptr; sp.xs = nullptr; sp.nmain = 1 << 30; sp.nzb = 0; sp.gpad = 0;
+    sp.dbg = TUNE(7);
     GemmParams& g = sp.g;
     if (g.K != g.KC * 128 || !g.partials) return MI355_ERR_UNSUPPORTED;
     int cps = 0;
@@ -357,8 +290,7 @@ extern "C" int mi355_gemm_splitk64(const void* gp, int wbits, int group_size, in
 #define SK_MB_(WB_, GS_, MB_) (cpw <= 3 ? launch_splitk64_t<WB_, GS_, MB_, 4, 3, 3>(sp, G, st) : launch_splitk64_t<WB_, GS_, MB_, 4, 5, 3>(sp, G, st))
 #define SK_(WB_, GS_) rc = mblk == 1 ? SK_MB_(WB_, GS_, 1) : mblk == 2 ? SK_MB_(WB_, GS_, 2) : mblk == 3 ? SK_MB_(WB_, GS_, 3) : SK_MB_(WB_, GS_, 4)
 #ifdef MI355_TUNING
-    if (wbits == 4 && group_size == 128 && mblk == 4 && cpw > 3 && sp.dbg == 9) {   // round 6, TIMING ONLY (results wrong): the 9-VALU unit without its zero-term blocks (--debug-set 7=9)
-        sp.nmain = 1 << 30;
+    if (wbits == 4 && group_size == 128 && mblk == 4 && cpw > 3 && sp.dbg == 16) {   // round 6, TIMING ONLY (results wrong): the 9-VALU unit of DESIGN 9 J (--debug-set 7=16; NOT 9: bits 1 / 2 of this switch remove the activation / weight traffic)
         rc = launch_splitk64_t<4, 4, 4, 4, 5, 3, false, 2>(sp, G, st);
         return rc == MI355_OK ? ns : rc;
     }
@@ -367,27 +299,4 @@ extern "C" int mi355_gemm_splitk64(const void* gp, int wbits, int group_size, in
 #undef SK_MB_
 #undef SK_
     return rc == MI355_OK ? ns : rc;
-}
-
-// ZS form of mi355_gemm_splitk64 (SplitK64Params): W4 g128, 49-64 rows, the plan of the plain form with its K splits over whole XCDs and >= 8 CUs left for the
-// zero-term blocks.  Writes ns + 1 slabs (the last one: the zero term) and returns that count; MI355_ERR_UNSUPPORTED otherwise (the caller uses the plain form).
-// zplane: quant.make_zero_plane of the weight; xs: per-tile row sums of the activation image's producer, [K / 8][64] fp32.
-extern "C" int mi355_gemm_splitk64_zs(const void* gp, int wbits, int group_size, int max_splits, const void* zplane, const float* xs, mi355_stream_t stream) {
-    SplitK64Params sp;
-    sp.g = *reinterpret_cast<const GemmParams*>(gp);
-    sp.dbg = 0;
-    GemmParams& g = sp.g;
-    if (g.K != g.KC * 128 || !g.partials || !zplane || !xs || wbits != 4 || group_size != 128 || g.M <= 48 || g.M > 64 || g.bf16) return MI355_ERR_UNSUPPORTED;
-    int cps = 0;
-    const int ns = mi355_gemm_splitk64_plan(g.M, g.NT, g.KC, wbits, group_size, max_splits - 1, &cps);
-    if (ns < 0) return ns;
-    g.nsplit = ns; g.cps = cps; g.mode = MODE_PARTIAL;
-    const int G = (g.NT + 3) / 4, cpw = (cps + 7) / 8;
-    sp.xmap = (8 % ns == 0 && G % (8 / ns) == 0 && (G * ns) % 8 == 0) ? 8 / ns : 0;
-    sp.gpad = (g.KC + 31) / 32 * 32;
-    sp.nmain = G * ns; sp.nzb = 256 - sp.nmain;
-    if (sp.xmap <= 0 || cpw <= 3 || cpw > 5 || sp.nzb < 8 || 3 * sp.gpad / 32 * 4 * 1024 > 8 * 4 * 4 * 1024) return MI355_ERR_UNSUPPORTED;
-    sp.zplane = zplane; sp.xs = xs;
-    const int rc = launch_splitk64_t<4, 4, 4, 4, 5, 3, false, 2>(sp, G, (hipStream_t)stream);
-    return rc == MI355_OK ? ns + 1 : rc;
 }

@@ -38,9 +38,6 @@ struct WideParams {
     const float* ssq;
     int   ssq_tiles, ssq_ld;
     float eps, unscale;
-    // round 6 (zero-point-free down_proj, gemm_splitk64.hip ZS): per-tile row sums of the SiLU image this launch stores, xs_out[tile * 64 + row] = the fp32 sum of the
-    // tile's 8 fp16 outputs of that row (fp16 SiLU image output only; null: not wanted)
-    float* xs_out;
     unsigned long long* stamps; // DBG & 4: wall_clock64 at start / after prologue / after the main loop / at the end, per wave
 };
 
@@ -311,30 +308,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const WideParams wp) {
         }
         if (wp.ssq && m < p.M) v *= reinterpret_cast<const float*>(smem + RS_OFF)[m];   // deferred RMSNorm of row m (see WideParams)
         else if (p.x_img && p.bf16) v *= kImgBfUnscale;   // a plain image of a bf16 tensor holds x 2^-8 (common.h img_val; the deferred norm's has its own exponent)
-        if (m < p.M) {
-            if (wp.xs_out) {   // fp16 SiLU image + the tile's row sum of the STORED values (the host sets xs_out only for that form; the four q lanes of a row are in here together)
-                if (p.bias) {
-                    const f16x4 bv = *reinterpret_cast<const f16x4*>(p.bias + n0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
-                }
-                f16x2 o;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const float g = (float)(f16)v[2 * t], u = (float)(f16)v[2 * t + 1];
-                    o[t] = (f16)((g / (1.f + __expf(-g))) * u);
-                }
-                // the STORED bits, opaque to the optimiser: left visible, hipcc derives the two halves a second time for the sum below with v_fma_mixlo_f16 (the exact product
-                // rounded once) next to the v_mul_f32 + v_cvt_pk_f16_f32 (rounded twice) it stores -- one ulp apart in 0.05 % of the elements
-                uint32_t ob = __builtin_bit_cast(uint32_t, o);
-                asm volatile("" : "+v"(ob));
-                *reinterpret_cast<uint32_t*>((f16*)p.y + act_img_index(m, n0 >> 1, (p.M + 15) >> 4)) = ob;
-                const f16x2 ov = __builtin_bit_cast(f16x2, ob);
-                float sx = (float)ov[0] + (float)ov[1];
-                sx += __shfl_xor(sx, 16); sx += __shfl_xor(sx, 32);
-                if (q == 0) wp.xs_out[(size_t)(t0 + tb) * 64 + m] = sx;
-            } else gemm_store(p, v, m, n0, blockIdx.y);
-        }
+        if (m < p.M) gemm_store(p, v, m, n0, blockIdx.y);
     };
     if constexpr (KEEP) {
         // wave (th, ks) parks the T x 3 sets of the row blocks != ks and sums row block ks of its half's T tiles: slices in order 0..3 as the
@@ -420,7 +394,7 @@ extern "C" void mi355_debug_ptr(void* p) { g_wide_stamps = (unsigned long long*)
 // Plan + launch.  Returns the number of slabs written (partial mode), MI355_OK (direct mode), or
 // MI355_ERR_UNSUPPORTED when the shape does not fit this kernel (the caller falls back to gemm.hip).
 static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_partial, int max_splits, const mi355_deferred_norm_t* dn,
-                            mi355_stream_t stream, float* xs_out = nullptr);
+                            mi355_stream_t stream);
 // does the direct (one launch, no slabs) form take this linear at 1-64 rows?  N alone has to fill the chip (gate_up)
 extern "C" int mi355_gemm_wide_direct_ok(const mi355_weight_t* w) {
     if (!w) return 0;                                // either activation dtype: the image entry (gemm.hip) decides
@@ -439,14 +413,8 @@ extern "C" int mi355_gemm_wide(const void* gp, int wbits, int group_size, int wa
 extern "C" int mi355_gemm_wide_img(const void* gp, int wbits, int group_size, const mi355_deferred_norm_t* dn, mi355_stream_t stream) {
     return gemm_wide_launch(gp, wbits, group_size, 0, 1, dn, stream);
 }
-// the same, also leaving the per-tile row sums of the stored fp16 SiLU image (WideParams.xs_out): W4 g128, fp16, MI355_EPI_SILU_MUL | MI355_EPI_OUT_IMAGE only
-extern "C" int mi355_gemm_wide_img_xs(const void* gp, int wbits, int group_size, const mi355_deferred_norm_t* dn, float* xs_out, mi355_stream_t stream) {
-    const GemmParams& g = *reinterpret_cast<const GemmParams*>(gp);
-    if (!xs_out || wbits != 4 || g.mode != MODE_SILU || !g.y_img || g.bf16 || g.N % 16 != 0) return MI355_ERR_UNSUPPORTED;
-    return gemm_wide_launch(gp, wbits, group_size, 0, 1, dn, stream, xs_out);
-}
 static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_partial, int max_splits, const mi355_deferred_norm_t* dn,
-                            mi355_stream_t stream, float* xs_out) {
+                            mi355_stream_t stream) {
     GemmParams g = *reinterpret_cast<const GemmParams*>(gp);
     constexpr int T = 5, TB = 2 * T, CUS = 256;     // tiles per wave / per block
     if (g.M < 1 || g.M > 64) return MI355_ERR_UNSUPPORTED;   // row-major callers come with > 16 rows (gemm.hip); fewer: the image entries only, on the two-row-block instances
@@ -472,7 +440,7 @@ static int gemm_wide_launch(const void* gp, int wbits, int group_size, int want_
     g.cps = (g.KC + nsplit - 1) / nsplit;
     g.nsplit = (g.KC + g.cps - 1) / g.cps;
     wp.g = g; wp.G = G; wp.stamps = WIDE_STAMPS;
-    wp.ssq = nullptr; wp.ssq_tiles = wp.ssq_ld = 0; wp.eps = 0.f; wp.unscale = 1.f; wp.xs_out = xs_out;
+    wp.ssq = nullptr; wp.ssq_tiles = wp.ssq_ld = 0; wp.eps = 0.f; wp.unscale = 1.f;
     if (dn) {
         if (want_partial) return MI355_ERR_UNSUPPORTED;   // the row factors are applied at the K-slice merge (after the per-channel scale of a W8 instance)
         wp.ssq = dn->tile_sumsq; wp.ssq_tiles = dn->tiles; wp.ssq_ld = dn->ld; wp.eps = dn->eps; wp.unscale = dn->unscale;

@@ -370,46 +370,6 @@ def linear_partial_img(x: ActImage, w: PackedWeight, max_splits: int = 16):
     return slabs[:rc]
 
 
-def linear_deferred_norm_img_xs(xg: ActImage, dn, w: PackedWeight, bias: Optional[torch.Tensor] = None):
-    """linear_deferred_norm_img with the SiLU-gate epilogue and an image output (fp16) that also returns the per-tile row sums of the stored image,
-    fp32 [w.N / 16, 64] (what linear_partial_img_zs rebuilds the per-group activation sums from).  (image, rowsums) or None."""
-    _chk(xg.data, torch.float16, "linear_deferred_norm_img_xs.x")
-    if xg.K != w.K:
-        raise _C.Mi355Error(f"linear_deferred_norm_img_xs: image K={xg.K} against K={w.K}")
-    st = None
-    if dn is not None:
-        ssq, eps, e = dn
-        _chk(ssq, torch.float32, "linear_deferred_norm_img_xs.tile_sumsq")
-        st = _C.DeferredNorm(ssq.data_ptr(), w.K // 16, ssq.shape[1], float(eps), float(2.0 ** e))
-    yi = _new_image(xg.M, w.N // 2, torch.float16, xg.data.device, torch.float16)
-    xs = torch.zeros(w.N // 16, 64, dtype=torch.float32, device=xg.data.device)
-    ws_struct = weight_struct(w, torch.float16)
-    rc = _C.lib().mi355_linear_deferred_norm_img_xs(xg.data.data_ptr(), xg.M, None if st is None else C.byref(st), C.byref(ws_struct), _p(bias),
-                                                    yi.data.data_ptr(), xs.data_ptr(), _stream())
-    if rc == ERR_UNSUPPORTED:
-        return None
-    _C.check(rc, "linear_deferred_norm_img_xs")
-    return yi, xs
-
-
-def linear_partial_img_zs(x: ActImage, w: PackedWeight, zero_plane: torch.Tensor, tile_rowsum: torch.Tensor, max_splits: int = 16):
-    """linear_partial_img with the zero point out of the MFMA operand (49-64 rows, W4 g128, fp16): zero_plane = quant.make_zero_plane(w.meta, w.N_pad),
-    tile_rowsum [K / 8, 64] as left by linear_deferred_norm_img_xs.  fp32 slabs [n, M, N_pad] (the last one is the zero term) or None."""
-    _chk(x.data, torch.float16, "linear_partial_img_zs.x")
-    _chk(zero_plane, torch.float16, "linear_partial_img_zs.zero_plane")
-    _chk(tile_rowsum, torch.float32, "linear_partial_img_zs.tile_rowsum")
-    if x.K != w.K or tile_rowsum.shape[0] * 8 != w.K:
-        raise _C.Mi355Error(f"linear_partial_img_zs: image K={x.K}, row sums for K={tile_rowsum.shape[0] * 8}, weight K={w.K}")
-    slabs = torch.empty(max_splits, x.M, w.N_pad, dtype=torch.float32, device=x.data.device)
-    ws_struct = weight_struct(w, x.src)
-    rc = _C.lib().mi355_linear_partial_img_zs(x.data.data_ptr(), x.M, C.byref(ws_struct), zero_plane.data_ptr(), tile_rowsum.data_ptr(), slabs.data_ptr(),
-                                              max_splits, _stream())
-    if rc == ERR_UNSUPPORTED:
-        return None
-    _C.check(rc, "linear_partial_img_zs")
-    return slabs[:rc]
-
-
 def qkv_rope_kv_write_img(x: ActImage, wqkv: PackedWeight, qkv_bias, cos_sin, positions, block_table, kv_base, scale_base,
                           nh: int, nkv: int, hd: int, page: int, q_len: int = 1, oob_count: Optional[torch.Tensor] = None):
     """qkv_rope_kv_write for 1-64 rows (the step driver: from 5) with the activations as an image; None when the shape is not taken."""

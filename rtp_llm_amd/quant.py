@@ -141,33 +141,6 @@ def make_meta(z_eff: torch.Tensor, scales: torch.Tensor, N_pad: int) -> torch.Te
     return m.view(torch.int32).reshape(G, N_pad).contiguous()
 
 
-def make_zero_plane(meta: torch.Tensor, N_pad: int) -> torch.Tensor:
-    """The zero point of a W4 g128 weight as MFMA A fragments, for the form of the deep-K linear that keeps it OUT of the dequantised operand
-    (mi355_linear_partial_img_zs, csrc/gemm_splitk64.hip ZS): W = s (q - z) = s q - s z (the reference's dequantisation, rtp_llm/device/device_impl.py:242-300), so
-    x W = x (s q) - sum_g (s z)[g, n] X[g] with X[g] the sum of the activations of group g.  The second term is a GEMM of depth G: s z is split hi + lo (fp16 each,
-    exact to 2^-22) and laid out as k' = part * G_pad + g with the parts (hi . X_hi), (hi . X_lo), (lo . X_hi).
-
-    meta: int32 [G, N_pad] of fp16x2 {-(1024 + z_eff), scale} (make_meta).  Returns fp16 [N_pad / 16, 3 G_pad / 32, 64, 8]: tile t, k-step j, lane (i = l % 16, q = l / 16),
-    element e holds - (s z)_part[g][16 t + i] for k' = 32 j + 8 q + e (0 where g >= G)."""
-    G = meta.shape[0]
-    assert meta.shape[1] == N_pad and N_pad % 16 == 0
-    m16 = meta.contiguous().view(torch.float16).reshape(G, N_pad, 2)
-    z = -(m16[..., 0].to(torch.float32)) - 1024.0              # z_eff, exact
-    sz = m16[..., 1].to(torch.float32) * z                       # [G, N_pad] fp32 (11-bit x 5-bit: exact)
-    hi = sz.to(torch.float16)
-    lo = (sz - hi.to(torch.float32)).to(torch.float16)
-    GP = (G + 31) // 32 * 32
-    parts = torch.zeros(3, GP, N_pad, dtype=torch.float16, device=meta.device)
-    parts[0, :G] = -hi
-    parts[1, :G] = -hi
-    parts[2, :G] = -lo
-    kp = parts.reshape(3 * GP, N_pad)                             # [k', n]
-    NKZ, NT = 3 * GP // 32, N_pad // 16
-    # [j, q, e, t, i] -> [t, j, q, i, e] -> lanes l = q * 16 + i
-    plane = kp.reshape(NKZ, 4, 8, NT, 16).permute(3, 0, 1, 4, 2).reshape(NT, NKZ, 64, 8)
-    return plane.contiguous()
-
-
 def interleave_gate_up(t: torch.Tensor, dim: int = -1) -> torch.Tensor:
     """[gate | up] halves along `dim` -> (g0,u0,g1,u1,...): the column order the fused
     SiLU-gate GEMM epilogue expects (each lane then owns (gate, up) pairs)."""
